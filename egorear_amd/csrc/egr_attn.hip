@@ -1,0 +1,261 @@
+// Joint-query attention kernels: deformable sampling (sample-then-project form), the 15/16-token
+// joint-to-joint attention core, and the fisheye anchor reprojection.
+#include "egr_common.h"
+
+namespace {
+
+constexpr int NPTS = 16;  // n_points of MSDeformAttn (heatmap_mvf_ex.py:772, egoposeformer_mvf_ex.py:460)
+
+// ------------------------------------------------------------------ deformable sampling
+// One workgroup per (b, joint, view) row, one wave per head.  Lanes 0..15 own the 16 sampling points:
+// they form the softmax over the logits with wave shuffles and the four bilinear corners (mmcv
+// ms_deform_attn_im2col_bilinear: pixel = loc*size - 0.5, zero padding).  The wave then walks the
+// (point, corner) list; every step is one fully coalesced read of a feature row (cf floats: 512 B for
+// cf = 128, a float2 per lane) and, when a positional table is given, of the head's dh-float slice.
+// The value projection is linear, so sampling first and projecting the 960 sampled rows per frame
+// afterwards (egr_conv2d on g, with the per-row in-bounds mass sigma scaling the bias) gives the same
+// result as projecting all 4096 tokens per view and then sampling — at ~1/70 of the FLOPs.
+template <int CPL>  // feature channels per lane = cf / 64
+__global__ __launch_bounds__(256) void msda_gather_kernel(const float* feat, const float* pos, int dh,
+                                                          const float* offs_logits, const float* anchors,
+                                                          const uint8_t* valid, int B, int V, int J, int heads, int hgt,
+                                                          int wid, float* g, float* e, float* sigma, uint8_t* rowmask) {
+    const int cf = CPL * 64;
+    const int row = blockIdx.x;  // (b, j, v)
+    const int v = row % V;
+    const int bj = row / V;
+    const int j = bj % J, b = bj / J;
+    const int lane = threadIdx.x & 63;
+    const int nw = blockDim.x >> 6;
+    const bool ok = valid[((int64_t)b * V + v) * J + j] != 0;
+    if (threadIdx.x == 0) rowmask[row] = ok ? 1 : 0;
+    const int hw = hgt * wid;
+    const float ax = anchors[(((int64_t)b * V + v) * J + j) * 2 + 0];
+    const float ay = anchors[(((int64_t)b * V + v) * J + j) * 2 + 1];
+    const float* fbase = feat + ((int64_t)v * B + b) * hw * cf;
+    const int stride_ol = heads * NPTS * 3;
+
+    for (int h = threadIdx.x >> 6; h < heads; h += nw) {
+        float accf[CPL];
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) accf[i] = 0.f;
+        float acce = 0.f, sig = 0.f;
+        if (ok) {  // wave-uniform: a masked row is overwritten with zeros after output_proj anyway
+            // ---- per-point setup on lanes 0..15 (other lanes mirror lane&15, harmless)
+            const int p = lane & 15;
+            const float* ol = offs_logits + (int64_t)bj * stride_ol;
+            float ox = ol[(h * NPTS + p) * 2 + 0], oy = ol[(h * NPTS + p) * 2 + 1];
+            float lg = ol[heads * NPTS * 2 + h * NPTS + p];
+            float mx = lg;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            float ex = expf(lg - mx);
+            float sm = ex;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+            const float aw = ex / sm;
+            const float locx = ax + ox / (float)wid, locy = ay + oy / (float)hgt;
+            const float w_im = locx * (float)wid - 0.5f, h_im = locy * (float)hgt - 0.5f;
+            const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)hgt) && (w_im < (float)wid);
+            const float hl = floorf(h_im), wl = floorf(w_im);
+            const float lh = h_im - hl, lw = w_im - wl, hh = 1.f - lh, hwt = 1.f - lw;
+            const int h0 = (int)hl, w0 = (int)wl, h1 = h0 + 1, w1 = w0 + 1;
+            float cw[4];
+            int ci[4];
+            cw[0] = (inside && h0 >= 0 && w0 >= 0) ? hh * hwt : 0.f;
+            cw[1] = (inside && h0 >= 0 && w1 <= wid - 1) ? hh * lw : 0.f;
+            cw[2] = (inside && h1 <= hgt - 1 && w0 >= 0) ? lh * hwt : 0.f;
+            cw[3] = (inside && h1 <= hgt - 1 && w1 <= wid - 1) ? lh * lw : 0.f;
+            ci[0] = h0 * wid + w0; ci[1] = h0 * wid + w1; ci[2] = h1 * wid + w0; ci[3] = h1 * wid + w1;
+            float mass = (cw[0] + cw[1]) + (cw[2] + cw[3]);
+            float sp = aw * mass;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sp += __shfl_xor(sp, o, 64);
+            sig = sp;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) cw[c] *= aw;
+            // ---- gather: (point, corner) list broadcast from the owning lane
+            const float* pbase = pos ? pos + (int64_t)v * hw * (heads * dh) + h * dh : nullptr;
+            for (int q = 0; q < NPTS; ++q) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float wgt = __shfl(cw[c], q, 64);
+                    int idx = __shfl(ci[c], q, 64);
+                    if (wgt == 0.f) continue;  // wave-uniform (broadcast value)
+                    const float* fr = fbase + (int64_t)idx * cf + lane * CPL;
+                    if constexpr (CPL == 2) {
+                        f32x2 t = *reinterpret_cast<const f32x2*>(fr);
+                        accf[0] = fmaf(wgt, t[0], accf[0]);
+                        accf[1] = fmaf(wgt, t[1], accf[1]);
+                    } else if constexpr (CPL == 4) {
+                        f32x4 t = *reinterpret_cast<const f32x4*>(fr);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) accf[i] = fmaf(wgt, t[i], accf[i]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < CPL; ++i) accf[i] = fmaf(wgt, fr[i], accf[i]);
+                    }
+                    if (pbase && lane < dh) acce = fmaf(wgt, pbase[(int64_t)idx * (heads * dh) + lane], acce);
+                }
+            }
+        }
+        float* go = g + ((int64_t)row * heads + h) * cf + lane * CPL;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) go[i] = accf[i];
+        if (e && lane < dh) e[(int64_t)row * heads * dh + h * dh + lane] = acce;
+        if (lane == 0) sigma[(int64_t)h * gridDim.x + row] = sig;  // (heads, rows): one contiguous rowscale vector per head
+    }
+}
+
+// ------------------------------------------------------------------ joint-to-joint attention core
+// One wave per (b, head); q, k, v head slices staged in LDS; 4 lanes share a score row.
+__global__ __launch_bounds__(64) void joint_mha_kernel(const float* qkv, float* out, int J, int heads, int d, float scale) {
+    __shared__ float sq[16 * 64], sk[16 * 64], sv[16 * 64], sp[16 * 16];
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int lane = threadIdx.x;
+    const int c = heads * d;
+    for (int i = lane; i < J * d; i += 64) {
+        int t = i / d, dd = i % d;
+        const float* r = qkv + ((int64_t)b * J + t) * 3 * c + h * d + dd;
+        sq[t * d + dd] = r[0];
+        sk[t * d + dd] = r[c];
+        sv[t * d + dd] = r[2 * c];
+    }
+    __syncthreads();
+    const int i = lane >> 2, gq = lane & 3;  // row i, columns gq, gq+4, gq+8, gq+12
+    float s[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int jj = gq + 4 * t;
+        float dot = 0.f;
+        if (i < J && jj < J)
+            for (int dd = 0; dd < d; ++dd) dot = fmaf(sq[i * d + dd], sk[jj * d + dd], dot);
+        s[t] = (i < J && jj < J) ? dot * scale : -INFINITY;
+        mx = fmaxf(mx, s[t]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        s[t] = (s[t] == -INFINITY) ? 0.f : expf(s[t] - mx);
+        sum += s[t];
+    }
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) sp[i * 16 + gq + 4 * t] = (i < J) ? s[t] / sum : 0.f;
+    __syncthreads();
+    for (int idx = lane; idx < J * d; idx += 64) {
+        int t = idx / d, dd = idx % d;
+        float o = 0.f;
+        for (int jj = 0; jj < J; ++jj) o = fmaf(sp[t * 16 + jj], sv[jj * d + dd], o);
+        out[((int64_t)b * J + t) * c + h * d + dd] = o;
+    }
+}
+
+// ------------------------------------------------------------------ fisheye reprojection
+constexpr int CAM_REC = 17;  // [npoly, cx, cy, W, H, poly[12]]
+
+__device__ __forceinline__ void fisheye_one(const float* cam, float x, float y, float z, float* u_out, float* v_out,
+                                            uint8_t* ok_out) {
+    const int npoly = (int)cam[0];
+    const float cx = cam[1], cy = cam[2], W = cam[3], H = cam[4];
+    float norm = sqrtf(x * x + y * y);
+    float theta = atanf(-z / norm);
+    // rho = sum_i a_i * theta^i, left to right from 0 (utils/camera_models.py:85)
+    float rho = 0.f, pw = 1.f;
+    for (int i = 0; i < npoly; ++i) {
+        rho = rho + cam[5 + i] * pw;
+        pw *= theta;
+    }
+    float u = x / norm * rho + cx;
+    float v = y / norm * rho + cy;
+    u = u / W;
+    v = v / H;
+    *ok_out = (u > 0.f && v > 0.f && u < 1.f && v < 1.f) ? 1 : 0;
+    *u_out = fminf(fmaxf(u, 0.f), 1.f);
+    *v_out = fminf(fmaxf(v, 0.f), 1.f);
+}
+
+__global__ __launch_bounds__(256) void fisheye_kernel(float* pts, const float* ctm, const float* cams, int B, int J,
+                                                      float* anchors, uint8_t* valid, float* q4) {
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * J) return;
+    const int b = idx / J, j = idx % J;
+    float x = pts[idx * 3 + 0], y = pts[idx * 3 + 1], z = pts[idx * 3 + 2];
+    // ego4view_syn rigid offsets (cm): FL, FR, BL, BR; the back cameras flip x,y first (camera_models.py:29-40,59-63)
+    const float offx[4] = {6.f, -6.f, -6.f, 6.f};
+    const float offy[4] = {0.f, 0.f, 37.f, 37.f};
+    for (int c = 0; c < 4; ++c) {
+        float px, py, pz;
+        if (ctm) {  // rw: M . [p*0.01, 1] * 100, no mutation
+            const float* m = ctm + ((int64_t)b * 4 + c) * 16;
+            float sx = x * 0.01f, sy = y * 0.01f, sz = z * 0.01f;
+            px = (m[0] * sx + m[1] * sy + m[2] * sz + m[3]) * 100.f;
+            py = (m[4] * sx + m[5] * sy + m[6] * sz + m[7]) * 100.f;
+            pz = (m[8] * sx + m[9] * sy + m[10] * sz + m[11]) * 100.f;
+        } else {  // syn: the reference mutates its argument in place, so the four cameras chain (F7)
+            if (c >= 2) { x = x * -1.f; y = y * -1.f; }
+            x += offx[c]; y += offy[c]; z += 0.f;
+            px = x; py = y; pz = z;
+        }
+        float u, v;
+        uint8_t ok;
+        fisheye_one(cams + c * CAM_REC, px, py, pz, &u, &v, &ok);
+        int64_t o = ((int64_t)b * 4 + c) * J + j;
+        anchors[o * 2 + 0] = u;
+        anchors[o * 2 + 1] = v;
+        valid[o] = ok;
+    }
+    if (!ctm) { pts[idx * 3 + 0] = x; pts[idx * 3 + 1] = y; pts[idx * 3 + 2] = z; }
+    q4[idx * 4 + 0] = (float)(j + 1) / (float)J;
+    q4[idx * 4 + 1] = x; q4[idx * 4 + 2] = y; q4[idx * 4 + 3] = z;
+}
+
+}  // namespace
+
+extern "C" int egr_msda_gather_f32(const float* feat, int32_t cf, const float* pos, int32_t dh, const float* offs_logits,
+                                   const float* anchors, const uint8_t* valid, int32_t b, int32_t views, int32_t joints,
+                                   int32_t heads, int32_t hgt, int32_t wid, float* g, float* e, float* sigma,
+                                   uint8_t* rowmask, void* stream) {
+    if (!feat || !offs_logits || !anchors || !valid || !g || !sigma || !rowmask) return EGR_ENULL;
+    if ((pos != nullptr) != (e != nullptr)) return EGR_ENULL;
+    if (b <= 0 || views <= 0 || joints <= 0 || heads <= 0 || heads > 16 || hgt <= 0 || wid <= 0) return EGR_EINVAL;
+    if (pos && (dh <= 0 || dh > 64)) return EGR_EINVAL;
+    int64_t rows = (int64_t)b * joints * views;
+    if (rows >= (1LL << 31)) return EGR_EINVAL;
+    dim3 grid((unsigned)rows), block(64 * (heads < 4 ? heads : 4));
+    hipStream_t s = (hipStream_t)stream;
+    if (cf == 128)
+        hipLaunchKernelGGL(msda_gather_kernel<2>, grid, block, 0, s, feat, pos, dh, offs_logits, anchors, valid, b, views,
+                           joints, heads, hgt, wid, g, e, sigma, rowmask);
+    else if (cf == 64)
+        hipLaunchKernelGGL(msda_gather_kernel<1>, grid, block, 0, s, feat, pos, dh, offs_logits, anchors, valid, b, views,
+                           joints, heads, hgt, wid, g, e, sigma, rowmask);
+    else if (cf == 256)
+        hipLaunchKernelGGL(msda_gather_kernel<4>, grid, block, 0, s, feat, pos, dh, offs_logits, anchors, valid, b, views,
+                           joints, heads, hgt, wid, g, e, sigma, rowmask);
+    else
+        return EGR_EINVAL;
+    return egr_launch_status();
+}
+
+extern "C" int egr_joint_mha_f32(const float* qkv, float* out, int32_t b, int32_t j, int32_t heads, int32_t d, float scale,
+                                 void* stream) {
+    if (!qkv || !out) return EGR_ENULL;
+    if (b <= 0 || j <= 0 || j > 16 || heads <= 0 || d <= 0 || d > 64) return EGR_EINVAL;
+    hipLaunchKernelGGL(joint_mha_kernel, dim3((unsigned)(b * heads)), dim3(64), 0, (hipStream_t)stream, qkv, out, j, heads, d,
+                       scale);
+    return egr_launch_status();
+}
+
+extern "C" int egr_fisheye_project_f32(float* pts, const float* ctm, const float* cams, int32_t b, int32_t joints,
+                                       float* anchors, uint8_t* valid, float* q4, void* stream) {
+    if (!pts || !cams || !anchors || !valid || !q4) return EGR_ENULL;
+    if (b <= 0 || joints <= 0) return EGR_EINVAL;
+    hipLaunchKernelGGL(fisheye_kernel, dim3((unsigned)((b * joints + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pts,
+                       ctm, cams, b, joints, anchors, valid, q4);
+    return egr_launch_status();
+}

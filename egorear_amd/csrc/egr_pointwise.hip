@@ -1,0 +1,284 @@
+// HBM-bound helper kernels of the hot path: pooling, bilinear upsampling, LayerNorm, argmax,
+// tiny dense layers.  All are channels-last with 16-byte vector accesses across channels
+// (coalesced: consecutive lanes touch consecutive channel quads of one pixel), one pass over the data.
+#include "egr_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ MaxPool2d (NHWC)
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* x, float* y, int n, int h, int w, int c4, int ho,
+                                                      int wo, int k, int stride, int pad) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t total = (int64_t)n * ho * wo * c4;
+    if (idx >= total) return;
+    int cq = (int)(idx % c4);
+    int64_t p = idx / c4;
+    int ox = (int)(p % wo);
+    p /= wo;
+    int oy = (int)(p % ho);
+    int img = (int)(p / ho);
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int dy = 0; dy < k; ++dy) {
+        int iy = oy * stride - pad + dy;
+        if (iy < 0 || iy >= h) continue;
+        for (int dx = 0; dx < k; ++dx) {
+            int ix = ox * stride - pad + dx;
+            if (ix < 0 || ix >= w) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(x + (((int64_t)img * h + iy) * w + ix) * (c4 * 4) + cq * 4);
+            best[0] = fmaxf(best[0], v[0]);
+            best[1] = fmaxf(best[1], v[1]);
+            best[2] = fmaxf(best[2], v[2]);
+            best[3] = fmaxf(best[3], v[3]);
+        }
+    }
+    *reinterpret_cast<f32x4*>(y + idx * 4) = best;
+}
+
+// ------------------------------------------------------------------ bilinear x2, align_corners=True (NHWC)
+// index / weight arithmetic follows ATen's area_pixel_compute_source_index(align_corners=True):
+// src = dst * (in-1)/(out-1) in fp32, i0 = (int)src, i1 = min(i0+1, in-1), l1 = src - i0, l0 = 1 - l1.
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float* x, int ldx, float* y, int ldy, int n, int h, int w,
+                                                         int c4) {
+    const int ho = 2 * h, wo = 2 * w;
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t total = (int64_t)n * ho * wo * c4;
+    if (idx >= total) return;
+    int cq = (int)(idx % c4);
+    int64_t p = idx / c4;
+    int ox = (int)(p % wo);
+    p /= wo;
+    int oy = (int)(p % ho);
+    int img = (int)(p / ho);
+    const float sh = (ho > 1) ? (float)(h - 1) / (float)(ho - 1) : 0.f;
+    const float sw = (wo > 1) ? (float)(w - 1) / (float)(wo - 1) : 0.f;
+    float fy = sh * (float)oy, fx = sw * (float)ox;
+    int y0 = (int)fy, x0 = (int)fx;
+    int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f);
+    float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    const float* base = x + (int64_t)img * h * w * ldx + cq * 4;
+    f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((int64_t)y0 * w + x0) * ldx);
+    f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((int64_t)y0 * w + x1) * ldx);
+    f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((int64_t)y1 * w + x0) * ldx);
+    f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((int64_t)y1 * w + x1) * ldx);
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = ly0 * (lx0 * v00[i] + lx1 * v01[i]) + ly1 * (lx0 * v10[i] + lx1 * v11[i]);
+    *reinterpret_cast<f32x4*>(y + (((int64_t)img * ho + oy) * wo + ox) * ldy + cq * 4) = o;
+}
+
+// ------------------------------------------------------------------ global average pool (NHWC)
+__global__ __launch_bounds__(256) void avgpool_kernel(const float* x, float* y, int n, int hw, int c) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)n * c) return;
+    int img = (int)(idx / c), ch = (int)(idx % c);
+    float s = 0.f;
+    for (int p = 0; p < hw; ++p) s += x[((int64_t)img * hw + p) * c + ch];
+    y[idx] = s / (float)hw;
+}
+
+// ------------------------------------------------------------------ LayerNorm (+ residual), one wave per row
+template <int VPL>  // values per lane = c / 64
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* res, const float* gamma,
+                                                        const float* beta, float* y, int rows, float eps) {
+    const int c = VPL * 64;
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        int ch = i * 64 + lane;
+        float t = x[(int64_t)row * c + ch];
+        if (res) t += res[(int64_t)row * c + ch];
+        v[i] = t;
+        s += t;
+    }
+    float mean = wave_sum(s) / (float)c;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        float dlt = v[i] - mean;
+        q += dlt * dlt;
+    }
+    float rstd = 1.0f / sqrtf(wave_sum(q) / (float)c + eps);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        int ch = i * 64 + lane;
+        y[(int64_t)row * c + ch] = (v[i] - mean) * rstd * gamma[ch] + beta[ch];
+    }
+}
+
+// ------------------------------------------------------------------ argmax over hw, one wave per row
+__global__ __launch_bounds__(256) void argmax_kernel(const float* hm, int rows, int hgt, int wid, float thr,
+                                                     float* anchors, float* maxvals, uint8_t* valid, int32_t* index) {
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int hw = hgt * wid;
+    const float* p = hm + (int64_t)row * hw;
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    // each lane walks its indices in increasing order, so '>' keeps the first maximum it sees
+    for (int base = lane * 4; base < hw; base += 256) {
+        if (base + 3 < hw) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(p + base);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (v[i] > best || bidx == 0x7fffffff) { best = v[i]; bidx = base + i; }
+        } else {
+            for (int i = 0; i < 4 && base + i < hw; ++i) {
+                float v = p[base + i];
+                if (v > best || bidx == 0x7fffffff) { best = v; bidx = base + i; }
+            }
+        }
+    }
+    // cross-lane: larger value wins, ties go to the smaller flat index (torch.max returns the first)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(best, o, 64);
+        int oi = __shfl_xor(bidx, o, 64);
+        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+    }
+    if (lane == 0) {
+        anchors[row * 2 + 0] = (float)(bidx % wid) / (float)wid;
+        anchors[row * 2 + 1] = (float)(bidx / wid) / (float)hgt;
+        maxvals[row] = best;
+        valid[row] = best >= thr ? 1 : 0;
+        index[row] = bidx;
+    }
+}
+
+// ------------------------------------------------------------------ tiny dense layer, K not a multiple of 32
+__global__ __launch_bounds__(256) void linear_smallk_kernel(const float* x, int64_t sxm, int64_t sxk, const float* w,
+                                                            const float* bias, float* y, int m, int n, int k, int act) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)m * n) return;
+    int row = (int)(idx / n), col = (int)(idx % n);
+    float s = 0.f;
+    for (int i = 0; i < k; ++i) s = fmaf(x[row * sxm + i * sxk], w[(int64_t)col * k + i], s);
+    if (bias) s += bias[col];
+    y[idx] = egr_act(s, act);
+}
+
+__global__ __launch_bounds__(256) void jqa_sum_kernel(const float* hm_embed, const float* embed, const float* bfb, float* y,
+                                                      int b, int j, int c) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)b * j * c) return;
+    int ch = (int)(idx % c);
+    int64_t r = idx / c;
+    int jj = (int)(r % j), bb = (int)(r / j);
+    // (joint_query_embed + bfb) + heatmap_embed, the reference's association order
+    y[idx] = (embed[jj * c + ch] + bfb[(int64_t)bb * c + ch]) + hm_embed[idx];
+}
+
+__global__ __launch_bounds__(256) void tokens_to_nhwc_kernel(const float* x, float* y, int b, int j, int hw) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)b * j * hw) return;
+    int jj = (int)(idx % j);
+    int64_t r = idx / j;
+    int p = (int)(r % hw), bb = (int)(r / hw);
+    y[idx] = x[((int64_t)bb * j + jj) * hw + p];
+}
+
+inline unsigned nblocks(int64_t total) { return (unsigned)((total + 255) / 256); }
+
+}  // namespace
+
+extern "C" int egr_maxpool_nhwc_f32(const float* x, float* y, int32_t n, int32_t h, int32_t w, int32_t c, int32_t k,
+                                    int32_t stride, int32_t pad, void* stream) {
+    if (!x || !y) return EGR_ENULL;
+    if (n <= 0 || c % 4 != 0 || k <= 0 || stride <= 0 || pad < 0 || 2 * pad > k) return EGR_EINVAL;
+    int ho = (h + 2 * pad - k) / stride + 1, wo = (w + 2 * pad - k) / stride + 1;
+    int64_t total = (int64_t)n * ho * wo * (c / 4);
+    if (total <= 0 || total >= (1LL << 31) * 256) return EGR_EINVAL;
+    hipLaunchKernelGGL(maxpool_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, n, h, w, c / 4, ho,
+                       wo, k, stride, pad);
+    return egr_launch_status();
+}
+
+extern "C" int egr_upsample2x_nhwc_f32(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t n, int32_t h,
+                                       int32_t w, int32_t c, void* stream) {
+    if (!x || !y) return EGR_ENULL;
+    if (n <= 0 || h <= 0 || w <= 0 || c % 4 != 0 || ldx % 4 != 0 || ldy % 4 != 0 || ldx < c || ldy < c) return EGR_EINVAL;
+    int64_t total = (int64_t)n * 4 * h * w * (c / 4);
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, n, h,
+                       w, c / 4);
+    return egr_launch_status();
+}
+
+extern "C" int egr_avgpool_nhwc_f32(const float* x, float* y, int32_t n, int32_t hw, int32_t c, void* stream) {
+    if (!x || !y) return EGR_ENULL;
+    if (n <= 0 || hw <= 0 || c <= 0) return EGR_EINVAL;
+    hipLaunchKernelGGL(avgpool_kernel, dim3(nblocks((int64_t)n * c)), dim3(256), 0, (hipStream_t)stream, x, y, n, hw, c);
+    return egr_launch_status();
+}
+
+extern "C" int egr_layernorm_f32(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                                 int32_t rows, int32_t c, float eps, void* stream) {
+    if (!x || !gamma || !beta || !y) return EGR_ENULL;
+    if (rows <= 0) return EGR_EINVAL;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (c) {
+        case 64: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, res, gamma, beta, y, rows, eps); break;
+        case 128: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, res, gamma, beta, y, rows, eps); break;
+        case 256: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, res, gamma, beta, y, rows, eps); break;
+        case 512: hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, x, res, gamma, beta, y, rows, eps); break;
+        case 1024: hipLaunchKernelGGL(layernorm_kernel<16>, grid, block, 0, s, x, res, gamma, beta, y, rows, eps); break;
+        default: return EGR_EINVAL;
+    }
+    return egr_launch_status();
+}
+
+extern "C" int egr_argmax_rows_f32(const float* hm, int32_t rows, int32_t hgt, int32_t wid, float thr, float* anchors,
+                                   float* maxvals, uint8_t* valid, int32_t* index, void* stream) {
+    if (!hm || !anchors || !maxvals || !valid || !index) return EGR_ENULL;
+    if (rows <= 0 || hgt <= 0 || wid <= 0 || (int64_t)hgt * wid >= (1 << 24) || ((hgt * wid) % 4 != 0)) return EGR_EINVAL;
+    hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, hm, rows, hgt,
+                       wid, thr, anchors, maxvals, valid, index);
+    return egr_launch_status();
+}
+
+extern "C" int egr_linear_smallk_f32(const float* x, int64_t sxm, int64_t sxk, const float* w, const float* bias,
+                                     float* y, int32_t m, int32_t n, int32_t k, int32_t act, void* stream) {
+    if (!x || !w || !y) return EGR_ENULL;
+    if (m <= 0 || n <= 0 || k <= 0) return EGR_EINVAL;
+    hipLaunchKernelGGL(linear_smallk_kernel, dim3(nblocks((int64_t)m * n)), dim3(256), 0, (hipStream_t)stream, x, sxm, sxk,
+                       w, bias, y, m, n, k, act);
+    return egr_launch_status();
+}
+
+extern "C" int egr_jqa_sum_f32(const float* hm_embed, const float* embed, const float* bfb, float* y, int32_t b, int32_t j,
+                               int32_t c, void* stream) {
+    if (!hm_embed || !embed || !bfb || !y) return EGR_ENULL;
+    if (b <= 0 || j <= 0 || c <= 0) return EGR_EINVAL;
+    hipLaunchKernelGGL(jqa_sum_kernel, dim3(nblocks((int64_t)b * j * c)), dim3(256), 0, (hipStream_t)stream, hm_embed,
+                       embed, bfb, y, b, j, c);
+    return egr_launch_status();
+}
+
+extern "C" int egr_tokens_to_nhwc_f32(const float* x, float* y, int32_t b, int32_t j, int32_t hw, void* stream) {
+    if (!x || !y) return EGR_ENULL;
+    if (b <= 0 || j <= 0 || hw <= 0) return EGR_EINVAL;
+    hipLaunchKernelGGL(tokens_to_nhwc_kernel, dim3(nblocks((int64_t)b * j * hw)), dim3(256), 0, (hipStream_t)stream, x, y,
+                       b, j, hw);
+    return egr_launch_status();
+}
+
+extern "C" const char* egr_version(void) { return "egorear_hip 0.1 (gfx950, fp32 MFMA)"; }
+
+extern "C" int egr_device_arch(char* buf, int32_t buflen) {
+    if (!buf || buflen <= 0) return EGR_ENULL;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return (int)e;
+    int i = 0;
+    for (; i < buflen - 1 && prop.gcnArchName[i]; ++i) buf[i] = prop.gcnArchName[i];
+    buf[i] = 0;
+    return 0;
+}

@@ -1,0 +1,345 @@
+"""ctypes binding of libegorear_hip.so (C ABI: include/egorear_hip.h).
+
+PyTorch is used here only as the owner of device memory and streams: every wrapper
+takes torch tensors, checks device / dtype / layout on the host (a kernel fault can
+reset the GPU), extracts raw pointers and the current HIP stream, and calls the C
+entry point.  There is no fallback: if the library is missing, import fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libegorear_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+RES_NONE, RES_BEFORE_ACT, RES_AFTER_ACT = 0, 1, 2
+
+EXPORTS = [
+    "egr_conv2d_nhwc_f32", "egr_stem_conv7x7_f32", "egr_maxpool_nhwc_f32", "egr_upsample2x_nhwc_f32",
+    "egr_avgpool_nhwc_f32", "egr_argmax_rows_f32", "egr_layernorm_f32", "egr_joint_mha_f32", "egr_msda_gather_f32",
+    "egr_fisheye_project_f32", "egr_linear_smallk_f32", "egr_jqa_sum_f32", "egr_tokens_to_nhwc_f32", "egr_version",
+    "egr_device_arch",
+]
+
+
+class NMap(C.Structure):
+    _fields_ = [("n_inner", C.c_int32), ("stride_inner", C.c_int64), ("stride_outer", C.c_int64)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
+        ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("ho", C.c_int32), ("wo", C.c_int32), ("ldx", C.c_int32), ("ldy", C.c_int32), ("ldr", C.c_int32),
+        ("xmap", NMap), ("ymap", NMap), ("rmap", NMap),
+        ("act", C.c_int32), ("res_mode", C.c_int32), ("out_nchw", C.c_int32), ("split_k", C.c_int32),
+    ]
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -m egorear_amd.csrc.build` "
+            "(or __graft_entry__.build()).  egorear_amd has no CPU / PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    lib.egr_conv2d_nhwc_f32.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.egr_stem_conv7x7_f32.argtypes = [vp, NMap, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.egr_maxpool_nhwc_f32.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.egr_upsample2x_nhwc_f32.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, vp]
+    lib.egr_avgpool_nhwc_f32.argtypes = [vp, vp, i32, i32, i32, vp]
+    lib.egr_argmax_rows_f32.argtypes = [vp, i32, i32, i32, f32, vp, vp, vp, vp, vp]
+    lib.egr_layernorm_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, f32, vp]
+    lib.egr_joint_mha_f32.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp]
+    lib.egr_msda_gather_f32.argtypes = [vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.egr_fisheye_project_f32.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp]
+    lib.egr_linear_smallk_f32.argtypes = [vp, i64, i64, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.egr_jqa_sum_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.egr_tokens_to_nhwc_f32.argtypes = [vp, vp, i32, i32, i32, vp]
+    lib.egr_version.restype = C.c_char_p
+    lib.egr_device_arch.argtypes = [C.c_char_p, i32]
+    for name in EXPORTS:
+        getattr(lib, name)  # fail at import if a symbol is missing
+        if name != "egr_version":
+            getattr(lib, name).restype = C.c_int
+    return lib
+
+
+lib = _load()
+
+_ERR = {-1: "EGR_EINVAL (unsupported shape/alignment)", -2: "EGR_ENULL (missing pointer)", -3: "EGR_EWORKSPACE"}
+
+
+def _check(rc: int, name: str):
+    if rc != 0:
+        raise RuntimeError(f"{name} failed: {_ERR.get(rc, 'hipError_t %d' % rc)}")
+
+
+def _p(t: Optional[torch.Tensor], dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("egorear_amd: tensor is not on a HIP device (no CPU path exists)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"egorear_amd: expected {dtype}, got {t.dtype}")
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _cont(t: torch.Tensor, what: str):
+    if not t.is_contiguous():
+        raise RuntimeError(f"egorear_amd: {what} must be contiguous")
+    return t
+
+
+def version() -> str:
+    return lib.egr_version().decode()
+
+
+def device_arch() -> str:
+    buf = C.create_string_buffer(256)
+    _check(lib.egr_device_arch(buf, 256), "egr_device_arch")
+    return buf.value.decode()
+
+
+# --------------------------------------------------------------------------- NHWC views
+
+class Img:
+    """A batch of channels-last images living (possibly as a channel slice) in a torch buffer.
+    t: (N, H, W, C) with stride(3) == 1 and dense H/W (stride(1) == W*ld, stride(2) == ld)."""
+    __slots__ = ("t", "n", "h", "w", "c", "ld", "nstride")
+
+    def __init__(self, t: torch.Tensor):
+        if t.dim() != 4 or t.stride(3) != 1:
+            raise RuntimeError("egorear_amd: expected a channels-last (N,H,W,C) tensor")
+        n, h, w, c = t.shape
+        ld = t.stride(2) if w > 1 else (t.stride(1) if h > 1 else max(c, 1))
+        if (w > 1 and h > 1 and t.stride(1) != w * ld):
+            raise RuntimeError("egorear_amd: image rows must be dense")
+        self.t, self.n, self.h, self.w, self.c, self.ld = t, n, h, w, c, ld
+        self.nstride = t.stride(0) if n > 1 else h * w * ld
+
+    def nmap(self) -> NMap:
+        return NMap(self.n, self.nstride, 0)
+
+
+def _nmap_of(n: int, stride: int) -> NMap:
+    return NMap(n, stride, 0)
+
+
+# --------------------------------------------------------------------------- ops
+
+def conv2d(x: Img, w: torch.Tensor, cout: int, kh: int, kw: int, stride: int, pad: int, *, scale=None, shift=None,
+           act: int = ACT_NONE, res: Optional[Img] = None, res_mode: int = RES_NONE, rowscale=None, rowmask=None,
+           out: Optional[Img] = None, out_nchw: Optional[torch.Tensor] = None, ymap: Optional[NMap] = None,
+           xmap: Optional[NMap] = None, rmap: Optional[NMap] = None, workspace: Optional[torch.Tensor] = None,
+           split_k: int = 1) -> Optional[Img]:
+    """Implicit-GEMM conv / linear.  Output goes to `out` (NHWC Img, maybe a channel slice), or to the raw
+    tensor `out_nchw` (channel-major planes placed by `ymap`), or to a fresh NHWC tensor."""
+    ho = (x.h + 2 * pad - kh) // stride + 1
+    wo = (x.w + 2 * pad - kw) // stride + 1
+    npad = (cout + 31) // 32 * 32
+    K = kh * kw * x.c
+    if w.dim() != 2 or w.shape[0] != npad or w.shape[1] != K:
+        raise RuntimeError(f"egorear_amd.conv2d: packed weight shape {tuple(w.shape)} != ({npad}, {K})")
+    _cont(w, "packed weight")
+    d = ConvDesc()
+    d.n, d.h, d.w, d.cin, d.cout = x.n, x.h, x.w, x.c, cout
+    d.kh, d.kw, d.stride, d.pad, d.ho, d.wo = kh, kw, stride, pad, ho, wo
+    d.ldx = x.ld
+    d.xmap = xmap if xmap is not None else x.nmap()
+    d.act, d.res_mode, d.split_k = act, res_mode, split_k
+    ret = None
+    if out_nchw is not None:
+        if ymap is None:
+            raise RuntimeError("egorear_amd.conv2d: out_nchw needs ymap")
+        d.out_nchw, d.ldy, d.ymap = 1, 0, ymap
+        yptr = _p(out_nchw)
+    else:
+        if out is None:
+            out = Img(torch.empty((x.n, ho, wo, cout), device=x.t.device, dtype=torch.float32))
+        if (out.n, out.h, out.w, out.c) != (x.n, ho, wo, cout) and ymap is None:
+            raise RuntimeError(f"egorear_amd.conv2d: output shape {(out.n, out.h, out.w, out.c)} != {(x.n, ho, wo, cout)}")
+        d.out_nchw, d.ldy = 0, out.ld
+        d.ymap = ymap if ymap is not None else out.nmap()
+        yptr = _p(out.t)
+        ret = out
+    if res_mode != RES_NONE:
+        if res is None:
+            raise RuntimeError("egorear_amd.conv2d: res_mode set without res")
+        d.ldr = res.ld
+        d.rmap = rmap if rmap is not None else res.nmap()
+    else:
+        d.rmap = NMap(1, 0, 0)
+    if scale is not None and scale.numel() < cout or shift is not None and shift.numel() < cout:
+        raise RuntimeError("egorear_amd.conv2d: scale/shift shorter than cout")
+    M = x.n * ho * wo
+    if rowscale is not None and rowscale.numel() < M or rowmask is not None and rowmask.numel() < M:
+        raise RuntimeError("egorear_amd.conv2d: rowscale/rowmask shorter than M")
+    ws_ptr, ws_n = (None, 0) if workspace is None else (_p(workspace), workspace.numel())
+    rc = lib.egr_conv2d_nhwc_f32(C.byref(d), _p(x.t), _p(w), _p(scale), _p(shift), _p(res.t) if res is not None else None,
+                                 _p(rowscale), _p(rowmask, torch.uint8), yptr, ws_ptr, ws_n, _stream())
+    _check(rc, "egr_conv2d_nhwc_f32")
+    return ret
+
+
+def stem(img: torch.Tensor, view0: int, nviews: int, wpack, scale, shift) -> Img:
+    """img (B, V, 3, H, W) NCHW contiguous; views [view0, view0+nviews) -> NHWC (nviews*B, H/2, W/2, 64), view-major."""
+    B, V, Cc, H, W = img.shape
+    if Cc != 3:
+        raise RuntimeError("egorear_amd.stem: 3-channel input expected")
+    _cont(img, "input image batch")
+    n = nviews * B
+    y = torch.empty((n, H // 2, W // 2, 64), device=img.device, dtype=torch.float32)
+    base = img.reshape(-1)[view0 * 3 * H * W:]
+    xmap = NMap(B, V * 3 * H * W, 3 * H * W)  # n = v*B + b -> (b*V + v) image
+    _check(lib.egr_stem_conv7x7_f32(_p(base), xmap, n, H, W, _p(_cont(wpack, "stem weight")), _p(scale), _p(shift), _p(y),
+                                    _stream()), "egr_stem_conv7x7_f32")
+    return Img(y)
+
+
+def maxpool(x: Img, k: int, stride: int, pad: int) -> Img:
+    if not x.t.is_contiguous():
+        raise RuntimeError("egorear_amd.maxpool: contiguous NHWC input expected")
+    ho = (x.h + 2 * pad - k) // stride + 1
+    wo = (x.w + 2 * pad - k) // stride + 1
+    y = torch.empty((x.n, ho, wo, x.c), device=x.t.device, dtype=torch.float32)
+    _check(lib.egr_maxpool_nhwc_f32(_p(x.t), _p(y), x.n, x.h, x.w, x.c, k, stride, pad, _stream()), "egr_maxpool_nhwc_f32")
+    return Img(y)
+
+
+def upsample2x(x: Img, out: Optional[Img] = None) -> Img:
+    if x.n > 1 and x.nstride != x.h * x.w * x.ld:
+        raise RuntimeError("egorear_amd.upsample2x: images must be densely stacked")
+    if out is None:
+        out = Img(torch.empty((x.n, 2 * x.h, 2 * x.w, x.c), device=x.t.device, dtype=torch.float32))
+    if (out.n, out.h, out.w, out.c) != (x.n, 2 * x.h, 2 * x.w, x.c) or (out.n > 1 and out.nstride != out.h * out.w * out.ld):
+        raise RuntimeError("egorear_amd.upsample2x: bad output view")
+    _check(lib.egr_upsample2x_nhwc_f32(_p(x.t), x.ld, _p(out.t), out.ld, x.n, x.h, x.w, x.c, _stream()),
+           "egr_upsample2x_nhwc_f32")
+    return out
+
+
+def avgpool(x: Img) -> torch.Tensor:
+    if not x.t.is_contiguous():
+        raise RuntimeError("egorear_amd.avgpool: contiguous input expected")
+    y = torch.empty((x.n, x.c), device=x.t.device, dtype=torch.float32)
+    _check(lib.egr_avgpool_nhwc_f32(_p(x.t), _p(y), x.n, x.h * x.w, x.c, _stream()), "egr_avgpool_nhwc_f32")
+    return y
+
+
+def argmax_rows(hm: torch.Tensor, thr: float):
+    """hm (..., H, W) contiguous -> anchors (rows,2) f32, maxvals (rows,), valid (rows,) u8, index (rows,) i32."""
+    _cont(hm, "heatmap")
+    H, W = hm.shape[-2:]
+    rows = hm.numel() // (H * W)
+    dev = hm.device
+    anchors = torch.empty((rows, 2), device=dev, dtype=torch.float32)
+    maxvals = torch.empty((rows,), device=dev, dtype=torch.float32)
+    valid = torch.empty((rows,), device=dev, dtype=torch.uint8)
+    index = torch.empty((rows,), device=dev, dtype=torch.int32)
+    _check(lib.egr_argmax_rows_f32(_p(hm), rows, H, W, float(thr), _p(anchors), _p(maxvals), _p(valid, torch.uint8),
+                                   _p(index, torch.int32), _stream()), "egr_argmax_rows_f32")
+    return anchors, maxvals, valid, index
+
+
+def layernorm(x: torch.Tensor, gamma, beta, res: Optional[torch.Tensor] = None, eps: float = 1e-5) -> torch.Tensor:
+    _cont(x, "layernorm input")
+    c = x.shape[-1]
+    rows = x.numel() // c
+    if res is not None and (res.shape != x.shape or not res.is_contiguous()):
+        raise RuntimeError("egorear_amd.layernorm: residual must match the input")
+    y = torch.empty_like(x)
+    _check(lib.egr_layernorm_f32(_p(x), _p(res), _p(gamma), _p(beta), _p(y), rows, c, eps, _stream()), "egr_layernorm_f32")
+    return y
+
+
+def joint_mha(qkv: torch.Tensor, b: int, j: int, heads: int, d: int, scale: float) -> torch.Tensor:
+    _cont(qkv, "qkv")
+    if qkv.numel() != b * j * 3 * heads * d:
+        raise RuntimeError("egorear_amd.joint_mha: qkv size mismatch")
+    out = torch.empty((b * j, heads * d), device=qkv.device, dtype=torch.float32)
+    _check(lib.egr_joint_mha_f32(_p(qkv), _p(out), b, j, heads, d, float(scale), _stream()), "egr_joint_mha_f32")
+    return out
+
+
+def msda_gather(feat: torch.Tensor, pos: Optional[torch.Tensor], offs_logits: torch.Tensor, anchors: torch.Tensor,
+                valid: torch.Tensor, b: int, views: int, joints: int, heads: int, dh: int, hgt: int, wid: int):
+    """feat (views, b, hgt*wid, cf) contiguous.  Returns g (rows, heads, cf), e (rows, heads*dh) | None,
+    sigma (heads, rows), rowmask (rows,) with rows = (b, joint, view)."""
+    _cont(feat, "feature memory"); _cont(offs_logits, "offs_logits"); _cont(anchors, "anchors"); _cont(valid, "valid")
+    cf = feat.shape[-1]
+    if feat.numel() != views * b * hgt * wid * cf:
+        raise RuntimeError("egorear_amd.msda_gather: feature memory size mismatch")
+    if offs_logits.numel() != b * joints * heads * 16 * 3:
+        raise RuntimeError("egorear_amd.msda_gather: offs_logits size mismatch")
+    if anchors.numel() != b * views * joints * 2 or valid.numel() != b * views * joints:
+        raise RuntimeError("egorear_amd.msda_gather: anchors/valid size mismatch")
+    if pos is not None:
+        _cont(pos, "positional table")
+        if pos.numel() != views * hgt * wid * heads * dh:
+            raise RuntimeError("egorear_amd.msda_gather: positional table size mismatch")
+    rows = b * joints * views
+    dev = feat.device
+    g = torch.empty((rows, heads, cf), device=dev, dtype=torch.float32)
+    e = torch.empty((rows, heads * dh), device=dev, dtype=torch.float32) if pos is not None else None
+    sigma = torch.empty((heads, rows), device=dev, dtype=torch.float32)
+    rowmask = torch.empty((rows,), device=dev, dtype=torch.uint8)
+    _check(lib.egr_msda_gather_f32(_p(feat), cf, _p(pos), dh, _p(offs_logits), _p(anchors), _p(valid, torch.uint8), b, views,
+                                   joints, heads, hgt, wid, _p(g), _p(e), _p(sigma), _p(rowmask, torch.uint8), _stream()),
+           "egr_msda_gather_f32")
+    return g, e, sigma, rowmask
+
+
+def fisheye_project(pts: torch.Tensor, ctm: Optional[torch.Tensor], cams: torch.Tensor):
+    """pts (b, joints, 3) is updated IN PLACE in syn mode (ctm None), as the reference does."""
+    _cont(pts, "pts")
+    b, joints = pts.shape[:2]
+    if cams.numel() != 4 * 17:
+        raise RuntimeError("egorear_amd.fisheye_project: cams must hold 4 records of 17 floats")
+    if ctm is not None:
+        _cont(ctm, "coord_trans_mat")
+        if ctm.numel() != b * 4 * 16:
+            raise RuntimeError("egorear_amd.fisheye_project: coord_trans_mat must be (b,4,4,4)")
+    dev = pts.device
+    anchors = torch.empty((b, 4, joints, 2), device=dev, dtype=torch.float32)
+    valid = torch.empty((b, 4, joints), device=dev, dtype=torch.uint8)
+    q4 = torch.empty((b * joints, 4), device=dev, dtype=torch.float32)
+    _check(lib.egr_fisheye_project_f32(_p(pts), _p(ctm), _p(cams), b, joints, _p(anchors), _p(valid, torch.uint8), _p(q4),
+                                       _stream()), "egr_fisheye_project_f32")
+    return anchors, valid, q4
+
+
+def linear_smallk(x: torch.Tensor, sxm: int, sxk: int, w: torch.Tensor, bias, m: int, n: int, k: int, act: int) -> torch.Tensor:
+    _cont(w, "weight")
+    if w.numel() != n * k or (m - 1) * sxm + (k - 1) * sxk >= x.numel():
+        raise RuntimeError("egorear_amd.linear_smallk: size mismatch")
+    y = torch.empty((m, n), device=x.device, dtype=torch.float32)
+    _check(lib.egr_linear_smallk_f32(_p(x), sxm, sxk, _p(w), _p(bias), _p(y), m, n, k, act, _stream()), "egr_linear_smallk_f32")
+    return y
+
+
+def jqa_sum(hm_embed: torch.Tensor, embed: torch.Tensor, bfb: torch.Tensor, b: int, j: int, c: int) -> torch.Tensor:
+    _cont(hm_embed, "hm_embed"); _cont(embed, "embed"); _cont(bfb, "bfb")
+    if hm_embed.numel() != b * j * c or embed.numel() != j * c or bfb.numel() != b * c:
+        raise RuntimeError("egorear_amd.jqa_sum: size mismatch")
+    y = torch.empty((b * j, c), device=hm_embed.device, dtype=torch.float32)
+    _check(lib.egr_jqa_sum_f32(_p(hm_embed), _p(embed), _p(bfb), _p(y), b, j, c, _stream()), "egr_jqa_sum_f32")
+    return y
+
+
+def tokens_to_nhwc(x: torch.Tensor, b: int, j: int, hw: int) -> torch.Tensor:
+    _cont(x, "tokens")
+    if x.numel() != b * j * hw:
+        raise RuntimeError("egorear_amd.tokens_to_nhwc: size mismatch")
+    y = torch.empty((b, hw, j), device=x.device, dtype=torch.float32)
+    _check(lib.egr_tokens_to_nhwc_f32(_p(x), _p(y), b, j, hw, _stream()), "egr_tokens_to_nhwc_f32")
+    return y

@@ -1,0 +1,159 @@
+/*
+ * egorear_hip.h — C ABI of the MI355X (gfx950) kernels for EgoRear's multi-view
+ * inference hot path (heatmap encoder -> MVFEx/JQA refinement -> 2D-to-3D lifting).
+ *
+ * The reference is pure Python on PyTorch; the boundary it offers for native code is
+ * its operator level.  Each entry point below names the reference
+ * interface it replaces (paths relative to /root/reference/pose_estimation/).  The
+ * one native op the reference itself binds is mmcv's
+ * MultiScaleDeformableAttnFunction (models/utils/deform_attn.py:9,155-162); here it is
+ * egr_msda_gather_f32 + egr_conv2d_nhwc_f32 (sample-then-project form).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless noted;
+ *   - activations are fp32, channels-last ("NHWC"): pixel-major, channel-minor, with an
+ *     explicit pixel stride `ld*` (floats) so that channel slices of a wider buffer can
+ *     be read/written in place (virtual concat);
+ *   - image index n of a batch maps to memory as
+ *         base + (n % n_inner) * stride_inner + (n / n_inner) * stride_outer
+ *     which covers plain batches (n_inner = N) and view-major <-> batch-major
+ *     re-orderings at the boundary;
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous, nothing
+ *     synchronises, allocates or frees, so every call is hipGraph-capturable;
+ *   - return value: 0 on success, a positive hipError_t from the launch, or a negative
+ *     EGR_E* code for arguments the kernels do not support (nothing is launched then).
+ */
+#ifndef EGOREAR_HIP_H
+#define EGOREAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EGR_EINVAL (-1)   /* unsupported shape / alignment */
+#define EGR_ENULL (-2)    /* required pointer is NULL */
+#define EGR_EWORKSPACE (-3) /* workspace too small */
+
+enum { EGR_ACT_NONE = 0, EGR_ACT_RELU = 1, EGR_ACT_GELU = 2 };           /* GELU = exact erf form */
+enum { EGR_RES_NONE = 0, EGR_RES_BEFORE_ACT = 1, EGR_RES_AFTER_ACT = 2 };
+
+/* image-index -> offset mapping (floats) */
+typedef struct {
+    int32_t n_inner;
+    int64_t stride_inner;
+    int64_t stride_outer;
+} egr_nmap;
+
+/*
+ * Convolution / linear layer as one implicit GEMM on fp32 MFMA.
+ *   y[n,ho,wo,co] = act( acc * scale[co] + shift[co] * (rowscale ? rowscale[m] : 1) (+ res) )
+ *   acc = sum_{kh,kw,ci} x[n, ho*stride-pad+kh, wo*stride-pad+kw, ci] * w[co, (kh,kw,ci)]
+ * with m = (n*ho_total + ho)*wo_total + wo.  A Linear layer is the case h=w=kh=kw=1, n=rows.
+ * Replaces nn.Conv2d(+BatchNorm2d eval)(+ReLU)(+residual) of models/backbones/resnet.py:43-137
+ * and of the conv stacks in models/estimator/egoposeformer_heatmap_mvf_ex.py:101-126,522-584 /
+ * egoposeformer_mvf_ex.py:144,229-239, and nn.Linear(+ReLU/GELU) of models/utils/transformer.py:8-93,
+ * deform_attn.py:60-63, egoposeformer_mvf_ex.py:156-162,241-262.
+ */
+typedef struct {
+    int32_t n, h, w, cin;        /* input: n images of h x w pixels, cin channels (cin % 32 == 0) */
+    int32_t cout;                /* true output channels; w holds round_up(cout,32) rows, zero padded */
+    int32_t kh, kw, stride, pad;
+    int32_t ho, wo;
+    int32_t ldx, ldy, ldr;       /* pixel strides (floats) of x, y, res */
+    egr_nmap xmap, ymap, rmap;   /* per-image placement of x, y, res */
+    int32_t act;                 /* EGR_ACT_* */
+    int32_t res_mode;            /* EGR_RES_* */
+    int32_t out_nchw;            /* 1: y is written channel-major: ymap(n) + co*ho*wo + pix */
+    int32_t split_k;             /* >1: partial sums go through `workspace` (split_k * M * round_up(cout,32) floats) */
+} egr_conv_desc;
+
+int egr_conv2d_nhwc_f32(const egr_conv_desc* d, const float* x, const float* w,
+                        const float* scale /* per co, NULL = 1 */, const float* shift /* per co, NULL = 0 */,
+                        const float* res /* NULL unless res_mode */, const float* rowscale /* per m, NULL = 1 */,
+                        const uint8_t* rowmask /* per m, NULL = keep; 0 -> row written as 0 */,
+                        float* y, float* workspace, size_t workspace_floats, void* stream);
+
+/* ResNet stem: conv 7x7 stride 2 pad 3 (3 -> 64) + BatchNorm(eval) + ReLU, NCHW fp32 input
+ * (h, w multiples of 64) -> NHWC output (n, h/2, w/2, 64).  w: [64][148] rows = (ci,kh,kw), last col 0.
+ * Replaces layer_s2 of models/backbones/resnet.py:16,49. */
+int egr_stem_conv7x7_f32(const float* x, egr_nmap xmap, int32_t n, int32_t h, int32_t w,
+                         const float* wpack, const float* scale, const float* shift, float* y, void* stream);
+
+/* MaxPool2d(k, stride, pad) on NHWC (resnet.py:17 maxpool 3/2/1; egoposeformer_mvf_ex.py:234 MaxPool2d(2)). c % 4 == 0. */
+int egr_maxpool_nhwc_f32(const float* x, float* y, int32_t n, int32_t h, int32_t w, int32_t c,
+                         int32_t k, int32_t stride, int32_t pad, void* stream);
+
+/* nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True) on NHWC; c % 4 == 0. */
+int egr_upsample2x_nhwc_f32(const float* x, int32_t ldx, float* y, int32_t ldy,
+                            int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
+
+/* Global average pool over hw pixels of NHWC (F.adaptive_avg_pool2d(.,(1,1)), heatmap_mvf_ex.py:659). */
+int egr_avgpool_nhwc_f32(const float* x, float* y, int32_t n, int32_t hw, int32_t c, void* stream);
+
+/* utils/loss.py:122-142 get_max_preds(normalize=True): per row of `hw` = hgt*wid values: first-index argmax,
+ * anchors (x/wid, y/hgt), maxvals, valid = max >= thr, raw flat index. */
+int egr_argmax_rows_f32(const float* hm, int32_t rows, int32_t hgt, int32_t wid, float thr,
+                        float* anchors /* rows x 2 */, float* maxvals, uint8_t* valid, int32_t* index, void* stream);
+
+/* y = LayerNorm(x (+ res)) * gamma + beta over the last dim c (c <= 1024, c % 64 == 0), eps 1e-5. */
+int egr_layernorm_f32(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                      int32_t rows, int32_t c, float eps, void* stream);
+
+/* Joint-to-joint attention core of SpatialMHA / EgoformerSpatialMHA (heatmap_mvf_ex.py:799-817,
+ * egoposeformer_mvf_ex.py:481-498): qkv (b, j, 3*c) -> out (b, j, c); softmax(q k^T * scale) v per head; j <= 16. */
+int egr_joint_mha_f32(const float* qkv, float* out, int32_t b, int32_t j, int32_t heads, int32_t d, float scale, void* stream);
+
+/*
+ * Deformable-attention sampling in sample-then-project form (replaces the mmcv CUDA op
+ * MultiScaleDeformableAttnFunction, models/utils/deform_attn.py:155-162, together with the
+ * softmax / location arithmetic of :122-137).  For every (b, joint, view, head):
+ *   loc_p   = anchor[b,view,joint] + offs[b,joint,head,p] / (wid, hgt)
+ *   a_p     = softmax_p(logits[b,joint,head,:])
+ *   S_p(.)  = mmcv bilinear sample at pixel = loc*size - 0.5, zero padding
+ *   g       = sum_p a_p S_p(feat[view,b])       (cf channels, all channels: the value projection is applied later)
+ *   e       = sum_p a_p S_p(pos[view][:, head*dh:(head+1)*dh])   (optional, pos may be NULL)
+ *   sigma   = sum_p a_p * (in-bounds bilinear weight mass)
+ * Rows are ordered (b, joint, view) so that the projected result is already the concatenation
+ * over views the fuse layer consumes.  rowmask[(b,joint,view)] = valid[b,view,joint].
+ * offs_logits: (b*joint, heads*P*2 + heads*P) — offsets then attention logits (P = 16 points).
+ */
+int egr_msda_gather_f32(const float* feat /* (views, b, hgt*wid, cf) */, int32_t cf,
+                        const float* pos /* (views, hgt*wid, heads*dh) or NULL */, int32_t dh,
+                        const float* offs_logits, const float* anchors /* (b, views, joints, 2) */,
+                        const uint8_t* valid /* (b, views, joints) */,
+                        int32_t b, int32_t views, int32_t joints, int32_t heads, int32_t hgt, int32_t wid,
+                        float* g /* (rows, heads, cf) */, float* e /* (rows, heads*dh) or NULL */,
+                        float* sigma /* (heads, rows) */, uint8_t* rowmask /* (rows) */, void* stream);
+
+/* utils/camera_models.py:53-104 + egoposeformer_mvf_ex.py:340-348,400-406: project the (b, joints, 3) proposals
+ * into the four fisheye cameras.  cams: 4 records [npoly, cx, cy, W, H, poly[12]] (fp32).  syn mode
+ * (ctm == NULL) reproduces the reference's in-place offset chain: `pts` is updated in place to the
+ * mutated anchors.  rw mode applies ctm (b, 4, 4, 4) to pts*0.01 and scales by 100, pts untouched.
+ * Also emits the decoder query input q4 = [ (joint+1)/joints, mutated pts ] (b, joints, 4). */
+int egr_fisheye_project_f32(float* pts, const float* ctm, const float* cams, int32_t b, int32_t joints,
+                            float* anchors /* (b, 4, joints, 2) */, uint8_t* valid /* (b, 4, joints) */,
+                            float* q4, void* stream);
+
+/* Small dense layer for K not a multiple of 32 (query_gen_mlp.0: K=4; head 1x1 conv: K=15):
+ * y[m, n] = act(sum_k x[m*sxm + k*sxk] * w[n*K + k] + bias[n]). */
+int egr_linear_smallk_f32(const float* x, int64_t sxm, int64_t sxk, const float* w, const float* bias, float* y,
+                          int32_t m, int32_t n, int32_t k, int32_t act, void* stream);
+
+/* JQA query pre-activation (heatmap_mvf_ex.py:664-665): y[b,j,:] = hm_embed[b,j,:] + embed[j,:] + bfb[b,:]. */
+int egr_jqa_sum_f32(const float* hm_embed, const float* embed, const float* bfb, float* y,
+                    int32_t b, int32_t j, int32_t c, void* stream);
+
+/* (b, j, s*s) token matrix -> NHWC (b, s, s, j) image with joints as channels (heatmap_mvf_ex.py:707-711). */
+int egr_tokens_to_nhwc_f32(const float* x, float* y, int32_t b, int32_t j, int32_t hw, void* stream);
+
+/* Library / device identification. */
+const char* egr_version(void);
+int egr_device_arch(char* buf, int32_t buflen); /* gcnArchName of the current device */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EGOREAR_HIP_H */

@@ -1,0 +1,40 @@
+"""The C-ABI library loads on a GPU-less host and exports every symbol include/egorear_hip.h declares
+(no compute calls here)."""
+import ctypes
+import os
+import re
+
+from conftest import REPO
+
+
+def _declared():
+    text = open(os.path.join(REPO, "include", "egorear_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(egr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported():
+    from egorear_amd import hip
+    names = _declared()
+    assert len(names) >= 15
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(hip.EXPORTS) == names
+
+
+def test_struct_layout_matches_header():
+    from egorear_amd import hip
+    assert ctypes.sizeof(hip.NMap) == 24
+    # 14 leading int32 + 3 nmaps (8-byte aligned) + 4 int32
+    assert ctypes.sizeof(hip.ConvDesc) == 56 + 3 * 24 + 16
+    assert hip.version().startswith("egorear_hip")
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "egorear_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, os.path.join(root, f)

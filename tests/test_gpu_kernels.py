@@ -1,0 +1,303 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point against a plain PyTorch
+(CPU, fp64 where it matters) statement of the same op, including the analytic known-answer
+cases of SURVEY.md §8c (argmax ties, MSDA at pixel centres / outside, F7 chain)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from egorear_amd import hip as h
+    assert torch.cuda.is_available()
+    assert "gfx950" in h.device_arch()
+    return h
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def pack_w(w):  # OIHW -> [cout_pad][(kh,kw,ci)]
+    co = w.shape[0]
+    w2 = w.permute(0, 2, 3, 1).reshape(co, -1)
+    npad = (co + 31) // 32 * 32
+    out = torch.zeros(npad, w2.shape[1])
+    out[:co] = w2
+    return out
+
+
+def close(got, ref, rel=2e-5):
+    ref = ref.double()
+    tol = rel * max(float(ref.abs().max()), 1e-6)
+    err = float((got.double().cpu() - ref).abs().max())
+    assert err <= tol, f"max err {err:.3e} > tol {tol:.3e}"
+
+
+CONV_CASES = [
+    # n, h, w, cin, cout, k, stride, act, res_mode, bn
+    (2, 16, 16, 64, 64, 3, 1, 1, 1, True),      # BasicBlock conv2 + identity + relu
+    (2, 16, 16, 64, 128, 3, 2, 1, 0, True),     # strided 3x3
+    (2, 16, 16, 64, 128, 1, 2, 0, 0, True),     # downsample 1x1 s2
+    (3, 8, 8, 512, 128, 1, 1, 1, 0, False),     # lateral 1x1
+    (1, 64, 64, 128, 256, 3, 2, 1, 0, False),   # big tile path (M = 1024 <= 4096 -> 64x64)
+    (5, 64, 64, 32, 128, 3, 1, 1, 2, False),    # M = 20480 -> 128x128 tiles, res after act
+    (5, 64, 64, 64, 64, 3, 1, 1, 0, True),      # M = 20480, N = 64 -> 256x64 tiles
+    (5, 64, 64, 128, 192, 1, 1, 0, 0, False),   # N = 192 (three 64-wide tiles)
+    (2, 32, 32, 128, 15, 1, 1, 0, 0, False),    # 15 output channels (padded to 32)
+    (37, 1, 1, 256, 48, 1, 1, 2, 0, False),     # linear + GELU, ragged rows
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_matches_torch(hip, case):
+    n, h, w, cin, cout, k, stride, act, res_mode, bn = case
+    pad = k // 2
+    x = rnd(n, h, w, cin, seed=1)
+    wt = rnd(cout, cin, k, k, seed=2, scale=1.0 / math.sqrt(cin * k * k))
+    scale = (rnd(cout, seed=3) * 0.4 + 1.0) if bn else None
+    shift = rnd(cout, seed=4)
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    res = rnd(n, ho, wo, cout, seed=5) if res_mode else None
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), wt.double(), None, stride, pad)
+    if scale is not None:
+        ref = ref * scale.double().view(1, -1, 1, 1)
+    ref = ref + shift.double().view(1, -1, 1, 1)
+    if res_mode == 1:
+        ref = ref + res.permute(0, 3, 1, 2).double()
+    if act == 1:
+        ref = F.relu(ref)
+    elif act == 2:
+        ref = F.gelu(ref)
+    if res_mode == 2:
+        ref = ref + res.permute(0, 3, 1, 2).double()
+    out = hip.conv2d(hip.Img(x.to(DEV)), pack_w(wt).to(DEV), cout, k, k, stride, pad,
+                     scale=scale.to(DEV) if scale is not None else None, shift=shift.to(DEV), act=act,
+                     res=hip.Img(res.to(DEV)) if res is not None else None, res_mode=res_mode)
+    close(out.t.permute(0, 3, 1, 2), ref)
+
+
+def test_conv_channel_slices_and_nchw_output(hip):
+    n, h, w, cin, cout = 4, 16, 16, 64, 32
+    wide = rnd(n, h, w, 2 * cin, seed=7).to(DEV)
+    wt = rnd(cout, cin, 1, 1, seed=8, scale=0.1)
+    ref = F.conv2d(wide[..., cin:].permute(0, 3, 1, 2).cpu().double(), wt.double())
+    cat = torch.zeros(n, h, w, 3 * cout, device=DEV)
+    hip.conv2d(hip.Img(wide[..., cin:]), pack_w(wt).to(DEV), cout, 1, 1, 1, 0, out=hip.Img(cat[..., cout:2 * cout]))
+    close(cat[..., cout:2 * cout].permute(0, 3, 1, 2), ref)
+    assert float(cat[..., :cout].abs().max()) == 0 and float(cat[..., 2 * cout:].abs().max()) == 0
+    # channel-major output with a (v,b) -> (b,v) image map: n = v*B + b, B = 2, V = 2
+    out = torch.zeros(2, 2, cout, h, w, device=DEV)
+    plane = cout * h * w
+    hip.conv2d(hip.Img(wide[..., cin:]), pack_w(wt).to(DEV), cout, 1, 1, 1, 0, out_nchw=out, ymap=hip.NMap(2, 2 * plane, plane))
+    got = out.permute(1, 0, 2, 3, 4).reshape(n, cout, h, w)
+    close(got, ref)
+
+
+def test_conv_split_k_linear_rowscale_rowmask(hip):
+    m, k, n_out = 6, 4096, 96
+    x = rnd(m, k, seed=11)
+    wt = rnd(n_out, k, seed=12, scale=1 / 64)
+    b = rnd(n_out, seed=13)
+    rs = rnd(m, seed=14)
+    mask = torch.tensor([1, 0, 1, 1, 0, 1], dtype=torch.uint8)
+    ref = x.double() @ wt.double().t() + b.double()[None] * rs.double()[:, None]
+    ref = ref * mask.double()[:, None]
+    ws = torch.empty(1 << 22, device=DEV)
+    wp = torch.zeros(96, k)
+    wp[:n_out] = wt
+    for split in (1, 0, 7):
+        out = hip.conv2d(hip.Img(x.to(DEV).view(m, 1, 1, k)), wp.to(DEV), n_out, 1, 1, 1, 0, shift=b.to(DEV),
+                         rowscale=rs.to(DEV), rowmask=mask.to(DEV), workspace=ws, split_k=split)
+        close(out.t.view(m, n_out), ref)
+
+
+def test_conv_rejects_bad_arguments(hip):
+    x = torch.zeros(1, 4, 4, 30, device=DEV)
+    with pytest.raises(RuntimeError):
+        hip.conv2d(hip.Img(x), torch.zeros(32, 30, device=DEV), 32, 1, 1, 1, 0)  # cin % 32 != 0
+    with pytest.raises(RuntimeError):
+        hip.conv2d(hip.Img(torch.zeros(1, 4, 4, 32)), torch.zeros(32, 32), 32, 1, 1, 1, 0)  # CPU tensors
+
+
+def test_stem_matches_torch(hip):
+    B, V = 2, 4
+    img = rnd(B, V, 3, 64, 128, seed=21)
+    wt = rnd(64, 3, 7, 7, seed=22, scale=0.1)
+    scale, shift = rnd(64, seed=23) * 0.3 + 1.0, rnd(64, seed=24)
+    wp = torch.zeros(64, 148)
+    wp[:, :147] = wt.reshape(64, 147)
+    y = hip.stem(img.to(DEV), 2, 2, wp.to(DEV), scale.to(DEV), shift.to(DEV))  # views 2,3 -> n = v*B + b
+    ref = F.conv2d(img[:, 2:].permute(1, 0, 2, 3, 4).reshape(2 * B, 3, 64, 128).double(), wt.double(), None, 2, 3)
+    ref = F.relu(ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+    close(y.t.permute(0, 3, 1, 2), ref)
+
+
+def test_pool_and_upsample_match_torch(hip):
+    x = rnd(3, 16, 16, 64, seed=31)
+    xc = x.permute(0, 3, 1, 2)
+    y = hip.maxpool(hip.Img(x.to(DEV)), 3, 2, 1)
+    assert torch.equal(y.t.cpu().permute(0, 3, 1, 2), F.max_pool2d(xc, 3, 2, 1))
+    y = hip.maxpool(hip.Img(x.to(DEV)), 2, 2, 0)
+    assert torch.equal(y.t.cpu().permute(0, 3, 1, 2), F.max_pool2d(xc, 2))
+    up = hip.upsample2x(hip.Img(x.to(DEV)))
+    ref = F.interpolate(xc, scale_factor=2, mode="bilinear", align_corners=True)
+    close(up.t.permute(0, 3, 1, 2), ref, rel=2e-6)
+    # a ramp is reproduced exactly at the original grid points' images (align_corners=True)
+    ramp = torch.arange(8.0).view(1, 1, 8, 1).expand(1, 8, 8, 4).contiguous()
+    up = hip.upsample2x(hip.Img(ramp.to(DEV))).t.cpu()
+    assert float(up[0, 0, 0, 0]) == 0.0 and float(up[0, 0, 15, 0]) == 7.0
+    avg = hip.avgpool(hip.Img(x.to(DEV)))
+    close(avg, xc.double().mean(dim=(2, 3)), rel=2e-6)
+
+
+def test_argmax_known_answers(hip):
+    hm = rnd(2, 3, 64, 64, seed=41) * 0.4
+    hm[0, 0, 10, 20] = 2.0
+    hm[0, 1, 5, 7] = 3.0
+    hm[0, 1, 40, 1] = 3.0          # tie: first (smaller flat index) wins
+    hm[0, 2] = 0.25                 # flat map: index 0, below threshold
+    hm[1, 0, 63, 63] = 0.5          # exactly at threshold -> valid
+    anchors, maxvals, valid, idx = hip.argmax_rows(hm.to(DEV), 0.5)
+    ref_max, ref_idx = torch.max(hm.view(6, -1), dim=1)
+    assert torch.equal(idx.cpu().long(), ref_idx)
+    assert torch.equal(maxvals.cpu(), ref_max)
+    assert idx.cpu().tolist()[:3] == [10 * 64 + 20, 5 * 64 + 7, 0]
+    assert valid.cpu().tolist()[:4] == [1, 1, 0, 1]
+    a = anchors.cpu()
+    assert a[0].tolist() == [20 / 64, 10 / 64] and a[3].tolist() == [63 / 64, 63 / 64]
+
+
+def test_layernorm_and_mha_match_torch(hip):
+    for c in (128, 256):
+        x, r = rnd(45, c, seed=51), rnd(45, c, seed=52)
+        g, b = rnd(c, seed=53) + 1.5, rnd(c, seed=54)
+        y = hip.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), res=r.to(DEV))
+        close(y, F.layer_norm((x + r).double(), (c,), g.double(), b.double(), 1e-5), rel=5e-6)
+    for (B, J, heads, d) in ((3, 15, 4, 64), (2, 16, 4, 32)):
+        C = heads * d
+        qkv = rnd(B, J, 3 * C, seed=55)
+        out = hip.joint_mha(qkv.to(DEV), B, J, heads, d, d ** -0.5)
+        q, k, v = [t.reshape(B, J, heads, d).permute(0, 2, 1, 3).double() for t in qkv.split(C, dim=-1)]
+        ref = ((q @ k.transpose(-1, -2)) * d ** -0.5).softmax(-1) @ v
+        close(out.view(B, J, C), ref.permute(0, 2, 1, 3).reshape(B, J, C), rel=5e-6)
+
+
+def test_smallk_jqa_tokens(hip):
+    x, w, b = rnd(33, 4, seed=61), rnd(128, 4, seed=62), rnd(128, seed=63)
+    y = hip.linear_smallk(x.to(DEV), 4, 1, w.to(DEV), b.to(DEV), 33, 128, 4, 1)
+    close(y, F.relu(x.double() @ w.double().t() + b.double()), rel=2e-6)
+    hm_e, emb, bfb = rnd(2 * 15, 256, seed=64), rnd(15, 256, seed=65), rnd(2, 256, seed=66)
+    y = hip.jqa_sum(hm_e.to(DEV), emb.to(DEV), bfb.to(DEV), 2, 15, 256)
+    assert torch.equal(y.cpu().view(2, 15, 256), (emb[None] + bfb[:, None]) + hm_e.view(2, 15, 256))
+    t = rnd(2, 15, 256, seed=67)
+    assert torch.equal(hip.tokens_to_nhwc(t.to(DEV), 2, 15, 256).cpu(), t.permute(0, 2, 1).contiguous())
+
+
+def _msda_dense(feat, pos, Wv, bv, offs, logits, anchors, valid, heads, hgt, wid):
+    """Dense statement: project all tokens, then mmcv-sample (oracle.msda_core), per view."""
+    from oracle import egorear_oracle as O
+    V, B, HW, cf = feat.shape
+    J = anchors.shape[2]
+    outs = []
+    for v in range(V):
+        mem = feat[v].double()
+        if pos is not None:
+            mem = mem + pos[v].double()[None]
+        value = (mem @ Wv.double().t() + bv.double()).view(B, HW, heads, -1)
+        aw = logits.double().view(B, J, heads, 16).softmax(-1)
+        loc = anchors[:, v].double()[:, :, None, None, :] + offs.double().view(B, J, heads, 16, 2) / torch.tensor([wid, hgt]).double()
+        outs.append(O.msda_core(value, hgt, wid, loc, aw))
+    return torch.stack(outs, dim=2)  # (B, J, V, C)
+
+
+@pytest.mark.parametrize("with_pos", [True, False])
+def test_msda_sample_then_project_equals_dense(hip, with_pos):
+    B, V, J, heads, hgt, wid, cf = 2, 4, 15, 4, 64, 64, 128
+    C = 256 if with_pos else 128
+    dh = C // heads
+    feat = rnd(V, B, hgt * wid, cf, seed=71)
+    # pre-projection f -> W_pre f + b_pre, positional table added after it, then W_v (see engine.pack_layer)
+    Wpre, bpre = rnd(C, cf, seed=72, scale=0.1), rnd(C, seed=73, scale=0.1)
+    pos = rnd(V, hgt * wid, C, seed=74, scale=0.5) if with_pos else None
+    Wv, bv = rnd(C, C, seed=75, scale=0.08), rnd(C, seed=76, scale=0.1)
+    offs = rnd(B * J, heads * 32, seed=77, scale=12.0)       # pixels; some samples leave the map
+    logits = rnd(B * J, heads * 16, seed=78, scale=2.0)
+    anchors = (rnd(B, V, J, 2, seed=79) + 1) / 2
+    anchors[0, 0, 0] = torch.tensor([0.0, 0.0])               # corner anchor: many zero-padded corners
+    anchors[0, 1, 1] = torch.tensor([63 / 64, 63 / 64])
+    valid = (rnd(B, V, J, seed=80) > -0.6).to(torch.uint8)
+    # dense reference: value = W_v (W_pre f + b_pre + pos) + b_v
+    mem_feat = feat.double() @ Wpre.double().t() + bpre.double()
+    ref = _msda_dense(mem_feat.float(), pos, Wv, bv, offs, logits, anchors, valid, heads, hgt, wid)
+    # sample-then-project on the device
+    ol = torch.cat([offs, logits], dim=1).contiguous()
+    Wfold = (Wv.double() @ Wpre.double()).float()
+    cfold = (Wv.double() @ bpre.double() + bv.double()).float()
+    pos_proj = (pos.double() @ Wv.double().t()).float().contiguous() if with_pos else None
+    g, e, sigma, rowmask = hip.msda_gather(feat.to(DEV), pos_proj.to(DEV) if with_pos else None, ol.to(DEV), anchors.to(DEV),
+                                           valid.to(DEV), B, V, J, heads, dh, hgt, wid)
+    rows = B * J * V
+    assert torch.equal(rowmask.cpu().view(B, J, V), valid.permute(0, 2, 1))
+    a = torch.empty(rows, C, device=DEV)
+    g2 = g.view(rows, heads * cf)
+    for h in range(heads):
+        hip.conv2d(hip.Img(g2[:, h * cf:(h + 1) * cf].view(rows, 1, 1, cf)), Wfold[h * dh:(h + 1) * dh].contiguous().to(DEV), dh,
+                   1, 1, 1, 0, shift=cfold[h * dh:(h + 1) * dh].contiguous().to(DEV), rowscale=sigma[h],
+                   res=hip.Img(e[:, h * dh:(h + 1) * dh].view(rows, 1, 1, dh)) if with_pos else None,
+                   res_mode=2 if with_pos else 0, out=hip.Img(a[:, h * dh:(h + 1) * dh].view(rows, 1, 1, dh)))
+    got = a.cpu().view(B, J, V, C)
+    m = valid.permute(0, 2, 1).bool()[..., None]
+    close(got * m, ref * m, rel=3e-5)
+
+
+def test_msda_known_answers(hip):
+    """Sampling exactly at a pixel centre returns that feature row; fully outside returns 0; sigma is the in-bounds mass."""
+    B, V, J, heads, hgt, wid, cf = 1, 1, 2, 4, 8, 8, 128
+    feat = rnd(V, B, hgt * wid, cf, seed=91)
+    ol = torch.zeros(B * J, heads * 48)
+    anchors = torch.zeros(B, V, J, 2)
+    anchors[0, 0, 0] = torch.tensor([(3 + 0.5) / wid, (5 + 0.5) / hgt])   # centre of pixel (y=5, x=3)
+    anchors[0, 0, 1] = torch.tensor([5.0, 5.0])                             # far outside
+    valid = torch.ones(B, V, J, dtype=torch.uint8)
+    g, e, sigma, rowmask = hip.msda_gather(feat.to(DEV), None, ol.to(DEV), anchors.to(DEV), valid.to(DEV), B, V, J, heads, 32,
+                                           hgt, wid)
+    g = g.cpu()
+    for h in range(heads):
+        close(g[0, h], feat[0, 0, 5 * wid + 3], rel=2e-6)
+        assert float(g[1, h].abs().max()) == 0.0
+    assert torch.allclose(sigma.cpu()[:, 0], torch.ones(heads), atol=1e-6) and float(sigma.cpu()[:, 1].abs().max()) == 0.0
+
+
+def test_fisheye_matches_oracle_and_f7_chain(hip, calib_dir):
+    from egorear_amd.camera import FishEyeCameraCalibratedModel as Cam
+    from oracle import egorear_oracle as O
+    names = O.CAMERAS
+    B, J = 3, 16
+    pts = rnd(B, J, 3, seed=101) * torch.tensor([40.0, 40.0, 50.0]) + torch.tensor([0.0, 10.0, -30.0])
+    for mode in ("ego4view_syn", "ego4view_rw"):
+        cams = torch.from_numpy(np.stack([Cam(mode, calib_dir, n).packed() for n in names])).to(DEV)
+        from egorear_amd import synth
+        ctm = synth.synth_coord_trans_mat(B) if mode == "ego4view_rw" else None
+        dpts = pts.clone().to(DEV)
+        a2, valid, q4 = hip.fisheye_project(dpts, ctm.to(DEV) if ctm is not None else None, cams)
+        opts = pts.clone()
+        ra, rv = O.reproject_3d_to_2d(O.make_cameras(mode, calib_dir), opts, ctm)
+        assert torch.equal(valid.cpu().bool(), rv)
+        assert float((a2.cpu() - ra).abs().max()) < 2e-6
+        assert torch.allclose(dpts.cpu(), opts, atol=1e-5)      # syn: (+12, 0, 0) chain; rw: untouched
+        if mode == "ego4view_syn":
+            assert torch.allclose(dpts.cpu() - pts, torch.tensor([12.0, 0.0, 0.0]).expand_as(pts), atol=1e-4)
+        else:
+            assert torch.equal(dpts.cpu(), pts)
+        q = q4.cpu().view(B, J, 4)
+        assert torch.allclose(q[..., 0], (torch.arange(1, J + 1) / J).expand(B, J))
+        assert torch.equal(q[..., 1:], dpts.cpu())

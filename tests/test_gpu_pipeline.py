@@ -1,0 +1,173 @@
+"""End-to-end parity of the HIP path (through the drop-in estimator classes and the C ABI)
+on a real MI355X: against the committed golden vectors of the REAL reference and against the
+CPU oracle on the same seeded inputs.  Bar (BASELINE.json north_star): bit-exact 2-D argmax joint
+indices, 3-D joint coordinates within 1e-3 cm."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+TOL_POSE_CM = 1e-3
+TOL_HM = 1e-4  # heatmap values are O(1); fp32 conv stacks in a different summation order
+
+
+def _golden_check(g, name, t, step_hw=8, step_c=1, tol=TOL_HM):
+    t = t.float().cpu()
+    np.testing.assert_allclose(t[:, :, ::step_c, ::step_hw, ::step_hw].numpy(), g[name + "_sl"], rtol=0, atol=tol)
+    assert abs(t.double().sum().item() - float(g[name + "_sum"])) <= tol * t.numel()
+
+
+def _build(cls, cfg):
+    from egorear_amd import synth
+    net = cls(**copy.deepcopy(cfg)).eval()
+    synth.load_synth(net, 42)
+    return net.to(DEV)
+
+
+@pytest.fixture(scope="module")
+def nets():
+    from egorear_amd import configs
+    from egorear_amd.estimator import EgoPoseFormerHeatmap, EgoPoseFormerHeatmapMVFEX, EgoPoseFormerMVFEX
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            if name == "heatmap":
+                cache[name] = _build(EgoPoseFormerHeatmap, configs.heatmap_cfg())
+            elif name == "mvfex":
+                cache[name] = _build(EgoPoseFormerHeatmapMVFEX, configs.heatmap_mvfex_cfg())
+            else:
+                cache[name] = _build(EgoPoseFormerMVFEX, configs.pose3d_cfg("ego4view_" + name))
+        return cache[name]
+    return get
+
+
+def test_library_is_the_native_one():
+    from egorear_amd import hip
+    assert os.path.basename(hip.LIB_PATH) == "libegorear_hip.so" and os.path.exists(hip.LIB_PATH)
+    assert "gfx950" in hip.device_arch()
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_heatmap_vs_reference_golden(seed, nets, golden_dir):
+    from egorear_amd import synth
+    g = np.load(os.path.join(golden_dir, f"heatmap_s{seed}.npz"))
+    net = nets("heatmap")
+    with torch.no_grad():
+        hm, feats, pyr = net(synth.synth_images(2, 2, seed=seed).to(DEV), return_feat=True)
+    assert hm.shape == (2, 2, 15, 64, 64) and feats.shape == (2, 2, 128, 64, 64) and pyr[-1].shape == (2, 2, 512, 8, 8)
+    _golden_check(g, "hm", hm)
+    _golden_check(g, "feat", feats, 16, 16, tol=5e-4)
+    _golden_check(g, "s32", pyr[-1], 4, 64, tol=5e-4)
+
+
+@pytest.mark.parametrize("seed,scale", [(0, 1.0), (1, 1.0), (2, 0.35)])
+def test_mvfex_vs_reference_golden(seed, scale, nets, golden_dir):
+    from egorear_amd import synth
+    g = np.load(os.path.join(golden_dir, f"mvfex_s{seed}.npz"))
+    net = nets("mvfex")
+    with torch.no_grad():
+        hms, fts = net(synth.synth_images(2, 4, seed=seed, scale=scale).to(DEV))
+    aux = net.__dict__["_egr_last_aux"]
+    np.testing.assert_array_equal(aux["argmax_idx"].cpu().numpy(), g["argmax_idx"])           # bit-exact
+    np.testing.assert_array_equal(aux["anchors_valid"].cpu().numpy().astype(bool), g["anchors_valid"])
+    np.testing.assert_array_equal(aux["anchors_2d"].cpu().numpy(), g["anchors_2d"])
+    np.testing.assert_allclose(aux["maxvals"].cpu().numpy(), g["maxvals"], rtol=0, atol=TOL_HM)
+    _golden_check(g, "hm_init", hms[0])
+    _golden_check(g, "hm_refined", hms[1])
+    _golden_check(g, "feat_init", fts[0], 16, 16, tol=5e-4)
+    _golden_check(g, "feat_refined", fts[1], 16, 16, tol=5e-4)
+    # get_anchors_2d_from_hm keeps the reference's return contract
+    pts, maxvals, mask = net.get_anchors_2d_from_hm(hms[0])
+    assert pts.shape == (2, 4, 15, 2) and mask.dtype == torch.bool
+
+
+@pytest.mark.parametrize("cam,seed", [("syn", 0), ("syn", 1), ("rw", 0)])
+def test_pose3d_vs_reference_golden(cam, seed, nets, golden_dir):
+    from egorear_amd import synth
+    from oracle import egorear_oracle as O
+    g = np.load(os.path.join(golden_dir, f"pose3d_{cam}_s{seed}.npz"))
+    net = nets(cam)
+    ctm = synth.synth_coord_trans_mat(2).to(DEV) if cam == "rw" else None
+    with torch.no_grad():
+        preds, hms = net(synth.synth_images(2, 4, seed=seed).to(DEV), ctm)
+    assert len(preds) == 4 and len(hms) == 2 and preds[0].shape == (2, 16, 3)
+    pred = torch.stack(preds).cpu().numpy()
+    np.testing.assert_allclose(pred, g["pred_pose"], rtol=0, atol=TOL_POSE_CM)
+    aux = net.__dict__["_egr_last_aux"]["pose3d"]
+    np.testing.assert_array_equal(aux["anchors_valid"].cpu().numpy().astype(bool), g["anchors_valid"])
+    np.testing.assert_allclose(aux["anchors_2d"].cpu().numpy(), g["anchors_2d"], rtol=0, atol=2e-5)
+    _golden_check(g, "hm_init", hms[0])
+    _golden_check(g, "hm_refined", hms[1])
+    mp = (O.compute_mpjpe_batch(preds[-1].cpu(), synth.synth_gt_pose(2)) * 10.0).numpy()
+    np.testing.assert_allclose(mp, g["mpjpe_mm"], rtol=0, atol=1e-2)   # MPJPE identical within 1e-3 cm = 1e-2 mm
+
+
+def test_rw_accepts_float64_coord_trans_mat(nets):
+    """The reference dataset yields float64 matrices and the reference then raises; the boundary casts."""
+    from egorear_amd import synth
+    net = nets("rw")
+    img = synth.synth_images(1, 4, seed=3).to(DEV)
+    ctm = synth.synth_coord_trans_mat(1)
+    with torch.no_grad():
+        a, _ = net(img, ctm.to(DEV))
+        b, _ = net(img, ctm.double().to(DEV))
+    assert torch.equal(a[-1], b[-1])
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            net(img, None)
+
+
+def test_pipeline_vs_oracle_other_batch_and_determinism(nets, calib_dir):
+    """Batch 3 (not a multiple of anything), fresh seed: HIP vs CPU oracle; and run-to-run bitwise determinism."""
+    from egorear_amd import synth
+    from oracle import egorear_oracle as O
+    net = nets("syn")
+    img = synth.synth_images(3, 4, seed=11)
+    with torch.no_grad():
+        preds, hms = net(img.to(DEV))
+        aux = net.__dict__["_egr_last_aux"]
+        idx = aux["heatmap"]["argmax_idx"].cpu()
+        preds2, hms2 = net(img.to(DEV))
+        sd = {k: v.cpu() for k, v in net.state_dict().items()}
+        o_preds, o_hms, o_aux = O.mvfex_forward(sd, O.make_cameras("ego4view_syn", calib_dir), img)
+    assert all(torch.equal(a, b) for a, b in zip(preds, preds2)) and all(torch.equal(a, b) for a, b in zip(hms, hms2))
+    assert torch.equal(idx.long(), o_aux["heatmap"]["argmax_idx"])
+    for p, q in zip(preds, o_preds):
+        assert float((p.cpu() - q).abs().max()) < TOL_POSE_CM
+    for p, q in zip(hms, o_hms):
+        assert float((p.cpu() - q).abs().max()) < TOL_HM
+
+
+def test_no_cpu_fallback_and_training_is_refused(nets):
+    from egorear_amd import configs, synth
+    from egorear_amd.estimator import EgoPoseFormerHeatmap
+    net = nets("heatmap")
+    with torch.no_grad(), pytest.raises(RuntimeError):
+        net(synth.synth_images(1, 2, seed=0))              # CPU tensor: refused, never computed on the host
+    cpu_net = EgoPoseFormerHeatmap(**configs.heatmap_cfg()).eval()
+    with torch.no_grad(), pytest.raises(RuntimeError):
+        cpu_net(synth.synth_images(1, 2, seed=0))
+    with pytest.raises(NotImplementedError):
+        net(synth.synth_images(1, 2, seed=0).to(DEV))      # grad enabled -> training path, a "next" row
+
+
+def test_state_dict_reload_invalidates_packed_weights(nets):
+    from egorear_amd import synth
+    net = nets("heatmap")
+    img = synth.synth_images(1, 2, seed=5).to(DEV)
+    with torch.no_grad():
+        a = net(img)
+        sd = {k: v.clone() for k, v in net.state_dict().items()}
+        sd2 = dict(sd)
+        sd2["conv_heatmap.bias"] = sd["conv_heatmap.bias"] + 1.0
+        net.load_state_dict(sd2, strict=True)
+        b = net(img)
+        net.load_state_dict(sd, strict=True)
+        c = net(img)
+    assert torch.allclose(b, a + 1.0, atol=1e-6) and torch.equal(a, c)
