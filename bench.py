@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on MI355X: 4-view frames/sec of the full inference hot path
+(heatmap encoders -> MVFEx/JQA refiners -> 2D-to-3D lifting), config `ego4view_syn_pose3d`,
+batch 64 per GPU, synthetic 256x256x4-view input resident in HBM, random-init weights (seeded).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-graph] [--no-cpu-baseline]
+
+N > 1 is launched by the driver with torch.distributed.run (one rank per GPU); inference shards the
+batch-of-frames axis with no data-path collective ("weak" scaling: B frames per GPU).  One JSON line
+is printed by rank 0.  A "step" is one forward of B frames.
+
+Extra objects on the line:
+  roofline     — dominant kernel (the fp32-MFMA implicit-GEMM conv/linear kernel): algorithmic FLOPs of
+                 its launches / their summed duration, measured with HIP events on the launch stream in an
+                 instrumented pass right after the timed region; peak = 157.3 TFLOP/s (fp32 MFMA, gfx950).
+  cpu_baseline — the CPU oracle (oracle/egorear_oracle.py, a PyTorch-CPU port of the reference path)
+                 timed on this box's host cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GFLOP_PER_FRAME = 64.36      # algorithmic conv+matmul FLOPs per 4-view frame
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    return ap.parse_args()
+
+
+def _host_cores() -> int:
+    """CPU share of this process (the GPU box exposes a slice of a large host: use the affinity mask, cap at 16)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("EGR_CPU_THREADS", "16"))))
+
+
+def _log(msg: str):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline(state_dict, batch: int, iters: int):
+    """Time the CPU oracle (kind 'port') on a bounded sample: `iters` forwards of `batch` frames."""
+    import torch
+    from egorear_amd import synth
+    from oracle import egorear_oracle as O
+    cores = _host_cores()
+    torch.set_num_threads(cores)
+    cams = O.make_cameras("ego4view_syn", os.path.join(REPO, "egorear_amd", "calib", "ego4view"))
+    img = synth.synth_images(batch, 4, seed=1234)
+    with torch.no_grad():
+        _log(f"cpu baseline: warm-up forward, batch {batch}, {cores} threads")
+        O.mvfex_forward(state_dict, cams, img)  # warm-up
+        _log("cpu baseline: timing")
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            O.mvfex_forward(state_dict, cams, img)
+        dt = time.perf_counter() - t0
+    return {"value": round(batch * iters / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{iters} forwards of batch {batch} (config ego4view_syn_pose3d, eval/no_grad, torch-CPU fp32, "
+                      f"{cores} threads), {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # RCCL; only used for the barrier and the max-over-ranks
+
+    from egorear_amd import configs, hip, synth
+    from egorear_amd.estimator import EgoPoseFormerMVFEX
+
+    B = args.batch
+    net = EgoPoseFormerMVFEX(**copy.deepcopy(configs.pose3d_cfg("ego4view_syn"))).eval()
+    synth.load_synth(net, 42)
+    cpu_sd = {k: v.clone() for k, v in net.state_dict().items()} if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    net = net.to(dev)
+    img = synth.synth_images(B, 4, seed=1234 + rank).to(dev)  # each rank: its own shard of frames, resident in HBM
+
+    def step():
+        return net(img)
+
+    use_graph = not args.no_graph
+    graph = None
+    with torch.no_grad():
+        _log("first step (packs weights)")
+        step()  # packs weights, warms the allocator
+        torch.cuda.synchronize()
+        _log("first step done")
+        if use_graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            _log("capturing hipGraph")
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outs = step()
+            _log("captured")
+            run = graph.replay
+        else:
+            run = step
+
+        for _ in range(args.warmup):
+            run()
+        torch.cuda.synchronize()
+        _log("warm-up done, timing")
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+        # ---- roofline leg: per-launch HIP-event timing of one instrumented (eager) step
+        roof = None
+        kernels = {}
+        _log(f"timed region done: {elapsed:.3f} s")
+        if rank == 0:
+            hip.PROFILE = []
+            step()
+            torch.cuda.synchronize()
+            prof, hip.PROFILE = hip.PROFILE, None
+            for name, s, e, flops, nbytes in prof:
+                k = kernels.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+                k["launches"] += 1
+                k["ms"] += s.elapsed_time(e)
+                k["flops"] += flops
+                k["bytes"] += nbytes
+            dom = max(kernels, key=lambda n: kernels[n]["ms"])
+            k = kernels[dom]
+            achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": k["launches"], "avg_launch_us": round(1e3 * k["ms"] / k["launches"], 2),
+                    "flops_per_launch": round(k["flops"] / k["launches"], 1),
+                    "kernel_ms_per_step": round(k["ms"], 3),
+                    "all_kernels_ms_per_step": round(sum(v["ms"] for v in kernels.values()), 3)}
+
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        fps = world * B * args.steps / elapsed
+        line = {
+            "metric": "4-view frames/sec (heatmap+MVFEx+3D lift)", "value": round(fps, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ego4view_syn_pose3d full pipeline (2x ResNet18+FPN encoders, 4 MVFEx/JQA refiners, "
+                                   "3D lifting head), 4 views x 256x256 fp32 per frame, eval/no_grad",
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"frames sharded over {world} GPU(s), no collective",
+                       "launch": "hipGraph replay" if use_graph else "eager"},
+            "path_tflops_per_gpu": round(fps / world * GFLOP_PER_FRAME / 1e3, 2),
+            "path_frac_of_f32_mfma_peak": round(fps / world * GFLOP_PER_FRAME / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+            "roofline": roof,
+        }
+        if kernels:
+            line["kernel_ms"] = {n: round(v["ms"], 3) for n, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])}
+        if cpu_sd is not None:
+            line["cpu_baseline"] = cpu_baseline(cpu_sd, args.cpu_batch, args.cpu_iters)
+        elif world == 1:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -80,6 +80,23 @@ def _check(rc: int, name: str):
         raise RuntimeError(f"{name} failed: {_ERR.get(rc, 'hipError_t %d' % rc)}")
 
 
+# When PROFILE is a list, every launch is bracketed by HIP events recorded on the launch stream (torch's current
+# stream) and (kernel name, start, end, algorithmic work) is appended; bench.py uses this for the roofline leg.
+PROFILE = None
+
+
+def _launch(name: str, cfunc, *args, flops: float = 0.0, nbytes: float = 0.0):
+    if PROFILE is None:
+        rc = cfunc(*args)
+    else:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = cfunc(*args)
+        e.record()
+        PROFILE.append((name, s, e, flops, nbytes))
+    _check(rc, name)
+
+
 def _p(t: Optional[torch.Tensor], dtype=torch.float32):
     if t is None:
         return None
@@ -185,9 +202,9 @@ def conv2d(x: Img, w: torch.Tensor, cout: int, kh: int, kw: int, stride: int, pa
     if rowscale is not None and rowscale.numel() < M or rowmask is not None and rowmask.numel() < M:
         raise RuntimeError("egorear_amd.conv2d: rowscale/rowmask shorter than M")
     ws_ptr, ws_n = (None, 0) if workspace is None else (_p(workspace), workspace.numel())
-    rc = lib.egr_conv2d_nhwc_f32(C.byref(d), _p(x.t), _p(w), _p(scale), _p(shift), _p(res.t) if res is not None else None,
-                                 _p(rowscale), _p(rowmask, torch.uint8), yptr, ws_ptr, ws_n, _stream())
-    _check(rc, "egr_conv2d_nhwc_f32")
+    _launch("egr_conv2d_nhwc_f32", lib.egr_conv2d_nhwc_f32, C.byref(d), _p(x.t), _p(w), _p(scale), _p(shift),
+            _p(res.t) if res is not None else None, _p(rowscale), _p(rowmask, torch.uint8), yptr, ws_ptr, ws_n, _stream(),
+            flops=2.0 * M * cout * K, nbytes=4.0 * (M * cout + x.n * x.h * x.w * x.c + cout * K))
     return ret
 
 
@@ -201,8 +218,8 @@ def stem(img: torch.Tensor, view0: int, nviews: int, wpack, scale, shift) -> Img
     y = torch.empty((n, H // 2, W // 2, 64), device=img.device, dtype=torch.float32)
     base = img.reshape(-1)[view0 * 3 * H * W:]
     xmap = NMap(B, V * 3 * H * W, 3 * H * W)  # n = v*B + b -> (b*V + v) image
-    _check(lib.egr_stem_conv7x7_f32(_p(base), xmap, n, H, W, _p(_cont(wpack, "stem weight")), _p(scale), _p(shift), _p(y),
-                                    _stream()), "egr_stem_conv7x7_f32")
+    _launch("egr_stem_conv7x7_f32", lib.egr_stem_conv7x7_f32, _p(base), xmap, n, H, W, _p(_cont(wpack, "stem weight")), _p(scale), _p(shift), _p(y),
+            _stream(), flops=2.0 * n * (H // 2) * (W // 2) * 64 * 147, nbytes=4.0 * n * (3 * H * W + (H // 2) * (W // 2) * 64))
     return Img(y)
 
 
@@ -212,7 +229,7 @@ def maxpool(x: Img, k: int, stride: int, pad: int) -> Img:
     ho = (x.h + 2 * pad - k) // stride + 1
     wo = (x.w + 2 * pad - k) // stride + 1
     y = torch.empty((x.n, ho, wo, x.c), device=x.t.device, dtype=torch.float32)
-    _check(lib.egr_maxpool_nhwc_f32(_p(x.t), _p(y), x.n, x.h, x.w, x.c, k, stride, pad, _stream()), "egr_maxpool_nhwc_f32")
+    _launch("egr_maxpool_nhwc_f32", lib.egr_maxpool_nhwc_f32, _p(x.t), _p(y), x.n, x.h, x.w, x.c, k, stride, pad, _stream())
     return Img(y)
 
 
@@ -223,8 +240,7 @@ def upsample2x(x: Img, out: Optional[Img] = None) -> Img:
         out = Img(torch.empty((x.n, 2 * x.h, 2 * x.w, x.c), device=x.t.device, dtype=torch.float32))
     if (out.n, out.h, out.w, out.c) != (x.n, 2 * x.h, 2 * x.w, x.c) or (out.n > 1 and out.nstride != out.h * out.w * out.ld):
         raise RuntimeError("egorear_amd.upsample2x: bad output view")
-    _check(lib.egr_upsample2x_nhwc_f32(_p(x.t), x.ld, _p(out.t), out.ld, x.n, x.h, x.w, x.c, _stream()),
-           "egr_upsample2x_nhwc_f32")
+    _launch("egr_upsample2x_nhwc_f32", lib.egr_upsample2x_nhwc_f32, _p(x.t), x.ld, _p(out.t), out.ld, x.n, x.h, x.w, x.c, _stream())
     return out
 
 
@@ -232,7 +248,7 @@ def avgpool(x: Img) -> torch.Tensor:
     if not x.t.is_contiguous():
         raise RuntimeError("egorear_amd.avgpool: contiguous input expected")
     y = torch.empty((x.n, x.c), device=x.t.device, dtype=torch.float32)
-    _check(lib.egr_avgpool_nhwc_f32(_p(x.t), _p(y), x.n, x.h * x.w, x.c, _stream()), "egr_avgpool_nhwc_f32")
+    _launch("egr_avgpool_nhwc_f32", lib.egr_avgpool_nhwc_f32, _p(x.t), _p(y), x.n, x.h * x.w, x.c, _stream())
     return y
 
 
@@ -246,8 +262,8 @@ def argmax_rows(hm: torch.Tensor, thr: float):
     maxvals = torch.empty((rows,), device=dev, dtype=torch.float32)
     valid = torch.empty((rows,), device=dev, dtype=torch.uint8)
     index = torch.empty((rows,), device=dev, dtype=torch.int32)
-    _check(lib.egr_argmax_rows_f32(_p(hm), rows, H, W, float(thr), _p(anchors), _p(maxvals), _p(valid, torch.uint8),
-                                   _p(index, torch.int32), _stream()), "egr_argmax_rows_f32")
+    _launch("egr_argmax_rows_f32", lib.egr_argmax_rows_f32, _p(hm), rows, H, W, float(thr), _p(anchors), _p(maxvals), _p(valid, torch.uint8),
+                                   _p(index, torch.int32), _stream())
     return anchors, maxvals, valid, index
 
 
@@ -258,7 +274,7 @@ def layernorm(x: torch.Tensor, gamma, beta, res: Optional[torch.Tensor] = None, 
     if res is not None and (res.shape != x.shape or not res.is_contiguous()):
         raise RuntimeError("egorear_amd.layernorm: residual must match the input")
     y = torch.empty_like(x)
-    _check(lib.egr_layernorm_f32(_p(x), _p(res), _p(gamma), _p(beta), _p(y), rows, c, eps, _stream()), "egr_layernorm_f32")
+    _launch("egr_layernorm_f32", lib.egr_layernorm_f32, _p(x), _p(res), _p(gamma), _p(beta), _p(y), rows, c, eps, _stream())
     return y
 
 
@@ -267,7 +283,7 @@ def joint_mha(qkv: torch.Tensor, b: int, j: int, heads: int, d: int, scale: floa
     if qkv.numel() != b * j * 3 * heads * d:
         raise RuntimeError("egorear_amd.joint_mha: qkv size mismatch")
     out = torch.empty((b * j, heads * d), device=qkv.device, dtype=torch.float32)
-    _check(lib.egr_joint_mha_f32(_p(qkv), _p(out), b, j, heads, d, float(scale), _stream()), "egr_joint_mha_f32")
+    _launch("egr_joint_mha_f32", lib.egr_joint_mha_f32, _p(qkv), _p(out), b, j, heads, d, float(scale), _stream())
     return out
 
 
@@ -293,9 +309,8 @@ def msda_gather(feat: torch.Tensor, pos: Optional[torch.Tensor], offs_logits: to
     e = torch.empty((rows, heads * dh), device=dev, dtype=torch.float32) if pos is not None else None
     sigma = torch.empty((heads, rows), device=dev, dtype=torch.float32)
     rowmask = torch.empty((rows,), device=dev, dtype=torch.uint8)
-    _check(lib.egr_msda_gather_f32(_p(feat), cf, _p(pos), dh, _p(offs_logits), _p(anchors), _p(valid, torch.uint8), b, views,
-                                   joints, heads, hgt, wid, _p(g), _p(e), _p(sigma), _p(rowmask, torch.uint8), _stream()),
-           "egr_msda_gather_f32")
+    _launch("egr_msda_gather_f32", lib.egr_msda_gather_f32, _p(feat), cf, _p(pos), dh, _p(offs_logits), _p(anchors), _p(valid, torch.uint8), b, views,
+                                   joints, heads, hgt, wid, _p(g), _p(e), _p(sigma), _p(rowmask, torch.uint8), _stream())
     return g, e, sigma, rowmask
 
 
@@ -313,8 +328,8 @@ def fisheye_project(pts: torch.Tensor, ctm: Optional[torch.Tensor], cams: torch.
     anchors = torch.empty((b, 4, joints, 2), device=dev, dtype=torch.float32)
     valid = torch.empty((b, 4, joints), device=dev, dtype=torch.uint8)
     q4 = torch.empty((b * joints, 4), device=dev, dtype=torch.float32)
-    _check(lib.egr_fisheye_project_f32(_p(pts), _p(ctm), _p(cams), b, joints, _p(anchors), _p(valid, torch.uint8), _p(q4),
-                                       _stream()), "egr_fisheye_project_f32")
+    _launch("egr_fisheye_project_f32", lib.egr_fisheye_project_f32, _p(pts), _p(ctm), _p(cams), b, joints, _p(anchors), _p(valid, torch.uint8), _p(q4),
+                                       _stream())
     return anchors, valid, q4
 
 
@@ -323,7 +338,7 @@ def linear_smallk(x: torch.Tensor, sxm: int, sxk: int, w: torch.Tensor, bias, m:
     if w.numel() != n * k or (m - 1) * sxm + (k - 1) * sxk >= x.numel():
         raise RuntimeError("egorear_amd.linear_smallk: size mismatch")
     y = torch.empty((m, n), device=x.device, dtype=torch.float32)
-    _check(lib.egr_linear_smallk_f32(_p(x), sxm, sxk, _p(w), _p(bias), _p(y), m, n, k, act, _stream()), "egr_linear_smallk_f32")
+    _launch("egr_linear_smallk_f32", lib.egr_linear_smallk_f32, _p(x), sxm, sxk, _p(w), _p(bias), _p(y), m, n, k, act, _stream())
     return y
 
 
@@ -332,7 +347,7 @@ def jqa_sum(hm_embed: torch.Tensor, embed: torch.Tensor, bfb: torch.Tensor, b: i
     if hm_embed.numel() != b * j * c or embed.numel() != j * c or bfb.numel() != b * c:
         raise RuntimeError("egorear_amd.jqa_sum: size mismatch")
     y = torch.empty((b * j, c), device=hm_embed.device, dtype=torch.float32)
-    _check(lib.egr_jqa_sum_f32(_p(hm_embed), _p(embed), _p(bfb), _p(y), b, j, c, _stream()), "egr_jqa_sum_f32")
+    _launch("egr_jqa_sum_f32", lib.egr_jqa_sum_f32, _p(hm_embed), _p(embed), _p(bfb), _p(y), b, j, c, _stream())
     return y
 
 
@@ -341,5 +356,5 @@ def tokens_to_nhwc(x: torch.Tensor, b: int, j: int, hw: int) -> torch.Tensor:
     if x.numel() != b * j * hw:
         raise RuntimeError("egorear_amd.tokens_to_nhwc: size mismatch")
     y = torch.empty((b, hw, j), device=x.device, dtype=torch.float32)
-    _check(lib.egr_tokens_to_nhwc_f32(_p(x), _p(y), b, j, hw, _stream()), "egr_tokens_to_nhwc_f32")
+    _launch("egr_tokens_to_nhwc_f32", lib.egr_tokens_to_nhwc_f32, _p(x), _p(y), b, j, hw, _stream())
     return y
