@@ -135,25 +135,8 @@ def main():
         else:
             run = step
 
-        for _ in range(args.warmup):
-            run()
-        torch.cuda.synchronize()
-        _log("warm-up done, timing")
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        from egorear_amd.dist import timed_steps
+        elapsed = timed_steps(run, args.steps, args.warmup, torch.cuda.synchronize, dev)
 
         # ---- roofline leg: per-launch HIP-event timing of one instrumented (eager) step
         roof = None
@@ -164,7 +147,7 @@ def main():
             step()
             torch.cuda.synchronize()
             prof, hip.PROFILE = hip.PROFILE, None
-            for name, s, e, flops, nbytes in prof:
+            for name, s, e, flops, nbytes, _tag in prof:
                 k = kernels.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
                 k["launches"] += 1
                 k["ms"] += s.elapsed_time(e)

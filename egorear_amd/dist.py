@@ -1,0 +1,46 @@
+"""Multi-process plumbing for the frame-sharded path.
+
+Inference shards independent frames over ranks; weights are replicated and no data-path collective exists.
+torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" in CPU tests) is used only to fence the timed region and to
+take the max over ranks."""
+from __future__ import annotations
+
+import time
+from typing import Callable, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_frames: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced [begin, end) slice of `n_frames` independent frames for `rank` (strong scaling)."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    base, rem = divmod(n_frames, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def timed_steps(run: Callable[[], object], steps: int, warmup: int, sync: Callable[[], None], device=None) -> float:
+    """W untimed + exactly K timed calls of `run`, bracketed by barrier + device sync on both sides;
+    returns the MAX elapsed seconds over ranks (works without an initialised process group too)."""
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    for _ in range(warmup):
+        run()
+    sync()
+    if multi:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    sync()
+    if multi:
+        dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if multi:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed

@@ -85,7 +85,7 @@ def _check(rc: int, name: str):
 PROFILE = None
 
 
-def _launch(name: str, cfunc, *args, flops: float = 0.0, nbytes: float = 0.0):
+def _launch(name: str, cfunc, *args, flops: float = 0.0, nbytes: float = 0.0, tag: str = ""):
     if PROFILE is None:
         rc = cfunc(*args)
     else:
@@ -93,7 +93,7 @@ def _launch(name: str, cfunc, *args, flops: float = 0.0, nbytes: float = 0.0):
         s.record()
         rc = cfunc(*args)
         e.record()
-        PROFILE.append((name, s, e, flops, nbytes))
+        PROFILE.append((name, s, e, flops, nbytes, tag))
     _check(rc, name)
 
 
@@ -204,7 +204,8 @@ def conv2d(x: Img, w: torch.Tensor, cout: int, kh: int, kw: int, stride: int, pa
     ws_ptr, ws_n = (None, 0) if workspace is None else (_p(workspace), workspace.numel())
     _launch("egr_conv2d_nhwc_f32", lib.egr_conv2d_nhwc_f32, C.byref(d), _p(x.t), _p(w), _p(scale), _p(shift),
             _p(res.t) if res is not None else None, _p(rowscale), _p(rowmask, torch.uint8), yptr, ws_ptr, ws_n, _stream(),
-            flops=2.0 * M * cout * K, nbytes=4.0 * (M * cout + x.n * x.h * x.w * x.c + cout * K))
+            flops=2.0 * M * cout * K, nbytes=4.0 * (M * cout + x.n * x.h * x.w * x.c + cout * K),
+            tag=f"M{M} N{cout} K{K} k{kh}s{stride} cin{x.c}" if PROFILE is not None else "")
     return ret
 
 
