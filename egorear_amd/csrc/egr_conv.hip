@@ -1,19 +1,27 @@
 // Implicit-GEMM convolution / linear layer on the fp32 matrix cores of gfx950.
 //
-//   GEMM view:  M = n*ho*wo output pixels,  N = cout,  K = kh*kw*cin  (k = (kh,kw,ci), ci fastest)
+//   GEMM view:  M = n*ho*wo output pixels,  N = cout,  K = kh*kw*cin,  k = (ci/32, kh, kw, ci%32)
 //   A[m][k]  = x[n, ho*s-p+kh, wo*s-p+kw, ci]   (NHWC gather, zero outside the image)
-//   B[k][co] = w[co][k]                           (weights pre-packed [cout_pad][K])
+//   B[k][co] = w[co][k]                           (weights pre-packed [cout_pad][cin/32][kh*kw][32])
 //
-// Tiling: a workgroup owns a BM x BN output tile and walks K in chunks of 32
-// (one filter tap x 32 input channels, so every A row of a chunk is 128 contiguous bytes).
-// Chunk t+1 is fetched global->registers (16-byte loads) while chunk t is multiplied out of LDS;
-// LDS rows are padded to 36 floats so the ds_read_b128 fragment reads are bank-conflict free.
-// Each wave owns FM x FN accumulator tiles of v_mfma_f32_32x32x2_f32; a ds_read_b128 gives a lane
-// four consecutive k of its row, which feed four MFMA k-steps (lane half h covers k = kk+4h+t in
-// step t — A and B use the same permutation, so the chunk's 32 products are each summed once).
-// f32 MFMA is a k-ordered fp32 fma chain, so results are deterministic and fp32-exact in the
-// reference's sense (no reduced-precision path exists on gfx950, and none is wanted: argmax
-// indices must match the reference bit for bit).
+// Structure:
+//  * a workgroup (4 waves) owns a BM x BN output tile and walks K in chunks of 32 = one filter tap x 32
+//    input channels, so every A row of a chunk is 128 contiguous bytes of one pixel;
+//  * staging is DIRECT-TO-LDS (global_load_lds_dwordx4, no VGPR round trip, no ds_write): chunk t+1 streams
+//    into the second LDS buffer while chunk t is multiplied; one barrier per chunk.  A wave-instruction
+//    writes 1 KiB = 8 rows x 128 B linearly, so rows are unpadded; bank conflicts of the ds_read_b128
+//    fragment reads are removed by an XOR swizzle applied on the SOURCE side (lane (row, seg) fetches
+//    logical 16-byte segment seg ^ ((row>>1)&7)) and undone by the same XOR on the read.  Pixels outside
+//    the image (conv halo) and weight rows beyond cout_pad fetch from a 16-byte zero buffer instead;
+//  * each wave owns FM x FN accumulator tiles of v_mfma_f32_32x32x2_f32; one ds_read_b128 gives a lane four
+//    consecutive k of its row, feeding four MFMA k-steps (lane half h covers k = kk+4h+t in step t — A and B
+//    use the same permutation, so each of the chunk's 32 products is summed exactly once);
+//  * the epilogue goes through LDS once more so that global stores (and residual loads) are 16 bytes per
+//    lane and whole 512-byte rows per wave: scale/shift (BatchNorm or bias), per-row bias scale, residual
+//    before/after the activation, ReLU / exact-erf GELU, row mask; NHWC (any pixel stride / channel offset)
+//    or channel-major planes.
+// f32 MFMA is a k-ordered fp32 fma chain: results are deterministic and fp32-exact in the reference's
+// sense (no reduced-precision path exists on gfx950, and none is wanted: argmax indices must match).
 #include "egr_common.h"
 
 namespace {
@@ -33,26 +41,38 @@ struct ConvArgs {
     int ktiles, ktiles_per_split;
     int tilesM, tilesN;
     int cblocks;  // cin / 32
+    int taps;     // kh * kw
+    int vec_ok;   // NHWC output / residual addresses are 16-byte aligned for every (row, channel quad)
 };
 
 constexpr int BK = 32;
-constexpr int LDSS = 36;  // padded LDS row stride (floats)
+
+__device__ __attribute__((aligned(16))) float egr_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <int BM, int BN>
+struct LdsPlan {
+    static constexpr int TILE = (BM + BN) * BK;             // floats per stage
+    static constexpr int CS = BN + 4;                       // epilogue staging row stride
+    static constexpr int STAGE = BM * CS + 2 * BM;          // staging + row offsets (y, res)
+    static constexpr int FLOATS = (2 * TILE > STAGE) ? 2 * TILE : STAGE;
+};
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvArgs a) {
-    constexpr int NT = WM * WN * 64;
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+    static_assert(WM * WN == 4, "four waves per workgroup");
+    constexpr int NT = 256;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 32, FN = TN / 32;
-    constexpr int RPT = NT / 8;  // rows covered per load pass
-    constexpr int IA = BM / RPT, IB = BN / RPT;
-    static_assert(BM % RPT == 0 && BN % RPT == 0, "tile/threads mismatch");
+    constexpr int IA = BM / 32, IB = BN / 32;  // 32 rows per load pass (8 rows per wave-instruction)
+    using P = LdsPlan<BM, BN>;
     static_assert(FM >= 1 && FN >= 1, "wave tile must be >= 32x32");
 
-    __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDSS];
-    __shared__ int s_yoff[BM];
-    __shared__ int s_roff[BM];
-    float* sA = lds;
-    float* sB = lds + BM * LDSS;
+    __shared__ __attribute__((aligned(16))) float lds[P::FLOATS];
 
     const egr_conv_desc& d = a.d;
     const int tid = threadIdx.x;
@@ -69,15 +89,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvArgs 
     const int split = blockIdx.y;
     const int kt0 = split * a.ktiles_per_split;
     const int kt1 = min(a.ktiles, kt0 + a.ktiles_per_split);
-
     const int HoWo = d.ho * d.wo;
-    const int seg = tid & 7, r0 = tid >> 3;
 
-    // ---- per-thread row descriptors for the A gather
-    int xb[IA], hi0[IA], wi0[IA];
+    // ---- per-lane staging roles: pass p covers tile rows p*32 + wave*8 + (lane>>3); physical segment lane&7
+    const int rsub = wave * 8 + (lane >> 3);
+    const int pseg = lane & 7;
+    int xb[IA], hi0[IA], wi0[IA], sega[IA];
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
-        int m = tm * BM + r0 + i * RPT;
+        int r = i * 32 + rsub;
+        int m = tm * BM + r;
+        sega[i] = (pseg ^ ((r >> 1) & 7)) * 4;
         if (m < a.M) {
             int n = m / HoWo;
             int pix = m - n * HoWo;
@@ -92,7 +114,111 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvArgs 
             wi0[i] = 0;
         }
     }
-    // ---- output row offsets (y / res) into LDS, read back in the epilogue
+    const float* wrow[IB];
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+        int r = i * 32 + rsub;
+        int co = tn * BN + r;
+        wrow[i] = (co < a.Npad) ? a.w + (int64_t)co * a.K + (pseg ^ ((r >> 1) & 7)) * 4 : nullptr;
+    }
+
+    // one 1-KiB DMA piece (8 rows x 128 B) of the next stage: pieces [0, IA) are A rows, [IA, IA+IB) weight rows
+    auto issue_piece = [&](int kt, int buf, int piece) {
+        float* sA = lds + buf * P::TILE;
+        if (piece < IA) {
+            int cb = kt / a.taps;               // K order: (channel chunk, kh, kw, 32 channels) — all taps of one
+            int tap = kt - cb * a.taps;         // chunk back to back, so the halo re-reads hit L1/L2
+            int c0 = cb * BK;
+            int kh = tap / d.kw, kw = tap - kh * d.kw;
+            int hi = hi0[piece] + kh, wi = wi0[piece] + kw;
+            bool ok = (hi >= 0) & (hi < d.h) & (wi >= 0) & (wi < d.w);
+            const float* p = ok ? a.x + (int64_t)xb[piece] + (int64_t)(hi * d.w + wi) * d.ldx + c0 + sega[piece] : egr_zero16;
+            glds16(p, sA + (piece * 32 + wave * 8) * BK);
+        } else {
+            int i = piece - IA;
+            const float* p = wrow[i] ? wrow[i] + kt * BK : egr_zero16;
+            glds16(p, sA + BM * BK + (i * 32 + wave * 8) * BK);
+        }
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment read offsets (floats) inside a stage: row * 32 + ((q ^ swz(row)) * 4), q = 2*g + half
+    int aoff[FM], aswz[FM], boff[FN], bswz[FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        int r = wm * TM + i * 32 + l31;
+        aoff[i] = r * BK;
+        aswz[i] = (r >> 1) & 7;
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        int r = wn * TN + j * 32 + l31;
+        boff[j] = BM * BK + r * BK;
+        bswz[j] = (r >> 1) & 7;
+    }
+
+    constexpr int NPIECE = IA + IB;
+
+    if (kt0 < kt1) {
+#pragma unroll
+        for (int pc = 0; pc < NPIECE; ++pc) issue_piece(kt0, 0, pc);
+    }
+    __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes stage 0
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        if (kt + 1 < kt1) {  // next chunk streams into the other stage while this one is multiplied
+#pragma unroll
+            for (int pc = 0; pc < NPIECE; ++pc) issue_piece(kt + 1, buf ^ 1, pc);
+        }
+        const float* st = lds + buf * P::TILE;
+        f32x4 av[2][FM], bv[2][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) av[0][i] = *reinterpret_cast<const f32x4*>(&st[aoff[i] + ((half ^ aswz[i]) << 2)]);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bv[0][j] = *reinterpret_cast<const f32x4*>(&st[boff[j] + ((half ^ bswz[j]) << 2)]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int cur = g & 1, nxt = cur ^ 1;
+            if (g < 3) {  // fragments of the next k-group are fetched under this group's MFMAs
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+                    av[nxt][i] = *reinterpret_cast<const f32x4*>(&st[aoff[i] + (((2 * (g + 1) + half) ^ aswz[i]) << 2)]);
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    bv[nxt][j] = *reinterpret_cast<const f32x4*>(&st[boff[j] + (((2 * (g + 1) + half) ^ bswz[j]) << 2)]);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i][t], bv[cur][j][t], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> LDS [BM][BN+4] -> 16-byte row-contiguous global accesses
+    float* sC = lds;
+    int* s_yoff = reinterpret_cast<int*>(lds + BM * P::CS);
+    int* s_roff = s_yoff + BM;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+                int row = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                sC[row * P::CS + wn * TN + j * 32 + l31] = acc[i][j][r];
+            }
     for (int r = tid; r < BM; r += NT) {
         int m = tm * BM + r;
         int yo = -1, ro = 0;
@@ -105,103 +231,75 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvArgs 
         s_yoff[r] = yo;
         s_roff[r] = ro;
     }
+    __syncthreads();
 
-    f32x16 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    f32x4 ra[IA], rb[IB];
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-
-    auto load_tiles = [&](int kt) {
-        int tap = kt / a.cblocks;
-        int c0 = (kt - tap * a.cblocks) * BK;
-        int kh = tap / d.kw, kw = tap - kh * d.kw;
-#pragma unroll
-        for (int i = 0; i < IA; ++i) {
-            int hi = hi0[i] + kh, wi = wi0[i] + kw;
-            bool ok = (hi >= 0) & (hi < d.h) & (wi >= 0) & (wi < d.w);
-            const float* p = a.x + (int64_t)xb[i] + (int64_t)(hi * d.w + wi) * d.ldx + c0 + seg * 4;
-            ra[i] = ok ? *reinterpret_cast<const f32x4*>(p) : zero4;
+    if (d.split_k > 1) {  // raw partial sums; the epilogue runs in splitk_reduce_kernel
+        constexpr int QPR = BN / 4;
+        for (int idx = tid; idx < BM * QPR; idx += NT) {
+            int row = idx / QPR, cq = idx - row * QPR;
+            int m = tm * BM + row, co = tn * BN + cq * 4;
+            if (m < a.M && co < a.Npad)
+                *reinterpret_cast<f32x4*>(&a.ws[((int64_t)split * a.M + m) * a.Npad + co]) =
+                    *reinterpret_cast<const f32x4*>(&sC[row * P::CS + cq * 4]);
         }
-#pragma unroll
-        for (int i = 0; i < IB; ++i) {
-            int co = tn * BN + r0 + i * RPT;
-            const float* p = a.w + (int64_t)co * a.K + kt * BK + seg * 4;
-            rb[i] = (co < a.Npad) ? *reinterpret_cast<const f32x4*>(p) : zero4;
-        }
-    };
-
-    if (kt0 < kt1) load_tiles(kt0);
-    for (int kt = kt0; kt < kt1; ++kt) {
-#pragma unroll
-        for (int i = 0; i < IA; ++i) *reinterpret_cast<f32x4*>(&sA[(r0 + i * RPT) * LDSS + seg * 4]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < IB; ++i) *reinterpret_cast<f32x4*>(&sB[(r0 + i * RPT) * LDSS + seg * 4]) = rb[i];
-        __syncthreads();
-        if (kt + 1 < kt1) load_tiles(kt + 1);
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 8) {
-            f32x4 av[FM], bv[FN];
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-                av[i] = *reinterpret_cast<const f32x4*>(&sA[(wm * TM + i * 32 + l31) * LDSS + kk + 4 * half]);
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-                bv[j] = *reinterpret_cast<const f32x4*>(&sB[(wn * TN + j * 32 + l31) * LDSS + kk + 4 * half]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-#pragma unroll
-                    for (int j = 0; j < FN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[j][t], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-
-    // ---- epilogue.  C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    if (d.split_k > 1) {
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                int co = tn * BN + wn * TN + j * 32 + l31;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int row = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    int m = tm * BM + row;
-                    if (m < a.M && co < a.Npad) a.ws[((int64_t)split * a.M + m) * a.Npad + co] = acc[i][j][r];
-                }
-            }
         return;
     }
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-        int co = tn * BN + wn * TN + j * 32 + l31;
-        bool cok = co < d.cout;
-        float sc = (cok && a.scale) ? a.scale[co] : 1.f;
-        float sh = (cok && a.shift) ? a.shift[co] : 0.f;
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int row = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+
+    if (d.out_nchw) {  // channel-major planes: lanes run along pixels (contiguous within a plane)
+        for (int c = 0; c < BN; ++c) {
+            int co = tn * BN + c;
+            if (co >= d.cout) break;
+            float sc = a.scale ? a.scale[co] : 1.f;
+            float sh = a.shift ? a.shift[co] : 0.f;
+            for (int row = tid; row < BM; row += NT) {
                 int yo = s_yoff[row];
-                if (!cok || yo < 0) continue;
+                if (yo < 0) continue;
                 int m = tm * BM + row;
-                float rs = a.rowscale ? a.rowscale[m] : 1.f;
-                float v = acc[i][j][r] * sc + sh * rs;
+                float v = sC[row * P::CS + c] * sc + sh * (a.rowscale ? a.rowscale[m] : 1.f);
                 if (d.res_mode == EGR_RES_BEFORE_ACT) v += a.res[(int64_t)s_roff[row] + co];
                 v = egr_act(v, d.act);
                 if (d.res_mode == EGR_RES_AFTER_ACT) v += a.res[(int64_t)s_roff[row] + co];
                 if (a.rowmask && !a.rowmask[m]) v = 0.f;
-                int64_t o = d.out_nchw ? ((int64_t)yo + (int64_t)co * HoWo) : ((int64_t)yo + co);
-                a.y[o] = v;
+                a.y[(int64_t)yo + (int64_t)co * HoWo] = v;
+            }
+        }
+        return;
+    }
+
+    constexpr int QPR = BN / 4;  // channel quads per tile row
+    for (int idx = tid; idx < BM * QPR; idx += NT) {
+        int row = idx / QPR, cq = idx - row * QPR;
+        int yo = s_yoff[row];
+        int co = tn * BN + cq * 4;
+        if (yo < 0 || co >= d.cout) continue;
+        int m = tm * BM + row;
+        f32x4 v = *reinterpret_cast<const f32x4*>(&sC[row * P::CS + cq * 4]);
+        const float rs = a.rowscale ? a.rowscale[m] : 1.f;
+        const bool keep = !(a.rowmask && !a.rowmask[m]);
+        if (a.vec_ok && co + 3 < d.cout) {
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, rr = {0.f, 0.f, 0.f, 0.f};
+            if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + co);
+            if (a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + co);
+            if (d.res_mode) rr = *reinterpret_cast<const f32x4*>(a.res + (int64_t)s_roff[row] + co);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = v[e] * sc[e] + sh[e] * rs;
+                if (d.res_mode == EGR_RES_BEFORE_ACT) t += rr[e];
+                t = egr_act(t, d.act);
+                if (d.res_mode == EGR_RES_AFTER_ACT) t += rr[e];
+                v[e] = keep ? t : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(a.y + (int64_t)yo + co) = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int c = co + e;
+                if (c >= d.cout) break;
+                float t = v[e] * (a.scale ? a.scale[c] : 1.f) + (a.shift ? a.shift[c] : 0.f) * rs;
+                if (d.res_mode == EGR_RES_BEFORE_ACT) t += a.res[(int64_t)s_roff[row] + c];
+                t = egr_act(t, d.act);
+                if (d.res_mode == EGR_RES_AFTER_ACT) t += a.res[(int64_t)s_roff[row] + c];
+                a.y[(int64_t)yo + c] = keep ? t : 0.f;
             }
         }
     }
@@ -237,11 +335,22 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
     a.tilesM = (a.M + BM - 1) / BM;
     a.tilesN = (a.Npad + BN - 1) / BN;
     dim3 grid((unsigned)(a.tilesM * a.tilesN), (unsigned)a.d.split_k, 1);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), grid, dim3(WM * WN * 64), 0, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
     return egr_launch_status();
 }
 
+enum { CFG_AUTO = -1, CFG_128x128 = 0, CFG_256x64 = 1, CFG_64x64 = 2, CFG_128x32 = 3, CFG_128x64 = 4, CFG_COUNT = 5 };
+const int kBM[CFG_COUNT] = {128, 256, 64, 128, 128};
+const int kBN[CFG_COUNT] = {128, 64, 64, 32, 64};
+int g_force_cfg = CFG_AUTO;
+
 }  // namespace
+
+extern "C" int egr_conv_force_config(int cfg) {
+    if (cfg < CFG_AUTO || cfg >= CFG_COUNT) return EGR_EINVAL;
+    g_force_cfg = cfg;
+    return 0;
+}
 
 extern "C" int egr_conv2d_nhwc_f32(const egr_conv_desc* dd, const float* x, const float* w, const float* scale,
                                    const float* shift, const float* res, const float* rowscale,
@@ -275,15 +384,25 @@ extern "C" int egr_conv2d_nhwc_f32(const egr_conv_desc* dd, const float* x, cons
     a.Npad = (d.cout + 31) / 32 * 32;
     a.K = d.kh * d.kw * d.cin;
     a.cblocks = d.cin / BK;
-    a.ktiles = d.kh * d.kw * a.cblocks;
+    a.taps = d.kh * d.kw;
+    a.ktiles = a.taps * a.cblocks;
+    // 16-byte epilogue accesses need every (row, channel-quad) address aligned
+    a.vec_ok = !d.out_nchw && (d.ldy % 4 == 0) && (((uintptr_t)y & 15) == 0) &&
+               ((d.ymap.stride_inner | d.ymap.stride_outer) % 4 == 0) &&
+               (!scale || ((uintptr_t)scale & 15) == 0) && (!shift || ((uintptr_t)shift & 15) == 0);
+    if (d.res_mode)
+        a.vec_ok = a.vec_ok && (d.ldr % 4 == 0) && (((uintptr_t)res & 15) == 0) &&
+                   ((d.rmap.stride_inner | d.rmap.stride_outer) % 4 == 0);
 
     // ---- tile configuration
-    enum { CFG_128x128, CFG_256x64, CFG_64x64, CFG_128x32 } cfg;
-    int bm, bn;
-    if (a.Npad == 32) { cfg = CFG_128x32; bm = 128; bn = 32; }
-    else if (a.M <= 4096) { cfg = CFG_64x64; bm = 64; bn = 64; }
-    else if (a.Npad % 128 == 0) { cfg = CFG_128x128; bm = 128; bn = 128; }
-    else { cfg = CFG_256x64; bm = 256; bn = 64; }
+    int cfg = g_force_cfg;
+    if (cfg == CFG_AUTO) {
+        if (a.Npad == 32) cfg = CFG_128x32;
+        else if (a.M <= 4096) cfg = CFG_64x64;
+        else if (a.Npad % 128 == 0) cfg = CFG_128x128;
+        else cfg = CFG_64x64;  // N = 64 / 192: measured faster than 256x64 and 128x64 (tools/conv_micro.py)
+    }
+    const int bm = kBM[cfg], bn = kBN[cfg];
 
     // ---- split-K: auto (0) fills the chip for skinny GEMMs with long K
     int blocks = ((a.M + bm - 1) / bm) * ((a.Npad + bn - 1) / bn);
@@ -301,6 +420,7 @@ extern "C" int egr_conv2d_nhwc_f32(const egr_conv_desc* dd, const float* x, cons
     if (d.split_k > 1) {
         if (!workspace) return EGR_ENULL;
         if ((size_t)d.split_k * a.M * a.Npad > workspace_floats) return EGR_EWORKSPACE;
+        if ((uintptr_t)workspace & 15) return EGR_EINVAL;
     }
     a.ktiles_per_split = (a.ktiles + d.split_k - 1) / d.split_k;
     d.split_k = (a.ktiles + a.ktiles_per_split - 1) / a.ktiles_per_split;  // no empty splits
@@ -311,6 +431,7 @@ extern "C" int egr_conv2d_nhwc_f32(const egr_conv_desc* dd, const float* x, cons
         case CFG_128x128: rc = launch_cfg<128, 128, 2, 2>(a, s); break;
         case CFG_256x64: rc = launch_cfg<256, 64, 4, 1>(a, s); break;
         case CFG_64x64: rc = launch_cfg<64, 64, 2, 2>(a, s); break;
+        case CFG_128x64: rc = launch_cfg<128, 64, 2, 2>(a, s); break;
         default: rc = launch_cfg<128, 32, 4, 1>(a, s); break;
     }
     if (rc) return rc;

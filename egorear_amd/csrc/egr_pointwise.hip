@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* x, float* y, 
 // index / weight arithmetic follows ATen's area_pixel_compute_source_index(align_corners=True):
 // src = dst * (in-1)/(out-1) in fp32, i0 = (int)src, i1 = min(i0+1, in-1), l1 = src - i0, l0 = 1 - l1.
 __global__ __launch_bounds__(256) void upsample2x_kernel(const float* x, int ldx, float* y, int ldy, int n, int h, int w,
-                                                         int c4) {
+                                                         int c4, int relu) {
     const int ho = 2 * h, wo = 2 * w;
     int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int64_t total = (int64_t)n * ho * wo * c4;
@@ -63,7 +63,10 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* x, int ldx
     f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((int64_t)y1 * w + x1) * ldx);
     f32x4 o;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = ly0 * (lx0 * v00[i] + lx1 * v01[i]) + ly1 * (lx0 * v10[i] + lx1 * v11[i]);
+    for (int i = 0; i < 4; ++i) {
+        float t = ly0 * (lx0 * v00[i] + lx1 * v01[i]) + ly1 * (lx0 * v10[i] + lx1 * v11[i]);
+        o[i] = (relu && t < 0.f) ? 0.f : t;
+    }
     *reinterpret_cast<f32x4*>(y + (((int64_t)img * ho + oy) * wo + ox) * ldy + cq * 4) = o;
 }
 
@@ -199,12 +202,12 @@ extern "C" int egr_maxpool_nhwc_f32(const float* x, float* y, int32_t n, int32_t
 }
 
 extern "C" int egr_upsample2x_nhwc_f32(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t n, int32_t h,
-                                       int32_t w, int32_t c, void* stream) {
+                                       int32_t w, int32_t c, int32_t relu, void* stream) {
     if (!x || !y) return EGR_ENULL;
     if (n <= 0 || h <= 0 || w <= 0 || c % 4 != 0 || ldx % 4 != 0 || ldy % 4 != 0 || ldx < c || ldy < c) return EGR_EINVAL;
     int64_t total = (int64_t)n * 4 * h * w * (c / 4);
     hipLaunchKernelGGL(upsample2x_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, n, h,
-                       w, c / 4);
+                       w, c / 4, relu);
     return egr_launch_status();
 }
 

@@ -45,12 +45,18 @@ def _pad_rows(w2d: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
+    """OIHW -> [cout][cin/32][kh*kw][32] (the kernel's K order: channel chunk, tap, channel-in-chunk)."""
+    co, ci, kh, kw = w.shape
+    return w.float().permute(0, 2, 3, 1).reshape(co, kh * kw, ci // 32, 32).permute(0, 2, 1, 3).reshape(co, -1).contiguous()
+
+
 def pack_conv(conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d] = None) -> PConv:
     p = PConv()
     w = conv.weight.detach()
     p.cout, p.cin, p.kh, p.kw = w.shape
     p.stride, p.pad = conv.stride[0], conv.padding[0]
-    p.w = _pad_rows(w.permute(0, 2, 3, 1).reshape(p.cout, -1).float())
+    p.w = _pad_rows(pack_conv_weight(w))
     bias = conv.bias.detach().float() if conv.bias is not None else None
     if bn is not None:
         scale = (bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps))
@@ -158,8 +164,19 @@ def run_stack(st: State, seq: nn.Sequential, x: Img, out: Optional[Img] = None, 
             x = conv(st, x, p, act, **kw)
             i += 2 if act else 1
         elif isinstance(m, nn.Upsample):
-            x = hip.upsample2x(x)
-            i += 1
+            # Upsample -> Conv2d(1x1) -> ReLU is evaluated as Conv2d(1x1) -> Upsample(+ReLU): the bias-carrying
+            # 1x1 conv commutes with bilinear interpolation, and runs on a quarter of the pixels this way.
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if (isinstance(nxt, nn.Conv2d) and nxt.kernel_size == (1, 1) and nxt.stride == (1, 1) and i + 2 < len(mods)
+                    and isinstance(mods[i + 2], nn.ReLU)):
+                p = st.get(nxt, lambda m=nxt: pack_conv(m))
+                lo = conv(st, x, p, ACT_NONE)
+                last = (i + 3) >= len(mods)
+                x = hip.upsample2x(lo, out=out if last else None, relu=True)
+                i += 3
+            else:
+                x = hip.upsample2x(x)
+                i += 1
         elif isinstance(m, nn.MaxPool2d):
             k = m.kernel_size if isinstance(m.kernel_size, int) else m.kernel_size[0]
             s = m.stride if isinstance(m.stride, int) else m.stride[0]

@@ -23,7 +23,7 @@ EXPORTS = [
     "egr_conv2d_nhwc_f32", "egr_stem_conv7x7_f32", "egr_maxpool_nhwc_f32", "egr_upsample2x_nhwc_f32",
     "egr_avgpool_nhwc_f32", "egr_argmax_rows_f32", "egr_layernorm_f32", "egr_joint_mha_f32", "egr_msda_gather_f32",
     "egr_fisheye_project_f32", "egr_linear_smallk_f32", "egr_jqa_sum_f32", "egr_tokens_to_nhwc_f32", "egr_version",
-    "egr_device_arch",
+    "egr_device_arch", "egr_conv_force_config",
 ]
 
 
@@ -51,7 +51,7 @@ def _load() -> C.CDLL:
     lib.egr_conv2d_nhwc_f32.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.egr_stem_conv7x7_f32.argtypes = [vp, NMap, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.egr_maxpool_nhwc_f32.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
-    lib.egr_upsample2x_nhwc_f32.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, vp]
+    lib.egr_upsample2x_nhwc_f32.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.egr_avgpool_nhwc_f32.argtypes = [vp, vp, i32, i32, i32, vp]
     lib.egr_argmax_rows_f32.argtypes = [vp, i32, i32, i32, f32, vp, vp, vp, vp, vp]
     lib.egr_layernorm_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, f32, vp]
@@ -63,6 +63,7 @@ def _load() -> C.CDLL:
     lib.egr_tokens_to_nhwc_f32.argtypes = [vp, vp, i32, i32, i32, vp]
     lib.egr_version.restype = C.c_char_p
     lib.egr_device_arch.argtypes = [C.c_char_p, i32]
+    lib.egr_conv_force_config.argtypes = [i32]
     for name in EXPORTS:
         getattr(lib, name)  # fail at import if a symbol is missing
         if name != "egr_version":
@@ -119,6 +120,10 @@ def _cont(t: torch.Tensor, what: str):
 
 def version() -> str:
     return lib.egr_version().decode()
+
+
+def conv_force_config(cfg: int):
+    _check(lib.egr_conv_force_config(cfg), "egr_conv_force_config")
 
 
 def device_arch() -> str:
@@ -234,14 +239,15 @@ def maxpool(x: Img, k: int, stride: int, pad: int) -> Img:
     return Img(y)
 
 
-def upsample2x(x: Img, out: Optional[Img] = None) -> Img:
+def upsample2x(x: Img, out: Optional[Img] = None, relu: bool = False) -> Img:
     if x.n > 1 and x.nstride != x.h * x.w * x.ld:
         raise RuntimeError("egorear_amd.upsample2x: images must be densely stacked")
     if out is None:
         out = Img(torch.empty((x.n, 2 * x.h, 2 * x.w, x.c), device=x.t.device, dtype=torch.float32))
     if (out.n, out.h, out.w, out.c) != (x.n, 2 * x.h, 2 * x.w, x.c) or (out.n > 1 and out.nstride != out.h * out.w * out.ld):
         raise RuntimeError("egorear_amd.upsample2x: bad output view")
-    _launch("egr_upsample2x_nhwc_f32", lib.egr_upsample2x_nhwc_f32, _p(x.t), x.ld, _p(out.t), out.ld, x.n, x.h, x.w, x.c, _stream())
+    _launch("egr_upsample2x_nhwc_f32", lib.egr_upsample2x_nhwc_f32, _p(x.t), x.ld, _p(out.t), out.ld, x.n, x.h, x.w, x.c, 1 if relu else 0, _stream(),
+            nbytes=4.0 * 5 * x.n * x.h * x.w * x.c)
     return out
 
 

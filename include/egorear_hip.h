@@ -50,7 +50,8 @@ typedef struct {
 /*
  * Convolution / linear layer as one implicit GEMM on fp32 MFMA.
  *   y[n,ho,wo,co] = act( acc * scale[co] + shift[co] * (rowscale ? rowscale[m] : 1) (+ res) )
- *   acc = sum_{kh,kw,ci} x[n, ho*stride-pad+kh, wo*stride-pad+kw, ci] * w[co, (kh,kw,ci)]
+ *   acc = sum_{kh,kw,ci} x[n, ho*stride-pad+kh, wo*stride-pad+kw, ci] * w[co, (ci/32, kh, kw, ci%32)]
+ * (weights packed [round_up(cout,32)][cin/32][kh*kw][32]: all taps of one 32-channel chunk are adjacent in K)
  * with m = (n*ho_total + ho)*wo_total + wo.  A Linear layer is the case h=w=kh=kw=1, n=rows.
  * Replaces nn.Conv2d(+BatchNorm2d eval)(+ReLU)(+residual) of models/backbones/resnet.py:43-137
  * and of the conv stacks in models/estimator/egoposeformer_heatmap_mvf_ex.py:101-126,522-584 /
@@ -76,6 +77,10 @@ int egr_conv2d_nhwc_f32(const egr_conv_desc* d, const float* x, const float* w,
                         const uint8_t* rowmask /* per m, NULL = keep; 0 -> row written as 0 */,
                         float* y, float* workspace, size_t workspace_floats, void* stream);
 
+/* Tuning knob for measurements: force the tile configuration of egr_conv2d_nhwc_f32
+ * (-1 auto, 0 128x128, 1 256x64, 2 64x64, 3 128x32, 4 128x64).  Process-wide; results do not depend on it. */
+int egr_conv_force_config(int cfg);
+
 /* ResNet stem: conv 7x7 stride 2 pad 3 (3 -> 64) + BatchNorm(eval) + ReLU, NCHW fp32 input
  * (h, w multiples of 64) -> NHWC output (n, h/2, w/2, 64).  w: [64][148] rows = (ci,kh,kw), last col 0.
  * Replaces layer_s2 of models/backbones/resnet.py:16,49. */
@@ -86,9 +91,11 @@ int egr_stem_conv7x7_f32(const float* x, egr_nmap xmap, int32_t n, int32_t h, in
 int egr_maxpool_nhwc_f32(const float* x, float* y, int32_t n, int32_t h, int32_t w, int32_t c,
                          int32_t k, int32_t stride, int32_t pad, void* stream);
 
-/* nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True) on NHWC; c % 4 == 0. */
+/* nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True) on NHWC; c % 4 == 0.  relu != 0 applies ReLU to
+ * the interpolated value: a bias-carrying 1x1 conv commutes with the interpolation (its weights sum to 1), so
+ * relu(conv1x1(up(x))) is evaluated as relu(up(conv1x1(x))) at a quarter of the conv work. */
 int egr_upsample2x_nhwc_f32(const float* x, int32_t ldx, float* y, int32_t ldy,
-                            int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
+                            int32_t n, int32_t h, int32_t w, int32_t c, int32_t relu, void* stream);
 
 /* Global average pool over hw pixels of NHWC (F.adaptive_avg_pool2d(.,(1,1)), heatmap_mvf_ex.py:659). */
 int egr_avgpool_nhwc_f32(const float* x, float* y, int32_t n, int32_t hw, int32_t c, void* stream);

@@ -26,9 +26,10 @@ def rnd(*shape, seed=0, scale=1.0):
     return (torch.rand(*shape, generator=g) * 2 - 1) * scale
 
 
-def pack_w(w):  # OIHW -> [cout_pad][(kh,kw,ci)]
+def pack_w(w):  # OIHW -> [cout_pad][(ci/32, kh, kw, ci%32)]
+    from egorear_amd.engine import pack_conv_weight
     co = w.shape[0]
-    w2 = w.permute(0, 2, 3, 1).reshape(co, -1)
+    w2 = pack_conv_weight(w)
     npad = (co + 31) // 32 * 32
     out = torch.zeros(npad, w2.shape[1])
     out[:co] = w2
@@ -151,6 +152,7 @@ def test_pool_and_upsample_match_torch(hip):
     up = hip.upsample2x(hip.Img(x.to(DEV)))
     ref = F.interpolate(xc, scale_factor=2, mode="bilinear", align_corners=True)
     close(up.t.permute(0, 3, 1, 2), ref, rel=2e-6)
+    close(hip.upsample2x(hip.Img(x.to(DEV)), relu=True).t.permute(0, 3, 1, 2), F.relu(ref), rel=2e-6)
     # a ramp is reproduced exactly at the original grid points' images (align_corners=True)
     ramp = torch.arange(8.0).view(1, 1, 8, 1).expand(1, 8, 8, 4).contiguous()
     up = hip.upsample2x(hip.Img(ramp.to(DEV))).t.cpu()

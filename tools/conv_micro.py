@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of egr_conv2d_nhwc_f32 on the hot path's dominant shapes, per tile configuration
+(interleaved rounds in one process).   python tools/conv_micro.py [--cfgs=-1,0,1,4] [--reps 20]"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from egorear_amd import hip
+
+# (n, h, w, cin, cout, k, stride, res_mode, label)   -- batch 64 x 4 views shapes from tools/conv_breakdown.py
+SHAPES = [
+    (128, 64, 64, 64, 64, 3, 1, 1, "layer1 3x3 64->64 (+res)"),
+    (128, 32, 32, 128, 128, 3, 1, 1, "layer2 3x3 128->128 (+res)"),
+    (128, 16, 16, 256, 256, 3, 1, 1, "layer3 3x3 256->256 (+res)"),
+    (128, 8, 8, 512, 512, 3, 1, 1, "layer4 3x3 512->512 (+res)"),
+    (64, 64, 64, 256, 512, 3, 2, 0, "refiner 3x3 s2 256->512"),
+    (128, 64, 64, 128, 128, 3, 1, 0, "fpn 3x3 128->128 @64"),
+    (128, 64, 64, 256, 128, 1, 1, 0, "1x1 256->128 @64 (fuse / heatmap .7)"),
+    (64, 64, 64, 128, 256, 1, 1, 0, "1x1 128->256 @64 (refiner proj .0)"),
+    (128, 64, 64, 128, 128, 1, 1, 0, "1x1 128->128 @64"),
+    (128, 64, 64, 64, 128, 1, 1, 0, "1x1 64->128 @64 (lateral0)"),
+    (256, 64, 64, 128, 64, 1, 1, 0, "1x1 128->64 @64 (conv_frame_feat.0)"),
+    (64, 64, 64, 128, 15, 1, 1, 0, "1x1 128->15 @64"),
+    (3840, 1, 1, 128, 64, 1, 1, 0, "head value proj M3840"),
+    (960, 1, 1, 256, 256, 1, 1, 0, "linear M960 256->256"),
+]
+ap = argparse.ArgumentParser()
+ap.add_argument("--cfgs", default="-1")
+ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--only", default="")
+a = ap.parse_args()
+cfgs = [int(c) for c in a.cfgs.split(",")]
+dev = "cuda"
+ws = torch.empty(1 << 24, device=dev)
+print(f"{'shape':40s} " + " ".join(f"cfg{c:>2d} TF/s" for c in cfgs))
+for (n, h, w, cin, cout, k, s, rm, label) in SHAPES:
+    if a.only and a.only not in label:
+        continue
+    pad = k // 2
+    x = torch.randn(n, h, w, cin, device=dev)
+    npad = (cout + 31) // 32 * 32
+    wt = torch.randn(npad, k * k * cin, device=dev) * 0.05
+    sc, sh = torch.rand(npad, device=dev) + 0.5, torch.randn(npad, device=dev)
+    ho, wo = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+    res = torch.randn(n, ho, wo, cout, device=dev) if rm else None
+    out = hip.Img(torch.empty(n, ho, wo, cout, device=dev))
+    flops = 2.0 * n * ho * wo * cout * k * k * cin
+    cells = []
+    for c in cfgs:
+        hip.conv_force_config(c)
+        try:
+            def run():
+                hip.conv2d(hip.Img(x), wt, cout, k, k, s, pad, scale=sc, shift=sh, act=1, res=hip.Img(res) if rm else None,
+                           res_mode=rm, out=out, workspace=ws, split_k=1)
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.reps):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / a.reps
+            cells.append(f"{flops / ms / 1e9:10.1f}")
+        except RuntimeError:
+            cells.append(f"{'err':>10s}")
+    hip.conv_force_config(-1)
+    print(f"{label:40s} " + " ".join(cells), flush=True)
