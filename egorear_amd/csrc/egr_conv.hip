@@ -22,9 +22,35 @@
 //    or channel-major planes.
 // f32 MFMA is a k-ordered fp32 fma chain: results are deterministic and fp32-exact in the reference's
 // sense (no reduced-precision path exists on gfx950, and none is wanted: argmax indices must match).
+#include <type_traits>
+
 #include "egr_common.h"
 
 namespace {
+
+// q = n / d for 0 <= n < 2^31 by multiply-high: l = ceil(log2 d), m = floor(2^32 (2^l - d) / d) + 1,
+// q = (umulhi(m, n) + n) >> l.
+struct FastDiv {
+    uint32_t mul, shift, d;
+};
+inline FastDiv make_fastdiv(int dd) {
+    FastDiv f;
+    uint32_t d = (uint32_t)dd;
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    f.mul = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+    f.shift = l;
+    f.d = d;
+    return f;
+}
+__device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
+    return (int)((__umulhi(f.mul, (uint32_t)n) + (uint32_t)n) >> f.shift);
+}
+__device__ __forceinline__ int64_t fmap(const egr_nmap& m, const FastDiv& f, int n) {
+    int o = fdiv(n, f);
+    int i = n - o * (int)f.d;
+    return (int64_t)i * m.stride_inner + (int64_t)o * m.stride_outer;
+}
 
 struct ConvArgs {
     egr_conv_desc d;
@@ -42,6 +68,7 @@ struct ConvArgs {
     int tilesM, tilesN;
     int cblocks;  // cin / 32
     int taps;     // kh * kw
+    FastDiv dHoWo, dWo, dXin, dYin, dRin;  // invariant-divisor division (no integer divide in the kernel)
     int vec_ok;   // NHWC output / residual addresses are 16-byte aligned for every (row, channel quad)
 };
 
@@ -58,8 +85,8 @@ template <int BM, int BN>
 struct LdsPlan {
     static constexpr int TILE = (BM + BN) * BK;             // floats per stage
     static constexpr int CS = BN + 4;                       // epilogue staging row stride
-    static constexpr int STAGE = BM * CS + 2 * BM;          // staging + row offsets (y, res)
-    static constexpr int FLOATS = (2 * TILE > STAGE) ? 2 * TILE : STAGE;
+    static constexpr int ROWOFF = (2 * TILE > BM * CS) ? 2 * TILE : BM * CS;  // row offsets (y, res) live past both
+    static constexpr int FLOATS = ROWOFF + 2 * BM;
 };
 
 template <int BM, int BN, int WM, int WN>
@@ -91,27 +118,50 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const int kt1 = min(a.ktiles, kt0 + a.ktiles_per_split);
     const int HoWo = d.ho * d.wo;
 
-    // ---- per-lane staging roles: pass p covers tile rows p*32 + wave*8 + (lane>>3); physical segment lane&7
+    // ---- per-lane staging roles: piece p covers tile rows p*32 + wave*8 + (lane>>3); physical segment lane&7.
+    // Per row, once: pointer to tap (0,0) of its receptive field (+ the swizzled 16-byte segment) and a bitmask of
+    // the taps that fall inside the image; per chunk the wave-uniform tap offset is added and the mask bit tested,
+    // so staging a chunk costs a handful of VALU ops per piece and no integer division.
     const int rsub = wave * 8 + (lane >> 3);
     const int pseg = lane & 7;
-    int xb[IA], hi0[IA], wi0[IA], sega[IA];
+    const float* arow[IA];
+    unsigned amask[IA];
+    int* s_yoff = reinterpret_cast<int*>(lds + P::ROWOFF);
+    int* s_roff = s_yoff + BM;
+    const unsigned fullmask = (d.kh * d.kw >= 32) ? 0xffffffffu : ((1u << (d.kh * d.kw)) - 1u);
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
         int r = i * 32 + rsub;
         int m = tm * BM + r;
-        sega[i] = (pseg ^ ((r >> 1) & 7)) * 4;
+        int seg = (pseg ^ ((r >> 1) & 7)) * 4;
+        arow[i] = egr_zero16;
+        amask[i] = 0u;
+        int yo = -1, ro = 0;
         if (m < a.M) {
-            int n = m / HoWo;
+            int n = fdiv(m, a.dHoWo);
             int pix = m - n * HoWo;
-            int ho = pix / d.wo;
+            int ho = fdiv(pix, a.dWo);
             int wo = pix - ho * d.wo;
-            xb[i] = (int)egr_map(d.xmap, n);
-            hi0[i] = ho * d.stride - d.pad;
-            wi0[i] = wo * d.stride - d.pad;
-        } else {
-            xb[i] = 0;
-            hi0[i] = -(1 << 20);
-            wi0[i] = 0;
+            int hi0 = ho * d.stride - d.pad, wi0 = wo * d.stride - d.pad;
+            arow[i] = a.x + fmap(d.xmap, a.dXin, n) + ((int64_t)hi0 * d.w + wi0) * d.ldx + seg;
+            // taps inside the image: kh in [kh_lo, kh_hi), kw in [kw_lo, kw_hi)
+            int kh_lo = max(0, -hi0), kh_hi = min(d.kh, d.h - hi0);
+            int kw_lo = max(0, -wi0), kw_hi = min(d.kw, d.w - wi0);
+            unsigned mk = fullmask;
+            if (kh_lo > 0 || kw_lo > 0 || kh_hi < d.kh || kw_hi < d.kw) {
+                mk = 0u;
+                unsigned rowbits = (kw_hi > kw_lo) ? (((1u << (kw_hi - kw_lo)) - 1u) << kw_lo) : 0u;
+                for (int kh = kh_lo; kh < kh_hi; ++kh) mk |= rowbits << (kh * d.kw);
+            }
+            amask[i] = mk;
+            if (pseg == 0) {
+                yo = (int)fmap(d.ymap, a.dYin, n) + (d.out_nchw ? pix : pix * d.ldy);
+                if (d.res_mode) ro = (int)fmap(d.rmap, a.dRin, n) + pix * d.ldr;
+            }
+        }
+        if (pseg == 0) {  // one lane per row publishes the output / residual offsets for the epilogue
+            s_yoff[r] = yo;
+            s_roff[r] = ro;
         }
     }
     const float* wrow[IB];
@@ -122,18 +172,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         wrow[i] = (co < a.Npad) ? a.w + (int64_t)co * a.K + (pseg ^ ((r >> 1) & 7)) * 4 : nullptr;
     }
 
-    // one 1-KiB DMA piece (8 rows x 128 B) of the next stage: pieces [0, IA) are A rows, [IA, IA+IB) weight rows
-    auto issue_piece = [&](int kt, int buf, int piece) {
+    // wave-uniform position of a chunk in K: (channel chunk cb, tap (kh, kw)); advanced incrementally
+    struct KPos { int cb, kh, kw; };
+    auto kpos_of = [&](int kt) { KPos p; p.cb = kt / a.taps; int t = kt - p.cb * a.taps; p.kh = t / d.kw; p.kw = t - p.kh * d.kw; return p; };
+    auto kpos_next = [&](KPos p) { if (++p.kw == d.kw) { p.kw = 0; if (++p.kh == d.kh) { p.kh = 0; ++p.cb; } } return p; };
+
+    // one 1-KiB DMA piece (8 rows x 128 B) of a stage: pieces [0, IA) are A rows, [IA, IA+IB) weight rows
+    auto issue_piece = [&](int kt, KPos kp, int buf, int piece) {
         float* sA = lds + buf * P::TILE;
         if (piece < IA) {
-            int cb = kt / a.taps;               // K order: (channel chunk, kh, kw, 32 channels) — all taps of one
-            int tap = kt - cb * a.taps;         // chunk back to back, so the halo re-reads hit L1/L2
-            int c0 = cb * BK;
-            int kh = tap / d.kw, kw = tap - kh * d.kw;
-            int hi = hi0[piece] + kh, wi = wi0[piece] + kw;
-            bool ok = (hi >= 0) & (hi < d.h) & (wi >= 0) & (wi < d.w);
-            const float* p = ok ? a.x + (int64_t)xb[piece] + (int64_t)(hi * d.w + wi) * d.ldx + c0 + sega[piece] : egr_zero16;
-            glds16(p, sA + (piece * 32 + wave * 8) * BK);
+            int tap = kp.kh * d.kw + kp.kw;
+            int64_t toff = ((int64_t)kp.kh * d.w + kp.kw) * d.ldx + kp.cb * BK;
+            // branch-free select between the pixel row and the zero buffer
+            const uint64_t keep = 0ull - (uint64_t)((amask[piece] >> tap) & 1u);
+            const uint64_t pa = (uint64_t)(arow[piece] + toff), pz = (uint64_t)egr_zero16;
+            glds16(reinterpret_cast<const float*>((pa & keep) | (pz & ~keep)), sA + (piece * 32 + wave * 8) * BK);
         } else {
             int i = piece - IA;
             const float* p = wrow[i] ? wrow[i] + kt * BK : egr_zero16;
@@ -166,17 +219,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 
     constexpr int NPIECE = IA + IB;
 
-    if (kt0 < kt1) {
-#pragma unroll
-        for (int pc = 0; pc < NPIECE; ++pc) issue_piece(kt0, 0, pc);
-    }
-    __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes stage 0
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int buf = (kt - kt0) & 1;
-        if (kt + 1 < kt1) {  // next chunk streams into the other stage while this one is multiplied
-#pragma unroll
-            for (int pc = 0; pc < NPIECE; ++pc) issue_piece(kt + 1, buf ^ 1, pc);
-        }
+    // multiply one staged chunk; when ISSUE, the next chunk's DMA pieces go out one per MFMA behind the first
+    // matrix instructions (pinned with sched_barrier), so their issue slots hide under the 64-cycle MFMAs
+    auto chunk = [&](int kt, int buf, KPos kp_next, auto issue_tag) {
+        constexpr bool ISSUE = decltype(issue_tag)::value;
         const float* st = lds + buf * P::TILE;
         f32x4 av[2][FM], bv[2][FN];
 #pragma unroll
@@ -199,16 +245,39 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
-                    for (int j = 0; j < FN; ++j)
+                    for (int j = 0; j < FN; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i][t], bv[cur][j][t], acc[i][j], 0, 0, 0);
+                        if constexpr (ISSUE) {
+                            const int n = ((g * 4 + t) * FM + i) * FN + j;
+                            if (n < NPIECE) {
+                                issue_piece(kt + 1, kp_next, buf ^ 1, n);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
         }
+    };
+
+    KPos kp = kpos_of(kt0);
+    if (kt0 < kt1) {
+#pragma unroll
+        for (int pc = 0; pc < NPIECE; ++pc) issue_piece(kt0, kp, 0, pc);
+    }
+    __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes stage 0
+    int kt = kt0;
+    for (; kt + 1 < kt1; ++kt) {
+        KPos kn = kpos_next(kp);
+        chunk(kt, (kt - kt0) & 1, kn, std::true_type{});
+        kp = kn;
+        __syncthreads();
+    }
+    if (kt < kt1) {
+        chunk(kt, (kt - kt0) & 1, kp, std::false_type{});
         __syncthreads();
     }
 
     // ---- epilogue: accumulators -> LDS [BM][BN+4] -> 16-byte row-contiguous global accesses
     float* sC = lds;
-    int* s_yoff = reinterpret_cast<int*>(lds + BM * P::CS);
-    int* s_roff = s_yoff + BM;
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -219,18 +288,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                 int row = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 sC[row * P::CS + wn * TN + j * 32 + l31] = acc[i][j][r];
             }
-    for (int r = tid; r < BM; r += NT) {
-        int m = tm * BM + r;
-        int yo = -1, ro = 0;
-        if (m < a.M) {
-            int n = m / HoWo;
-            int pix = m - n * HoWo;
-            yo = (int)egr_map(d.ymap, n) + (d.out_nchw ? pix : pix * d.ldy);
-            if (d.res_mode) ro = (int)egr_map(d.rmap, n) + pix * d.ldr;
-        }
-        s_yoff[r] = yo;
-        s_roff[r] = ro;
-    }
     __syncthreads();
 
     if (d.split_k > 1) {  // raw partial sums; the epilogue runs in splitk_reduce_kernel
@@ -266,42 +323,52 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         return;
     }
 
-    constexpr int QPR = BN / 4;  // channel quads per tile row
-    for (int idx = tid; idx < BM * QPR; idx += NT) {
-        int row = idx / QPR, cq = idx - row * QPR;
-        int yo = s_yoff[row];
-        int co = tn * BN + cq * 4;
-        if (yo < 0 || co >= d.cout) continue;
-        int m = tm * BM + row;
+    constexpr int QPR = BN / 4;          // channel quads per tile row
+    constexpr int RPI = NT / QPR;        // rows covered per iteration; a thread keeps one channel quad throughout
+    static_assert(NT % QPR == 0 && BM % RPI == 0, "epilogue mapping");
+    const int cq = tid % QPR, row0 = tid / QPR;
+    const int co = tn * BN + cq * 4;
+    if (co >= d.cout) return;
+    const bool vec = a.vec_ok && co + 3 < d.cout;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (co + e < d.cout) {
+            if (a.scale) sc[e] = a.scale[co + e];
+            if (a.shift) sh[e] = a.shift[co + e];
+        }
+#pragma unroll 4
+    for (int it = 0; it < BM / RPI; ++it) {
+        const int row = row0 + it * RPI;
+        const int yo = s_yoff[row];
+        if (yo < 0) continue;
+        const int m = tm * BM + row;
         f32x4 v = *reinterpret_cast<const f32x4*>(&sC[row * P::CS + cq * 4]);
         const float rs = a.rowscale ? a.rowscale[m] : 1.f;
         const bool keep = !(a.rowmask && !a.rowmask[m]);
-        if (a.vec_ok && co + 3 < d.cout) {
-            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, rr = {0.f, 0.f, 0.f, 0.f};
-            if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + co);
-            if (a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + co);
-            if (d.res_mode) rr = *reinterpret_cast<const f32x4*>(a.res + (int64_t)s_roff[row] + co);
+        f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+        if (d.res_mode) {
+            const float* rp = a.res + (int64_t)s_roff[row] + co;
+            if (vec) rr = *reinterpret_cast<const f32x4*>(rp);
+            else
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = v[e] * sc[e] + sh[e] * rs;
-                if (d.res_mode == EGR_RES_BEFORE_ACT) t += rr[e];
-                t = egr_act(t, d.act);
-                if (d.res_mode == EGR_RES_AFTER_ACT) t += rr[e];
-                v[e] = keep ? t : 0.f;
-            }
-            *reinterpret_cast<f32x4*>(a.y + (int64_t)yo + co) = v;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                int c = co + e;
-                if (c >= d.cout) break;
-                float t = v[e] * (a.scale ? a.scale[c] : 1.f) + (a.shift ? a.shift[c] : 0.f) * rs;
-                if (d.res_mode == EGR_RES_BEFORE_ACT) t += a.res[(int64_t)s_roff[row] + c];
-                t = egr_act(t, d.act);
-                if (d.res_mode == EGR_RES_AFTER_ACT) t += a.res[(int64_t)s_roff[row] + c];
-                a.y[(int64_t)yo + c] = keep ? t : 0.f;
-            }
+                for (int e = 0; e < 4; ++e)
+                    if (co + e < d.cout) rr[e] = rp[e];
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = v[e] * sc[e] + sh[e] * rs;
+            if (d.res_mode == EGR_RES_BEFORE_ACT) t += rr[e];
+            t = egr_act(t, d.act);
+            if (d.res_mode == EGR_RES_AFTER_ACT) t += rr[e];
+            v[e] = keep ? t : 0.f;
+        }
+        float* yp = a.y + (int64_t)yo + co;
+        if (vec) *reinterpret_cast<f32x4*>(yp) = v;
+        else
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (co + e < d.cout) yp[e] = v[e];
     }
 }
 
@@ -361,7 +428,7 @@ extern "C" int egr_conv2d_nhwc_f32(const egr_conv_desc* dd, const float* x, cons
     a.d = *dd;
     egr_conv_desc& d = a.d;
     if (d.cin <= 0 || d.cin % BK != 0 || d.cout <= 0 || d.kh <= 0 || d.kw <= 0 || d.stride <= 0) return EGR_EINVAL;
-    if (d.n <= 0 || d.ho <= 0 || d.wo <= 0) return EGR_EINVAL;
+    if (d.n <= 0 || d.ho <= 0 || d.wo <= 0 || d.kh * d.kw > 32) return EGR_EINVAL;
     if (d.ldx % 4 != 0 || ((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return EGR_EINVAL;  // 16-byte A/B loads
     if (d.res_mode != EGR_RES_NONE && !res) return EGR_ENULL;
     if (d.xmap.n_inner <= 0 || d.ymap.n_inner <= 0 || (d.res_mode && d.rmap.n_inner <= 0)) return EGR_EINVAL;
@@ -383,6 +450,11 @@ extern "C" int egr_conv2d_nhwc_f32(const egr_conv_desc* dd, const float* x, cons
     a.M = (int)M64;
     a.Npad = (d.cout + 31) / 32 * 32;
     a.K = d.kh * d.kw * d.cin;
+    a.dHoWo = make_fastdiv(d.ho * d.wo);
+    a.dWo = make_fastdiv(d.wo);
+    a.dXin = make_fastdiv(d.xmap.n_inner);
+    a.dYin = make_fastdiv(d.ymap.n_inner);
+    a.dRin = make_fastdiv(d.res_mode ? d.rmap.n_inner : 1);
     a.cblocks = d.cin / BK;
     a.taps = d.kh * d.kw;
     a.ktiles = a.taps * a.cblocks;

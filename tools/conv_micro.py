@@ -31,11 +31,15 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--cfgs", default="-1")
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--only", default="")
+ap.add_argument("--ksweep", action="store_true", help="1x1, N=128, M=524288: K = 32..1024 (fixed per-block cost)")
 a = ap.parse_args()
 cfgs = [int(c) for c in a.cfgs.split(",")]
+if a.ksweep:
+    SHAPES = [(128, 64, 64, k, 128, 1, 1, 0, f"1x1 K={k} N=128 M=524288") for k in (32, 64, 128, 256, 512, 1024)]
+    SHAPES += [(128, 64, 64, k, 128, 3, 1, 0, f"3x3 cin={k} N=128 M=524288") for k in (32, 64, 128)]
 dev = "cuda"
 ws = torch.empty(1 << 24, device=dev)
-print(f"{'shape':40s} " + " ".join(f"cfg{c:>2d} TF/s" for c in cfgs))
+print(f"{'shape':40s} " + " ".join(f"cfg{c:>2d} TF/s" for c in cfgs) + "   ms(last cfg)")
 for (n, h, w, cin, cout, k, s, rm, label) in SHAPES:
     if a.only and a.only not in label:
         continue
@@ -69,4 +73,4 @@ for (n, h, w, cin, cout, k, s, rm, label) in SHAPES:
         except RuntimeError:
             cells.append(f"{'err':>10s}")
     hip.conv_force_config(-1)
-    print(f"{label:40s} " + " ".join(cells), flush=True)
+    print(f"{label:40s} " + " ".join(cells) + f"   {ms:8.4f}", flush=True)
