@@ -22,13 +22,23 @@ __global__ __launch_bounds__(256) void msda_gather_kernel(const float* feat, con
                                                           int wid, float* g, float* e, float* sigma, uint8_t* rowmask) {
     const int cf = CPL * 64;
     const int row = blockIdx.x;  // (b, j, v)
+    {   // grouped launch: query sets (e.g. the four refiners) share feat / anchors / valid, own everything else
+        const int grp = blockIdx.y;
+        const int64_t rows = gridDim.x;
+        if (pos) pos += (int64_t)grp * V * hgt * wid * heads * dh;
+        offs_logits += (int64_t)grp * B * J * heads * NPTS * 3;
+        g += grp * rows * heads * cf;
+        if (e) e += grp * rows * heads * dh;
+        sigma += grp * rows * heads;
+        if (grp) rowmask = nullptr;  // identical for every group: written once
+    }
     const int v = row % V;
     const int bj = row / V;
     const int j = bj % J, b = bj / J;
     const int lane = threadIdx.x & 63;
     const int nw = blockDim.x >> 6;
     const bool ok = valid[((int64_t)b * V + v) * J + j] != 0;
-    if (threadIdx.x == 0) rowmask[row] = ok ? 1 : 0;
+    if (threadIdx.x == 0 && rowmask) rowmask[row] = ok ? 1 : 0;
     const int hw = hgt * wid;
     const float ax = anchors[(((int64_t)b * V + v) * J + j) * 2 + 0];
     const float ay = anchors[(((int64_t)b * V + v) * J + j) * 2 + 1];
@@ -219,14 +229,15 @@ __global__ __launch_bounds__(256) void fisheye_kernel(float* pts, const float* c
 extern "C" int egr_msda_gather_f32(const float* feat, int32_t cf, const float* pos, int32_t dh, const float* offs_logits,
                                    const float* anchors, const uint8_t* valid, int32_t b, int32_t views, int32_t joints,
                                    int32_t heads, int32_t hgt, int32_t wid, float* g, float* e, float* sigma,
-                                   uint8_t* rowmask, void* stream) {
+                                   uint8_t* rowmask, int32_t groups, void* stream) {
+    if (groups <= 0 || groups > 65535) return EGR_EINVAL;
     if (!feat || !offs_logits || !anchors || !valid || !g || !sigma || !rowmask) return EGR_ENULL;
     if ((pos != nullptr) != (e != nullptr)) return EGR_ENULL;
     if (b <= 0 || views <= 0 || joints <= 0 || heads <= 0 || heads > 16 || hgt <= 0 || wid <= 0) return EGR_EINVAL;
     if (pos && (dh <= 0 || dh > 64)) return EGR_EINVAL;
     int64_t rows = (int64_t)b * joints * views;
     if (rows >= (1LL << 31)) return EGR_EINVAL;
-    dim3 grid((unsigned)rows), block(64 * (heads < 4 ? heads : 4));
+    dim3 grid((unsigned)rows, (unsigned)groups), block(64 * (heads < 4 ? heads : 4));
     hipStream_t s = (hipStream_t)stream;
     if (cf == 128)
         hipLaunchKernelGGL(msda_gather_kernel<2>, grid, block, 0, s, feat, pos, dh, offs_logits, anchors, valid, b, views,

@@ -102,6 +102,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[P::FLOATS];
 
     const egr_conv_desc& d = a.d;
+    const int grp = blockIdx.z;  // grouped launch: same shape, own operands
+    const float* const xg = a.x + grp * d.gx;
+    const float* const wg = a.w + grp * d.gw;
+    const float* const scg = a.scale ? a.scale + grp * d.gp : nullptr;
+    const float* const shg = a.shift ? a.shift + grp * d.gp : nullptr;
+    const float* const resg = a.res ? a.res + grp * d.gr : nullptr;
+    const float* const rsg = a.rowscale ? a.rowscale + grp * d.grs : nullptr;
+    const uint8_t* const rmg = a.rowmask ? a.rowmask + grp * d.grm : nullptr;
+    float* const yg = a.y + grp * d.gy;
+    float* const wsg = a.ws ? a.ws + (int64_t)grp * d.split_k * a.M * a.Npad : nullptr;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -143,7 +153,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             int ho = fdiv(pix, a.dWo);
             int wo = pix - ho * d.wo;
             int hi0 = ho * d.stride - d.pad, wi0 = wo * d.stride - d.pad;
-            arow[i] = a.x + fmap(d.xmap, a.dXin, n) + ((int64_t)hi0 * d.w + wi0) * d.ldx + seg;
+            arow[i] = xg + fmap(d.xmap, a.dXin, n) + ((int64_t)hi0 * d.w + wi0) * d.ldx + seg;
             // taps inside the image: kh in [kh_lo, kh_hi), kw in [kw_lo, kw_hi)
             int kh_lo = max(0, -hi0), kh_hi = min(d.kh, d.h - hi0);
             int kw_lo = max(0, -wi0), kw_hi = min(d.kw, d.w - wi0);
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     for (int i = 0; i < IB; ++i) {
         int r = i * 32 + rsub;
         int co = tn * BN + r;
-        wrow[i] = (co < a.Npad) ? a.w + (int64_t)co * a.K + (pseg ^ ((r >> 1) & 7)) * 4 : nullptr;
+        wrow[i] = (co < a.Npad) ? wg + (int64_t)co * a.K + (pseg ^ ((r >> 1) & 7)) * 4 : nullptr;
     }
 
     // wave-uniform position of a chunk in K: (channel chunk cb, tap (kh, kw)); advanced incrementally
@@ -296,7 +306,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             int row = idx / QPR, cq = idx - row * QPR;
             int m = tm * BM + row, co = tn * BN + cq * 4;
             if (m < a.M && co < a.Npad)
-                *reinterpret_cast<f32x4*>(&a.ws[((int64_t)split * a.M + m) * a.Npad + co]) =
+                *reinterpret_cast<f32x4*>(&wsg[((int64_t)split * a.M + m) * a.Npad + co]) =
                     *reinterpret_cast<const f32x4*>(&sC[row * P::CS + cq * 4]);
         }
         return;
@@ -306,18 +316,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         for (int c = 0; c < BN; ++c) {
             int co = tn * BN + c;
             if (co >= d.cout) break;
-            float sc = a.scale ? a.scale[co] : 1.f;
-            float sh = a.shift ? a.shift[co] : 0.f;
+            float sc = scg ? scg[co] : 1.f;
+            float sh = shg ? shg[co] : 0.f;
             for (int row = tid; row < BM; row += NT) {
                 int yo = s_yoff[row];
                 if (yo < 0) continue;
                 int m = tm * BM + row;
-                float v = sC[row * P::CS + c] * sc + sh * (a.rowscale ? a.rowscale[m] : 1.f);
-                if (d.res_mode == EGR_RES_BEFORE_ACT) v += a.res[(int64_t)s_roff[row] + co];
+                float v = sC[row * P::CS + c] * sc + sh * (rsg ? rsg[m] : 1.f);
+                if (d.res_mode == EGR_RES_BEFORE_ACT) v += resg[(int64_t)s_roff[row] + co];
                 v = egr_act(v, d.act);
-                if (d.res_mode == EGR_RES_AFTER_ACT) v += a.res[(int64_t)s_roff[row] + co];
-                if (a.rowmask && !a.rowmask[m]) v = 0.f;
-                a.y[(int64_t)yo + (int64_t)co * HoWo] = v;
+                if (d.res_mode == EGR_RES_AFTER_ACT) v += resg[(int64_t)s_roff[row] + co];
+                if (rmg && !rmg[m]) v = 0.f;
+                yg[(int64_t)yo + (int64_t)co * HoWo] = v;
             }
         }
         return;
@@ -334,8 +344,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
         if (co + e < d.cout) {
-            if (a.scale) sc[e] = a.scale[co + e];
-            if (a.shift) sh[e] = a.shift[co + e];
+            if (scg) sc[e] = scg[co + e];
+            if (shg) sh[e] = shg[co + e];
         }
 #pragma unroll 4
     for (int it = 0; it < BM / RPI; ++it) {
@@ -344,11 +354,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         if (yo < 0) continue;
         const int m = tm * BM + row;
         f32x4 v = *reinterpret_cast<const f32x4*>(&sC[row * P::CS + cq * 4]);
-        const float rs = a.rowscale ? a.rowscale[m] : 1.f;
-        const bool keep = !(a.rowmask && !a.rowmask[m]);
+        const float rs = rsg ? rsg[m] : 1.f;
+        const bool keep = !(rmg && !rmg[m]);
         f32x4 rr = {0.f, 0.f, 0.f, 0.f};
         if (d.res_mode) {
-            const float* rp = a.res + (int64_t)s_roff[row] + co;
+            const float* rp = resg + (int64_t)s_roff[row] + co;
             if (vec) rr = *reinterpret_cast<const f32x4*>(rp);
             else
 #pragma unroll
@@ -363,7 +373,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             if (d.res_mode == EGR_RES_AFTER_ACT) t += rr[e];
             v[e] = keep ? t : 0.f;
         }
-        float* yp = a.y + (int64_t)yo + co;
+        float* yp = yg + (int64_t)yo + co;
         if (vec) *reinterpret_cast<f32x4*>(yp) = v;
         else
 #pragma unroll
@@ -375,33 +385,41 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 // split-K second pass: sum the partial slabs in fixed order (deterministic) and apply the epilogue.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a) {
     const egr_conv_desc& d = a.d;
+    const int grp = blockIdx.y;
+    const float* const scg = a.scale ? a.scale + grp * d.gp : nullptr;
+    const float* const shg = a.shift ? a.shift + grp * d.gp : nullptr;
+    const float* const resg = a.res ? a.res + grp * d.gr : nullptr;
+    const float* const rsg = a.rowscale ? a.rowscale + grp * d.grs : nullptr;
+    const uint8_t* const rmg = a.rowmask ? a.rowmask + grp * d.grm : nullptr;
+    float* const yg = a.y + grp * d.gy;
+    const float* const wsg = a.ws + (int64_t)grp * d.split_k * a.M * a.Npad;
     int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int64_t total = (int64_t)a.M * d.cout;
     if (idx >= total) return;
     int m = (int)(idx / d.cout);
     int co = (int)(idx - (int64_t)m * d.cout);
     float s = 0.f;
-    for (int sp = 0; sp < d.split_k; ++sp) s += a.ws[((int64_t)sp * a.M + m) * a.Npad + co];
+    for (int sp = 0; sp < d.split_k; ++sp) s += wsg[((int64_t)sp * a.M + m) * a.Npad + co];
     const int HoWo = d.ho * d.wo;
     int n = m / HoWo, pix = m - n * HoWo;
-    float sc = a.scale ? a.scale[co] : 1.f;
-    float sh = a.shift ? a.shift[co] : 0.f;
-    float rs = a.rowscale ? a.rowscale[m] : 1.f;
+    float sc = scg ? scg[co] : 1.f;
+    float sh = shg ? shg[co] : 0.f;
+    float rs = rsg ? rsg[m] : 1.f;
     float v = s * sc + sh * rs;
     int64_t ro = d.res_mode ? egr_map(d.rmap, n) + (int64_t)pix * d.ldr + co : 0;
-    if (d.res_mode == EGR_RES_BEFORE_ACT) v += a.res[ro];
+    if (d.res_mode == EGR_RES_BEFORE_ACT) v += resg[ro];
     v = egr_act(v, d.act);
-    if (d.res_mode == EGR_RES_AFTER_ACT) v += a.res[ro];
-    if (a.rowmask && !a.rowmask[m]) v = 0.f;
+    if (d.res_mode == EGR_RES_AFTER_ACT) v += resg[ro];
+    if (rmg && !rmg[m]) v = 0.f;
     int64_t yo = egr_map(d.ymap, n) + (d.out_nchw ? ((int64_t)co * HoWo + pix) : ((int64_t)pix * d.ldy + co));
-    a.y[yo] = v;
+    yg[yo] = v;
 }
 
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(ConvArgs& a, hipStream_t s) {
     a.tilesM = (a.M + BM - 1) / BM;
     a.tilesN = (a.Npad + BN - 1) / BN;
-    dim3 grid((unsigned)(a.tilesM * a.tilesN), (unsigned)a.d.split_k, 1);
+    dim3 grid((unsigned)(a.tilesM * a.tilesN), (unsigned)a.d.split_k, (unsigned)a.d.groups);
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
     return egr_launch_status();
 }
@@ -433,6 +451,9 @@ extern "C" int egr_conv2d_nhwc_f32(const egr_conv_desc* dd, const float* x, cons
     if (d.res_mode != EGR_RES_NONE && !res) return EGR_ENULL;
     if (d.xmap.n_inner <= 0 || d.ymap.n_inner <= 0 || (d.res_mode && d.rmap.n_inner <= 0)) return EGR_EINVAL;
     if ((d.xmap.stride_inner | d.xmap.stride_outer) % 4 != 0) return EGR_EINVAL;
+    if (d.groups <= 0) d.groups = 1;
+    if (d.groups > 1 && ((d.gx | d.gw | d.gp | d.gy | d.gr) % 4 != 0)) return EGR_EINVAL;  // keep 16-byte alignment per group
+    if (d.groups > 65535) return EGR_EINVAL;
     int64_t M64 = (int64_t)d.n * d.ho * d.wo;
     if (M64 >= (1LL << 31)) return EGR_EINVAL;
     // 32-bit offsets inside the kernel: bound the furthest element each operand can touch
@@ -477,21 +498,21 @@ extern "C" int egr_conv2d_nhwc_f32(const egr_conv_desc* dd, const float* x, cons
     const int bm = kBM[cfg], bn = kBN[cfg];
 
     // ---- split-K: auto (0) fills the chip for skinny GEMMs with long K
-    int blocks = ((a.M + bm - 1) / bm) * ((a.Npad + bn - 1) / bn);
+    int blocks = ((a.M + bm - 1) / bm) * ((a.Npad + bn - 1) / bn) * d.groups;
     if (d.split_k <= 0) {
         d.split_k = 1;
         if (blocks < 128 && a.ktiles >= 32 && workspace) {
             int s = 256 / blocks;
             if (s > a.ktiles / 8) s = a.ktiles / 8;
             if (s > 32) s = 32;
-            while (s > 1 && (size_t)s * a.M * a.Npad > workspace_floats) --s;
+            while (s > 1 && (size_t)s * a.M * a.Npad * d.groups > workspace_floats) --s;
             if (s > 1) d.split_k = s;
         }
     }
     if (d.split_k > a.ktiles) d.split_k = a.ktiles;
     if (d.split_k > 1) {
         if (!workspace) return EGR_ENULL;
-        if ((size_t)d.split_k * a.M * a.Npad > workspace_floats) return EGR_EWORKSPACE;
+        if ((size_t)d.split_k * a.M * a.Npad * d.groups > workspace_floats) return EGR_EWORKSPACE;
         if ((uintptr_t)workspace & 15) return EGR_EINVAL;
     }
     a.ktiles_per_split = (a.ktiles + d.split_k - 1) / d.split_k;
@@ -509,7 +530,7 @@ extern "C" int egr_conv2d_nhwc_f32(const egr_conv_desc* dd, const float* x, cons
     if (rc) return rc;
     if (d.split_k > 1) {
         int64_t total = (int64_t)a.M * d.cout;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)d.groups), dim3(256), 0, s, a);
         rc = egr_launch_status();
     }
     return rc;

@@ -83,11 +83,16 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const float* x, float* y, 
 // ------------------------------------------------------------------ LayerNorm (+ residual), one wave per row
 template <int VPL>  // values per lane = c / 64
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* res, const float* gamma,
-                                                        const float* beta, float* y, int rows, float eps) {
+                                                        const float* beta, float* y, int rows, float eps, int rpg) {
     const int c = VPL * 64;
     int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     if (row >= rows) return;
+    if (rpg > 0) {  // grouped: per-group affine parameters
+        int g = row / rpg;
+        gamma += g * c;
+        beta += g * c;
+    }
     float v[VPL];
     float s = 0.f;
 #pragma unroll
@@ -155,10 +160,15 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* hm, int rows, 
 
 // ------------------------------------------------------------------ tiny dense layer, K not a multiple of 32
 __global__ __launch_bounds__(256) void linear_smallk_kernel(const float* x, int64_t sxm, int64_t sxk, const float* w,
-                                                            const float* bias, float* y, int m, int n, int k, int act) {
+                                                            const float* bias, float* y, int m, int n, int k, int act, int rpg) {
     int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (int64_t)m * n) return;
     int row = (int)(idx / n), col = (int)(idx % n);
+    if (rpg > 0) {
+        int g = row / rpg;
+        w += (int64_t)g * n * k;
+        if (bias) bias += g * n;
+    }
     float s = 0.f;
     for (int i = 0; i < k; ++i) s = fmaf(x[row * sxm + i * sxk], w[(int64_t)col * k + i], s);
     if (bias) s += bias[col];
@@ -166,12 +176,13 @@ __global__ __launch_bounds__(256) void linear_smallk_kernel(const float* x, int6
 }
 
 __global__ __launch_bounds__(256) void jqa_sum_kernel(const float* hm_embed, const float* embed, const float* bfb, float* y,
-                                                      int b, int j, int c) {
+                                                      int b, int j, int c, int bpg) {
     int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (int64_t)b * j * c) return;
     int ch = (int)(idx % c);
     int64_t r = idx / c;
     int jj = (int)(r % j), bb = (int)(r / j);
+    if (bpg > 0) embed += (int64_t)(bb / bpg) * j * c;
     // (joint_query_embed + bfb) + heatmap_embed, the reference's association order
     y[idx] = (embed[jj * c + ch] + bfb[(int64_t)bb * c + ch]) + hm_embed[idx];
 }
@@ -219,17 +230,17 @@ extern "C" int egr_avgpool_nhwc_f32(const float* x, float* y, int32_t n, int32_t
 }
 
 extern "C" int egr_layernorm_f32(const float* x, const float* res, const float* gamma, const float* beta, float* y,
-                                 int32_t rows, int32_t c, float eps, void* stream) {
+                                 int32_t rows, int32_t c, float eps, int32_t rows_per_group, void* stream) {
     if (!x || !gamma || !beta || !y) return EGR_ENULL;
     if (rows <= 0) return EGR_EINVAL;
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
     switch (c) {
-        case 64: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, res, gamma, beta, y, rows, eps); break;
-        case 128: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, res, gamma, beta, y, rows, eps); break;
-        case 256: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, res, gamma, beta, y, rows, eps); break;
-        case 512: hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, x, res, gamma, beta, y, rows, eps); break;
-        case 1024: hipLaunchKernelGGL(layernorm_kernel<16>, grid, block, 0, s, x, res, gamma, beta, y, rows, eps); break;
+        case 64: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, res, gamma, beta, y, rows, eps, rows_per_group); break;
+        case 128: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, res, gamma, beta, y, rows, eps, rows_per_group); break;
+        case 256: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, res, gamma, beta, y, rows, eps, rows_per_group); break;
+        case 512: hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, x, res, gamma, beta, y, rows, eps, rows_per_group); break;
+        case 1024: hipLaunchKernelGGL(layernorm_kernel<16>, grid, block, 0, s, x, res, gamma, beta, y, rows, eps, rows_per_group); break;
         default: return EGR_EINVAL;
     }
     return egr_launch_status();
@@ -245,20 +256,21 @@ extern "C" int egr_argmax_rows_f32(const float* hm, int32_t rows, int32_t hgt, i
 }
 
 extern "C" int egr_linear_smallk_f32(const float* x, int64_t sxm, int64_t sxk, const float* w, const float* bias,
-                                     float* y, int32_t m, int32_t n, int32_t k, int32_t act, void* stream) {
+                                     float* y, int32_t m, int32_t n, int32_t k, int32_t act, int32_t rows_per_group,
+                                     void* stream) {
     if (!x || !w || !y) return EGR_ENULL;
     if (m <= 0 || n <= 0 || k <= 0) return EGR_EINVAL;
     hipLaunchKernelGGL(linear_smallk_kernel, dim3(nblocks((int64_t)m * n)), dim3(256), 0, (hipStream_t)stream, x, sxm, sxk,
-                       w, bias, y, m, n, k, act);
+                       w, bias, y, m, n, k, act, rows_per_group);
     return egr_launch_status();
 }
 
 extern "C" int egr_jqa_sum_f32(const float* hm_embed, const float* embed, const float* bfb, float* y, int32_t b, int32_t j,
-                               int32_t c, void* stream) {
+                               int32_t c, int32_t b_per_group, void* stream) {
     if (!hm_embed || !embed || !bfb || !y) return EGR_ENULL;
     if (b <= 0 || j <= 0 || c <= 0) return EGR_EINVAL;
     hipLaunchKernelGGL(jqa_sum_kernel, dim3(nblocks((int64_t)b * j * c)), dim3(256), 0, (hipStream_t)stream, hm_embed,
-                       embed, bfb, y, b, j, c);
+                       embed, bfb, y, b, j, c, b_per_group);
     return egr_launch_status();
 }
 

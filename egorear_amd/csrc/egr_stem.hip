@@ -25,6 +25,7 @@ struct StemArgs {
     const float* shift;
     float* y;
     int tiles_x, tiles_y;
+    int64_t gx;
 };
 
 __device__ __forceinline__ constexpr int patch_off(int k) {
@@ -40,13 +41,18 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     int bid = blockIdx.x;
+    const int grp = blockIdx.y;  // grouped launch (e.g. the two stereo estimators)
     const int tpi = a.tiles_x * a.tiles_y;
     const int n = bid / tpi;
     int t = bid - n * tpi;
     const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
-    const float* img = a.x + egr_map(a.xmap, n);
+    const float* img = a.x + grp * a.gx + egr_map(a.xmap, n);
+    const float* wpack = a.wpack + grp * 64 * KPAD;
+    const float* scale = a.scale + grp * 64;
+    const float* shift = a.shift + grp * 64;
+    float* y = a.y + (int64_t)grp * a.n * a.ho * a.wo * 64;
 
     for (int i = tid; i < 3 * PH * PW; i += 256) {
         int ci = i / (PH * PW);
@@ -59,7 +65,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
     }
     for (int i = tid; i < 64 * KPAD; i += 256) {
         int co = i / KPAD, k = i - co * KPAD;
-        s_w[co * WS + k] = a.wpack[i];
+        s_w[co * WS + k] = wpack[i];
     }
     __syncthreads();
 
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         int co = j * 32 + l31;
-        float sc = a.scale[co], sh = a.shift[co];
+        float sc = scale[co], sh = shift[co];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             int oy = oy0 + 2 * wave + i;
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
                 int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 float v = acc[i][j][r] * sc + sh;
                 v = v > 0.f ? v : 0.f;
-                a.y[(((int64_t)n * a.ho + oy) * a.wo + ox) * 64 + co] = v;
+                y[(((int64_t)n * a.ho + oy) * a.wo + ox) * 64 + co] = v;
             }
         }
     }
@@ -109,15 +115,18 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
 }  // namespace
 
 extern "C" int egr_stem_conv7x7_f32(const float* x, egr_nmap xmap, int32_t n, int32_t h, int32_t w, const float* wpack,
-                                    const float* scale, const float* shift, float* y, void* stream) {
+                                    const float* scale, const float* shift, float* y, int32_t groups, int64_t gx,
+                                    void* stream) {
     if (!x || !wpack || !scale || !shift || !y) return EGR_ENULL;
+    if (groups <= 0 || groups > 65535) return EGR_EINVAL;
     if (n <= 0 || h <= 0 || w <= 0 || h % (2 * TH) != 0 || w % (2 * TW) != 0 || xmap.n_inner <= 0) return EGR_EINVAL;
     StemArgs a;
     a.x = x; a.xmap = xmap; a.n = n; a.h = h; a.w = w; a.ho = h / 2; a.wo = w / 2;
     a.wpack = wpack; a.scale = scale; a.shift = shift; a.y = y;
     a.tiles_x = a.wo / TW; a.tiles_y = a.ho / TH;
+    a.gx = gx;
     int64_t blocks = (int64_t)n * a.tiles_x * a.tiles_y;
     if (blocks >= (1LL << 31)) return EGR_EINVAL;
-    hipLaunchKernelGGL(stem_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(stem_kernel, dim3((unsigned)blocks, (unsigned)groups), dim3(256), 0, (hipStream_t)stream, a);
     return egr_launch_status();
 }

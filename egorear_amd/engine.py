@@ -9,15 +9,23 @@ exists at the boundary: the stem kernel reads the (B,V,3,H,W) input through an i
 map, the 15-channel heatmap convs write (B,V,15,64,64) planes through one, and feature
 tensors handed back to callers are permuted *views* of the view-major buffers.
 
-Weights are re-packed once per module/device (conv OIHW -> [cout_pad][(kh,kw,ci)],
+Grouped launches: modules that share an architecture but own their weights — the two
+stereo estimators (front/back), the two initial-heatmap stacks, the four per-view
+refiners — run as ONE launch per op with a group index selecting weights and
+activations at uniform strides (view-major layout makes every group a contiguous
+slice).  A forward of the full model is ~120 launches instead of ~330, and small-grid
+layers fill the chip.
+
+Weights are re-packed once per module/device (conv OIHW -> [cout_pad][cin/32][kh*kw][32],
 BatchNorm as per-channel scale/shift applied in the conv epilogue, q/k/v and
 offset/logit projections concatenated, the deformable-attention value path folded for
-the sample-then-project form) and cached; `invalidate(module)` drops the cache.
+the sample-then-project form, group members stacked) and cached; `invalidate(module)`
+drops the cache (load_state_dict does it automatically).
 """
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Optional
+from typing import Dict, Optional, Sequence
 
 import numpy as np
 import torch
@@ -32,16 +40,29 @@ _WORKSPACE_FLOATS = 16 << 20  # split-K partial slabs (64 MB)
 # --------------------------------------------------------------------------- packed parameters
 
 class PConv:
-    __slots__ = ("w", "scale", "shift", "cout", "cin", "kh", "kw", "stride", "pad")
+    """Packed conv / linear weights of `groups` same-shape modules (groups == 1: plain 2-D tensors)."""
+    __slots__ = ("w", "scale", "shift", "cout", "cin", "kh", "kw", "stride", "pad", "groups")
+
+
+def _npad(cout: int) -> int:
+    return (cout + 31) // 32 * 32
 
 
 def _pad_rows(w2d: torch.Tensor) -> torch.Tensor:
     cout = w2d.shape[0]
-    npad = (cout + 31) // 32 * 32
+    npad = _npad(cout)
     if npad == cout:
         return w2d.contiguous()
     out = torch.zeros((npad, w2d.shape[1]), device=w2d.device, dtype=w2d.dtype)
     out[:cout] = w2d
+    return out
+
+
+def _pad_vec(v: Optional[torch.Tensor], cout: int) -> Optional[torch.Tensor]:
+    if v is None:
+        return None
+    out = torch.zeros(_npad(cout), device=v.device, dtype=torch.float32)
+    out[:cout] = v.float()
     return out
 
 
@@ -51,37 +72,54 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
     return w.float().permute(0, 2, 3, 1).reshape(co, kh * kw, ci // 32, 32).permute(0, 2, 1, 3).reshape(co, -1).contiguous()
 
 
-def pack_conv(conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d] = None) -> PConv:
+def _bn_affine(bn: nn.BatchNorm2d, bias: Optional[torch.Tensor]):
+    scale = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+    shift = bn.bias.detach().double() - bn.running_mean.detach().double() * scale
+    if bias is not None:
+        shift = shift + bias.detach().double() * scale
+    return scale.float(), shift.float()
+
+
+def _stack(ts: Sequence[Optional[torch.Tensor]]) -> Optional[torch.Tensor]:
+    if ts[0] is None:
+        return None
+    return (torch.stack(list(ts), 0) if len(ts) > 1 else ts[0]).contiguous()
+
+
+def pack_convs(convs: Sequence[nn.Conv2d], bns: Optional[Sequence[nn.BatchNorm2d]] = None) -> PConv:
     p = PConv()
-    w = conv.weight.detach()
-    p.cout, p.cin, p.kh, p.kw = w.shape
-    p.stride, p.pad = conv.stride[0], conv.padding[0]
-    p.w = _pad_rows(pack_conv_weight(w))
-    bias = conv.bias.detach().float() if conv.bias is not None else None
-    if bn is not None:
-        scale = (bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps))
-        shift = bn.bias.detach().double() - bn.running_mean.detach().double() * scale
-        if bias is not None:
-            shift = shift + bias.double() * scale
-        p.scale, p.shift = scale.float().contiguous(), shift.float().contiguous()
-    else:
-        p.scale, p.shift = None, (bias.contiguous() if bias is not None else None)
+    c0 = convs[0]
+    p.cout, p.cin, p.kh, p.kw = c0.weight.shape
+    p.stride, p.pad, p.groups = c0.stride[0], c0.padding[0], len(convs)
+    ws, scs, shs = [], [], []
+    for i, c in enumerate(convs):
+        ws.append(_pad_rows(pack_conv_weight(c.weight.detach())))
+        if bns is not None:
+            sc, sh = _bn_affine(bns[i], c.bias)
+            scs.append(_pad_vec(sc, p.cout))
+            shs.append(_pad_vec(sh, p.cout))
+        else:
+            scs.append(None)
+            shs.append(_pad_vec(c.bias.detach(), p.cout) if c.bias is not None else None)
+    p.w, p.scale, p.shift = _stack(ws), _stack(scs), _stack(shs)
     return p
 
 
-def pack_linear_w(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> PConv:
+def pack_linears(pairs: Sequence) -> PConv:
+    """pairs: (weight (N,K), bias (N,) | None) per group member."""
     p = PConv()
-    w = weight.detach().float()
-    p.cout, p.cin = w.shape
+    w0 = pairs[0][0]
+    p.cout, p.cin = w0.shape
     p.kh = p.kw = p.stride = 1
-    p.pad = 0
-    p.w = _pad_rows(w)
-    p.scale, p.shift = None, (bias.detach().float().contiguous() if bias is not None else None)
+    p.pad, p.groups = 0, len(pairs)
+    p.w = _stack([_pad_rows(w.detach().float()) for w, _ in pairs])
+    p.scale = None
+    p.shift = _stack([_pad_vec(b.detach(), p.cout) if b is not None else None for _, b in pairs])
     return p
 
 
-def pack_linear(lin: nn.Linear) -> PConv:
-    return pack_linear_w(lin.weight, lin.bias)
+def pack_linear_mods(lins: Sequence[nn.Linear]) -> PConv:
+    return pack_linears([(l.weight, l.bias) for l in lins])
 
 
 def _rows(t: torch.Tensor) -> Img:
@@ -95,11 +133,11 @@ class State:
 
     def __init__(self, device):
         self.device = device
-        self.packs: Dict[int, object] = {}
+        self.packs: Dict[object, object] = {}
         self.workspace = torch.empty(_WORKSPACE_FLOATS, device=device, dtype=torch.float32)
 
     def get(self, key, builder):
-        k = id(key) if not isinstance(key, (str, tuple)) else key
+        k = key if isinstance(key, (str, tuple)) else id(key)
         v = self.packs.get(k)
         if v is None:
             with torch.no_grad():
@@ -136,28 +174,31 @@ def _check_input(img: torch.Tensor, mod: nn.Module):
 # --------------------------------------------------------------------------- generic steps
 
 def conv(st: State, x: Img, p: PConv, act=ACT_NONE, **kw) -> Optional[Img]:
+    """x / out / res hold the images of all p.groups groups back to back (see hip.conv2d)."""
     return hip.conv2d(x, p.w, p.cout, p.kh, p.kw, p.stride, p.pad, scale=p.scale, shift=p.shift, act=act,
-                      workspace=st.workspace, split_k=kw.pop("split_k", 0), **kw)
+                      workspace=st.workspace, split_k=kw.pop("split_k", 0), groups=p.groups, **kw)
 
 
 def linear(st: State, x: torch.Tensor, p: PConv, act=ACT_NONE, **kw) -> torch.Tensor:
+    """x (groups*rows, cin) -> (groups*rows, cout)."""
     out = conv(st, _rows(x), p, act, **kw)
     return out.t.view(x.shape[0], p.cout)
 
 
-def run_stack(st: State, seq: nn.Sequential, x: Img, out: Optional[Img] = None, last_kw: Optional[dict] = None) -> Optional[Img]:
-    """Execute a tree.stack(): Conv2d(+ReLU) fuse into one launch; Upsample / MaxPool2d are their own kernels.
-    `out` / `last_kw` apply to the final conv."""
-    mods = list(seq)
+def run_stack(st: State, seqs: Sequence[nn.Sequential], x: Img, out: Optional[Img] = None,
+              last_kw: Optional[dict] = None) -> Optional[Img]:
+    """Execute tree.stack()s (one per group, identical structure): Conv2d(+ReLU) fuse into one launch; Upsample /
+    MaxPool2d are their own kernels (no weights: they simply run over all groups' images).  `out` / `last_kw`
+    apply to the final op."""
+    mods = [list(s) for s in seqs]
+    m0 = mods[0]
     i = 0
-    while i < len(mods):
-        m = mods[i]
+    while i < len(m0):
+        m = m0[i]
         if isinstance(m, nn.Conv2d):
-            act = ACT_NONE
-            if i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
-                act = ACT_RELU
-            last = (i + (2 if act else 1)) >= len(mods)
-            p = st.get(m, lambda m=m: pack_conv(m))
+            act = ACT_RELU if (i + 1 < len(m0) and isinstance(m0[i + 1], nn.ReLU)) else ACT_NONE
+            last = (i + (2 if act else 1)) >= len(m0)
+            p = st.get(m, lambda i=i: pack_convs([g[i] for g in mods]))
             kw = dict(last_kw or {}) if last else {}
             if last and out is not None:
                 kw["out"] = out
@@ -166,12 +207,12 @@ def run_stack(st: State, seq: nn.Sequential, x: Img, out: Optional[Img] = None, 
         elif isinstance(m, nn.Upsample):
             # Upsample -> Conv2d(1x1) -> ReLU is evaluated as Conv2d(1x1) -> Upsample(+ReLU): the bias-carrying
             # 1x1 conv commutes with bilinear interpolation, and runs on a quarter of the pixels this way.
-            nxt = mods[i + 1] if i + 1 < len(mods) else None
-            if (isinstance(nxt, nn.Conv2d) and nxt.kernel_size == (1, 1) and nxt.stride == (1, 1) and i + 2 < len(mods)
-                    and isinstance(mods[i + 2], nn.ReLU)):
-                p = st.get(nxt, lambda m=nxt: pack_conv(m))
+            nxt = m0[i + 1] if i + 1 < len(m0) else None
+            if (isinstance(nxt, nn.Conv2d) and nxt.kernel_size == (1, 1) and nxt.stride == (1, 1) and i + 2 < len(m0)
+                    and isinstance(m0[i + 2], nn.ReLU)):
+                p = st.get(nxt, lambda i=i: pack_convs([g[i + 1] for g in mods]))
                 lo = conv(st, x, p, ACT_NONE)
-                last = (i + 3) >= len(mods)
+                last = (i + 3) >= len(m0)
                 x = hip.upsample2x(lo, out=out if last else None, relu=True)
                 i += 3
             else:
@@ -190,53 +231,62 @@ def run_stack(st: State, seq: nn.Sequential, x: Img, out: Optional[Img] = None, 
 
 # --------------------------------------------------------------------------- backbone (a1-a3)
 
-def _pack_stem(conv1: nn.Conv2d, bn: nn.BatchNorm2d):
-    w = conv1.weight.detach().float().reshape(64, 147)
-    wp = torch.zeros((64, 148), device=w.device, dtype=torch.float32)
-    wp[:, :147] = w
-    scale = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
-    shift = bn.bias.detach().double() - bn.running_mean.detach().double() * scale
-    return wp.contiguous(), scale.float().contiguous(), shift.float().contiguous()
+def _pack_stems(trunks) -> tuple:
+    wps, scs, shs = [], [], []
+    for t in trunks:
+        conv1, bn = t.layer_s2[0], t.layer_s2[1]
+        w = conv1.weight.detach().float().reshape(64, 147)
+        wp = torch.zeros((64, 148), device=w.device, dtype=torch.float32)
+        wp[:, :147] = w
+        sc, sh = _bn_affine(bn, None)
+        wps.append(wp)
+        scs.append(sc)
+        shs.append(sh)
+    return torch.stack(wps).contiguous(), torch.stack(scs).contiguous(), torch.stack(shs).contiguous()
 
 
-def _basic_block(st: State, blk, x: Img, out: Optional[Img] = None) -> Img:
+def _basic_block(st: State, blks, x: Img, out: Optional[Img] = None) -> Img:
+    b0 = blks[0]
     identity = x
-    if blk.downsample is not None:
-        pd = st.get(blk.downsample, lambda: pack_conv(blk.downsample[0], blk.downsample[1]))
+    if b0.downsample is not None:
+        pd = st.get(b0.downsample, lambda: pack_convs([b.downsample[0] for b in blks], [b.downsample[1] for b in blks]))
         identity = conv(st, x, pd, ACT_NONE)
-    p1 = st.get(blk.conv1, lambda: pack_conv(blk.conv1, blk.bn1))
-    p2 = st.get(blk.conv2, lambda: pack_conv(blk.conv2, blk.bn2))
+    p1 = st.get(b0.conv1, lambda: pack_convs([b.conv1 for b in blks], [b.bn1 for b in blks]))
+    p2 = st.get(b0.conv2, lambda: pack_convs([b.conv2 for b in blks], [b.bn2 for b in blks]))
     y = conv(st, x, p1, ACT_RELU)
     return conv(st, y, p2, ACT_RELU, res=identity, res_mode=RES_BEFORE_ACT, out=out)
 
 
-def run_backbone(st: State, enc, img: torch.Tensor, view0: int, nviews: int, feat_out: Img, s32_out: Optional[Img] = None):
-    """ResNet-18 trunk + FPN for views [view0, view0+nviews) (resnet.py:43-74,121-137).
-    Writes the stride-4 feature into `feat_out` (nviews*B, 64, 64, 128) and, if given, the stride-32 feature
-    into `s32_out`; returns the pyramid [s4, s8, s16, s32]."""
-    trunk, neck = enc.backbone, enc.neck
-    wp, sc, sh = st.get(trunk.layer_s2, lambda: _pack_stem(trunk.layer_s2[0], trunk.layer_s2[1]))
-    x = hip.stem(img, view0, nviews, wp, sc, sh)
+def run_backbone(st: State, encs, img: torch.Tensor, view0: int, nviews: int, feat_out: Img, s32_out: Optional[Img] = None):
+    """ResNet-18 trunk + FPN (resnet.py:43-74,121-137) of len(encs) encoders in grouped launches: encoder g processes
+    views [view0 + g*nviews, view0 + (g+1)*nviews).  Writes the stride-4 features into `feat_out`
+    (G*nviews*B, 64, 64, 128) and, if given, the stride-32 features into `s32_out`; returns the pyramid [s4..s32]."""
+    G = len(encs)
+    trunks, necks = [e.backbone for e in encs], [e.neck for e in encs]
+    t0, n0 = trunks[0], necks[0]
+    wp, sc, sh = st.get(t0.layer_s2, lambda: _pack_stems(trunks))
+    x = hip.stem(img, view0, nviews, wp, sc, sh, groups=G)
     x = hip.maxpool(x, 3, 2, 1)
     pyramid = []
-    stages = (trunk.layer_s4[1], trunk.layer_s8, trunk.layer_s16, trunk.layer_s32)
-    for si, stage in enumerate(stages):
-        for bi, blk in enumerate(stage):
-            last = si == len(stages) - 1 and bi == len(stage) - 1
-            x = _basic_block(st, blk, x, out=s32_out if last else None)
+    stages = [(t.layer_s4[1], t.layer_s8, t.layer_s16, t.layer_s32) for t in trunks]
+    for si in range(4):
+        nblk = len(stages[0][si])
+        for bi in range(nblk):
+            last = si == 3 and bi == nblk - 1
+            x = _basic_block(st, [stages[g][si][bi] for g in range(G)], x, out=s32_out if last else None)
         pyramid.append(x)
     # FPN top-down: lateral conv writes the left half of a 256-wide buffer, the x2 upsample the right half
     n = x.n
-    lat = conv(st, pyramid[3], st.get(neck.lateral_convs[3], lambda: pack_conv(neck.lateral_convs[3][0])), ACT_RELU)
+    c = n0.out_channels
+    lat = conv(st, pyramid[3], st.get(n0.lateral_convs[3], lambda: pack_convs([k.lateral_convs[3][0] for k in necks])), ACT_RELU)
     for i in (3, 2, 1):
         lo = pyramid[i - 1]
-        cat = torch.empty((n, lo.h, lo.w, 2 * neck.out_channels), device=img.device, dtype=torch.float32)
-        c = neck.out_channels
-        conv(st, lo, st.get(neck.lateral_convs[i - 1], lambda i=i: pack_conv(neck.lateral_convs[i - 1][0])), ACT_RELU,
+        cat = torch.empty((n, lo.h, lo.w, 2 * c), device=img.device, dtype=torch.float32)
+        conv(st, lo, st.get(n0.lateral_convs[i - 1], lambda i=i: pack_convs([k.lateral_convs[i - 1][0] for k in necks])), ACT_RELU,
              out=Img(cat[..., :c]))
         hip.upsample2x(lat, out=Img(cat[..., c:]))
-        fused = conv(st, Img(cat), st.get(neck.fuse_convs[i - 1], lambda i=i: pack_conv(neck.fuse_convs[i - 1][0])), ACT_RELU)
-        lat = conv(st, fused, st.get(neck.fpn_convs[i - 1], lambda i=i: pack_conv(neck.fpn_convs[i - 1][0])), ACT_RELU,
+        fused = conv(st, Img(cat), st.get(n0.fuse_convs[i - 1], lambda i=i: pack_convs([k.fuse_convs[i - 1][0] for k in necks])), ACT_RELU)
+        lat = conv(st, fused, st.get(n0.fpn_convs[i - 1], lambda i=i: pack_convs([k.fpn_convs[i - 1][0] for k in necks])), ACT_RELU,
                    out=feat_out if i == 1 else None)
     return pyramid
 
@@ -249,27 +299,31 @@ def _vb_view(t: torch.Tensor, V: int, B: int) -> torch.Tensor:
 
 # --------------------------------------------------------------------------- EgoPoseFormerHeatmap API
 
-def heatmap_backbone_api(mod, img):
-    _check_input(img, mod)
+def _heatmap_core(mod, img):
     st = _state(mod, img.device)
     B, V = img.shape[:2]
-    feat = torch.empty((V * B, img.shape[3] // 4, img.shape[4] // 4, mod.encoder.neck.out_channels), device=img.device,
-                       dtype=torch.float32)
-    pyr = run_backbone(st, mod.encoder, img.contiguous(), 0, V, Img(feat))
+    H4, W4 = img.shape[3] // 4, img.shape[4] // 4
+    feat = torch.empty((V * B, H4, W4, mod.encoder.neck.out_channels), device=img.device, dtype=torch.float32)
+    pyr = run_backbone(st, [mod.encoder], img.contiguous(), 0, V, Img(feat))
+    return st, feat, pyr
+
+
+def heatmap_backbone_api(mod, img):
+    _check_input(img, mod)
+    B, V = img.shape[:2]
+    _, feat, pyr = _heatmap_core(mod, img)
     return _vb_view(feat, V, B), [_vb_view(p.t, V, B) for p in pyr]
 
 
 def heatmap_forward_api(mod, img, return_feat=False):
     """EgoPoseFormerHeatmap.forward (egoposeformer_heatmap.py:29-44)."""
     _check_input(img, mod)
-    st = _state(mod, img.device)
     B, V = img.shape[:2]
-    H4, W4 = img.shape[3] // 4, img.shape[4] // 4
-    feat = torch.empty((V * B, H4, W4, mod.encoder.neck.out_channels), device=img.device, dtype=torch.float32)
-    pyr = run_backbone(st, mod.encoder, img.contiguous(), 0, V, Img(feat))
+    st, feat, pyr = _heatmap_core(mod, img)
+    H4, W4 = feat.shape[1:3]
     hm = torch.empty((B, V, mod.num_heatmap, H4, W4), device=img.device, dtype=torch.float32)
     plane = mod.num_heatmap * H4 * W4
-    conv(st, Img(feat), st.get(mod.conv_heatmap, lambda: pack_conv(mod.conv_heatmap)), ACT_NONE, out_nchw=hm,
+    conv(st, Img(feat), st.get(mod.conv_heatmap, lambda: pack_convs([mod.conv_heatmap])), ACT_NONE, out_nchw=hm,
          ymap=NMap(B, V * plane, plane))
     if return_feat:
         return hm, _vb_view(feat, V, B), [_vb_view(p.t, V, B) for p in pyr]
@@ -280,128 +334,145 @@ def heatmap_forward_api(mod, img, return_feat=False):
 
 class PLayer:
     __slots__ = ("offs_logits", "head_w", "head_shift", "pos_proj", "out_proj", "fuse", "ln_cross", "qkv", "mha_out",
-                 "ln_spatial", "ffn0", "ffn1", "ln_ffn", "heads", "dh", "C")
+                 "ln_spatial", "ffn0", "ffn1", "ln_ffn", "heads", "dh", "C", "groups")
 
 
-def pack_layer(layer, pre_w: torch.Tensor, pre_b: torch.Tensor, pos: Optional[torch.Tensor]) -> PLayer:
-    """Fold the linear chain in front of the sampling so that sampling can come first:
+def pack_layers(layers, pres, poss) -> PLayer:
+    """Pack `len(layers)` same-shape transformer layers as one group.  Per layer, fold the linear chain in front of the
+    sampling so that sampling can come first:
         value = W_v (W_pre f + b_pre [+ pos]) + b_v
       sampled & weighted:  W_v W_pre g + (W_v b_pre + b_v) sigma + W_v e
     (g, e, sigma from egr_msda_gather_f32).  W_pre/b_pre is the 1x1 conv in front of the attention
     (frame_feat_multi_view_proj for MVFEx, feat_proj for the lifting head).  Folded in fp64, stored fp32."""
-    ca = layer.cross_attn
     P = PLayer()
-    P.heads, P.C = ca.n_heads, ca.d_model
+    ca0 = layers[0].cross_attn
+    P.heads, P.C, P.groups = ca0.n_heads, ca0.d_model, len(layers)
     P.dh = P.C // P.heads
-    dev = ca.value_proj.weight.device
-    Wv, bv = ca.value_proj.weight.detach().double(), ca.value_proj.bias.detach().double()
-    Wp, bp = pre_w.detach().double().reshape(pre_w.shape[0], -1), pre_b.detach().double()
-    Wfold = (Wv @ Wp).float()                      # (C, cf)
-    cfold = (Wv @ bp + bv).float()                 # (C,)
-    P.head_w = [_pad_rows(Wfold[h * P.dh:(h + 1) * P.dh].contiguous()) for h in range(P.heads)]
-    P.head_shift = [cfold[h * P.dh:(h + 1) * P.dh].contiguous() for h in range(P.heads)]
-    P.pos_proj = None
-    if pos is not None:  # (1, V, HW, C) -> (V, HW, C) projected by W_v
-        pp = pos.detach()[0].double() @ Wv.t()
-        P.pos_proj = pp.float().contiguous()
-    ol_w = torch.cat([ca.sampling_offsets.weight.detach(), ca.attention_weights.weight.detach()], 0)
-    ol_b = torch.cat([ca.sampling_offsets.bias.detach(), ca.attention_weights.bias.detach()], 0)
-    P.offs_logits = pack_linear_w(ol_w, ol_b)
-    P.out_proj = pack_linear(ca.output_proj)
-    P.fuse = pack_linear(layer.fuse_mlp)
-    sa = layer.spatial_attn
-    P.qkv = pack_linear_w(torch.cat([sa.q_proj.weight.detach(), sa.k_proj.weight.detach(), sa.v_proj.weight.detach()], 0),
-                          torch.cat([sa.q_proj.bias.detach(), sa.k_proj.bias.detach(), sa.v_proj.bias.detach()], 0))
-    P.mha_out = pack_linear(sa.out_proj)
-    P.ffn0 = pack_linear(layer.ffn.layers[0][0])
-    P.ffn1 = pack_linear(layer.ffn.layers[1])
-    f32 = lambda t: t.detach().float().contiguous()
-    P.ln_cross = (f32(layer.norm_cross.weight), f32(layer.norm_cross.bias))
-    P.ln_spatial = (f32(layer.norm_spatial.weight), f32(layer.norm_spatial.bias))
-    P.ln_ffn = (f32(layer.norm_ffn.weight), f32(layer.norm_ffn.bias))
-    assert dev == P.head_w[0].device
+    head_w = [[] for _ in range(P.heads)]
+    head_shift = [[] for _ in range(P.heads)]
+    pos_proj = []
+    for layer, (pre_w, pre_b), pos in zip(layers, pres, poss):
+        ca = layer.cross_attn
+        Wv, bv = ca.value_proj.weight.detach().double(), ca.value_proj.bias.detach().double()
+        Wp, bp = pre_w.detach().double().reshape(pre_w.shape[0], -1), pre_b.detach().double()
+        Wfold = (Wv @ Wp).float()                      # (C, cf)
+        cfold = (Wv @ bp + bv).float()                 # (C,)
+        for h in range(P.heads):
+            head_w[h].append(_pad_rows(Wfold[h * P.dh:(h + 1) * P.dh].contiguous()))
+            head_shift[h].append(_pad_vec(cfold[h * P.dh:(h + 1) * P.dh], P.dh))
+        if pos is not None:                            # (1, V, HW, C) -> (V, HW, C) projected by W_v
+            pos_proj.append((pos.detach()[0].double() @ Wv.t()).float())
+    P.head_w = [_stack(w) for w in head_w]
+    P.head_shift = [_stack(s) for s in head_shift]
+    P.pos_proj = torch.stack(pos_proj).contiguous() if pos_proj else None
+    cas = [l.cross_attn for l in layers]
+    P.offs_logits = pack_linears([(torch.cat([c.sampling_offsets.weight.detach(), c.attention_weights.weight.detach()], 0),
+                                   torch.cat([c.sampling_offsets.bias.detach(), c.attention_weights.bias.detach()], 0)) for c in cas])
+    P.out_proj = pack_linear_mods([c.output_proj for c in cas])
+    P.fuse = pack_linear_mods([l.fuse_mlp for l in layers])
+    sas = [l.spatial_attn for l in layers]
+    P.qkv = pack_linears([(torch.cat([s.q_proj.weight.detach(), s.k_proj.weight.detach(), s.v_proj.weight.detach()], 0),
+                           torch.cat([s.q_proj.bias.detach(), s.k_proj.bias.detach(), s.v_proj.bias.detach()], 0)) for s in sas])
+    P.mha_out = pack_linear_mods([s.out_proj for s in sas])
+    P.ffn0 = pack_linear_mods([l.ffn.layers[0][0] for l in layers])
+    P.ffn1 = pack_linear_mods([l.ffn.layers[1] for l in layers])
+
+    def ln(name):
+        return (torch.cat([getattr(l, name).weight.detach().float() for l in layers]).contiguous(),
+                torch.cat([getattr(l, name).bias.detach().float() for l in layers]).contiguous())
+    P.ln_cross, P.ln_spatial, P.ln_ffn = ln("norm_cross"), ln("norm_spatial"), ln("norm_ffn")
     return P
 
 
 def run_layer(st: State, P: PLayer, x: torch.Tensor, memory: torch.Tensor, anchors: torch.Tensor, valid: torch.Tensor,
               B: int, V: int, J: int, hgt: int, wid: int) -> torch.Tensor:
     """One MultiViewTransformerLayer / EgoPoseFormerTransformerLayer (heatmap_mvf_ex.py:874-935,
-    egoposeformer_mvf_ex.py:546-588).  x (B*J, C); memory (V, B, hgt*wid, cf) *un-projected* features."""
-    C, heads, dh = P.C, P.heads, P.dh
-    ol = linear(st, x, P.offs_logits)                                   # (B*J, heads*16*3); shared by all views
-    g, e, sigma, rowmask = hip.msda_gather(memory, P.pos_proj, ol, anchors, valid, B, V, J, heads, dh, hgt, wid)
+    egoposeformer_mvf_ex.py:546-588) for P.groups query sets at once.  x (G*B*J, C); memory (V, B, hgt*wid, cf)
+    *un-projected* features shared by all groups; anchors / valid shared."""
+    G, C, heads, dh = P.groups, P.C, P.heads, P.dh
+    ol = linear(st, x, P.offs_logits)                                   # (G*B*J, heads*16*3); shared by all views
+    g, e, sigma, rowmask = hip.msda_gather(memory, P.pos_proj, ol, anchors, valid, B, V, J, heads, dh, hgt, wid, groups=G)
     rows = B * J * V
     cf = g.shape[-1]
-    a = torch.empty((rows, C), device=x.device, dtype=torch.float32)
-    g2 = g.view(rows, heads * cf)
-    for h in range(heads):                                              # per-head folded value projection
-        hip.conv2d(_rows(g2[:, h * cf:(h + 1) * cf]), P.head_w[h], dh, 1, 1, 1, 0, shift=P.head_shift[h],
-                   rowscale=sigma[h], res=_rows(e[:, h * dh:(h + 1) * dh]) if e is not None else None,
-                   res_mode=RES_AFTER_ACT if e is not None else RES_NONE, out=_rows(a[:, h * dh:(h + 1) * dh]),
-                   workspace=None, split_k=1)
-    o = linear(st, a, P.out_proj, rowmask=rowmask)                      # masked_fill(~valid) after output_proj
-    f = linear(st, o.view(B * J, V * C), P.fuse)                        # cat over views is the row layout already
-    x = hip.layernorm(f, P.ln_cross[0], P.ln_cross[1], res=x)
+    a = torch.empty((G * rows, C), device=x.device, dtype=torch.float32)
+    g2 = g.view(G * rows, heads * cf)
+    e2 = e.view(G * rows, C) if e is not None else None
+    sig = sigma.view(G * heads * rows)
+    for h in range(heads):                                              # per-head folded value projection, all groups
+        hip.conv2d(_rows(g2[:rows, h * cf:(h + 1) * cf]), P.head_w[h], dh, 1, 1, 1, 0, shift=P.head_shift[h],
+                   rowscale=sig[h * rows:], grs=heads * rows,
+                   res=_rows(e2[:rows, h * dh:(h + 1) * dh]) if e2 is not None else None,
+                   res_mode=RES_AFTER_ACT if e2 is not None else RES_NONE,
+                   out=_rows(a[:rows, h * dh:(h + 1) * dh]), workspace=None, split_k=1,
+                   groups=G, gx=rows * heads * cf, gr=rows * C, gy=rows * C)
+    o = linear(st, a, P.out_proj, rowmask=rowmask, grm=0)               # masked_fill(~valid) after output_proj
+    f = linear(st, o.view(G * B * J, V * C), P.fuse)                    # cat over views is the row layout already
+    x = hip.layernorm(f, P.ln_cross[0], P.ln_cross[1], res=x, groups=G)
     qkv = linear(st, x, P.qkv)
-    att = hip.joint_mha(qkv, B, J, heads, dh, dh ** -0.5)
-    x = hip.layernorm(linear(st, att, P.mha_out), P.ln_spatial[0], P.ln_spatial[1], res=x)
+    att = hip.joint_mha(qkv, G * B, J, heads, dh, dh ** -0.5)
+    x = hip.layernorm(linear(st, att, P.mha_out), P.ln_spatial[0], P.ln_spatial[1], res=x, groups=G)
     h1 = linear(st, x, P.ffn0, ACT_GELU)
-    x = hip.layernorm(linear(st, h1, P.ffn1), P.ln_ffn[0], P.ln_ffn[1], res=x)
+    x = hip.layernorm(linear(st, h1, P.ffn1), P.ln_ffn[0], P.ln_ffn[1], res=x, groups=G)
     return x
 
 
 # --------------------------------------------------------------------------- EgoPoseFormerHeatmapMVFEX (a5-a18)
 
-class PRefiner:
+class PRefiners:
     __slots__ = ("hp0", "hp2", "fc_bfb", "fc_query", "embed", "layer", "post_norm", "head0_w", "head0_b", "head3")
 
 
-def _pack_refiner(r) -> PRefiner:
-    P = PRefiner()
-    P.hp0, P.hp2 = pack_linear(r.heatmap_proj[0]), pack_linear(r.heatmap_proj[2])
-    P.fc_bfb, P.fc_query = pack_linear(r.fc_bfb), pack_linear(r.fc_query[0])
-    P.embed = r.joint_query_embed.weight.detach().float().contiguous()
-    mv = r.frame_feat_multi_view_proj
-    P.layer = pack_layer(r.transformer_layers[0], mv.weight, mv.bias, r.frame_feat_multi_view_pos_embed)
-    P.post_norm = (r.post_norm[0].weight.detach().float().contiguous(), r.post_norm[0].bias.detach().float().contiguous())
-    head = r.head_layers[0].head
-    P.head0_w = head[0].weight.detach().float().reshape(head[0].weight.shape[0], -1).contiguous()   # (64, 15)
-    P.head0_b = head[0].bias.detach().float().contiguous()
-    P.head3 = pack_conv(head[3])
+def _pack_refiners(rs) -> PRefiners:
+    P = PRefiners()
+    P.hp0 = pack_linear_mods([r.heatmap_proj[0] for r in rs])
+    P.hp2 = pack_linear_mods([r.heatmap_proj[2] for r in rs])
+    P.fc_bfb = pack_linear_mods([r.fc_bfb for r in rs])
+    P.fc_query = pack_linear_mods([r.fc_query[0] for r in rs])
+    P.embed = torch.stack([r.joint_query_embed.weight.detach().float() for r in rs]).contiguous()
+    P.layer = pack_layers([r.transformer_layers[0] for r in rs],
+                          [(r.frame_feat_multi_view_proj.weight, r.frame_feat_multi_view_proj.bias) for r in rs],
+                          [r.frame_feat_multi_view_pos_embed for r in rs])
+    P.post_norm = (torch.cat([r.post_norm[0].weight.detach().float() for r in rs]).contiguous(),
+                   torch.cat([r.post_norm[0].bias.detach().float() for r in rs]).contiguous())
+    P.head0_w = torch.stack([r.head_layers[0].head[0].weight.detach().float().reshape(r.head_layers[0].head[0].weight.shape[0], -1)
+                             for r in rs]).contiguous()                                   # (G, 64, 15)
+    P.head0_b = torch.stack([r.head_layers[0].head[0].bias.detach().float() for r in rs]).contiguous()
+    P.head3 = pack_convs([r.head_layers[0].head[3] for r in rs])
     return P
 
 
-def _run_refiner(st: State, r, v: int, B: int, V: int, hm_init: torch.Tensor, feat_all: torch.Tensor, s32_all: torch.Tensor,
-                 anchors, valid, feat_refined_out: Img, hm_refined: torch.Tensor):
-    """HeatmapMVF.forward for view v (heatmap_mvf_ex.py:652-731)."""
-    P: PRefiner = st.get(r, lambda: _pack_refiner(r))
-    J, C = r.num_heatmap, r.embed_dims
-    hgt, wid = r.feat_shape
+def _run_refiners(st: State, rs, B: int, V: int, hm_init: torch.Tensor, feat_all: torch.Tensor, s32_all: torch.Tensor,
+                  anchors, valid, feat_ref: torch.Tensor, hm_ref: torch.Tensor):
+    """The four HeatmapMVF refiners (heatmap_mvf_ex.py:652-731), refiner g = view g, as one group of G = V."""
+    G = len(rs)
+    assert G == V
+    r0 = rs[0]
+    P: PRefiners = st.get(r0, lambda: _pack_refiners(rs))
+    J, C = r0.num_heatmap, r0.embed_dims
+    hgt, wid = r0.feat_shape
     hw = hgt * wid
-    dev = feat_all.device
     # --- joint queries (JQA): heatmap_proj(hm) + fc_bfb(avgpool s32) + embedding -> fc_query
-    hm_rows = Img(hm_init.view(B * V, J, 1, hw)[v::V])                       # (B, J, 1, hw): rows of this view
-    t = conv(st, hm_rows, P.hp0, ACT_RELU)                                   # (B, J, 1, C)
-    hm_embed = linear(st, t.t.view(B * J, C), P.hp2)
-    bfb = linear(st, hip.avgpool(Img(s32_all[v * B:(v + 1) * B])), P.fc_bfb)
-    x = linear(st, hip.jqa_sum(hm_embed, P.embed, bfb, B, J, C), P.fc_query, ACT_RELU)
-    # --- own-view feature projection
-    own = Img(feat_all[v * B:(v + 1) * B])
-    ff = run_stack(st, r.frame_feat_proj_layers, own)                        # (B, 32, 32, 128)
-    # --- transformer layer over the 4-view memory (sampled un-projected, see pack_layer)
+    hm_rows = Img(hm_init.view(B * V, J, 1, hw)[0::V])                        # group 0 = view 0 rows; group stride = J*hw
+    t = conv(st, hm_rows, P.hp0, ACT_RELU, gx=J * hw)                        # (G*B, J, 1, C)
+    hm_embed = linear(st, t.t.view(G * B * J, C), P.hp2)
+    bfb = linear(st, hip.avgpool(Img(s32_all)), P.fc_bfb)                    # s32_all is (V*B, 8, 8, 512) = (G, B, ...)
+    x = linear(st, hip.jqa_sum(hm_embed, P.embed, bfb, G * B, J, C, groups=G), P.fc_query, ACT_RELU)
+    # --- own-view feature projection: group g reads feat_all[g*B:(g+1)*B]
+    ff = run_stack(st, [r.frame_feat_proj_layers for r in rs], Img(feat_all))  # (G*B, 32, 32, 128)
+    # --- transformer layer over the 4-view memory (sampled un-projected, see pack_layers)
     x = run_layer(st, P.layer, x, feat_all.view(V, B, hw, feat_all.shape[-1]), anchors, valid, B, V, J, hgt, wid)
     # --- head: LN -> (B, J, 16, 16) image with joints as channels -> 1x1 15->64, up x2, 1x1 64->128 (+ frame_feat)
-    xn = hip.layernorm(x, P.post_norm[0], P.post_norm[1])
+    xn = hip.layernorm(x, P.post_norm[0], P.post_norm[1], groups=G)
     side = int(math.isqrt(C))
-    tok = hip.tokens_to_nhwc(xn, B, J, C)                                    # (B, 256, J)
-    h0 = hip.linear_smallk(tok, J, 1, P.head0_w, P.head0_b, B * C, P.head0_w.shape[0], J, ACT_RELU)
-    h0 = hip.upsample2x(Img(h0.view(B, side, side, -1)))
-    summed = conv(st, h0, P.head3, ACT_RELU, res=ff, res_mode=RES_AFTER_ACT)  # offset_pred + frame_feat
-    run_stack(st, r.frame_feat_refined_proj_layers[0], summed, out=feat_refined_out)
-    # --- refined heatmap, written as (B, V, 15, 64, 64) planes of view v
+    tok = hip.tokens_to_nhwc(xn, G * B, J, C)                                # (G*B, 256, J)
+    h0 = hip.linear_smallk(tok, J, 1, P.head0_w, P.head0_b, G * B * C, P.head0_w.shape[1], J, ACT_RELU, groups=G)
+    h0 = hip.upsample2x(Img(h0.view(G * B, side, side, -1)))
+    summed = conv(st, h0, P.head3, ACT_RELU, res=ff, res_mode=RES_AFTER_ACT)   # offset_pred + frame_feat
+    run_stack(st, [r.frame_feat_refined_proj_layers[0] for r in rs], summed, out=Img(feat_ref))
+    # --- refined heatmaps, written as (B, V, 15, 64, 64) planes; group g = view g
     plane = J * hw
-    run_stack(st, r.conv_heatmap_layers[0], feat_refined_out,
-              last_kw={"out_nchw": hm_refined.view(-1)[v * plane:], "ymap": NMap(B, V * plane, 0)})
+    run_stack(st, [r.conv_heatmap_layers[0] for r in rs], Img(feat_ref),
+              last_kw={"out_nchw": hm_ref, "ymap": NMap(B, V * plane, 0), "gy": plane})
 
 
 def _anchors(hm: torch.Tensor, thr: float):
@@ -424,23 +495,20 @@ def _mvfex(mod, img: torch.Tensor, heatmap_for_anchor=None):
     J = mod.num_heatmap
     dev = img.device
     feat_all = torch.empty((V * B, H4, W4, 128), device=dev, dtype=torch.float32)
-    front, back = mod.heatmap_estimator_stereo_front, mod.heatmap_estimator_stereo_back
     s32_all = torch.empty((V * B, H4 // 8, W4 // 8, 512), device=dev, dtype=torch.float32)
-    run_backbone(st, front.encoder, img, 0, 2, Img(feat_all[:2 * B]), Img(s32_all[:2 * B]))
-    run_backbone(st, back.encoder, img, 2, 2, Img(feat_all[2 * B:]), Img(s32_all[2 * B:]))
-    # --- initial heatmaps per stereo pair, written straight into (B, V, J, H4, W4)
+    front, back = mod.heatmap_estimator_stereo_front, mod.heatmap_estimator_stereo_back
+    run_backbone(st, [front.encoder, back.encoder], img, 0, 2, Img(feat_all), Img(s32_all))   # G = 2 stereo estimators
+    # --- initial heatmaps per stereo pair (G = 2), written straight into (B, V, J, H4, W4)
     hm_init = torch.empty((B, V, J, H4, W4), device=dev, dtype=torch.float32)
     plane = J * H4 * W4
-    for seq, v0 in ((mod.conv_heatmap_layers_stereo_front, 0), (mod.conv_heatmap_layers_stereo_back, 2)):
-        run_stack(st, seq, Img(feat_all[v0 * B:(v0 + 2) * B]),
-                  last_kw={"out_nchw": hm_init.view(-1)[v0 * plane:], "ymap": NMap(B, V * plane, plane)})
+    run_stack(st, [mod.conv_heatmap_layers_stereo_front, mod.conv_heatmap_layers_stereo_back], Img(feat_all),
+              last_kw={"out_nchw": hm_init, "ymap": NMap(B, V * plane, plane), "gy": 2 * plane})
     src = heatmap_for_anchor.contiguous() if isinstance(heatmap_for_anchor, torch.Tensor) else hm_init
     anchors, maxvals, valid, index = _anchors(src, mod.heatmap_threshold)
-    # --- four refiners (own weights each), every one attending to all four views
+    # --- four refiners (own weights each, G = 4), every one attending to all four views
     feat_ref = torch.empty_like(feat_all)
     hm_ref = torch.empty_like(hm_init)
-    for v, r in enumerate(mod.refiners()):
-        _run_refiner(st, r, v, B, V, hm_init, feat_all, s32_all, anchors, valid, Img(feat_ref[v * B:(v + 1) * B]), hm_ref)
+    _run_refiners(st, mod.refiners(), B, V, hm_init, feat_all, s32_all, anchors, valid, feat_ref, hm_ref)
     aux = {"anchors_2d": anchors, "maxvals": maxvals, "anchors_valid": valid, "argmax_idx": index}
     return hm_init, hm_ref, feat_all, feat_ref, aux
 
@@ -467,18 +535,20 @@ def _pack_pose3d(p3) -> PPose:
     n_out = w0.shape[0]
     # reference flattens "(b v) c h w -> b (v c h w)" (egoposeformer_mvf_ex.py:317); ours is (v, h, w, c)
     w0p = w0.view(n_out, V, 128, 8, 8).permute(0, 1, 3, 4, 2).reshape(n_out, -1)
-    P.mlp0 = pack_linear_w(w0p, p3.mlp_pred[0][0].bias)
-    P.mlp1 = pack_linear(p3.mlp_pred[1][0])
-    P.mlp2 = pack_linear(p3.mlp_pred[2])
+    P.mlp0 = pack_linears([(w0p, p3.mlp_pred[0][0].bias)])
+    P.mlp1 = pack_linear_mods([p3.mlp_pred[1][0]])
+    P.mlp2 = pack_linear_mods([p3.mlp_pred[2]])
     qg = p3.query_gen_mlp
     P.qg0_w, P.qg0_b = qg[0].weight.detach().float().contiguous(), qg[0].bias.detach().float().contiguous()
-    P.qg2, P.qg4 = pack_linear(qg[2]), pack_linear(qg[4])
+    P.qg2, P.qg4 = pack_linear_mods([qg[2]]), pack_linear_mods([qg[4]])
     fp = p3.feat_proj
-    P.layers = [pack_layer(l, fp.weight, fp.bias, None) for l in p3.layers]
-    f32 = lambda t: t.detach().float().contiguous()
+    P.layers = [pack_layers([l], [(fp.weight, fp.bias)], [None]) for l in p3.layers]
+
+    def f32(t):
+        return t.detach().float().contiguous()
     P.post = [(f32(n.weight), f32(n.bias)) for n in p3.post_norm]
-    P.reg0 = [pack_linear(r[0]) for r in p3.reg_mlp]
-    P.reg2 = [pack_linear(r[2]) for r in p3.reg_mlp]
+    P.reg0 = [pack_linear_mods([r[0]]) for r in p3.reg_mlp]
+    P.reg2 = [pack_linear_mods([r[2]]) for r in p3.reg_mlp]
     rec = np.stack([c.packed() for c in p3.cameras()])
     P.cams = torch.from_numpy(rec).to(w0.device)
     return P
@@ -493,7 +563,7 @@ def _pose3d(p3, st: State, feat_init: torch.Tensor, feat_final: torch.Tensor, B:
     src = feat_init if p3.use_pred_heatmap_init else feat_final
     # --- proposal: conv stack on the refined features, flattened per frame, 3-layer MLP (_forward_mlp_conv)
     flat = torch.empty((B, V * 8 * 8 * 128), device=dev, dtype=torch.float32)
-    run_stack(st, p3.conv_frame_feat, Img(feat_final),
+    run_stack(st, [p3.conv_frame_feat], Img(feat_final),
               out=Img(flat.view(B * V, 8, 8, 128)), last_kw={"ymap": NMap(B, V * 8192, 8192)})  # (v,b) -> (b,v)
     h = linear(st, flat, P.mlp0, ACT_GELU)
     h = linear(st, h, P.mlp1, ACT_GELU)

@@ -38,6 +38,9 @@ class ConvDesc(C.Structure):
         ("ho", C.c_int32), ("wo", C.c_int32), ("ldx", C.c_int32), ("ldy", C.c_int32), ("ldr", C.c_int32),
         ("xmap", NMap), ("ymap", NMap), ("rmap", NMap),
         ("act", C.c_int32), ("res_mode", C.c_int32), ("out_nchw", C.c_int32), ("split_k", C.c_int32),
+        ("groups", C.c_int32),
+        ("gx", C.c_int64), ("gw", C.c_int64), ("gp", C.c_int64), ("gy", C.c_int64), ("gr", C.c_int64),
+        ("grs", C.c_int64), ("grm", C.c_int64),
     ]
 
 
@@ -49,17 +52,17 @@ def _load() -> C.CDLL:
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     lib.egr_conv2d_nhwc_f32.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
-    lib.egr_stem_conv7x7_f32.argtypes = [vp, NMap, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.egr_stem_conv7x7_f32.argtypes = [vp, NMap, i32, i32, i32, vp, vp, vp, vp, i32, i64, vp]
     lib.egr_maxpool_nhwc_f32.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.egr_upsample2x_nhwc_f32.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.egr_avgpool_nhwc_f32.argtypes = [vp, vp, i32, i32, i32, vp]
     lib.egr_argmax_rows_f32.argtypes = [vp, i32, i32, i32, f32, vp, vp, vp, vp, vp]
-    lib.egr_layernorm_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, f32, vp]
+    lib.egr_layernorm_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, f32, i32, vp]
     lib.egr_joint_mha_f32.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp]
-    lib.egr_msda_gather_f32.argtypes = [vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.egr_msda_gather_f32.argtypes = [vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp]
     lib.egr_fisheye_project_f32.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp]
-    lib.egr_linear_smallk_f32.argtypes = [vp, i64, i64, vp, vp, vp, i32, i32, i32, i32, vp]
-    lib.egr_jqa_sum_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.egr_linear_smallk_f32.argtypes = [vp, i64, i64, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.egr_jqa_sum_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.egr_tokens_to_nhwc_f32.argtypes = [vp, vp, i32, i32, i32, vp]
     lib.egr_version.restype = C.c_char_p
     lib.egr_device_arch.argtypes = [C.c_char_p, i32]
@@ -163,15 +166,29 @@ def conv2d(x: Img, w: torch.Tensor, cout: int, kh: int, kw: int, stride: int, pa
            act: int = ACT_NONE, res: Optional[Img] = None, res_mode: int = RES_NONE, rowscale=None, rowmask=None,
            out: Optional[Img] = None, out_nchw: Optional[torch.Tensor] = None, ymap: Optional[NMap] = None,
            xmap: Optional[NMap] = None, rmap: Optional[NMap] = None, workspace: Optional[torch.Tensor] = None,
-           split_k: int = 1) -> Optional[Img]:
+           split_k: int = 1, groups: int = 1, gx: Optional[int] = None, gy: Optional[int] = None,
+           gr: Optional[int] = None, grs: int = 0, grm: int = 0) -> Optional[Img]:
     """Implicit-GEMM conv / linear.  Output goes to `out` (NHWC Img, maybe a channel slice), or to the raw
-    tensor `out_nchw` (channel-major planes placed by `ymap`), or to a fresh NHWC tensor."""
+    tensor `out_nchw` (channel-major planes placed by `ymap`), or to a fresh NHWC tensor.
+
+    groups > 1: `groups` same-shape problems in one launch.  w is (groups, cout_pad, K), scale/shift
+    (groups, cout_pad).  x / out / res hold the images of all groups back to back (group stride = images per group x
+    image stride) unless an explicit element stride gx / gy / gr is given, in which case they describe group 0."""
+    if groups > 1:
+        if gx is None:
+            if x.n % groups:
+                raise RuntimeError("egorear_amd.conv2d: images not divisible by groups")
+            ng = x.n // groups
+            gx = ng * x.nstride
+            x = Img(x.t[:ng])
+        ng = x.n
     ho = (x.h + 2 * pad - kh) // stride + 1
     wo = (x.w + 2 * pad - kw) // stride + 1
     npad = (cout + 31) // 32 * 32
     K = kh * kw * x.c
-    if w.dim() != 2 or w.shape[0] != npad or w.shape[1] != K:
-        raise RuntimeError(f"egorear_amd.conv2d: packed weight shape {tuple(w.shape)} != ({npad}, {K})")
+    wshape = (groups, npad, K) if groups > 1 else (npad, K)
+    if tuple(w.shape) != wshape:
+        raise RuntimeError(f"egorear_amd.conv2d: packed weight shape {tuple(w.shape)} != {wshape}")
     _cont(w, "packed weight")
     d = ConvDesc()
     d.n, d.h, d.w, d.cin, d.cout = x.n, x.h, x.w, x.c, cout
@@ -179,53 +196,71 @@ def conv2d(x: Img, w: torch.Tensor, cout: int, kh: int, kw: int, stride: int, pa
     d.ldx = x.ld
     d.xmap = xmap if xmap is not None else x.nmap()
     d.act, d.res_mode, d.split_k = act, res_mode, split_k
+    d.groups, d.gx, d.gw, d.gp, d.grs, d.grm = groups, (gx or 0), (npad * K if groups > 1 else 0), (npad if groups > 1 else 0), grs, grm
     ret = None
     if out_nchw is not None:
-        if ymap is None:
-            raise RuntimeError("egorear_amd.conv2d: out_nchw needs ymap")
-        d.out_nchw, d.ldy, d.ymap = 1, 0, ymap
+        if ymap is None or (groups > 1 and gy is None):
+            raise RuntimeError("egorear_amd.conv2d: out_nchw needs ymap (and gy when grouped)")
+        d.out_nchw, d.ldy, d.ymap, d.gy = 1, 0, ymap, (gy or 0)
         yptr = _p(out_nchw)
     else:
+        full = out
         if out is None:
-            out = Img(torch.empty((x.n, ho, wo, cout), device=x.t.device, dtype=torch.float32))
+            full = Img(torch.empty((groups * x.n, ho, wo, cout), device=x.t.device, dtype=torch.float32))
+            out = full
+        if groups > 1 and gy is None:
+            if out.n != groups * x.n:
+                raise RuntimeError("egorear_amd.conv2d: grouped output must hold groups x n images")
+            gy = x.n * out.nstride
+            out = Img(out.t[:x.n])
         if (out.n, out.h, out.w, out.c) != (x.n, ho, wo, cout) and ymap is None:
             raise RuntimeError(f"egorear_amd.conv2d: output shape {(out.n, out.h, out.w, out.c)} != {(x.n, ho, wo, cout)}")
-        d.out_nchw, d.ldy = 0, out.ld
+        d.out_nchw, d.ldy, d.gy = 0, out.ld, (gy or 0)
         d.ymap = ymap if ymap is not None else out.nmap()
         yptr = _p(out.t)
-        ret = out
+        ret = full
     if res_mode != RES_NONE:
         if res is None:
             raise RuntimeError("egorear_amd.conv2d: res_mode set without res")
-        d.ldr = res.ld
+        if groups > 1 and gr is None:
+            if res.n != groups * x.n:
+                raise RuntimeError("egorear_amd.conv2d: grouped residual must hold groups x n images")
+            gr = x.n * res.nstride
+            res = Img(res.t[:x.n])
+        d.ldr, d.gr = res.ld, (gr or 0)
         d.rmap = rmap if rmap is not None else res.nmap()
     else:
         d.rmap = NMap(1, 0, 0)
-    if scale is not None and scale.numel() < cout or shift is not None and shift.numel() < cout:
-        raise RuntimeError("egorear_amd.conv2d: scale/shift shorter than cout")
+    for t, nm in ((scale, "scale"), (shift, "shift")):
+        if t is not None and t.numel() < (groups * npad if groups > 1 else cout):
+            raise RuntimeError(f"egorear_amd.conv2d: {nm} shorter than expected")
     M = x.n * ho * wo
-    if rowscale is not None and rowscale.numel() < M or rowmask is not None and rowmask.numel() < M:
+    if rowscale is not None and rowscale.numel() < (groups - 1) * grs + M or rowmask is not None and rowmask.numel() < (groups - 1) * grm + M:
         raise RuntimeError("egorear_amd.conv2d: rowscale/rowmask shorter than M")
     ws_ptr, ws_n = (None, 0) if workspace is None else (_p(workspace), workspace.numel())
     _launch("egr_conv2d_nhwc_f32", lib.egr_conv2d_nhwc_f32, C.byref(d), _p(x.t), _p(w), _p(scale), _p(shift),
             _p(res.t) if res is not None else None, _p(rowscale), _p(rowmask, torch.uint8), yptr, ws_ptr, ws_n, _stream(),
-            flops=2.0 * M * cout * K, nbytes=4.0 * (M * cout + x.n * x.h * x.w * x.c + cout * K),
-            tag=f"M{M} N{cout} K{K} k{kh}s{stride} cin{x.c}" if PROFILE is not None else "")
+            flops=2.0 * M * cout * K * groups, nbytes=4.0 * groups * (M * cout + x.n * x.h * x.w * x.c + cout * K),
+            tag=f"G{groups} M{M} N{cout} K{K} k{kh}s{stride} cin{x.c}" if PROFILE is not None else "")
     return ret
 
 
-def stem(img: torch.Tensor, view0: int, nviews: int, wpack, scale, shift) -> Img:
-    """img (B, V, 3, H, W) NCHW contiguous; views [view0, view0+nviews) -> NHWC (nviews*B, H/2, W/2, 64), view-major."""
+def stem(img: torch.Tensor, view0: int, nviews: int, wpack, scale, shift, groups: int = 1) -> Img:
+    """img (B, V, 3, H, W) NCHW contiguous.  Group g handles views [view0 + g*nviews, view0 + (g+1)*nviews) with its own
+    weights (wpack (groups,64,148), scale/shift (groups,64)); output NHWC (groups*nviews*B, H/2, W/2, 64), view-major."""
     B, V, Cc, H, W = img.shape
     if Cc != 3:
         raise RuntimeError("egorear_amd.stem: 3-channel input expected")
     _cont(img, "input image batch")
+    if view0 + groups * nviews > V or wpack.numel() != groups * 64 * 148 or scale.numel() != groups * 64 or shift.numel() != groups * 64:
+        raise RuntimeError("egorear_amd.stem: views / weights mismatch")
     n = nviews * B
-    y = torch.empty((n, H // 2, W // 2, 64), device=img.device, dtype=torch.float32)
+    y = torch.empty((groups * n, H // 2, W // 2, 64), device=img.device, dtype=torch.float32)
     base = img.reshape(-1)[view0 * 3 * H * W:]
     xmap = NMap(B, V * 3 * H * W, 3 * H * W)  # n = v*B + b -> (b*V + v) image
-    _launch("egr_stem_conv7x7_f32", lib.egr_stem_conv7x7_f32, _p(base), xmap, n, H, W, _p(_cont(wpack, "stem weight")), _p(scale), _p(shift), _p(y),
-            _stream(), flops=2.0 * n * (H // 2) * (W // 2) * 64 * 147, nbytes=4.0 * n * (3 * H * W + (H // 2) * (W // 2) * 64))
+    _launch("egr_stem_conv7x7_f32", lib.egr_stem_conv7x7_f32, _p(base), xmap, n, H, W, _p(_cont(wpack, "stem weight")), _p(scale),
+            _p(shift), _p(y), groups, nviews * 3 * H * W, _stream(),
+            flops=2.0 * groups * n * (H // 2) * (W // 2) * 64 * 147, nbytes=4.0 * groups * n * (3 * H * W + (H // 2) * (W // 2) * 64))
     return Img(y)
 
 
@@ -274,14 +309,17 @@ def argmax_rows(hm: torch.Tensor, thr: float):
     return anchors, maxvals, valid, index
 
 
-def layernorm(x: torch.Tensor, gamma, beta, res: Optional[torch.Tensor] = None, eps: float = 1e-5) -> torch.Tensor:
+def layernorm(x: torch.Tensor, gamma, beta, res: Optional[torch.Tensor] = None, eps: float = 1e-5, groups: int = 1) -> torch.Tensor:
     _cont(x, "layernorm input")
     c = x.shape[-1]
     rows = x.numel() // c
     if res is not None and (res.shape != x.shape or not res.is_contiguous()):
         raise RuntimeError("egorear_amd.layernorm: residual must match the input")
+    if gamma.numel() != groups * c or beta.numel() != groups * c or rows % groups:
+        raise RuntimeError("egorear_amd.layernorm: gamma/beta/groups mismatch")
     y = torch.empty_like(x)
-    _launch("egr_layernorm_f32", lib.egr_layernorm_f32, _p(x), _p(res), _p(gamma), _p(beta), _p(y), rows, c, eps, _stream())
+    _launch("egr_layernorm_f32", lib.egr_layernorm_f32, _p(x), _p(res), _p(gamma), _p(beta), _p(y), rows, c, eps,
+            rows // groups if groups > 1 else 0, _stream())
     return y
 
 
@@ -295,29 +333,30 @@ def joint_mha(qkv: torch.Tensor, b: int, j: int, heads: int, d: int, scale: floa
 
 
 def msda_gather(feat: torch.Tensor, pos: Optional[torch.Tensor], offs_logits: torch.Tensor, anchors: torch.Tensor,
-                valid: torch.Tensor, b: int, views: int, joints: int, heads: int, dh: int, hgt: int, wid: int):
-    """feat (views, b, hgt*wid, cf) contiguous.  Returns g (rows, heads, cf), e (rows, heads*dh) | None,
-    sigma (heads, rows), rowmask (rows,) with rows = (b, joint, view)."""
+                valid: torch.Tensor, b: int, views: int, joints: int, heads: int, dh: int, hgt: int, wid: int, groups: int = 1):
+    """feat (views, b, hgt*wid, cf) contiguous.  Returns g (G, rows, heads, cf), e (G, rows, heads*dh) | None,
+    sigma (G, heads, rows), rowmask (rows,) with rows = (b, joint, view); G query sets (offs_logits (G, b*joints, .),
+    pos (G, views, hgt*wid, heads*dh)) share feat / anchors / valid."""
     _cont(feat, "feature memory"); _cont(offs_logits, "offs_logits"); _cont(anchors, "anchors"); _cont(valid, "valid")
     cf = feat.shape[-1]
     if feat.numel() != views * b * hgt * wid * cf:
         raise RuntimeError("egorear_amd.msda_gather: feature memory size mismatch")
-    if offs_logits.numel() != b * joints * heads * 16 * 3:
+    if offs_logits.numel() != groups * b * joints * heads * 16 * 3:
         raise RuntimeError("egorear_amd.msda_gather: offs_logits size mismatch")
     if anchors.numel() != b * views * joints * 2 or valid.numel() != b * views * joints:
         raise RuntimeError("egorear_amd.msda_gather: anchors/valid size mismatch")
     if pos is not None:
         _cont(pos, "positional table")
-        if pos.numel() != views * hgt * wid * heads * dh:
+        if pos.numel() != groups * views * hgt * wid * heads * dh:
             raise RuntimeError("egorear_amd.msda_gather: positional table size mismatch")
     rows = b * joints * views
     dev = feat.device
-    g = torch.empty((rows, heads, cf), device=dev, dtype=torch.float32)
-    e = torch.empty((rows, heads * dh), device=dev, dtype=torch.float32) if pos is not None else None
-    sigma = torch.empty((heads, rows), device=dev, dtype=torch.float32)
+    g = torch.empty((groups, rows, heads, cf), device=dev, dtype=torch.float32)
+    e = torch.empty((groups, rows, heads * dh), device=dev, dtype=torch.float32) if pos is not None else None
+    sigma = torch.empty((groups, heads, rows), device=dev, dtype=torch.float32)
     rowmask = torch.empty((rows,), device=dev, dtype=torch.uint8)
     _launch("egr_msda_gather_f32", lib.egr_msda_gather_f32, _p(feat), cf, _p(pos), dh, _p(offs_logits), _p(anchors), _p(valid, torch.uint8), b, views,
-                                   joints, heads, hgt, wid, _p(g), _p(e), _p(sigma), _p(rowmask, torch.uint8), _stream())
+                                   joints, heads, hgt, wid, _p(g), _p(e), _p(sigma), _p(rowmask, torch.uint8), groups, _stream())
     return g, e, sigma, rowmask
 
 
@@ -340,21 +379,25 @@ def fisheye_project(pts: torch.Tensor, ctm: Optional[torch.Tensor], cams: torch.
     return anchors, valid, q4
 
 
-def linear_smallk(x: torch.Tensor, sxm: int, sxk: int, w: torch.Tensor, bias, m: int, n: int, k: int, act: int) -> torch.Tensor:
+def linear_smallk(x: torch.Tensor, sxm: int, sxk: int, w: torch.Tensor, bias, m: int, n: int, k: int, act: int,
+                  groups: int = 1) -> torch.Tensor:
     _cont(w, "weight")
-    if w.numel() != n * k or (m - 1) * sxm + (k - 1) * sxk >= x.numel():
+    if w.numel() != groups * n * k or m % groups or (m - 1) * sxm + (k - 1) * sxk >= x.numel():
         raise RuntimeError("egorear_amd.linear_smallk: size mismatch")
     y = torch.empty((m, n), device=x.device, dtype=torch.float32)
-    _launch("egr_linear_smallk_f32", lib.egr_linear_smallk_f32, _p(x), sxm, sxk, _p(w), _p(bias), _p(y), m, n, k, act, _stream())
+    _launch("egr_linear_smallk_f32", lib.egr_linear_smallk_f32, _p(x), sxm, sxk, _p(w), _p(bias), _p(y), m, n, k, act,
+            m // groups if groups > 1 else 0, _stream())
     return y
 
 
-def jqa_sum(hm_embed: torch.Tensor, embed: torch.Tensor, bfb: torch.Tensor, b: int, j: int, c: int) -> torch.Tensor:
+def jqa_sum(hm_embed: torch.Tensor, embed: torch.Tensor, bfb: torch.Tensor, b: int, j: int, c: int, groups: int = 1) -> torch.Tensor:
+    """b counts all frames of all groups (groups x frames per group); embed is (groups, j, c)."""
     _cont(hm_embed, "hm_embed"); _cont(embed, "embed"); _cont(bfb, "bfb")
-    if hm_embed.numel() != b * j * c or embed.numel() != j * c or bfb.numel() != b * c:
+    if hm_embed.numel() != b * j * c or embed.numel() != groups * j * c or bfb.numel() != b * c or b % groups:
         raise RuntimeError("egorear_amd.jqa_sum: size mismatch")
     y = torch.empty((b * j, c), device=hm_embed.device, dtype=torch.float32)
-    _launch("egr_jqa_sum_f32", lib.egr_jqa_sum_f32, _p(hm_embed), _p(embed), _p(bfb), _p(y), b, j, c, _stream())
+    _launch("egr_jqa_sum_f32", lib.egr_jqa_sum_f32, _p(hm_embed), _p(embed), _p(bfb), _p(y), b, j, c,
+            b // groups if groups > 1 else 0, _stream())
     return y
 
 

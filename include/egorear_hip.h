@@ -68,7 +68,12 @@ typedef struct {
     int32_t act;                 /* EGR_ACT_* */
     int32_t res_mode;            /* EGR_RES_* */
     int32_t out_nchw;            /* 1: y is written channel-major: ymap(n) + co*ho*wo + pix */
-    int32_t split_k;             /* >1: partial sums go through `workspace` (split_k * M * round_up(cout,32) floats) */
+    int32_t split_k;             /* >1: partial sums go through `workspace` (groups * split_k * M * round_up(cout,32) floats) */
+    /* Grouped launch: `groups` independent problems of identical shape (e.g. the two stereo estimators, the four
+     * per-view refiners — same architecture, own weights) in one launch.  Group g uses x + g*gx, w + g*gw,
+     * scale/shift + g*gp, res + g*gr, rowscale + g*grs, rowmask + g*grm, y + g*gy (strides in elements; 0 = shared). */
+    int32_t groups;
+    int64_t gx, gw, gp, gy, gr, grs, grm;
 } egr_conv_desc;
 
 int egr_conv2d_nhwc_f32(const egr_conv_desc* d, const float* x, const float* w,
@@ -85,7 +90,9 @@ int egr_conv_force_config(int cfg);
  * (h, w multiples of 64) -> NHWC output (n, h/2, w/2, 64).  w: [64][148] rows = (ci,kh,kw), last col 0.
  * Replaces layer_s2 of models/backbones/resnet.py:16,49. */
 int egr_stem_conv7x7_f32(const float* x, egr_nmap xmap, int32_t n, int32_t h, int32_t w,
-                         const float* wpack, const float* scale, const float* shift, float* y, void* stream);
+                         const float* wpack, const float* scale, const float* shift, float* y,
+                         int32_t groups /* group g: x + g*gx, wpack + g*64*148, scale/shift + g*64, y + g*n*(h/2)*(w/2)*64 */,
+                         int64_t gx, void* stream);
 
 /* MaxPool2d(k, stride, pad) on NHWC (resnet.py:17 maxpool 3/2/1; egoposeformer_mvf_ex.py:234 MaxPool2d(2)). c % 4 == 0. */
 int egr_maxpool_nhwc_f32(const float* x, float* y, int32_t n, int32_t h, int32_t w, int32_t c,
@@ -107,7 +114,8 @@ int egr_argmax_rows_f32(const float* hm, int32_t rows, int32_t hgt, int32_t wid,
 
 /* y = LayerNorm(x (+ res)) * gamma + beta over the last dim c (c <= 1024, c % 64 == 0), eps 1e-5. */
 int egr_layernorm_f32(const float* x, const float* res, const float* gamma, const float* beta, float* y,
-                      int32_t rows, int32_t c, float eps, void* stream);
+                      int32_t rows, int32_t c, float eps, int32_t rows_per_group /* gamma/beta + (row/rows_per_group)*c; 0 = one group */,
+                      void* stream);
 
 /* Joint-to-joint attention core of SpatialMHA / EgoformerSpatialMHA (heatmap_mvf_ex.py:799-817,
  * egoposeformer_mvf_ex.py:481-498): qkv (b, j, 3*c) -> out (b, j, c); softmax(q k^T * scale) v per head; j <= 16. */
@@ -133,7 +141,9 @@ int egr_msda_gather_f32(const float* feat /* (views, b, hgt*wid, cf) */, int32_t
                         const uint8_t* valid /* (b, views, joints) */,
                         int32_t b, int32_t views, int32_t joints, int32_t heads, int32_t hgt, int32_t wid,
                         float* g /* (rows, heads, cf) */, float* e /* (rows, heads*dh) or NULL */,
-                        float* sigma /* (heads, rows) */, uint8_t* rowmask /* (rows) */, void* stream);
+                        float* sigma /* (heads, rows) */, uint8_t* rowmask /* (rows) */,
+                        int32_t groups /* query sets sharing feat/anchors/valid: pos, offs_logits, g, e, sigma are [groups][...] */,
+                        void* stream);
 
 /* utils/camera_models.py:53-104 + egoposeformer_mvf_ex.py:340-348,400-406: project the (b, joints, 3) proposals
  * into the four fisheye cameras.  cams: 4 records [npoly, cx, cy, W, H, poly[12]] (fp32).  syn mode
@@ -147,11 +157,13 @@ int egr_fisheye_project_f32(float* pts, const float* ctm, const float* cams, int
 /* Small dense layer for K not a multiple of 32 (query_gen_mlp.0: K=4; head 1x1 conv: K=15):
  * y[m, n] = act(sum_k x[m*sxm + k*sxk] * w[n*K + k] + bias[n]). */
 int egr_linear_smallk_f32(const float* x, int64_t sxm, int64_t sxk, const float* w, const float* bias, float* y,
-                          int32_t m, int32_t n, int32_t k, int32_t act, void* stream);
+                          int32_t m, int32_t n, int32_t k, int32_t act,
+                          int32_t rows_per_group /* w + (row/rows_per_group)*n*k, bias + ..*n; 0 = one group */, void* stream);
 
 /* JQA query pre-activation (heatmap_mvf_ex.py:664-665): y[b,j,:] = hm_embed[b,j,:] + embed[j,:] + bfb[b,:]. */
 int egr_jqa_sum_f32(const float* hm_embed, const float* embed, const float* bfb, float* y,
-                    int32_t b, int32_t j, int32_t c, void* stream);
+                    int32_t b, int32_t j, int32_t c, int32_t b_per_group /* embed + (b/b_per_group)*j*c; 0 = one group */,
+                    void* stream);
 
 /* (b, j, s*s) token matrix -> NHWC (b, s, s, j) image with joints as channels (heatmap_mvf_ex.py:707-711). */
 int egr_tokens_to_nhwc_f32(const float* x, float* y, int32_t b, int32_t j, int32_t hw, void* stream);

@@ -121,6 +121,58 @@ def test_conv_split_k_linear_rowscale_rowmask(hip):
         close(out.t.view(m, n_out), ref)
 
 
+def test_grouped_conv_equals_separate_launches(hip):
+    """groups > 1: same-shape problems with their own weights / scale / shift / residual in one launch."""
+    G, n, h, w, cin, cout = 3, 2, 16, 16, 64, 48
+    x = rnd(G * n, h, w, cin, seed=201).to(DEV)
+    res = rnd(G * n, h, w, cout, seed=202).to(DEV)
+    wts = [rnd(cout, cin, 3, 3, seed=210 + g, scale=0.05) for g in range(G)]
+    scs = [rnd(64, seed=220 + g) * 0.3 + 1.0 for g in range(G)]
+    shs = [rnd(64, seed=230 + g) for g in range(G)]
+    wp = torch.stack([pack_w(wt) for wt in wts]).to(DEV)
+    out = hip.conv2d(hip.Img(x), wp, cout, 3, 3, 1, 1, scale=torch.stack(scs).to(DEV), shift=torch.stack(shs).to(DEV), act=1,
+                     res=hip.Img(res), res_mode=1, groups=G)
+    assert out.t.shape == (G * n, h, w, cout)
+    for g in range(G):
+        one = hip.conv2d(hip.Img(x[g * n:(g + 1) * n]), wp[g].contiguous(), cout, 3, 3, 1, 1, scale=scs[g].to(DEV),
+                         shift=shs[g].to(DEV), act=1, res=hip.Img(res[g * n:(g + 1) * n]), res_mode=1)
+        assert torch.equal(out.t[g * n:(g + 1) * n], one.t)           # bitwise: same kernel, same tiles
+        ref = F.conv2d(x[g * n:(g + 1) * n].permute(0, 3, 1, 2).cpu().double(), wts[g].double(), None, 1, 1)
+        ref = F.relu(ref * scs[g][:cout].double().view(1, -1, 1, 1) + shs[g][:cout].double().view(1, -1, 1, 1)
+                     + res[g * n:(g + 1) * n].permute(0, 3, 1, 2).cpu().double())
+        close(one.t.permute(0, 3, 1, 2), ref)
+
+
+def test_grouped_small_kernels(hip):
+    G, rows, c = 4, 30, 256
+    x, r = rnd(G * rows, c, seed=241), rnd(G * rows, c, seed=242)
+    gam, bet = rnd(G, c, seed=243) + 1.5, rnd(G, c, seed=244)
+    y = hip.layernorm(x.to(DEV), gam.to(DEV), bet.to(DEV), res=r.to(DEV), groups=G).cpu()
+    for g in range(G):
+        close(y[g * rows:(g + 1) * rows], F.layer_norm((x + r)[g * rows:(g + 1) * rows].double(), (c,), gam[g].double(), bet[g].double(), 1e-5), rel=5e-6)
+    xs, ws, bs = rnd(G * 20, 15, seed=245), rnd(G, 64, 15, seed=246), rnd(G, 64, seed=247)
+    y = hip.linear_smallk(xs.to(DEV), 15, 1, ws.to(DEV), bs.to(DEV), G * 20, 64, 15, 1, groups=G).cpu()
+    for g in range(G):
+        close(y[g * 20:(g + 1) * 20], F.relu(xs[g * 20:(g + 1) * 20].double() @ ws[g].double().t() + bs[g].double()), rel=2e-6)
+    hm_e, emb, bfb = rnd(G * 2 * 15, 256, seed=248), rnd(G, 15, 256, seed=249), rnd(G * 2, 256, seed=250)
+    y = hip.jqa_sum(hm_e.to(DEV), emb.to(DEV), bfb.to(DEV), G * 2, 15, 256, groups=G).cpu().view(G, 2, 15, 256)
+    assert torch.equal(y, (emb[:, None] + bfb.view(G, 2, 1, 256)) + hm_e.view(G, 2, 15, 256))
+
+
+def test_grouped_gather_equals_separate(hip):
+    B, V, J, heads, hgt, wid, cf, dh, G = 2, 4, 15, 4, 64, 64, 128, 64, 3
+    feat = rnd(V, B, hgt * wid, cf, seed=261).to(DEV)
+    pos = rnd(G, V, hgt * wid, heads * dh, seed=262).to(DEV)
+    ol = torch.cat([rnd(G * B * J, heads * 32, seed=263, scale=10.0), rnd(G * B * J, heads * 16, seed=264)], 1).contiguous().to(DEV)
+    anchors = ((rnd(B, V, J, 2, seed=265) + 1) / 2).to(DEV)
+    valid = (rnd(B, V, J, seed=266) > -0.5).to(torch.uint8).to(DEV)
+    g, e, s, m = hip.msda_gather(feat, pos, ol, anchors, valid, B, V, J, heads, dh, hgt, wid, groups=G)
+    for k in range(G):
+        g1, e1, s1, m1 = hip.msda_gather(feat, pos[k].contiguous(), ol[k * B * J:(k + 1) * B * J].contiguous(), anchors, valid,
+                                         B, V, J, heads, dh, hgt, wid)
+        assert torch.equal(g[k], g1[0]) and torch.equal(e[k], e1[0]) and torch.equal(s[k], s1[0]) and torch.equal(m, m1)
+
+
 def test_conv_rejects_bad_arguments(hip):
     x = torch.zeros(1, 4, 4, 30, device=DEV)
     with pytest.raises(RuntimeError):
@@ -247,6 +299,7 @@ def test_msda_sample_then_project_equals_dense(hip, with_pos):
     pos_proj = (pos.double() @ Wv.double().t()).float().contiguous() if with_pos else None
     g, e, sigma, rowmask = hip.msda_gather(feat.to(DEV), pos_proj.to(DEV) if with_pos else None, ol.to(DEV), anchors.to(DEV),
                                            valid.to(DEV), B, V, J, heads, dh, hgt, wid)
+    g, e, sigma = g[0], (e[0] if e is not None else None), sigma[0]   # single query set (groups = 1)
     rows = B * J * V
     assert torch.equal(rowmask.cpu().view(B, J, V), valid.permute(0, 2, 1))
     a = torch.empty(rows, C, device=DEV)
@@ -272,7 +325,7 @@ def test_msda_known_answers(hip):
     valid = torch.ones(B, V, J, dtype=torch.uint8)
     g, e, sigma, rowmask = hip.msda_gather(feat.to(DEV), None, ol.to(DEV), anchors.to(DEV), valid.to(DEV), B, V, J, heads, 32,
                                            hgt, wid)
-    g = g.cpu()
+    g, sigma = g[0].cpu(), sigma[0]
     for h in range(heads):
         close(g[0, h], feat[0, 0, 5 * wid + 3], rel=2e-6)
         assert float(g[1, h].abs().max()) == 0.0
