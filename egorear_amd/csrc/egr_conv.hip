@@ -68,7 +68,10 @@ struct ConvArgs {
     int tilesM, tilesN;
     int cblocks;  // cin / 32
     int taps;     // kh * kw
-    FastDiv dHoWo, dWo, dXin, dYin, dRin;  // invariant-divisor division (no integer divide in the kernel)
+    FastDiv dHoWo, dWo, dXin, dYin, dRin, dTilesN;  // invariant-divisor division (no integer divide in the kernel)
+    int howo_shift, wo_shift;        // >= 0 when ho*wo / wo are powers of two (every layer of the path): shifts, no division
+    int x_plain, y_plain, r_plain;   // image map is a plain batch (n_inner >= n): offset = n * stride_inner
+    unsigned long long* dbg;  // diagnostic only: per-block phase stamps (s_memtime), NULL in normal operation
     int vec_ok;   // NHWC output / residual addresses are 16-byte aligned for every (row, channel quad)
 };
 
@@ -102,6 +105,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[P::FLOATS];
 
     const egr_conv_desc& d = a.d;
+    auto stamp = [&](int slot) {
+        if (a.dbg && threadIdx.x == 0)
+            a.dbg[((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * 8 + slot] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
     const int grp = blockIdx.z;  // grouped launch: same shape, own operands
     const float* const xg = a.x + grp * d.gx;
     const float* const wg = a.w + grp * d.gw;
@@ -122,7 +130,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     int bid = blockIdx.x;
     const int nb = gridDim.x;
     if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
-    const int tn = bid % a.tilesN, tm = bid / a.tilesN;
+    const int tm = (a.tilesN == 1) ? bid : fdiv(bid, a.dTilesN);
+    const int tn = bid - tm * a.tilesN;
     const int split = blockIdx.y;
     const int kt0 = split * a.ktiles_per_split;
     const int kt1 = min(a.ktiles, kt0 + a.ktiles_per_split);
@@ -141,32 +150,38 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const unsigned fullmask = (d.kh * d.kw >= 32) ? 0xffffffffu : ((1u << (d.kh * d.kw)) - 1u);
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
-        int r = i * 32 + rsub;
-        int m = tm * BM + r;
-        int seg = (pseg ^ ((r >> 1) & 7)) * 4;
+        const int r = i * 32 + rsub;
+        const int m = tm * BM + r;
+        const int seg = (pseg ^ ((r >> 1) & 7)) * 4;
         arow[i] = egr_zero16;
         amask[i] = 0u;
         int yo = -1, ro = 0;
         if (m < a.M) {
-            int n = fdiv(m, a.dHoWo);
-            int pix = m - n * HoWo;
-            int ho = fdiv(pix, a.dWo);
-            int wo = pix - ho * d.wo;
-            int hi0 = ho * d.stride - d.pad, wi0 = wo * d.stride - d.pad;
-            arow[i] = xg + fmap(d.xmap, a.dXin, n) + ((int64_t)hi0 * d.w + wi0) * d.ldx + seg;
+            // (n, ho, wo) of output pixel m: shifts when the geometry is a power of two, multiply-high otherwise
+            int n, pix, ho, wo;
+            if (a.howo_shift >= 0) { n = m >> a.howo_shift; pix = m & (HoWo - 1); }
+            else { n = fdiv(m, a.dHoWo); pix = m - n * HoWo; }
+            if (a.wo_shift >= 0) { ho = pix >> a.wo_shift; wo = pix & (d.wo - 1); }
+            else { ho = fdiv(pix, a.dWo); wo = pix - ho * d.wo; }
+            const int hi0 = ho * d.stride - d.pad, wi0 = wo * d.stride - d.pad;
+            // 32-bit element offsets (the host bounds every operand below 2^31 elements); may be negative for halo rows
+            const int xo = a.x_plain ? n * (int)d.xmap.stride_inner : (int)fmap(d.xmap, a.dXin, n);
+            arow[i] = xg + (xo + (hi0 * d.w + wi0) * d.ldx + seg);
             // taps inside the image: kh in [kh_lo, kh_hi), kw in [kw_lo, kw_hi)
-            int kh_lo = max(0, -hi0), kh_hi = min(d.kh, d.h - hi0);
-            int kw_lo = max(0, -wi0), kw_hi = min(d.kw, d.w - wi0);
-            unsigned mk = fullmask;
-            if (kh_lo > 0 || kw_lo > 0 || kh_hi < d.kh || kw_hi < d.kw) {
-                mk = 0u;
-                unsigned rowbits = (kw_hi > kw_lo) ? (((1u << (kw_hi - kw_lo)) - 1u) << kw_lo) : 0u;
+            const int kh_lo = max(0, -hi0), kh_hi = min(d.kh, d.h - hi0);
+            const int kw_lo = max(0, -wi0), kw_hi = min(d.kw, d.w - wi0);
+            const unsigned rowbits = (kw_hi > kw_lo) ? (((1u << (kw_hi - kw_lo)) - 1u) << kw_lo) : 0u;
+            unsigned mk = 0u;
+            if (d.kh <= 3) {  // branch-free for the 1x1 / 3x3 layers of the path
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) mk |= (kh >= kh_lo && kh < kh_hi) ? (rowbits << (kh * d.kw)) : 0u;
+            } else {
                 for (int kh = kh_lo; kh < kh_hi; ++kh) mk |= rowbits << (kh * d.kw);
             }
-            amask[i] = mk;
+            amask[i] = mk & fullmask;
             if (pseg == 0) {
-                yo = (int)fmap(d.ymap, a.dYin, n) + (d.out_nchw ? pix : pix * d.ldy);
-                if (d.res_mode) ro = (int)fmap(d.rmap, a.dRin, n) + pix * d.ldr;
+                yo = (a.y_plain ? n * (int)d.ymap.stride_inner : (int)fmap(d.ymap, a.dYin, n)) + (d.out_nchw ? pix : pix * d.ldy);
+                if (d.res_mode) ro = (a.r_plain ? n * (int)d.rmap.stride_inner : (int)fmap(d.rmap, a.dRin, n)) + pix * d.ldr;
             }
         }
         if (pseg == 0) {  // one lane per row publishes the output / residual offsets for the epilogue
@@ -187,18 +202,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     auto kpos_of = [&](int kt) { KPos p; p.cb = kt / a.taps; int t = kt - p.cb * a.taps; p.kh = t / d.kw; p.kw = t - p.kh * d.kw; return p; };
     auto kpos_next = [&](KPos p) { if (++p.kw == d.kw) { p.kw = 0; if (++p.kh == d.kh) { p.kh = 0; ++p.cb; } } return p; };
 
-    // one 1-KiB DMA piece (8 rows x 128 B) of a stage: pieces [0, IA) are A rows, [IA, IA+IB) weight rows
-    auto issue_piece = [&](int kt, KPos kp, int buf, int piece) {
-        float* sA = lds + buf * P::TILE;
+    // one 1-KiB DMA piece (8 rows x 128 B) of a stage: pieces [0, IA) are A rows, [IA, IA+IB) weight rows.
+    // The stage buffer is a compile-time constant so LDS addresses fold into instruction immediates.
+    const uint32_t zlo = (uint32_t)(uint64_t)egr_zero16, zhi = (uint32_t)((uint64_t)egr_zero16 >> 32);
+    auto issue_piece = [&](int kt, KPos kp, auto buf_tag, int piece) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        float* sA = lds + BUF * P::TILE;
         if (piece < IA) {
-            int tap = kp.kh * d.kw + kp.kw;
-            int64_t toff = ((int64_t)kp.kh * d.w + kp.kw) * d.ldx + kp.cb * BK;
-            // branch-free select between the pixel row and the zero buffer
-            const uint64_t keep = 0ull - (uint64_t)((amask[piece] >> tap) & 1u);
-            const uint64_t pa = (uint64_t)(arow[piece] + toff), pz = (uint64_t)egr_zero16;
-            glds16(reinterpret_cast<const float*>((pa & keep) | (pz & ~keep)), sA + (piece * 32 + wave * 8) * BK);
+            const int tap = kp.kh * d.kw + kp.kw;
+            const int toff = (kp.kh * d.w + kp.kw) * d.ldx + kp.cb * BK;     // wave-uniform, 32-bit
+            const uint64_t pa = (uint64_t)(arow[piece] + toff);
+            const bool ok = (amask[piece] >> tap) & 1u;
+            // select between the pixel row and the zero buffer with two 32-bit v_cndmask (no branch, no 64-bit logic)
+            const uint32_t lo = ok ? (uint32_t)pa : zlo, hi = ok ? (uint32_t)(pa >> 32) : zhi;
+            glds16(reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo), sA + (piece * 32 + wave * 8) * BK);
         } else {
-            int i = piece - IA;
+            const int i = piece - IA;
             const float* p = wrow[i] ? wrow[i] + kt * BK : egr_zero16;
             glds16(p, sA + BM * BK + (i * 32 + wave * 8) * BK);
         }
@@ -212,43 +231,46 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // fragment read offsets (floats) inside a stage: row * 32 + ((q ^ swz(row)) * 4), q = 2*g + half
-    int aoff[FM], aswz[FM], boff[FN], bswz[FN];
+    // fragment read offsets (floats) inside a stage for the four k-groups of a chunk, computed once:
+    // row * 32 + ((q ^ swz(row)) * 4) with q = 2*g + half
+    int afo[FM][4], bfo[FN][4];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-        int r = wm * TM + i * 32 + l31;
-        aoff[i] = r * BK;
-        aswz[i] = (r >> 1) & 7;
+        const int r = wm * TM + i * 32 + l31;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) afo[i][g] = r * BK + (((2 * g + half) ^ ((r >> 1) & 7)) << 2);
     }
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-        int r = wn * TN + j * 32 + l31;
-        boff[j] = BM * BK + r * BK;
-        bswz[j] = (r >> 1) & 7;
+        const int r = wn * TN + j * 32 + l31;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bfo[j][g] = BM * BK + r * BK + (((2 * g + half) ^ ((r >> 1) & 7)) << 2);
     }
 
     constexpr int NPIECE = IA + IB;
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
 
     // multiply one staged chunk; when ISSUE, the next chunk's DMA pieces go out one per MFMA behind the first
     // matrix instructions (pinned with sched_barrier), so their issue slots hide under the 64-cycle MFMAs
-    auto chunk = [&](int kt, int buf, KPos kp_next, auto issue_tag) {
+    auto chunk = [&](int kt, auto buf_tag, KPos kp_next, auto issue_tag) {
+        constexpr int BUF = decltype(buf_tag)::value;
         constexpr bool ISSUE = decltype(issue_tag)::value;
-        const float* st = lds + buf * P::TILE;
+        using NB = std::integral_constant<int, BUF ^ 1>;
+        const float* st = lds + BUF * P::TILE;
         f32x4 av[2][FM], bv[2][FN];
 #pragma unroll
-        for (int i = 0; i < FM; ++i) av[0][i] = *reinterpret_cast<const f32x4*>(&st[aoff[i] + ((half ^ aswz[i]) << 2)]);
+        for (int i = 0; i < FM; ++i) av[0][i] = *reinterpret_cast<const f32x4*>(&st[afo[i][0]]);
 #pragma unroll
-        for (int j = 0; j < FN; ++j) bv[0][j] = *reinterpret_cast<const f32x4*>(&st[boff[j] + ((half ^ bswz[j]) << 2)]);
+        for (int j = 0; j < FN; ++j) bv[0][j] = *reinterpret_cast<const f32x4*>(&st[bfo[j][0]]);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int cur = g & 1, nxt = cur ^ 1;
             if (g < 3) {  // fragments of the next k-group are fetched under this group's MFMAs
 #pragma unroll
-                for (int i = 0; i < FM; ++i)
-                    av[nxt][i] = *reinterpret_cast<const f32x4*>(&st[aoff[i] + (((2 * (g + 1) + half) ^ aswz[i]) << 2)]);
+                for (int i = 0; i < FM; ++i) av[nxt][i] = *reinterpret_cast<const f32x4*>(&st[afo[i][g + 1]]);
 #pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    bv[nxt][j] = *reinterpret_cast<const f32x4*>(&st[boff[j] + (((2 * (g + 1) + half) ^ bswz[j]) << 2)]);
+                for (int j = 0; j < FN; ++j) bv[nxt][j] = *reinterpret_cast<const f32x4*>(&st[bfo[j][g + 1]]);
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -260,7 +282,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                         if constexpr (ISSUE) {
                             const int n = ((g * 4 + t) * FM + i) * FN + j;
                             if (n < NPIECE) {
-                                issue_piece(kt + 1, kp_next, buf ^ 1, n);
+                                issue_piece(kt + 1, kp_next, NB{}, n);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                         }
@@ -268,24 +290,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         }
     };
 
+    stamp(1);  // row decode done
     KPos kp = kpos_of(kt0);
     if (kt0 < kt1) {
 #pragma unroll
-        for (int pc = 0; pc < NPIECE; ++pc) issue_piece(kt0, kp, 0, pc);
+        for (int pc = 0; pc < NPIECE; ++pc) issue_piece(kt0, kp, B0{}, pc);
     }
     __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes stage 0
+    stamp(2);  // first chunk landed
     int kt = kt0;
-    for (; kt + 1 < kt1; ++kt) {
-        KPos kn = kpos_next(kp);
-        chunk(kt, (kt - kt0) & 1, kn, std::true_type{});
-        kp = kn;
+    for (; kt + 2 < kt1; kt += 2) {  // two chunks per trip: stage indices are compile-time constants
+        KPos k1 = kpos_next(kp);
+        chunk(kt, B0{}, k1, std::true_type{});
         __syncthreads();
+        KPos k2 = kpos_next(k1);
+        chunk(kt + 1, B1{}, k2, std::true_type{});
+        __syncthreads();
+        kp = k2;
     }
-    if (kt < kt1) {
-        chunk(kt, (kt - kt0) & 1, kp, std::false_type{});
+    if (kt + 1 < kt1) {  // two chunks left
+        KPos k1 = kpos_next(kp);
+        chunk(kt, B0{}, k1, std::true_type{});
+        __syncthreads();
+        chunk(kt + 1, B1{}, k1, std::false_type{});
+        __syncthreads();
+    } else if (kt < kt1) {  // one chunk left
+        chunk(kt, B0{}, kp, std::false_type{});
         __syncthreads();
     }
 
+    stamp(3);  // k loop done
     // ---- epilogue: accumulators -> LDS [BM][BN+4] -> 16-byte row-contiguous global accesses
     float* sC = lds;
 #pragma unroll
@@ -299,6 +333,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                 sC[row * P::CS + wn * TN + j * 32 + l31] = acc[i][j][r];
             }
     __syncthreads();
+    stamp(4);  // accumulators staged
 
     if (d.split_k > 1) {  // raw partial sums; the epilogue runs in splitk_reduce_kernel
         constexpr int QPR = BN / 4;
@@ -347,7 +382,53 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             if (scg) sc[e] = scg[co + e];
             if (shg) sh[e] = shg[co + e];
         }
-#pragma unroll 4
+
+    if (vec && !rsg && !rmg) {
+        // fast path (every conv of the CNN stages): 16-byte accesses, activation / residual mode resolved at compile
+        // time so the row loop is branch-free straight-line code
+        auto rows_fast = [&](auto act_tag, auto res_tag) {
+            constexpr int ACT = decltype(act_tag)::value;
+            constexpr int RES = decltype(res_tag)::value;
+#pragma unroll 8
+            for (int it = 0; it < BM / RPI; ++it) {
+                const int row = row0 + it * RPI;
+                const int yo = s_yoff[row];
+                if (yo < 0) continue;
+                f32x4 v = *reinterpret_cast<const f32x4*>(&sC[row * P::CS + cq * 4]);
+                f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (RES != EGR_RES_NONE) rr = *reinterpret_cast<const f32x4*>(resg + (int64_t)s_roff[row] + co);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = v[e] * sc[e] + sh[e];
+                    if constexpr (RES == EGR_RES_BEFORE_ACT) t += rr[e];
+                    if constexpr (ACT == EGR_ACT_RELU) t = t > 0.f ? t : 0.f;
+                    if constexpr (ACT == EGR_ACT_GELU) t = 0.5f * t * (1.0f + erff(t * 0.70710678118654752440f));
+                    if constexpr (RES == EGR_RES_AFTER_ACT) t += rr[e];
+                    v[e] = t;
+                }
+                *reinterpret_cast<f32x4*>(yg + (int64_t)yo + co) = v;
+            }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        const int key = d.act * 3 + d.res_mode;
+        switch (key) {
+            case 0: rows_fast(I0{}, I0{}); break;
+            case 1: rows_fast(I0{}, I1{}); break;
+            case 2: rows_fast(I0{}, I2{}); break;
+            case 3: rows_fast(I1{}, I0{}); break;
+            case 4: rows_fast(I1{}, I1{}); break;
+            case 5: rows_fast(I1{}, I2{}); break;
+            case 6: rows_fast(I2{}, I0{}); break;
+            case 7: rows_fast(I2{}, I1{}); break;
+            default: rows_fast(I2{}, I2{}); break;
+        }
+        stamp(5);  // stores issued
+        return;
+    }
+
+    // generic path: ragged channel counts (cout = 15, 3, 48 ...), unaligned outputs, per-row scale / mask
     for (int it = 0; it < BM / RPI; ++it) {
         const int row = row0 + it * RPI;
         const int yo = s_yoff[row];
@@ -380,6 +461,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             for (int e = 0; e < 4; ++e)
                 if (co + e < d.cout) yp[e] = v[e];
     }
+    stamp(5);  // stores issued
 }
 
 // split-K second pass: sum the partial slabs in fixed order (deterministic) and apply the epilogue.
@@ -419,6 +501,7 @@ template <int BM, int BN, int WM, int WN>
 int launch_cfg(ConvArgs& a, hipStream_t s) {
     a.tilesM = (a.M + BM - 1) / BM;
     a.tilesN = (a.Npad + BN - 1) / BN;
+    a.dTilesN = make_fastdiv(a.tilesN);
     dim3 grid((unsigned)(a.tilesM * a.tilesN), (unsigned)a.d.split_k, (unsigned)a.d.groups);
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
     return egr_launch_status();
@@ -428,8 +511,14 @@ enum { CFG_AUTO = -1, CFG_128x128 = 0, CFG_256x64 = 1, CFG_64x64 = 2, CFG_128x32
 const int kBM[CFG_COUNT] = {128, 256, 64, 128, 128};
 const int kBN[CFG_COUNT] = {128, 64, 64, 32, 64};
 int g_force_cfg = CFG_AUTO;
+unsigned long long* g_dbg = nullptr;
 
 }  // namespace
+
+extern "C" int egr_conv_debug_stamps(unsigned long long* buf) {  // diagnostic: 8 x u64 per workgroup, NULL = off
+    g_dbg = buf;
+    return 0;
+}
 
 extern "C" int egr_conv_force_config(int cfg) {
     if (cfg < CFG_AUTO || cfg >= CFG_COUNT) return EGR_EINVAL;
@@ -468,9 +557,16 @@ extern "C" int egr_conv2d_nhwc_f32(const egr_conv_desc* dd, const float* x, cons
 
     a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.res = res; a.rowscale = rowscale; a.rowmask = rowmask;
     a.y = y; a.ws = workspace;
+    a.dbg = g_dbg;
     a.M = (int)M64;
     a.Npad = (d.cout + 31) / 32 * 32;
     a.K = d.kh * d.kw * d.cin;
+    auto log2_exact = [](int v) { int l = 0; while ((1 << l) < v) ++l; return ((1 << l) == v) ? l : -1; };
+    a.howo_shift = log2_exact(d.ho * d.wo);
+    a.wo_shift = log2_exact(d.wo);
+    a.x_plain = d.xmap.n_inner >= d.n;
+    a.y_plain = d.ymap.n_inner >= d.n;
+    a.r_plain = d.res_mode ? (d.rmap.n_inner >= d.n) : 1;
     a.dHoWo = make_fastdiv(d.ho * d.wo);
     a.dWo = make_fastdiv(d.wo);
     a.dXin = make_fastdiv(d.xmap.n_inner);
