@@ -56,6 +56,23 @@ def _host_cores() -> int:
     return max(1, min(n, int(os.environ.get("EGR_CPU_THREADS", "16"))))
 
 
+def _pmc_traffic(batch: int):
+    """HBM bytes per launch of the conv kernel from the committed rocprofv3 PMC passes (profiles/*pmc_traffic.json,
+    produced by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command, with the
+    gfx950 x2 correction on FETCH_SIZE).  Counters cannot be collected from inside the timed run; null if the file
+    is absent or was measured at another batch size."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            t = json.load(f)
+        return t["hbm_bytes_per_launch"] if t.get("batch") == batch else None
+    except Exception:
+        return None
+
+
 def _log(msg: str):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -94,10 +111,15 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(1, torch.cuda.device_count())  # one GPU per rank; ranks only share a device in rehearsals
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    backend = os.environ.get("EGR_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; "gloo" only for rehearsals on one GPU
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # RCCL; only used for the barrier and the max-over-ranks
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # only used for the barrier and the max-over-ranks
+        else:
+            dist.init_process_group(backend)
 
     from egorear_amd import configs, hip, synth
     from egorear_amd.estimator import EgoPoseFormerMVFEX
@@ -136,7 +158,7 @@ def main():
             run = step
 
         from egorear_amd.dist import timed_steps
-        elapsed = timed_steps(run, args.steps, args.warmup, torch.cuda.synchronize, dev)
+        elapsed = timed_steps(run, args.steps, args.warmup, torch.cuda.synchronize, dev if backend == "nccl" else None)
 
         # ---- roofline leg: per-launch HIP-event timing of one instrumented (eager) step
         roof = None
@@ -157,9 +179,10 @@ def main():
             k = kernels[dom]
             achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": _pmc_traffic(B),
                     "launches_per_step": k["launches"], "avg_launch_us": round(1e3 * k["ms"] / k["launches"], 2),
                     "flops_per_launch": round(k["flops"] / k["launches"], 1),
+                    "algorithmic_bytes_per_launch": round(k["bytes"] / k["launches"], 1),
                     "kernel_ms_per_step": round(k["ms"], 3),
                     "all_kernels_ms_per_step": round(sum(v["ms"] for v in kernels.values()), 3)}
 

@@ -89,7 +89,7 @@ struct LdsPlan {
     static constexpr int TILE = (BM + BN) * BK;             // floats per stage
     static constexpr int CS = BN + 4;                       // epilogue staging row stride
     static constexpr int ROWOFF = (2 * TILE > BM * CS) ? 2 * TILE : BM * CS;  // row offsets (y, res) live past both
-    static constexpr int FLOATS = ROWOFF + 2 * BM;
+    static constexpr int FLOATS = ROWOFF + 4 * BM;                            // + per-row input offset and tap mask
 };
 
 template <int BM, int BN, int WM, int WN>
@@ -138,24 +138,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const int HoWo = d.ho * d.wo;
 
     // ---- per-lane staging roles: piece p covers tile rows p*32 + wave*8 + (lane>>3); physical segment lane&7.
-    // Per row, once: pointer to tap (0,0) of its receptive field (+ the swizzled 16-byte segment) and a bitmask of
-    // the taps that fall inside the image; per chunk the wave-uniform tap offset is added and the mask bit tested,
-    // so staging a chunk costs a handful of VALU ops per piece and no integer division.
+    // Row geometry is decoded ONCE per row (thread r < BM handles row r) into a small LDS table: element offset of
+    // tap (0,0) of the row's receptive field, bitmask of the taps that fall inside the image, output / residual
+    // offsets.  Per chunk a lane then adds the wave-uniform tap offset and tests one mask bit.
     const int rsub = wave * 8 + (lane >> 3);
     const int pseg = lane & 7;
-    const float* arow[IA];
-    unsigned amask[IA];
     int* s_yoff = reinterpret_cast<int*>(lds + P::ROWOFF);
     int* s_roff = s_yoff + BM;
+    int* s_xoff = s_roff + BM;
+    unsigned* s_mask = reinterpret_cast<unsigned*>(s_xoff + BM);
     const unsigned fullmask = (d.kh * d.kw >= 32) ? 0xffffffffu : ((1u << (d.kh * d.kw)) - 1u);
-#pragma unroll
-    for (int i = 0; i < IA; ++i) {
-        const int r = i * 32 + rsub;
+    for (int r = tid; r < BM; r += NT) {
         const int m = tm * BM + r;
-        const int seg = (pseg ^ ((r >> 1) & 7)) * 4;
-        arow[i] = egr_zero16;
-        amask[i] = 0u;
-        int yo = -1, ro = 0;
+        int xo = 0, yo = -1, ro = 0;
+        unsigned mk = 0u;
         if (m < a.M) {
             // (n, ho, wo) of output pixel m: shifts when the geometry is a power of two, multiply-high otherwise
             int n, pix, ho, wo;
@@ -165,29 +161,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             else { ho = fdiv(pix, a.dWo); wo = pix - ho * d.wo; }
             const int hi0 = ho * d.stride - d.pad, wi0 = wo * d.stride - d.pad;
             // 32-bit element offsets (the host bounds every operand below 2^31 elements); may be negative for halo rows
-            const int xo = a.x_plain ? n * (int)d.xmap.stride_inner : (int)fmap(d.xmap, a.dXin, n);
-            arow[i] = xg + (xo + (hi0 * d.w + wi0) * d.ldx + seg);
+            xo = (a.x_plain ? n * (int)d.xmap.stride_inner : (int)fmap(d.xmap, a.dXin, n)) + (hi0 * d.w + wi0) * d.ldx;
             // taps inside the image: kh in [kh_lo, kh_hi), kw in [kw_lo, kw_hi)
             const int kh_lo = max(0, -hi0), kh_hi = min(d.kh, d.h - hi0);
             const int kw_lo = max(0, -wi0), kw_hi = min(d.kw, d.w - wi0);
             const unsigned rowbits = (kw_hi > kw_lo) ? (((1u << (kw_hi - kw_lo)) - 1u) << kw_lo) : 0u;
-            unsigned mk = 0u;
             if (d.kh <= 3) {  // branch-free for the 1x1 / 3x3 layers of the path
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh) mk |= (kh >= kh_lo && kh < kh_hi) ? (rowbits << (kh * d.kw)) : 0u;
             } else {
                 for (int kh = kh_lo; kh < kh_hi; ++kh) mk |= rowbits << (kh * d.kw);
             }
-            amask[i] = mk & fullmask;
-            if (pseg == 0) {
-                yo = (a.y_plain ? n * (int)d.ymap.stride_inner : (int)fmap(d.ymap, a.dYin, n)) + (d.out_nchw ? pix : pix * d.ldy);
-                if (d.res_mode) ro = (a.r_plain ? n * (int)d.rmap.stride_inner : (int)fmap(d.rmap, a.dRin, n)) + pix * d.ldr;
-            }
+            mk &= fullmask;
+            yo = (a.y_plain ? n * (int)d.ymap.stride_inner : (int)fmap(d.ymap, a.dYin, n)) + (d.out_nchw ? pix : pix * d.ldy);
+            if (d.res_mode) ro = (a.r_plain ? n * (int)d.rmap.stride_inner : (int)fmap(d.rmap, a.dRin, n)) + pix * d.ldr;
         }
-        if (pseg == 0) {  // one lane per row publishes the output / residual offsets for the epilogue
-            s_yoff[r] = yo;
-            s_roff[r] = ro;
-        }
+        s_xoff[r] = xo;
+        s_mask[r] = mk;
+        s_yoff[r] = yo;
+        s_roff[r] = ro;
     }
     const float* wrow[IB];
 #pragma unroll
@@ -196,6 +188,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         int co = tn * BN + r;
         wrow[i] = (co < a.Npad) ? wg + (int64_t)co * a.K + (pseg ^ ((r >> 1) & 7)) * 4 : nullptr;
     }
+    const float* arow[IA];
+    unsigned amask[IA];
 
     // wave-uniform position of a chunk in K: (channel chunk cb, tap (kh, kw)); advanced incrementally
     struct KPos { int cb, kh, kw; };
@@ -290,11 +284,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         }
     };
 
-    stamp(1);  // row decode done
     KPos kp = kpos_of(kt0);
+    if (kt0 < kt1) {  // weight pieces of the first chunk need no row geometry: their latency overlaps the decode
+#pragma unroll
+        for (int pc = IA; pc < NPIECE; ++pc) issue_piece(kt0, kp, B0{}, pc);
+    }
+    __syncthreads();  // row table visible (also drains the weight DMA; it had the whole decode to land)
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+        const int r = i * 32 + rsub;
+        arow[i] = xg + (s_xoff[r] + (pseg ^ ((r >> 1) & 7)) * 4);
+        amask[i] = s_mask[r];
+    }
+    stamp(1);  // row decode done
     if (kt0 < kt1) {
 #pragma unroll
-        for (int pc = 0; pc < NPIECE; ++pc) issue_piece(kt0, kp, B0{}, pc);
+        for (int pc = 0; pc < IA; ++pc) issue_piece(kt0, kp, B0{}, pc);
     }
     __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes stage 0
     stamp(2);  // first chunk landed
