@@ -186,6 +186,28 @@ def main():
                     "kernel_ms_per_step": round(k["ms"], 3),
                     "all_kernels_ms_per_step": round(sum(v["ms"] for v in kernels.values()), 3)}
 
+    pre_leg = None
+    if rank == 0:
+        # §8(f) rank 1, timed separately (never part of `value`): raw uint8 872x872 frames -> model input, on the GPU
+        from egorear_amd.preprocess import FramePreprocessor
+        pre = FramePreprocessor(device=dev)
+        nfr = min(B, 16)
+        raw = synth.synth_raw_frames(nfr, 4, seed=1234).to(dev)
+        with torch.no_grad():
+            for _ in range(3):
+                pre(raw)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                pre(raw)
+            e1.record()
+            torch.cuda.synchronize()
+        pms = e0.elapsed_time(e1) / 10
+        pbytes = nfr * 4 * (872 * 872 * 3 + 2 * 872 * 256 * 3 + 256 * 256 * 12)
+        pre_leg = {"frames_per_s": round(nfr / pms * 1e3, 1), "ms_per_batch": round(pms, 3), "batch": nfr,
+                   "algorithmic_GBps": round(pbytes / pms / 1e6, 1), "bound": "hbm", "frac_of_8TBps": round(pbytes / pms / 1e6 / PEAK_HBM_GBS, 4),
+                   "what": "uint8 (B,4,872,872,3) -> PIL-exact bicubic 256x256 + /255 + ImageNet normalise -> fp32 (B,4,3,256,256)"}
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         fps = world * B * args.steps / elapsed
@@ -200,6 +222,7 @@ def main():
             "path_tflops_per_gpu": round(fps / world * GFLOP_PER_FRAME / 1e3, 2),
             "path_frac_of_f32_mfma_peak": round(fps / world * GFLOP_PER_FRAME / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
             "roofline": roof,
+            "preprocess": pre_leg,
         }
         if kernels:
             line["kernel_ms"] = {n: round(v["ms"], 3) for n, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])}

@@ -191,6 +191,20 @@ def synth_images(batch: int, views: int, seed: int = 1234, size: int = 256, scal
     return ((0.7 * noise + 0.8 * low) * scale).contiguous()
 
 
+def synth_raw_frames(batch: int, views: int, seed: int = 1234, size: int = 872) -> torch.Tensor:
+    """Raw camera frames as the loader sees them: uint8 (B, V, size, size, 3), uniform noise blended with a
+    low-frequency pattern (SURVEY.md §8d "Synthetic inputs")."""
+    shape = (batch, views, size, size, 3)
+    n = int(np.prod(shape))
+    noise = uniform01("raw", seed, n).reshape(shape)
+    yy = np.linspace(0.0, 1.0, size, dtype=np.float32).reshape(1, 1, size, 1, 1)
+    xx = np.linspace(0.0, 1.0, size, dtype=np.float32).reshape(1, 1, 1, size, 1)
+    ph = uniform01("raw.phase", seed, batch * views * 3).reshape(batch, views, 1, 1, 3)
+    low = 0.5 + 0.5 * np.sin(6.2831853 * (1.5 * xx + ph)) * np.cos(6.2831853 * (yy - ph))
+    img = np.clip((0.55 * noise + 0.45 * low) * 255.0, 0, 255).astype(np.uint8)
+    return torch.from_numpy(img)
+
+
 def synth_gt_pose(batch: int, seed: int = 1235) -> torch.Tensor:
     g = normalish("gt_pose", seed, (batch, 16, 3)) * 30.0
     return g + torch.tensor([0.0, 20.0, 40.0])

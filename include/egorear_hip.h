@@ -168,6 +168,16 @@ int egr_jqa_sum_f32(const float* hm_embed, const float* embed, const float* bfb,
 /* (b, j, s*s) token matrix -> NHWC (b, s, s, j) image with joints as channels (heatmap_mvf_ex.py:707-711). */
 int egr_tokens_to_nhwc_f32(const float* x, float* y, int32_t b, int32_t j, int32_t hw, void* stream);
 
+/* Frame pre-processing, replaces PIL.Image.resize([ow,oh], BICUBIC) + ToTensor + Normalize of
+ * datasets/ego4view_syn/ego4view_syn_pose3d.py:41-44,159-162: src (n, h, w, 3) uint8 -> dst (n, 3, oh, ow) fp32.
+ * bounds_* (out, 2) [first tap, tap count] and coef_* (out, ksize) 22-bit fixed-point weights are Pillow's
+ * precompute_coeffs / normalize_coeffs_8bpc tables (host-computed); tmp (n, h, ow, 3) uint8 scratch;
+ * mean / stdv: 3 HOST floats; u8out (n, oh, ow, 3) optional uint8 copy of the resized image (NULL to skip). */
+int egr_preprocess_u8_f32(const uint8_t* src, int32_t n, int32_t h, int32_t w, int32_t oh, int32_t ow,
+                          const int32_t* bounds_h, const int32_t* coef_h, int32_t ksize_h,
+                          const int32_t* bounds_v, const int32_t* coef_v, int32_t ksize_v,
+                          const float* mean, const float* stdv, uint8_t* tmp, float* dst, uint8_t* u8out, void* stream);
+
 /* Library / device identification. */
 const char* egr_version(void);
 int egr_device_arch(char* buf, int32_t buflen); /* gcnArchName of the current device */
