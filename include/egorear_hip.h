@@ -178,6 +178,13 @@ int egr_preprocess_u8_f32(const uint8_t* src, int32_t n, int32_t h, int32_t w, i
                           const int32_t* bounds_v, const int32_t* coef_v, int32_t ksize_v,
                           const float* mean, const float* stdv, uint8_t* tmp, float* dst, uint8_t* u8out, void* stream);
 
+/* Pose evaluation metrics per sample, replaces evaluate_pose of
+ * pl_wrappers/egoposeformer/pose_3d_mvf_ex.py:317-333 (utils/loss.py:9-48, models/utils/pose_metric.py:104-167):
+ * pred, gt (b, joints, 3) fp32 in cm -> out (b, 4) = [MPJPE mm, PA-MPJPE mm (similarity-aligned), PCK@pck_thr_mm %,
+ * AUC % over n_auc thresholds linspace(0, pck_thr_mm, n_auc)]; aligned (b, joints, 3) optional (NULL to skip). */
+int egr_pose_metrics_f32(const float* pred, const float* gt, int32_t b, int32_t joints, float pck_thr_mm, int32_t n_auc,
+                         float* out, float* aligned, void* stream);
+
 /* Library / device identification. */
 const char* egr_version(void);
 int egr_device_arch(char* buf, int32_t buflen); /* gcnArchName of the current device */

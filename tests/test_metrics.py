@@ -1,0 +1,59 @@
+"""Pose evaluation metrics: oracle pinned by the reference's own functions; HIP kernel vs oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import metrics_oracle as M
+from oracle.make_golden_metrics import cases
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return np.load(os.path.join(golden_dir, "metrics.npz"))
+
+
+def test_oracle_matches_reference_golden(golden):
+    pred, gt = cases()
+    o = M.evaluate_pose(pred, gt)
+    np.testing.assert_allclose(o["mpjpe"], golden["mpjpe"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(o["pa_mpjpe"], golden["pa_mpjpe"], rtol=0, atol=2e-3)       # mm; float32 numpy SVD inside
+    np.testing.assert_array_equal(o["pck_3d"], golden["pck_3d"])
+    np.testing.assert_allclose(o["auc_3d"], golden["auc_3d"], rtol=0, atol=1e-4)
+    assert golden["mpjpe"][3] == 0.0 and golden["pa_mpjpe"][4] < 1e-3 < golden["mpjpe"][4]   # KATs: perfect / pure similarity
+
+
+@pytest.mark.gpu
+def test_hip_metrics_match_reference(golden):
+    from egorear_amd import metrics
+    pred, gt = cases()
+    out, aligned = metrics.pose_metrics(pred.cuda(), gt.double().cuda(), return_aligned=True)    # float64 gt like the dataset
+    out = out.cpu().numpy()
+    np.testing.assert_allclose(out[:, 0], golden["mpjpe"], rtol=0, atol=1e-2)        # 1e-3 cm
+    np.testing.assert_allclose(out[:, 1], golden["pa_mpjpe"], rtol=0, atol=1e-2)
+    np.testing.assert_array_equal(out[:, 2], golden["pck_3d"])
+    assert np.abs(out[:, 3] - golden["auc_3d"]).max() < 1e-3, np.abs(out[:, 3] - golden["auc_3d"]).max()   # percent; fp32 averaging order
+    np.testing.assert_allclose(aligned.cpu().numpy(), golden["aligned"], rtol=0, atol=2e-3)
+    ev = metrics.evaluate_pose(pred.cuda(), gt.cuda(), "test")
+    assert list(ev) == ["test_mpjpe", "test_pa_mpjpe", "test_pck_3d", "test_auc_3d"] and ev["test_mpjpe"].is_cuda
+    np.testing.assert_allclose(metrics.compute_mpjpe_batch(pred.cuda(), gt.cuda()).cpu().numpy() * 10, golden["mpjpe"], atol=1e-2)
+    with pytest.raises(RuntimeError):
+        metrics.pose_metrics(pred, gt)
+
+
+@pytest.mark.gpu
+def test_hip_metrics_degenerate_inputs():
+    """Planar and reflected point sets exercise the det(R) = +1 correction and the rank-2 covariance."""
+    from egorear_amd import metrics
+    g = torch.Generator().manual_seed(5)
+    gt = torch.randn(6, 16, 3, generator=g) * 20
+    pred = gt.clone()
+    pred[0, :, 2] = 0.0; gt[0, :, 2] = 0.0                     # planar
+    pred[1] = gt[1] * torch.tensor([1.0, 1.0, -1.0])           # reflection: no proper rotation aligns it exactly
+    pred[2] = gt[2] @ torch.tensor([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])   # pure rotation
+    pred[3:] = gt[3:] + torch.randn(3, 16, 3, generator=g) * 5
+    o = M.evaluate_pose(pred, gt)
+    out = metrics.pose_metrics(pred.cuda(), gt.cuda()).cpu().numpy()
+    np.testing.assert_allclose(out[:, 1], o["pa_mpjpe"], rtol=0, atol=2e-2)
+    assert out[2, 1] < 1e-2 and out[1, 1] > 1.0
