@@ -167,3 +167,37 @@ extern "C" int egr_pose_metrics_f32(const float* pred, const float* gt, int32_t 
                        pck_thr_mm, n_auc, out, aligned);
     return egr_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Ground-truth heat-map synthesis: replaces generate_target of generate_heatmap.py:10-48
+// (offline numpy loop writing one .npy per frame and camera).  One workgroup per (sample, joint) map: zero fill and a
+// (2*tmp+1)^2 Gaussian window centred on int(x / stride + 0.5), clipped to the map; the window table is computed on the
+// host with numpy float32 exactly as the reference does, so values are bit-identical.
+namespace {
+__global__ __launch_bounds__(256) void gt_heatmap_kernel(const double* joints, int maps, double stride, int hs, int tmp,
+                                                         const float* gauss, float* out) {
+    const int map = blockIdx.x;
+    if (map >= maps) return;
+    float* o = out + (int64_t)map * hs * hs;
+    const double jx = joints[2 * map], jy = joints[2 * map + 1];
+    const int mu_x = (int)(jx / stride + 0.5), mu_y = (int)(jy / stride + 0.5);   // C cast == Python int(): toward zero
+    const int ulx = mu_x - tmp, uly = mu_y - tmp, brx = mu_x + tmp + 1, bry = mu_y + tmp + 1;
+    const bool visible = !(ulx >= hs || uly >= hs || brx < 0 || bry < 0);
+    const int size = 2 * tmp + 1;
+    for (int i = threadIdx.x; i < hs * hs; i += 256) {
+        int y = i / hs, x = i - y * hs;
+        float v = 0.f;
+        if (visible && x >= ulx && x < brx && y >= uly && y < bry) v = gauss[(y - uly) * size + (x - ulx)];
+        o[i] = v;
+    }
+}
+}  // namespace
+
+extern "C" int egr_gt_heatmap_f32(const double* joints, int32_t maps, double image_size, int32_t heatmap_size, int32_t tmp_size,
+                                  const float* gauss, float* out, void* stream) {
+    if (!joints || !gauss || !out) return EGR_ENULL;
+    if (maps <= 0 || heatmap_size <= 0 || tmp_size < 0 || image_size <= 0) return EGR_EINVAL;
+    hipLaunchKernelGGL(gt_heatmap_kernel, dim3((unsigned)maps), dim3(256), 0, (hipStream_t)stream, joints, maps,
+                       image_size / (double)heatmap_size, heatmap_size, tmp_size, gauss, out);
+    return egr_launch_status();
+}

@@ -23,7 +23,7 @@ EXPORTS = [
     "egr_conv2d_nhwc_f32", "egr_stem_conv7x7_f32", "egr_maxpool_nhwc_f32", "egr_upsample2x_nhwc_f32",
     "egr_avgpool_nhwc_f32", "egr_argmax_rows_f32", "egr_layernorm_f32", "egr_joint_mha_f32", "egr_msda_gather_f32",
     "egr_fisheye_project_f32", "egr_linear_smallk_f32", "egr_jqa_sum_f32", "egr_tokens_to_nhwc_f32", "egr_version",
-    "egr_device_arch", "egr_conv_force_config", "egr_preprocess_u8_f32", "egr_pose_metrics_f32",
+    "egr_device_arch", "egr_conv_force_config", "egr_preprocess_u8_f32", "egr_pose_metrics_f32", "egr_gt_heatmap_f32",
 ]
 
 
@@ -67,6 +67,7 @@ def _load() -> C.CDLL:
     lib.egr_version.restype = C.c_char_p
     lib.egr_device_arch.argtypes = [C.c_char_p, i32]
     lib.egr_conv_force_config.argtypes = [i32]
+    lib.egr_gt_heatmap_f32.argtypes = [vp, i32, C.c_double, i32, i32, vp, vp, vp]
     lib.egr_pose_metrics_f32.argtypes = [vp, vp, i32, i32, f32, i32, vp, vp, vp]
     lib.egr_preprocess_u8_f32.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     for name in EXPORTS:

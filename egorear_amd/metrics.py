@@ -45,3 +45,33 @@ def evaluate_pose(pred_pose: torch.Tensor, gt_pose: torch.Tensor, prefix: str) -
     out[prefix + "_pck_3d"] = m[:, 2]
     out[prefix + "_auc_3d"] = m[:, 3]
     return out
+
+
+# --------------------------------------------------------------------------- GT heat maps
+
+def _gauss_table(sigma: float):
+    """The reference's window, computed as it computes it (generate_heatmap.py:33-37): float32 numpy."""
+    import numpy as np
+    tmp_size = sigma * 3
+    size = 2 * tmp_size + 1
+    x = np.arange(0, size, 1, np.float32)
+    y = x[:, np.newaxis]
+    x0 = y0 = size // 2
+    g = np.exp(-((x - x0) ** 2 + (y - y0) ** 2) / (2 * sigma ** 2))
+    return int(tmp_size), np.ascontiguousarray(g.astype(np.float32))
+
+
+def generate_target(joints: torch.Tensor, image_size: int = 872, heatmap_size: int = 64, sigma: float = 1.0) -> torch.Tensor:
+    """generate_heatmap.py:10-48 on the device: joints (..., J, 2) pixel coordinates (any float dtype, device tensor)
+    -> (..., J, heatmap_size, heatmap_size) fp32."""
+    if not joints.is_cuda:
+        raise RuntimeError("egorear_amd.metrics.generate_target: device tensor expected (no CPU path)")
+    j64 = joints.detach().to(torch.float64).contiguous()
+    lead = tuple(j64.shape[:-1])
+    maps = j64.numel() // 2
+    tmp, g = _gauss_table(sigma)
+    gt = torch.from_numpy(g).to(joints.device)
+    out = torch.empty(lead + (heatmap_size, heatmap_size), device=joints.device, dtype=torch.float32)
+    hip._launch("egr_gt_heatmap_f32", hip.lib.egr_gt_heatmap_f32, hip._p(j64, torch.float64), maps, float(image_size), heatmap_size, tmp,
+                hip._p(gt), hip._p(out), hip._stream())
+    return out

@@ -185,6 +185,12 @@ int egr_preprocess_u8_f32(const uint8_t* src, int32_t n, int32_t h, int32_t w, i
 int egr_pose_metrics_f32(const float* pred, const float* gt, int32_t b, int32_t joints, float pck_thr_mm, int32_t n_auc,
                          float* out, float* aligned, void* stream);
 
+/* Ground-truth heat maps, replaces generate_target of generate_heatmap.py:10-48:
+ * joints (maps, 2) float64 pixel coordinates in the image_size frame -> out (maps, heatmap_size, heatmap_size) fp32 with a
+ * (2*tmp_size+1)^2 Gaussian window `gauss` (host table) centred on int(x * heatmap_size / image_size + 0.5). */
+int egr_gt_heatmap_f32(const double* joints, int32_t maps, double image_size, int32_t heatmap_size, int32_t tmp_size,
+                       const float* gauss, float* out, void* stream);
+
 /* Library / device identification. */
 const char* egr_version(void);
 int egr_device_arch(char* buf, int32_t buflen); /* gcnArchName of the current device */

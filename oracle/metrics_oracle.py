@@ -44,3 +44,28 @@ def evaluate_pose(pred: torch.Tensor, gt: torch.Tensor, cm2mm: float = 10.0):
     return {"mpjpe": (mpjpe(pred, gt) * cm2mm).numpy(), "pa_mpjpe": (mpjpe(s1, gt) * cm2mm).numpy(),
             "pck_3d": (pck(pred * cm2mm, gt * cm2mm, 150) * 100.0).numpy(), "auc_3d": (auc * 100.0).numpy(),
             "aligned": s1.numpy()}
+
+
+def generate_target(joints: np.ndarray, image_size=872, heatmap_size=64, num_joints=15, sigma=1):
+    """generate_heatmap.py:10-48, restated (joints (J,2) pixel coordinates) -> (J, hs, hs) float32."""
+    target = np.zeros((num_joints, heatmap_size, heatmap_size), dtype=np.float32)
+    tmp_size = sigma * 3
+    for j in range(num_joints):
+        stride = image_size / heatmap_size
+        mu_x = int(joints[j][0] / stride + 0.5)
+        mu_y = int(joints[j][1] / stride + 0.5)
+        ul = [int(mu_x - tmp_size), int(mu_y - tmp_size)]
+        br = [int(mu_x + tmp_size + 1), int(mu_y + tmp_size + 1)]
+        if ul[0] >= heatmap_size or ul[1] >= heatmap_size or br[0] < 0 or br[1] < 0:
+            continue
+        size = 2 * tmp_size + 1
+        x = np.arange(0, size, 1, np.float32)
+        y = x[:, np.newaxis]
+        x0 = y0 = size // 2
+        g = np.exp(-((x - x0) ** 2 + (y - y0) ** 2) / (2 * sigma ** 2))
+        gx = max(0, -ul[0]), min(br[0], heatmap_size) - ul[0]
+        gy = max(0, -ul[1]), min(br[1], heatmap_size) - ul[1]
+        ix = max(0, ul[0]), min(br[0], heatmap_size)
+        iy = max(0, ul[1]), min(br[1], heatmap_size)
+        target[j][iy[0]:iy[1], ix[0]:ix[1]] = g[gy[0]:gy[1], gx[0]:gx[1]]
+    return target

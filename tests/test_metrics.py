@@ -57,3 +57,27 @@ def test_hip_metrics_degenerate_inputs():
     out = metrics.pose_metrics(pred.cuda(), gt.cuda()).cpu().numpy()
     np.testing.assert_allclose(out[:, 1], o["pa_mpjpe"], rtol=0, atol=2e-2)
     assert out[2, 1] < 1e-2 and out[1, 1] > 1.0
+
+
+# --------------------------------------------------------------------------- GT heat maps
+
+def test_gt_heatmap_oracle_matches_reference_golden(golden_dir):
+    from oracle.make_golden_heatmap_gt import joints_case
+    g = np.load(os.path.join(golden_dir, "gt_heatmap.npz"))["heatmaps"]
+    j = joints_case()
+    out = np.stack([M.generate_target(j[i], 872, 64, 16, 1.0) for i in range(4)])
+    assert np.array_equal(out, g)                               # bit-exact
+    assert g[0, 5].sum() == 0 and g[0, 0].max() == 1.0          # far outside -> empty map; inside -> unit peak
+
+
+@pytest.mark.gpu
+def test_hip_gt_heatmap_is_bit_exact(golden_dir):
+    from egorear_amd import metrics
+    from oracle.make_golden_heatmap_gt import joints_case
+    g = np.load(os.path.join(golden_dir, "gt_heatmap.npz"))["heatmaps"]
+    j = torch.from_numpy(joints_case())
+    out = metrics.generate_target(j.cuda())
+    assert out.shape == (4, 16, 64, 64)
+    assert np.array_equal(out.cpu().numpy(), g)
+    # the dataset drops channel 0 (Head): 15 maps per view feed the heat-map loss (App. B-13)
+    assert np.array_equal(out[:, 1:].cpu().numpy(), g[:, 1:])
