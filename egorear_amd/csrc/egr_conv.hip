@@ -110,6 +110,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             a.dbg[((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * 8 + slot] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
+    if (a.dbg && threadIdx.x == 0)  // physical placement, for co-residency analysis (tools/conv_stamps.py)
+        a.dbg[((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * 8 + 6] =
+            ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u) << 16) |
+            (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu);
     const int grp = blockIdx.z;  // grouped launch: same shape, own operands
     const float* const xg = a.x + grp * d.gx;
     const float* const wg = a.w + grp * d.gw;

@@ -18,13 +18,53 @@ __device__ __forceinline__ int clip8(int v) {
     return v < 0 ? 0 : (v > 255 ? 255 : v);
 }
 
-// horizontal pass: (n, h, w, 3) u8 -> (n, h, ow, 3) u8; one thread per (n, y, ox)
+// horizontal pass: (n, h, w, 3) u8 -> (n, h, ow, 3) u8; one thread per (n, y, ox).
+// The 3*cnt (<= 48) source bytes of a window are fetched as aligned dwords (neighbouring lanes overlap heavily: L1 hits)
+// and unpacked with shifts, instead of 45 byte loads.
+constexpr int MAXK = 24;  // taps per output (872 -> 256 needs 15)
+
 __global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t* src, uint8_t* tmp, int n, int h, int w, int ow,
                                                        const int32_t* bounds, const int32_t* coef, int ksize) {
+    // requires ksize <= 16 and (h*w*3) % 4 == 0 (host-checked): 48 window bytes + up to 3 bytes of misalignment = 13 dwords
     int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (int64_t)n * h * ow) return;
     int ox = (int)(idx % ow);
     int64_t row = idx / ow;  // n*h + y
+    int xmin = bounds[2 * ox], cnt = bounds[2 * ox + 1];
+    const int32_t* k = coef + (int64_t)ox * ksize;
+    const int64_t b0 = (row * w + xmin) * 3;          // first source byte
+    const int64_t a0 = b0 & ~(int64_t)3;               // aligned start
+    const unsigned sh = (unsigned)(b0 - a0);           // 0..3
+    const int64_t total = (int64_t)n * h * w * 3;
+    const uint32_t* p32 = reinterpret_cast<const uint32_t*>(src + a0);
+    uint32_t raw[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) raw[i] = (a0 + 4 * i < total) ? p32[i] : 0u;
+    uint32_t al[12];  // window realigned to byte 0 (v_alignbyte_b32)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) al[i] = __builtin_amdgcn_alignbyte(raw[i + 1], raw[i], sh);
+    int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+#pragma unroll
+    for (int x = 0; x < 16; ++x) {
+        int kk = (x < cnt && x < ksize) ? k[x < ksize ? x : 0] : 0;
+        const int bb = 3 * x;
+        s0 += (int)((al[bb >> 2] >> (8 * (bb & 3))) & 0xff) * kk;
+        s1 += (int)((al[(bb + 1) >> 2] >> (8 * ((bb + 1) & 3))) & 0xff) * kk;
+        s2 += (int)((al[(bb + 2) >> 2] >> (8 * ((bb + 2) & 3))) & 0xff) * kk;
+    }
+    uint8_t* o = tmp + idx * 3;
+    o[0] = (uint8_t)clip8(s0);
+    o[1] = (uint8_t)clip8(s1);
+    o[2] = (uint8_t)clip8(s2);
+}
+
+// generic horizontal pass (any ksize / size): byte loads
+__global__ __launch_bounds__(256) void resize_h_generic_kernel(const uint8_t* src, uint8_t* tmp, int n, int h, int w, int ow,
+                                                               const int32_t* bounds, const int32_t* coef, int ksize) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)n * h * ow) return;
+    int ox = (int)(idx % ow);
+    int64_t row = idx / ow;
     int xmin = bounds[2 * ox], cnt = bounds[2 * ox + 1];
     const int32_t* k = coef + (int64_t)ox * ksize;
     const uint8_t* p = src + (row * w + xmin) * 3;
@@ -41,38 +81,57 @@ __global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t* src, uint8
     o[2] = (uint8_t)clip8(s2);
 }
 
-// vertical pass + ToTensor + Normalize: (n, h, ow, 3) u8 -> (n, 3, oh, ow) f32; one thread per (n, oy, ox)
+// vertical pass + ToTensor + Normalize: (n, h, ow, 3) u8 -> (n, 3, oh, ow) f32; one thread per (n, oy, 4 consecutive ox):
+// 12 source bytes per row = 3 aligned dwords, 4 consecutive floats per colour plane = one 16-byte store each.
 __global__ __launch_bounds__(256) void resize_v_norm_kernel(const uint8_t* tmp, float* dst, int n, int h, int ow, int oh,
                                                             const int32_t* bounds, const int32_t* coef, int ksize, float m0,
                                                             float m1, float m2, float d0, float d1, float d2, uint8_t* u8out) {
+    const int owq = ow >> 2;
     int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (int64_t)n * oh * ow) return;
-    int ox = (int)(idx % ow);
-    int64_t r = idx / ow;
+    if (idx >= (int64_t)n * oh * owq) return;
+    int oxq = (int)(idx % owq);
+    int64_t r = idx / owq;
     int oy = (int)(r % oh);
     int img = (int)(r / oh);
     int ymin = bounds[2 * oy], cnt = bounds[2 * oy + 1];
     const int32_t* k = coef + (int64_t)oy * ksize;
-    const uint8_t* p = tmp + (((int64_t)img * h + ymin) * ow + ox) * 3;
-    int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(tmp + (((int64_t)img * h + ymin) * ow + oxq * 4) * 3);
+    const int rowdw = ow * 3 / 4;
+    int acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = 1 << (PRECISION_BITS - 1);
     for (int y = 0; y < cnt; ++y) {
         int kk = k[y];
-        const uint8_t* q = p + (int64_t)y * ow * 3;
-        s0 += q[0] * kk;
-        s1 += q[1] * kk;
-        s2 += q[2] * kk;
+        uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+        p += rowdw;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[i] += (int)((w0 >> (8 * i)) & 0xff) * kk;
+            acc[4 + i] += (int)((w1 >> (8 * i)) & 0xff) * kk;
+            acc[8 + i] += (int)((w2 >> (8 * i)) & 0xff) * kk;
+        }
     }
-    int c0 = clip8(s0), c1 = clip8(s1), c2 = clip8(s2);
+    int c8[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) c8[i] = clip8(acc[i]);
     if (u8out) {  // optional: Pillow's uint8 result, HWC
-        uint8_t* u = u8out + idx * 3;
-        u[0] = (uint8_t)c0; u[1] = (uint8_t)c1; u[2] = (uint8_t)c2;
+        uint8_t* u = u8out + (((int64_t)img * oh + oy) * ow + oxq * 4) * 3;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) u[i] = (uint8_t)c8[i];
     }
-    int64_t plane = (int64_t)oh * ow;
-    float* o = dst + (int64_t)img * 3 * plane + (int64_t)oy * ow + ox;
+    const int64_t plane = (int64_t)oh * ow;
+    float* o = dst + (int64_t)img * 3 * plane + (int64_t)oy * ow + oxq * 4;
     // ToTensor: x / 255 (fp32 division); Normalize: (x - mean) / std — same operations, same order, as torchvision
-    o[0] = ((float)c0 / 255.0f - m0) / d0;
-    o[plane] = ((float)c1 / 255.0f - m1) / d1;
-    o[2 * plane] = ((float)c2 / 255.0f - m2) / d2;
+    f32x4 r0, r1, r2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        r0[i] = ((float)c8[3 * i + 0] / 255.0f - m0) / d0;
+        r1[i] = ((float)c8[3 * i + 1] / 255.0f - m1) / d1;
+        r2[i] = ((float)c8[3 * i + 2] / 255.0f - m2) / d2;
+    }
+    *reinterpret_cast<f32x4*>(o) = r0;
+    *reinterpret_cast<f32x4*>(o + plane) = r1;
+    *reinterpret_cast<f32x4*>(o + 2 * plane) = r2;
 }
 
 }  // namespace
@@ -83,11 +142,17 @@ extern "C" int egr_preprocess_u8_f32(const uint8_t* src, int32_t n, int32_t h, i
                                      const float* stdv, uint8_t* tmp, float* dst, uint8_t* u8out, void* stream) {
     if (!src || !bounds_h || !coef_h || !bounds_v || !coef_v || !mean || !stdv || !tmp || !dst) return EGR_ENULL;
     if (n <= 0 || h <= 0 || w <= 0 || oh <= 0 || ow <= 0 || ksize_h <= 0 || ksize_v <= 0) return EGR_EINVAL;
+    if (ow % 4 != 0 || ksize_h > MAXK || ksize_v > MAXK || ((uintptr_t)src & 3) || ((uintptr_t)tmp & 3) || ((uintptr_t)dst & 15))
+        return EGR_EINVAL;  // 4 output columns per thread, aligned dword / 16-byte accesses
     hipStream_t s = (hipStream_t)stream;
-    int64_t t1 = (int64_t)n * h * ow, t2 = (int64_t)n * oh * ow;
+    int64_t t1 = (int64_t)n * h * ow, t2 = (int64_t)n * oh * (ow / 4);
     if (t1 >= (1LL << 31) * 256 || t2 >= (1LL << 31) * 256) return EGR_EINVAL;
-    hipLaunchKernelGGL(resize_h_kernel, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, s, src, tmp, n, h, w, ow, bounds_h,
-                       coef_h, ksize_h);
+    if (ksize_h <= 16 && ((int64_t)h * w * 3) % 4 == 0)
+        hipLaunchKernelGGL(resize_h_kernel, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, s, src, tmp, n, h, w, ow, bounds_h,
+                           coef_h, ksize_h);
+    else
+        hipLaunchKernelGGL(resize_h_generic_kernel, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, s, src, tmp, n, h, w, ow,
+                           bounds_h, coef_h, ksize_h);
     int rc = egr_launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(resize_v_norm_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, s, tmp, dst, n, h, ow, oh,

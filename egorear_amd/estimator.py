@@ -23,6 +23,16 @@ from .tree import (FFNParams, HeadLayerParams, JointTransformerLayer, ResnetBack
 _PKG_CALIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "calib", "ego4view")
 
 
+def _no_dynamo(fn):
+    """run.py wraps `model.network` in torch.compile whenever the YAML says `compile: True` (run.py:7-9; every shipped
+    config does).  The forward here is a sequence of C-ABI launches, which Dynamo cannot trace: keep it out of the
+    tracer so the compiled wrapper simply calls through (inference gains nothing from Inductor on this path)."""
+    try:
+        return torch.compiler.disable(fn)
+    except AttributeError:  # very old torch
+        return fn
+
+
 def _require_inference(module: nn.Module):
     if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
         raise NotImplementedError(
@@ -40,11 +50,13 @@ class EgoPoseFormerHeatmap(nn.Module):
         self.encoder = ResnetBackbone(**encoder_cfg)
         self.conv_heatmap = nn.Conv2d(self.encoder.get_output_channel(), num_heatmap, 1)
 
+    @_no_dynamo
     def forward_backbone(self, img, return_feat=False):
         from . import engine
         _require_inference(self)
         return engine.heatmap_backbone_api(self, img)
 
+    @_no_dynamo
     def forward(self, img, return_feat=False):
         from . import engine
         _require_inference(self)
@@ -140,6 +152,7 @@ class EgoPoseFormerHeatmapMVFEX(nn.Module):
         from . import engine
         return engine.anchors_from_heatmap_api(self, heatmap)
 
+    @_no_dynamo
     def forward(self, img, heatmap_for_anchor=None):
         from . import engine
         _require_inference(self)
@@ -200,6 +213,7 @@ class EgoPoseFormerPose3D(nn.Module):
         return [self.camera_front_left_model, self.camera_front_right_model,
                 self.camera_back_left_model, self.camera_back_right_model]
 
+    @_no_dynamo
     def forward(self, frame_feats_init, frame_feats_final, heatmap, coord_trans_mat=None, origin_3d=None):
         from . import engine
         _require_inference(self)
@@ -220,6 +234,7 @@ class EgoPoseFormerMVFEX(nn.Module):
                            "use_pred_heatmap_init": self.use_pred_heatmap_init, "camera_model": camera_model})
         self.pose3d_estimator = EgoPoseFormerPose3D(**pose3d_cfg)
 
+    @_no_dynamo
     def forward(self, img, coord_trans_mat=None, origin_3d=None):
         from . import engine
         _require_inference(self)

@@ -86,6 +86,11 @@ int egr_conv2d_nhwc_f32(const egr_conv_desc* d, const float* x, const float* w,
  * (-1 auto, 0 128x128, 1 256x64, 2 64x64, 3 128x32, 4 128x64).  Process-wide; results do not depend on it. */
 int egr_conv_force_config(int cfg);
 
+/* Diagnostic only (tools/conv_stamps.py): when `buf` is non-NULL every conv workgroup writes 8 x uint64 — s_memtime at
+ * [0] start, [1] row decode done, [2] first chunk landed, [3] K loop done, [4] accumulators staged, [5] stores issued, and
+ * [6] its physical placement (XCC id << 16 | HW_ID) — to buf[8 * workgroup].  NULL (the default) disables it. */
+int egr_conv_debug_stamps(unsigned long long* buf);
+
 /* ResNet stem: conv 7x7 stride 2 pad 3 (3 -> 64) + BatchNorm(eval) + ReLU, NCHW fp32 input
  * (h, w multiples of 64) -> NHWC output (n, h/2, w/2, 64).  w: [64][148] rows = (ci,kh,kw), last col 0.
  * Replaces layer_s2 of models/backbones/resnet.py:16,49. */

@@ -171,3 +171,50 @@ def test_state_dict_reload_invalidates_packed_weights(nets):
         net.load_state_dict(sd, strict=True)
         c = net(img)
     assert torch.allclose(b, a + 1.0, atol=1e-6) and torch.equal(a, c)
+
+
+def test_torch_compile_wrapper_calls_through(nets):
+    """run.py does `model.network = torch.compile(model.network, mode=...)` for every shipped YAML (compile: True)."""
+    from egorear_amd import synth
+    net = nets("syn")
+    img = synth.synth_images(1, 4, seed=9).to(DEV)
+    compiled = torch.compile(net, mode="default")
+    with torch.no_grad():
+        a, ha = net(img)
+        b, hb = compiled(img)
+    assert all(torch.equal(x, y) for x, y in zip(a, b)) and all(torch.equal(x, y) for x, y in zip(ha, hb))
+    # checkpoints saved from a compiled module carry the "_orig_mod." prefix the reference strips (utils/state_dict.py:3-21)
+    keys = list(compiled.state_dict().keys())
+    assert all(k.startswith("_orig_mod.") for k in keys) and len(keys) == 698
+
+
+def test_heatmap_for_anchor_argument(nets, calib_dir):
+    """EgoPoseFormerHeatmapMVFEX.forward(img, heatmap_for_anchor): anchors come from the supplied heat map
+    (heatmap_mvf_ex.py:293-296), everything else unchanged."""
+    from egorear_amd import synth
+    from oracle import egorear_oracle as O
+    net = nets("mvfex")
+    img = synth.synth_images(1, 4, seed=21)
+    hfa = synth.uniform("hfa", 3, (1, 4, 15, 64, 64), -0.2, 1.2)
+    with torch.no_grad():
+        hms, fts = net(img.to(DEV), hfa.to(DEV))
+        idx = net.__dict__["_egr_last_aux"]["argmax_idx"].cpu().long()
+        sd = {k: v.cpu() for k, v in net.state_dict().items()}
+        o_hms, o_fts, o_aux = O.heatmap_mvfex_forward(sd, "", img, 0.5, hfa)
+    assert torch.equal(idx, o_aux["argmax_idx"]) and torch.equal(idx, hfa.view(1, 4, 15, -1).argmax(-1))
+    assert float((hms[1].cpu() - o_hms[1]).abs().max()) < TOL_HM
+    assert float((fts[1].cpu() - o_fts[1]).abs().max()) < 5e-4
+
+
+def test_pose3d_estimator_standalone_api(nets):
+    """EgoPoseFormerPose3D.forward(frame_feats_init, frame_feats_final, heatmap, ...) accepts foreign (B,V,C,H,W) tensors."""
+    from egorear_amd import synth
+    net = nets("syn")
+    img = synth.synth_images(2, 4, seed=23).to(DEV)
+    with torch.no_grad():
+        preds, hms = net(img)
+        _, fts = net.heatmap_estimator(img)
+        a = net.pose3d_estimator(fts[0], fts[1], hms[1])                                   # our own views: zero-copy
+        b = net.pose3d_estimator(fts[0].contiguous(), fts[1].contiguous(), hms[1])         # plain NCHW copies
+    for p, q, r in zip(preds, a, b):
+        assert torch.equal(p, q) and torch.equal(p, r)

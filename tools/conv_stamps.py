@@ -26,5 +26,26 @@ for (n, h, w, cin, cout, k, s, label) in SH:
     names = ["decode", "1st DMA", "k-loop", "stage", "store issue"]
     print(f"{label:18s} blocks {blocks:5d}  kernel span {span:10.0f} cyc | per block: total {tot.mean():8.0f} | " +
           " ".join(f"{nm} {d[:, i].mean():7.0f}" for i, nm in enumerate(names)))
+    # co-residency: group blocks by physical CU (XCC id, SE/SH/CU bits of HW_ID) and measure how much of the time at least
+    # one resident block is inside its K loop (MFMA can be busy) vs none (MFMA certainly idle)
+    ids = buf.view(blocks, 8)[:, 6].cpu().numpy()
+    cu = (ids >> 16) * 4096 + ((ids >> 8) & 0x7f)
+    import numpy as np
+    tt = t.numpy()
+    busy = idle = 0.0; both = 0.0
+    for c in np.unique(cu):
+        sel = tt[cu == c]
+        ev = []
+        for r in sel:
+            ev.append((r[2], +1)); ev.append((r[3], -1))       # K loop interval [first chunk landed, k loop done]
+        ev.sort()
+        lo, hi = sel[:, 0].min(), sel[:, 5].max()
+        cur, last, b1, b2 = 0, lo, 0.0, 0.0
+        for (x, dlt) in ev:
+            if cur >= 1: b1 += x - last
+            if cur >= 2: b2 += x - last
+            cur += dlt; last = x
+        busy += b1; both += b2; idle += (hi - lo) - b1
+    print(f"{'':18s} CUs seen {len(np.unique(cu))}; per-CU time with >=1 block in its K loop {busy / (busy + idle):.2f}, with 2 in K loop {both / (busy + idle):.2f}, none {idle / (busy + idle):.2f}")
     # concurrency: sum of block lifetimes / span / 512 slots
     print(f"{'':18s} occupancy of 512 slots: {tot.sum() / span / 512:.2f}; start-to-start gap on a slot ~ {span * 512 / blocks - tot.mean():8.0f} cyc")
