@@ -246,6 +246,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     }
 
     constexpr int NPIECE = IA + IB;
+    constexpr int DMA_EVERY = (FM * FN >= 4) ? 2 : 1;  // big tiles: one DMA piece behind every 2nd MFMA (measured +2.5 %)
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
 
@@ -279,8 +280,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i][t], bv[cur][j][t], acc[i][j], 0, 0, 0);
                         if constexpr (ISSUE) {
                             const int n = ((g * 4 + t) * FM + i) * FN + j;
-                            if (n < NPIECE) {
-                                issue_piece(kt + 1, kp_next, NB{}, n);
+                            if ((n % DMA_EVERY) == 0 && (n / DMA_EVERY) < NPIECE) {
+                                issue_piece(kt + 1, kp_next, NB{}, n / DMA_EVERY);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                         }

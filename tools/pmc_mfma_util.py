@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""MFMA utilisation of the conv kernel from a rocprofv3 PMC pass:
+    rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d DIR -- python3 bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline
+    python tools/pmc_mfma_util.py DIR out.json
+SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD (64 per v_mfma_f32_32x32x2_f32), summed over the chip's 1024 SIMDs;
+GRBM_GUI_ACTIVE is summed over the 8 XCDs (guide: effective clock = GRBM_GUI_ACTIVE / 8 / wall time)."""
+import collections, csv, glob, json, sys
+f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)[0]
+per = collections.defaultdict(lambda: collections.defaultdict(float)); dur = collections.defaultdict(float); seen = set()
+for r in csv.DictReader(open(f)):
+    k = "conv_igemm" if "conv_igemm" in r["Kernel_Name"] else ("stem" if "stem_kernel" in r["Kernel_Name"] else "other")
+    per[k][r["Counter_Name"]] += float(r["Counter_Value"])
+    if (r["Dispatch_Id"]) not in seen:
+        seen.add(r["Dispatch_Id"]); dur[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+out = {}
+for k in ("conv_igemm", "stem"):
+    busy, gui = per[k]["SQ_VALU_MFMA_BUSY_CYCLES"], per[k]["GRBM_GUI_ACTIVE"]
+    cycles = gui / 8.0
+    out[k] = {"mfma_busy_simd_cycles": busy, "elapsed_cycles": cycles, "mfma_util": busy / (cycles * 1024.0),
+              "effective_clock_GHz": cycles / max(dur[k], 1.0), "kernel_time_ms": dur[k] / 1e6}
+json.dump(out, open(sys.argv[2], "w"), indent=1); print(json.dumps(out))
