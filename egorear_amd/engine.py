@@ -105,6 +105,18 @@ def pack_convs(convs: Sequence[nn.Conv2d], bns: Optional[Sequence[nn.BatchNorm2d
     return p
 
 
+def pack_convs_cin_slice(convs: Sequence[nn.Conv2d], c0: int, c1: int, with_bias: bool) -> PConv:
+    """Input-channel slice [c0, c1) of 1x1 convs as its own conv (used to split a conv over a channel concat)."""
+    p = PConv()
+    k0 = convs[0]
+    p.cout, p.cin, p.kh, p.kw = k0.weight.shape[0], c1 - c0, 1, 1
+    p.stride, p.pad, p.groups = 1, 0, len(convs)
+    p.w = _stack([_pad_rows(pack_conv_weight(c.weight.detach()[:, c0:c1])) for c in convs])
+    p.scale = None
+    p.shift = _stack([_pad_vec(c.bias.detach(), p.cout) for c in convs]) if (with_bias and k0.bias is not None) else None
+    return p
+
+
 def pack_linears(pairs: Sequence) -> PConv:
     """pairs: (weight (N,K), bias (N,) | None) per group member."""
     p = PConv()
@@ -275,17 +287,20 @@ def run_backbone(st: State, encs, img: torch.Tensor, view0: int, nviews: int, fe
             last = si == 3 and bi == nblk - 1
             x = _basic_block(st, [stages[g][si][bi] for g in range(G)], x, out=s32_out if last else None)
         pyramid.append(x)
-    # FPN top-down: lateral conv writes the left half of a 256-wide buffer, the x2 upsample the right half
-    n = x.n
+    # FPN top-down (resnet.py:121-137).  The fuse conv over cat(lateral, up2(coarser)) is split by linearity:
+    #   W . cat(a, up2(b)) + bias = W_a . a + bias + up2(W_b . b)
+    # so the W_b half runs on the coarse grid (a quarter of the pixels), is upsampled, and enters the W_a conv as a
+    # pre-activation residual; the 256-wide concat buffer is never materialised.
     c = n0.out_channels
     lat = conv(st, pyramid[3], st.get(n0.lateral_convs[3], lambda: pack_convs([k.lateral_convs[3][0] for k in necks])), ACT_RELU)
     for i in (3, 2, 1):
         lo = pyramid[i - 1]
-        cat = torch.empty((n, lo.h, lo.w, 2 * c), device=img.device, dtype=torch.float32)
-        conv(st, lo, st.get(n0.lateral_convs[i - 1], lambda i=i: pack_convs([k.lateral_convs[i - 1][0] for k in necks])), ACT_RELU,
-             out=Img(cat[..., :c]))
-        hip.upsample2x(lat, out=Img(cat[..., c:]))
-        fused = conv(st, Img(cat), st.get(n0.fuse_convs[i - 1], lambda i=i: pack_convs([k.fuse_convs[i - 1][0] for k in necks])), ACT_RELU)
+        fine = conv(st, lo, st.get(n0.lateral_convs[i - 1], lambda i=i: pack_convs([k.lateral_convs[i - 1][0] for k in necks])), ACT_RELU)
+        fuse = n0.fuse_convs[i - 1]
+        pa = st.get((id(fuse), "a"), lambda i=i: pack_convs_cin_slice([k.fuse_convs[i - 1][0] for k in necks], 0, c, True))
+        pb = st.get((id(fuse), "b"), lambda i=i: pack_convs_cin_slice([k.fuse_convs[i - 1][0] for k in necks], c, 2 * c, False))
+        coarse = hip.upsample2x(conv(st, lat, pb, ACT_NONE))
+        fused = conv(st, fine, pa, ACT_RELU, res=coarse, res_mode=RES_BEFORE_ACT)
         lat = conv(st, fused, st.get(n0.fpn_convs[i - 1], lambda i=i: pack_convs([k.fpn_convs[i - 1][0] for k in necks])), ACT_RELU,
                    out=feat_out if i == 1 else None)
     return pyramid
