@@ -218,3 +218,17 @@ def test_pose3d_estimator_standalone_api(nets):
         b = net.pose3d_estimator(fts[0].contiguous(), fts[1].contiguous(), hms[1])         # plain NCHW copies
     for p, q, r in zip(preds, a, b):
         assert torch.equal(p, q) and torch.equal(p, r)
+
+
+def test_graphed_forward_replays_identically(nets):
+    from egorear_amd import synth
+    from egorear_amd.runner import GraphedForward
+    net = nets("syn")
+    g = GraphedForward(net)
+    for seed in (31, 32):
+        img = synth.synth_images(2, 4, seed=seed).to(DEV)
+        with torch.no_grad():
+            ref_p, ref_h = net(img)
+        p, h = g(img)
+        assert all(torch.equal(a, b) for a, b in zip(p, ref_p)) and all(torch.equal(a, b) for a, b in zip(h, ref_h))
+    assert len(g._graphs) == 1          # same shape -> one capture, replayed
