@@ -163,18 +163,37 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             else { n = fdiv(m, a.dHoWo); pix = m - n * HoWo; }
             if (a.wo_shift >= 0) { ho = pix >> a.wo_shift; wo = pix & (d.wo - 1); }
             else { ho = fdiv(pix, a.dWo); wo = pix - ho * d.wo; }
-            const int hi0 = ho * d.stride - d.pad, wi0 = wo * d.stride - d.pad;
-            // 32-bit element offsets (the host bounds every operand below 2^31 elements); may be negative for halo rows
-            xo = (a.x_plain ? n * (int)d.xmap.stride_inner : (int)fmap(d.xmap, a.dXin, n)) + (hi0 * d.w + wi0) * d.ldx;
-            // taps inside the image: kh in [kh_lo, kh_hi), kw in [kw_lo, kw_hi)
-            const int kh_lo = max(0, -hi0), kh_hi = min(d.kh, d.h - hi0);
-            const int kw_lo = max(0, -wi0), kw_hi = min(d.kw, d.w - wi0);
-            const unsigned rowbits = (kw_hi > kw_lo) ? (((1u << (kw_hi - kw_lo)) - 1u) << kw_lo) : 0u;
-            if (d.kh <= 3) {  // branch-free for the 1x1 / 3x3 layers of the path
+            const int xbase = a.x_plain ? n * (int)d.xmap.stride_inner : (int)fmap(d.xmap, a.dXin, n);
+            if (!d.transposed) {
+                const int hi0 = ho * d.stride - d.pad, wi0 = wo * d.stride - d.pad;
+                // 32-bit element offsets (the host bounds every operand below 2^31 elements); may be negative for halo rows
+                xo = xbase + (hi0 * d.w + wi0) * d.ldx;
+                // taps inside the image: kh in [kh_lo, kh_hi), kw in [kw_lo, kw_hi)
+                const int kh_lo = max(0, -hi0), kh_hi = min(d.kh, d.h - hi0);
+                const int kw_lo = max(0, -wi0), kw_hi = min(d.kw, d.w - wi0);
+                const unsigned rowbits = (kw_hi > kw_lo) ? (((1u << (kw_hi - kw_lo)) - 1u) << kw_lo) : 0u;
+                if (d.kh <= 3) {  // branch-free for the 1x1 / 3x3 layers of the path
 #pragma unroll
-                for (int kh = 0; kh < 3; ++kh) mk |= (kh >= kh_lo && kh < kh_hi) ? (rowbits << (kh * d.kw)) : 0u;
+                    for (int kh = 0; kh < 3; ++kh) mk |= (kh >= kh_lo && kh < kh_hi) ? (rowbits << (kh * d.kw)) : 0u;
+                } else {
+                    for (int kh = kh_lo; kh < kh_hi; ++kh) mk |= rowbits << (kh * d.kw);
+                }
             } else {
-                for (int kh = kh_lo; kh < kh_hi; ++kh) mk |= rowbits << (kh * d.kw);
+                // data gradient: output pixel (ho, wo) is an INPUT pixel of the forward conv; tap (kh, kw) reads
+                // dy[(ho+pad-kh)/stride, (wo+pad-kw)/stride] when both divisions are exact and in range.  Base = floor
+                // of the tap-0 position; tap (kh, kw) sits (kh/stride, kw/stride) pixels before it (see issue_piece).
+                const int th = ho + d.pad, tw = wo + d.pad;
+                const int bh = th / d.stride, bw = tw / d.stride;          // th, tw >= 0
+                xo = xbase + (bh * d.w + bw) * d.ldx;
+                for (int kh = 0; kh < d.kh; ++kh) {
+                    const int sh_ = th - kh;
+                    if (sh_ < 0 || sh_ % d.stride != 0 || sh_ / d.stride >= d.h) continue;
+                    for (int kw = 0; kw < d.kw; ++kw) {
+                        const int sw_ = tw - kw;
+                        if (sw_ < 0 || sw_ % d.stride != 0 || sw_ / d.stride >= d.w) continue;
+                        mk |= 1u << (kh * d.kw + kw);
+                    }
+                }
             }
             mk &= fullmask;
             yo = (a.y_plain ? n * (int)d.ymap.stride_inner : (int)fmap(d.ymap, a.dYin, n)) + (d.out_nchw ? pix : pix * d.ldy);
@@ -208,7 +227,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         float* sA = lds + BUF * P::TILE;
         if (piece < IA) {
             const int tap = kp.kh * d.kw + kp.kw;
-            const int toff = (kp.kh * d.w + kp.kw) * d.ldx + kp.cb * BK;     // wave-uniform, 32-bit
+            // wave-uniform, 32-bit.  Transposed mode: th - kh = stride*(bh - kh/stride) + (th%stride - kh%stride), and the mask
+            // bit is set only where the remainders agree, so the source pixel is (bh - kh/stride, bw - kw/stride).
+            const int toff = d.transposed ? -((kp.kh / d.stride) * d.w + (kp.kw / d.stride)) * d.ldx + kp.cb * BK
+                                          : (kp.kh * d.w + kp.kw) * d.ldx + kp.cb * BK;
             const uint64_t pa = (uint64_t)(arow[piece] + toff);
             const bool ok = (amask[piece] >> tap) & 1u;
             // select between the pixel row and the zero buffer with two 32-bit v_cndmask (no branch, no 64-bit logic)

@@ -1,0 +1,278 @@
+// Weight gradient of a convolution / linear layer on fp32 MFMA (training row, SURVEY.md §8f rank 2 — a brick, the
+// training step is not assembled yet).
+//
+//   dW[co][k] = sum_m dy[m][co] * A[m][k],   A[m][k] = x[n, ho*s-p+kh, wo*s-p+kw, ci]  (the forward im2col row),
+//   m = (n, ho, wo) over all output pixels,  k = (ci/32, kh, kw, ci%32) — the forward kernel's K order, so dW comes out in
+//   the packed weight layout [cout][cin/32][kh*kw][32].
+//
+// Here the pixel index m is the REDUCTION dimension.  A workgroup owns a BCO x 128 tile of dW and walks its share of the
+// pixels in stages of 32 rows: the dy rows (BCO contiguous floats each) and the gathered x rows (4 K-chunks of 128
+// contiguous bytes each, zero outside the image) stream into two LDS stages by global_load_lds; the MFMA operands are
+// read k-major straight from those row-major tiles (lane = channel, so ds_read_b32 is conflict free):
+//   a[i = co][k = m],  b[k = m][j = kcol]  ->  D[co][kcol] += dy[m][co] * A[m][kcol].
+// The pixels are split over gridDim.y; every split writes its partial tile to a slab and a second kernel sums the slabs
+// in fixed order (deterministic, no float atomics).
+#include <type_traits>
+
+#include "egr_common.h"
+
+namespace {
+
+struct WgradArgs {
+    const float* x;
+    const float* dy;
+    float* ws;   // [splits][cout][K]
+    float* dw;   // [cout][K]
+    egr_nmap xmap, ymap;
+    int n, h, w, cin, cout, kh, kw, stride, pad, ho, wo, ldx, ldy;
+    int M, K, chunks, taps;
+    int splits, rows_per_split;
+    int tilesCO, tilesK;
+    int accumulate;  // dw += sum instead of dw = sum
+};
+
+__device__ __attribute__((aligned(16))) float egr_wg_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ void wg_glds16(const float* g, float* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+constexpr int RS = 32;    // rows (pixels) per stage
+constexpr int BKO = 128;  // K columns per tile = 4 chunks
+
+template <int BCO>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+    constexpr int TM = BCO / 2, FM = TM / 32, FN = 2;        // waves 2 (co) x 2 (k); wave tile TM x 64
+    constexpr int STAGE = RS * (BCO + BKO);                  // floats
+    constexpr int DY_ROWS_PER_PIECE = 256 / BCO;             // 1 KiB = 256 floats
+    constexpr int DY_PIECES = RS / DY_ROWS_PER_PIECE;        // per stage
+    constexpr int A_PIECES = RS / 2;                         // 2 rows x 4 chunks x 128 B per piece
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+    __shared__ int s_xoff[2][RS];
+    __shared__ int s_yoff[2][RS];
+    __shared__ unsigned s_mask[2][RS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int tk = blockIdx.x % a.tilesK, tco = blockIdx.x / a.tilesK;
+    const int co0 = tco * BCO, chunk0 = tk * 4;
+    const int split = blockIdx.y;
+    const int m_begin = split * a.rows_per_split;
+    const int m_end = min(a.M, m_begin + a.rows_per_split);
+    const int nstages = (m_end > m_begin) ? (m_end - m_begin + RS - 1) / RS : 0;
+    const int HoWo = a.ho * a.wo;
+
+    // per-lane constants of the A pieces: lane -> (row parity, chunk, 16-byte segment)
+    const int a_chunk = (lane >> 3) & 3, a_seg = lane & 7, a_rsub = lane >> 5;
+    const int chunk = chunk0 + a_chunk;
+    const bool chunk_ok = chunk < a.chunks;
+    int a_tap = 0, a_toff = 0;
+    if (chunk_ok) {
+        int cb = chunk / a.taps;
+        a_tap = chunk - cb * a.taps;
+        int kh = a_tap / a.kw, kw = a_tap - kh * a.kw;
+        a_toff = (kh * a.w + kw) * a.ldx + cb * 32 + a_seg * 4;
+    }
+    // dy pieces: lane -> (row within piece, 16-byte segment)
+    const int d_rsub = lane / (BCO / 4), d_seg = lane % (BCO / 4);
+    const bool d_ok = (co0 + d_seg * 4) < a.cout;  // cout % 4 == 0 is required by the host
+
+    auto decode = [&](int stage, int tb) {  // rows of `stage` -> table tb; lanes 0..7 of every wave: 32 rows
+        if (lane < 8) {
+            int r = wave * 8 + lane;
+            int m = m_begin + stage * RS + r;
+            int xo = 0, yo = -1;
+            unsigned mk = 0u;
+            if (stage < nstages && m < m_end) {
+                int n = m / HoWo, pix = m - n * HoWo;
+                int ho = pix / a.wo, wo = pix - ho * a.wo;
+                int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
+                xo = (int)egr_map(a.xmap, n) + (hi0 * a.w + wi0) * a.ldx;
+                yo = (int)egr_map(a.ymap, n) + pix * a.ldy;
+                for (int kh = 0; kh < a.kh; ++kh)
+                    for (int kw = 0; kw < a.kw; ++kw) {
+                        int hi = hi0 + kh, wi = wi0 + kw;
+                        if (hi >= 0 && hi < a.h && wi >= 0 && wi < a.w) mk |= 1u << (kh * a.kw + kw);
+                    }
+            }
+            s_xoff[tb][r] = xo;
+            s_yoff[tb][r] = yo;
+            s_mask[tb][r] = mk;
+        }
+    };
+
+    auto issue = [&](int tb, auto buf_tag) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        float* sDy = lds + BUF * STAGE;
+        float* sA = sDy + RS * BCO;
+#pragma unroll
+        for (int j = 0; j < DY_PIECES / 4; ++j) {
+            const int piece = wave * (DY_PIECES / 4) + j;
+            const int r = piece * DY_ROWS_PER_PIECE + d_rsub;
+            const int yo = s_yoff[tb][r];
+            const float* p = (yo >= 0 && d_ok) ? a.dy + yo + co0 + d_seg * 4 : egr_wg_zero16;
+            wg_glds16(p, sDy + piece * 256);
+        }
+#pragma unroll
+        for (int j = 0; j < A_PIECES / 4; ++j) {
+            const int piece = wave * (A_PIECES / 4) + j;
+            const int r = piece * 2 + a_rsub;
+            const bool ok = chunk_ok && s_yoff[tb][r] >= 0 && ((s_mask[tb][r] >> a_tap) & 1u);
+            const float* p = ok ? a.x + (s_xoff[tb][r] + a_toff) : egr_wg_zero16;
+            wg_glds16(p, sA + piece * 256);
+        }
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](auto buf_tag) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        const float* sDy = lds + BUF * STAGE;
+        const float* sA = sDy + RS * BCO;
+#pragma unroll
+        for (int ks = 0; ks < RS / 2; ++ks) {
+            const int row = 2 * ks + half;
+            float av[FM], bv[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) av[i] = sDy[row * BCO + wm * TM + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bv[j] = sA[row * BKO + wn * 64 + j * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    // pipeline: table t+1 is decoded while stage t is multiplied; DMA of stage t+1 is issued right after the barrier
+    decode(0, 0);
+    __syncthreads();
+    if (nstages > 0) issue(0, B0{});
+    decode(1, 1);
+    for (int t = 0; t < nstages; t += 2) {
+        __syncthreads();                       // stage t landed (vmcnt(0)), table t+1 visible
+        if (t + 1 < nstages) issue(1, B1{});
+        decode(t + 2, 0);
+        compute(B0{});
+        if (t + 1 >= nstages) break;
+        __syncthreads();                       // stage t+1 landed, table t+2 visible
+        if (t + 2 < nstages) issue(0, B0{});
+        decode(t + 3, 1);
+        compute(B1{});
+    }
+
+    // partial tile -> slab [split][co][k]; C/D map: col = lane&31 (k column), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (co)
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int kcol = chunk0 * 32 + wn * 64 + j * 32 + l31;
+            if (kcol >= a.K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (co < a.cout) a.ws[((int64_t)split * a.cout + co) * a.K + kcol] = acc[i][j][r];
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a) {
+    int64_t idx = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int64_t total = (int64_t)a.cout * a.K;
+    if (idx >= total) return;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < a.splits; ++sp) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(a.ws + (int64_t)sp * total + idx);
+        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+    f32x4* o = reinterpret_cast<f32x4*>(a.dw + idx);
+    if (a.accumulate) { f32x4 p = *o; s[0] += p[0]; s[1] += p[1]; s[2] += p[2]; s[3] += p[3]; }
+    *o = s;
+}
+
+// per-channel sum over rows: bias gradient (and the building block of the BatchNorm reductions)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* x, int64_t rows, int c, int ld, float* partial, int rows_per_block) {
+    // block handles rows [b*rpb, ...), thread t handles channels t, t+256, ...
+    int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+        float s = 0.f;
+        for (int64_t r = r0; r < r1; ++r) s += x[r * ld + ch];
+        partial[(int64_t)blockIdx.x * c + ch] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, int nblk, int c, float* out, int accumulate) {
+    int ch = blockIdx.x * 256 + threadIdx.x;
+    if (ch >= c) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * c + ch];
+    out[ch] = (float)s + (accumulate ? out[ch] : 0.f);
+}
+
+}  // namespace
+
+extern "C" int egr_conv2d_wgrad_f32(const egr_conv_desc* dd, const float* x, const float* dy, float* dw, float* db,
+                                    float* workspace, size_t workspace_floats, int32_t accumulate, void* stream) {
+    if (!dd || !x || !dy || !dw || !workspace) return EGR_ENULL;
+    const egr_conv_desc& d = *dd;
+    if (d.groups > 1 || d.transposed || d.out_nchw) return EGR_EINVAL;
+    if (d.cin <= 0 || d.cin % 32 != 0 || d.cout <= 0 || d.cout % 4 != 0 || d.kh * d.kw > 32 || d.kh <= 0 || d.kw <= 0) return EGR_EINVAL;
+    if (d.ldx % 4 != 0 || d.ldy % 4 != 0 || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || ((uintptr_t)dw & 15) || ((uintptr_t)workspace & 15))
+        return EGR_EINVAL;
+    if (d.xmap.n_inner <= 0 || d.ymap.n_inner <= 0) return EGR_EINVAL;
+    WgradArgs a;
+    a.x = x; a.dy = dy; a.ws = workspace; a.dw = dw;
+    a.xmap = d.xmap; a.ymap = d.ymap;
+    a.n = d.n; a.h = d.h; a.w = d.w; a.cin = d.cin; a.cout = d.cout; a.kh = d.kh; a.kw = d.kw; a.stride = d.stride; a.pad = d.pad;
+    a.ho = d.ho; a.wo = d.wo; a.ldx = d.ldx; a.ldy = d.ldy;
+    int64_t M64 = (int64_t)d.n * d.ho * d.wo;
+    if (M64 <= 0 || M64 >= (1LL << 31)) return EGR_EINVAL;
+    a.M = (int)M64;
+    a.taps = d.kh * d.kw;
+    a.chunks = a.taps * (d.cin / 32);
+    a.K = a.chunks * 32;
+    a.accumulate = accumulate;
+    const int bco = (d.cout > 64) ? 128 : 64;
+    a.tilesCO = (d.cout + bco - 1) / bco;
+    a.tilesK = (a.chunks + 3) / 4;
+    const int tiles = a.tilesCO * a.tilesK;
+    int splits = (1024 + tiles - 1) / tiles;
+    int max_splits = (a.M + 4 * RS - 1) / (4 * RS);  // at least 4 stages per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    const size_t per_split = (size_t)d.cout * a.K;
+    if ((size_t)splits * per_split > workspace_floats) splits = (int)(workspace_floats / per_split);
+    if (splits < 1) return EGR_EWORKSPACE;
+    a.rows_per_split = ((a.M + splits - 1) / splits + RS - 1) / RS * RS;
+    a.splits = (a.M + a.rows_per_split - 1) / a.rows_per_split;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)tiles, (unsigned)a.splits);
+    if (bco == 128) hipLaunchKernelGGL(conv_wgrad_kernel<128>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(conv_wgrad_kernel<64>, grid, dim3(256), 0, s, a);
+    int rc = egr_launch_status();
+    if (rc) return rc;
+    const int64_t total = (int64_t)d.cout * a.K;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, a);
+    rc = egr_launch_status();
+    if (rc || !db) return rc;
+    // bias gradient: column sums of dy (plain batch only)
+    if (d.ymap.n_inner < d.n || d.ymap.stride_inner != (int64_t)d.ho * d.wo * d.ldy) return EGR_EINVAL;
+    const int rpb = 1024;
+    int nblk = (int)((M64 + rpb - 1) / rpb);
+    if ((size_t)nblk * d.cout > workspace_floats) return EGR_EWORKSPACE;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)nblk), dim3(256), 0, s, dy, M64, d.cout, d.ldy, workspace, rpb);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((d.cout + 255) / 256)), dim3(256), 0, s, workspace, nblk, d.cout, db,
+                       accumulate);
+    return egr_launch_status();
+}

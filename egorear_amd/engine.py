@@ -72,6 +72,12 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
     return w.float().permute(0, 2, 3, 1).reshape(co, kh * kw, ci // 32, 32).permute(0, 2, 1, 3).reshape(co, -1).contiguous()
 
 
+def unpack_conv_weight(wp: torch.Tensor, cin: int, kh: int, kw: int) -> torch.Tensor:
+    """Inverse of pack_conv_weight: [cout][cin/32][kh*kw][32] -> OIHW (used for weight gradients)."""
+    co = wp.shape[0]
+    return wp.reshape(co, cin // 32, kh * kw, 32).permute(0, 2, 1, 3).reshape(co, kh, kw, cin).permute(0, 3, 1, 2).contiguous()
+
+
 def _bn_affine(bn: nn.BatchNorm2d, bias: Optional[torch.Tensor]):
     scale = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
     shift = bn.bias.detach().double() - bn.running_mean.detach().double() * scale

@@ -23,7 +23,7 @@ EXPORTS = [
     "egr_conv2d_nhwc_f32", "egr_stem_conv7x7_f32", "egr_maxpool_nhwc_f32", "egr_upsample2x_nhwc_f32",
     "egr_avgpool_nhwc_f32", "egr_argmax_rows_f32", "egr_layernorm_f32", "egr_joint_mha_f32", "egr_msda_gather_f32",
     "egr_fisheye_project_f32", "egr_linear_smallk_f32", "egr_jqa_sum_f32", "egr_tokens_to_nhwc_f32", "egr_version",
-    "egr_device_arch", "egr_conv_force_config", "egr_preprocess_u8_f32", "egr_pose_metrics_f32", "egr_gt_heatmap_f32", "egr_conv_debug_stamps",
+    "egr_device_arch", "egr_conv_force_config", "egr_preprocess_u8_f32", "egr_pose_metrics_f32", "egr_gt_heatmap_f32", "egr_conv_debug_stamps", "egr_conv2d_wgrad_f32",
 ]
 
 
@@ -41,6 +41,7 @@ class ConvDesc(C.Structure):
         ("groups", C.c_int32),
         ("gx", C.c_int64), ("gw", C.c_int64), ("gp", C.c_int64), ("gy", C.c_int64), ("gr", C.c_int64),
         ("grs", C.c_int64), ("grm", C.c_int64),
+        ("transposed", C.c_int32),
     ]
 
 
@@ -67,6 +68,7 @@ def _load() -> C.CDLL:
     lib.egr_version.restype = C.c_char_p
     lib.egr_device_arch.argtypes = [C.c_char_p, i32]
     lib.egr_conv_force_config.argtypes = [i32]
+    lib.egr_conv2d_wgrad_f32.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, C.c_size_t, i32, vp]
     lib.egr_gt_heatmap_f32.argtypes = [vp, i32, C.c_double, i32, i32, vp, vp, vp]
     lib.egr_pose_metrics_f32.argtypes = [vp, vp, i32, i32, f32, i32, vp, vp, vp]
     lib.egr_preprocess_u8_f32.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
@@ -166,7 +168,7 @@ def conv2d(x: Img, w: torch.Tensor, cout: int, kh: int, kw: int, stride: int, pa
            out: Optional[Img] = None, out_nchw: Optional[torch.Tensor] = None, ymap: Optional[NMap] = None,
            xmap: Optional[NMap] = None, rmap: Optional[NMap] = None, workspace: Optional[torch.Tensor] = None,
            split_k: int = 1, groups: int = 1, gx: Optional[int] = None, gy: Optional[int] = None,
-           gr: Optional[int] = None, grs: int = 0, grm: int = 0) -> Optional[Img]:
+           gr: Optional[int] = None, grs: int = 0, grm: int = 0, transposed_out_hw: Optional[tuple] = None) -> Optional[Img]:
     """Implicit-GEMM conv / linear.  Output goes to `out` (NHWC Img, maybe a channel slice), or to the raw
     tensor `out_nchw` (channel-major planes placed by `ymap`), or to a fresh NHWC tensor.
 
@@ -181,8 +183,13 @@ def conv2d(x: Img, w: torch.Tensor, cout: int, kh: int, kw: int, stride: int, pa
             gx = ng * x.nstride
             x = Img(x.t[:ng])
         ng = x.n
-    ho = (x.h + 2 * pad - kh) // stride + 1
-    wo = (x.w + 2 * pad - kw) // stride + 1
+    if transposed_out_hw is not None:   # data gradient: x is dy, the output is dx of the given spatial size
+        ho, wo = transposed_out_hw
+        if (ho + 2 * pad - kh) // stride + 1 != x.h or (wo + 2 * pad - kw) // stride + 1 != x.w:
+            raise RuntimeError("egorear_amd.conv2d: transposed_out_hw inconsistent with dy's size")
+    else:
+        ho = (x.h + 2 * pad - kh) // stride + 1
+        wo = (x.w + 2 * pad - kw) // stride + 1
     npad = (cout + 31) // 32 * 32
     K = kh * kw * x.c
     wshape = (groups, npad, K) if groups > 1 else (npad, K)
@@ -195,6 +202,7 @@ def conv2d(x: Img, w: torch.Tensor, cout: int, kh: int, kw: int, stride: int, pa
     d.ldx = x.ld
     d.xmap = xmap if xmap is not None else x.nmap()
     d.act, d.res_mode, d.split_k = act, res_mode, split_k
+    d.transposed = 1 if transposed_out_hw is not None else 0
     d.groups, d.gx, d.gw, d.gp, d.grs, d.grm = groups, (gx or 0), (npad * K if groups > 1 else 0), (npad if groups > 1 else 0), grs, grm
     ret = None
     if out_nchw is not None:
@@ -242,6 +250,28 @@ def conv2d(x: Img, w: torch.Tensor, cout: int, kh: int, kw: int, stride: int, pa
             flops=2.0 * M * cout * K * groups, nbytes=4.0 * groups * (M * cout + x.n * x.h * x.w * x.c + cout * K),
             tag=f"G{groups} M{M} N{cout} K{K} k{kh}s{stride} cin{x.c}" if PROFILE is not None else "")
     return ret
+
+
+def conv2d_wgrad(x: Img, dy: Img, kh: int, kw: int, stride: int, pad: int, workspace: torch.Tensor, *, want_bias: bool = False,
+                 dw: Optional[torch.Tensor] = None, db: Optional[torch.Tensor] = None, accumulate: bool = False):
+    """Weight (+ bias) gradient of the forward conv x -> y (training-row brick).  x, dy NHWC Imgs.  Returns (dw, db):
+    dw (cout, kh*kw*cin) in the packed K order of conv2d (engine.unpack_conv_weight turns it back into OIHW)."""
+    cin, cout = x.c, dy.c
+    if (x.n, (x.h + 2 * pad - kh) // stride + 1, (x.w + 2 * pad - kw) // stride + 1) != (dy.n, dy.h, dy.w):
+        raise RuntimeError("egorear_amd.conv2d_wgrad: dy does not match the forward output geometry")
+    d = ConvDesc()
+    d.n, d.h, d.w, d.cin, d.cout = x.n, x.h, x.w, cin, cout
+    d.kh, d.kw, d.stride, d.pad, d.ho, d.wo = kh, kw, stride, pad, dy.h, dy.w
+    d.ldx, d.ldy, d.xmap, d.ymap, d.rmap = x.ld, dy.ld, x.nmap(), dy.nmap(), NMap(1, 0, 0)
+    d.groups = 1
+    K = kh * kw * cin
+    if dw is None:
+        dw = torch.empty((cout, K), device=x.t.device, dtype=torch.float32)
+    if want_bias and db is None:
+        db = torch.empty((cout,), device=x.t.device, dtype=torch.float32)
+    _launch("egr_conv2d_wgrad_f32", lib.egr_conv2d_wgrad_f32, C.byref(d), _p(x.t), _p(dy.t), _p(_cont(dw, "dw")), _p(db),
+            _p(workspace), workspace.numel(), 1 if accumulate else 0, _stream(), flops=2.0 * dy.n * dy.h * dy.w * cout * K)
+    return dw, db
 
 
 def stem(img: torch.Tensor, view0: int, nviews: int, wpack, scale, shift, groups: int = 1) -> Img:

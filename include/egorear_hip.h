@@ -74,6 +74,12 @@ typedef struct {
      * scale/shift + g*gp, res + g*gr, rowscale + g*grs, rowmask + g*grm, y + g*gy (strides in elements; 0 = shared). */
     int32_t groups;
     int64_t gx, gw, gp, gy, gr, grs, grm;
+    /* Transposed (data-gradient) mode, first brick of the training row: with `transposed` = 1 the
+     * launch computes dx = conv_transpose(dy, W): x is dy (n, h, w, cin = forward cout), y is dx (n, ho, wo, cout = forward
+     * cin) — ho/wo are given, not derived — stride/pad/kh/kw are the FORWARD conv's, and w is the forward weight packed with
+     * its in/out channels swapped ([cin_fwd_pad][cout_fwd/32][kh*kw][32]).  Row m = (n, hi, wi) gathers
+     * dy[n, (hi+pad-kh)/stride, (wi+pad-kw)/stride, :] for the taps where the division is exact and in range. */
+    int32_t transposed;
 } egr_conv_desc;
 
 int egr_conv2d_nhwc_f32(const egr_conv_desc* d, const float* x, const float* w,
@@ -81,6 +87,14 @@ int egr_conv2d_nhwc_f32(const egr_conv_desc* d, const float* x, const float* w,
                         const float* res /* NULL unless res_mode */, const float* rowscale /* per m, NULL = 1 */,
                         const uint8_t* rowmask /* per m, NULL = keep; 0 -> row written as 0 */,
                         float* y, float* workspace, size_t workspace_floats, void* stream);
+
+/* Weight (and bias) gradient of the conv / linear layer described by `d` (forward geometry; groups = 1), a brick of the
+ * training row: dw[co][(ci/32, kh, kw, ci%32)] (+)= sum over output pixels of dy[m][co] * im2col(x)[m][k],
+ * db[co] (+)= sum_m dy[m][co] (db may be NULL).  dw is in the packed weight layout of egr_conv2d_nhwc_f32.  The pixels are
+ * split over workgroups; partial tiles go through `workspace` and are summed in fixed order (deterministic).
+ * Replaces autograd of nn.Conv2d / nn.Linear for config 5 (pl_wrappers/egoposeformer/pose_3d_mvf_ex.py:117-153). */
+int egr_conv2d_wgrad_f32(const egr_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
+                         float* workspace, size_t workspace_floats, int32_t accumulate, void* stream);
 
 /* Tuning knob for measurements: force the tile configuration of egr_conv2d_nhwc_f32
  * (-1 auto, 0 128x128, 1 256x64, 2 64x64, 3 128x32, 4 128x64).  Process-wide; results do not depend on it. */
