@@ -42,8 +42,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=4)
-    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-iters", type=int, default=12)
     return ap.parse_args()
 
 
