@@ -210,6 +210,11 @@ def synth_gt_pose(batch: int, seed: int = 1235) -> torch.Tensor:
     return g + torch.tensor([0.0, 20.0, 40.0])
 
 
+def synth_joint_px(batch: int, views: int = 4, joints: int = 15, seed: int = 1237, image_size: int = 872) -> torch.Tensor:
+    """(B,V,J,2) fp32 joint positions in image pixels for GT heat maps; ~10 % fall outside the image (empty maps)."""
+    return uniform("gt_joint_px", seed, (batch, views, joints, 2), -0.06 * image_size, 1.06 * image_size)
+
+
 def synth_coord_trans_mat(batch: int, seed: int = 1236) -> torch.Tensor:
     """(B,4,4,4) fp32 rigid transforms: rotation <= 15 deg about a random axis, |t| <= 0.1 m."""
     ax = normalish("ctm.axis", seed, (batch, 4, 3))

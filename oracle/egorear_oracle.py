@@ -47,9 +47,33 @@ def _lin(sd: SD, p: str, x):
     return F.linear(x, sd[p + ".weight"], sd.get(p + ".bias"))
 
 
+# BatchNorm mode.  eval (default): running statistics.  train (`with bn_train() as updates:`): batch statistics, and the
+# buffers nn.BatchNorm2d would have written (momentum 0.1, unbiased running_var, num_batches_tracked + 1) are collected
+# in `updates` instead of mutating `sd` (the wrappers call network.train(): pose_3d_mvf_ex.py:115).
+_BN_TRAIN: Optional[dict] = None
+
+
+class bn_train:
+    def __enter__(self):
+        global _BN_TRAIN
+        _BN_TRAIN = {}
+        return _BN_TRAIN
+
+    def __exit__(self, *exc):
+        global _BN_TRAIN
+        _BN_TRAIN = None
+        return False
+
+
 def _bn(sd: SD, p: str, x):
-    # eval-mode BatchNorm2d: running statistics, eps 1e-5
-    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], False, 0.1, 1e-5)
+    # BatchNorm2d, eps 1e-5
+    if _BN_TRAIN is None:
+        return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], False, 0.1, 1e-5)
+    rm, rv = sd[p + ".running_mean"].detach().clone(), sd[p + ".running_var"].detach().clone()
+    y = F.batch_norm(x, rm, rv, sd[p + ".weight"], sd[p + ".bias"], True, 0.1, 1e-5)
+    _BN_TRAIN[p + ".running_mean"], _BN_TRAIN[p + ".running_var"] = rm, rv
+    _BN_TRAIN[p + ".num_batches_tracked"] = sd[p + ".num_batches_tracked"] + 1
+    return y
 
 
 def _ln(sd: SD, p: str, x):
@@ -239,9 +263,11 @@ def init_heatmap_head(sd: SD, p: str, x):
     return _conv(sd, p + ".9", x)
 
 
-def heatmap_mvf(sd: SD, p: str, heatmap, frame_feat, feat_mv, anchors_2d, anchors_valid, s32_own):
+def heatmap_mvf(sd: SD, p: str, heatmap, frame_feat, feat_mv, anchors_2d, anchors_valid, s32_own, detach_heatmap_feat: bool = True):
     """HeatmapMVF.forward, JQA branch, one transformer layer, non-1x1 heatmap head
-    (heatmap_mvf_ex.py:652-731).  Returns (heatmap_refined, frame_feat_refined)."""
+    (heatmap_mvf_ex.py:652-731).  Returns (heatmap_refined, frame_feat_refined).
+    Gradient stops follow the source: `frame_feat.detach()` (:715, unconditional) and, with detach_heatmap_feat
+    (all shipped configs), `frame_feat_refined.detach()` in front of the heat-map convs (:717-721)."""
     B, V, C, H, W = feat_mv.shape
     hm_embed = _lin(sd, p + ".heatmap_proj.2", F.relu(_lin(sd, p + ".heatmap_proj.0", heatmap.reshape(B, heatmap.shape[1], H * W))))
     bfb = F.adaptive_avg_pool2d(s32_own, (1, 1)).view(B, -1)
@@ -263,41 +289,53 @@ def heatmap_mvf(sd: SD, p: str, heatmap, frame_feat, feat_mv, anchors_2d, anchor
     hp = p + ".head_layers.0.head"
     off = F.relu(_conv(sd, hp + ".3", _up2(F.relu(_conv(sd, hp + ".0", _x)))))
     rp = p + ".frame_feat_refined_proj_layers.0"
-    refined = F.relu(_conv(sd, rp + ".3", _up2(F.relu(_conv(sd, rp + ".0", off + ff)))))
+    refined = F.relu(_conv(sd, rp + ".3", _up2(F.relu(_conv(sd, rp + ".0", off + ff.detach())))))
     cp = p + ".conv_heatmap_layers.0"
-    h = F.relu(_conv(sd, cp + ".0", refined, 2, 1))
+    h = F.relu(_conv(sd, cp + ".0", refined.detach() if detach_heatmap_feat else refined, 2, 1))
     h = F.relu(_conv(sd, cp + ".2", h))
     h = F.relu(_conv(sd, cp + ".5", _up2(h)))
     h = _conv(sd, cp + ".7", h)
     return h, refined
 
 
-def heatmap_mvfex_forward(sd: SD, p: str, img, heatmap_threshold: float = 0.5, heatmap_for_anchor=None):
+def heatmap_mvfex_forward(sd: SD, p: str, img, heatmap_threshold: float = 0.5, heatmap_for_anchor=None,
+                          full_training: bool = True, use_pred_heatmap_init: bool = True, no_detach_feat_init: bool = False,
+                          detach_heatmap_feat: bool = True):
     """EgoPoseFormerHeatmapMVFEX.forward, num_views==4, use_1by1_conv False
-    (heatmap_mvf_ex.py:236-352).  In eval/no_grad the detach/clone branches are value-neutral.
+    (heatmap_mvf_ex.py:236-352).  In eval/no_grad the detach/clone branches are value-neutral; under autograd they are
+    the gradient stops of :262-288 (flag defaults = the shipped pose3d configs).
     Returns ([hm_init, hm_refined], [feat_init, feat_refined], aux) where aux carries the
     argmax intermediates the parity tests pin."""
     pre = (p + ".") if p else ""
     B = img.shape[0]
-    f_front, pyr_front = heatmap_backbone(sd, pre + "heatmap_estimator_stereo_front", img[:, 0:2])
-    f_back, pyr_back = heatmap_backbone(sd, pre + "heatmap_estimator_stereo_back", img[:, 2:])
-    feat = torch.cat((f_front, f_back), dim=1)  # (B,4,128,64,64)
+    with torch.enable_grad() if (full_training and torch.is_grad_enabled()) else torch.no_grad():   # :262-266
+        f_front, pyr_front = heatmap_backbone(sd, pre + "heatmap_estimator_stereo_front", img[:, 0:2])
+        f_back, pyr_back = heatmap_backbone(sd, pre + "heatmap_estimator_stereo_back", img[:, 2:])
+    feat_init = torch.cat((f_front, f_back), dim=1)  # (B,4,128,64,64)
     s32 = torch.cat((pyr_front[-1], pyr_back[-1]), dim=1)  # (B,4,512,8,8)
-    _, V, C, H, W = feat.shape
-    hm_front = init_heatmap_head(sd, pre + "conv_heatmap_layers_stereo_front", feat[:, 0:2].reshape(B * 2, C, H, W))
-    hm_back = init_heatmap_head(sd, pre + "conv_heatmap_layers_stereo_back", feat[:, 2:].reshape(B * 2, C, H, W))
-    hm_init = torch.cat((hm_front.view(B, 2, -1, H, W), hm_back.view(B, 2, -1, H, W)), dim=1)
-    src = heatmap_for_anchor if isinstance(heatmap_for_anchor, torch.Tensor) else hm_init
+    _, V, C, H, W = feat_init.shape
+    head_in = feat_init.detach() if use_pred_heatmap_init else feat_init  # :273 / :284
+    hm_front = init_heatmap_head(sd, pre + "conv_heatmap_layers_stereo_front", head_in[:, 0:2].reshape(B * 2, C, H, W))
+    hm_back = init_heatmap_head(sd, pre + "conv_heatmap_layers_stereo_back", head_in[:, 2:].reshape(B * 2, C, H, W))
+    hm_init_out = torch.cat((hm_front.view(B, 2, -1, H, W), hm_back.view(B, 2, -1, H, W)), dim=1)
+    if use_pred_heatmap_init:                                             # :275-282
+        hm_init = hm_init_out.detach().clone()
+        feat, s32 = (feat_init, s32) if no_detach_feat_init else (feat_init.detach().clone(), s32.detach().clone())
+    else:
+        hm_init, feat = hm_init_out, feat_init
+    src = heatmap_for_anchor if isinstance(heatmap_for_anchor, torch.Tensor) else hm_init_out
     J = src.shape[2]
-    pts, maxvals, valid, idx = get_max_preds(src.reshape(B * V, J, H, W), heatmap_threshold, True)
+    with torch.no_grad():                                                 # :128 (decorated @torch.no_grad()) + :297
+        pts, maxvals, valid, idx = get_max_preds(src.detach().reshape(B * V, J, H, W), heatmap_threshold, True)
     anchors_2d, anchors_valid = pts.view(B, V, J, 2), valid.view(B, V, J)
     hms, feats = [], []
     for v, name in enumerate(REFINERS):
-        h, f = heatmap_mvf(sd, pre + "heatmap_refiner_" + name, hm_init[:, v], feat[:, v], feat, anchors_2d, anchors_valid, s32[:, v])
+        h, f = heatmap_mvf(sd, pre + "heatmap_refiner_" + name, hm_init[:, v], feat[:, v], feat, anchors_2d, anchors_valid, s32[:, v],
+                           detach_heatmap_feat)
         hms.append(h)
         feats.append(f)
     aux = {"argmax_idx": idx.view(B, V, J), "maxvals": maxvals.view(B, V, J), "anchors_valid": anchors_valid, "anchors_2d": anchors_2d, "s32": s32}
-    return [hm_init, torch.stack(hms, dim=1)], [feat, torch.stack(feats, dim=1)], aux
+    return [hm_init_out, torch.stack(hms, dim=1)], [feat_init, torch.stack(feats, dim=1)], aux
 
 
 # --------------------------------------------------------------------------- fisheye camera (a22)
@@ -393,7 +431,8 @@ def pose3d_forward(sd: SD, p: str, cams, feat_init, feat_final, coord_trans_mat=
     anchors_3d = mlp_pred.clone().detach()  # (:441)
     # decoder
     mem = ff.permute(0, 1, 3, 4, 2).reshape(B, V, H * W, -1)
-    anchors_2d, anchors_valid = reproject_3d_to_2d(cams, anchors_3d, coord_trans_mat)  # mutates anchors_3d in syn mode
+    with torch.no_grad():                                                # _reproject_3d_to_2d is @torch.no_grad() (:339)
+        anchors_2d, anchors_valid = reproject_3d_to_2d(cams, anchors_3d, coord_trans_mat)  # mutates anchors_3d in syn mode
     anchors_2d = anchors_2d.to(mem.dtype)
     joint_inds = (torch.arange(1, J + 1).to(mem.dtype).reshape(1, J, 1).repeat(B, 1, 1)) / float(J)
     q = torch.cat((joint_inds, anchors_3d), dim=-1)
