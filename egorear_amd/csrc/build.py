@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["egr_conv.hip", "egr_stem.hip", "egr_pointwise.hip", "egr_attn.hip", "egr_preprocess.hip", "egr_metrics.hip", "egr_wgrad.hip"]
+SOURCES = ["egr_conv.hip", "egr_stem.hip", "egr_pointwise.hip", "egr_attn.hip", "egr_preprocess.hip", "egr_metrics.hip", "egr_wgrad.hip", "egr_train.hip", "egr_msda_bwd.hip"]
 LIB = os.path.join(HERE, "libegorear_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(REPO, "include"), "-I" + HERE]
 
@@ -36,12 +36,13 @@ def _stale(target: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     headers = [os.path.join(HERE, "egr_common.h"), os.path.join(REPO, "include", "egorear_hip.h")]
+    train_headers = [os.path.join(REPO, "include", "egorear_train.h")]
     hipcc = _hipcc()
     jobs = []
     for src in SOURCES:
         s = os.path.join(HERE, src)
         o = os.path.join(HERE, "build", src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + headers):
+        if force or _stale(o, [s] + headers + (train_headers if src in ("egr_train.hip", "egr_msda_bwd.hip") else [])):
             jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
 
     def run(cmd):

@@ -1,0 +1,890 @@
+// Training-step kernels other than the convolution gradients (include/egorear_train.h): BatchNorm in training mode and
+// its backward, ReLU / GELU / LayerNorm / max-pool / bilinear-upsample backward, the joint-attention core backward,
+// boundary layout changes, the wrapper's losses, gradient norm and fused AdamW.  All HBM-bound: 16-byte accesses across
+// channels, one pass per tensor, fp64 only inside per-channel / scalar reductions.
+#include "egr_common.h"
+#include "egorear_train.h"
+
+namespace {
+
+inline unsigned nblocks(int64_t total) { return (unsigned)((total + 255) / 256); }
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------ BatchNorm (training mode)
+// Partial per-channel sums over a slab of rows.  FWD: (sum x, sum x^2).  BWD: (sum dz, sum dz*xhat), dz = dy*[y>0].
+// 256 threads = (256 / (c/4)) row lanes x (c/4) channel quads; fp64 accumulators; LDS reduce over the row lanes.
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* x, const float* dy, const float* y, const float* mean,
+                                                         const float* invstd, int64_t rpg, int c, int nblk, double* ws) {
+    __shared__ double red[256 * 8];
+    const int g = blockIdx.y, blk = blockIdx.x;
+    const int c4 = c >> 2;
+    const int rpi = 256 / c4;
+    const int cl = threadIdx.x % c4, rl = threadIdx.x / c4;
+    const int64_t chunk = (rpg + nblk - 1) / nblk;
+    const int64_t r0 = (int64_t)blk * chunk, r1 = (r0 + chunk < rpg) ? r0 + chunk : rpg;
+    const int64_t base = (int64_t)g * rpg;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0};
+    if (BWD) {
+        mu = *reinterpret_cast<const f32x4*>(mean + g * c + cl * 4);
+        is = *reinterpret_cast<const f32x4*>(invstd + g * c + cl * 4);
+    }
+    for (int64_t r = r0 + rl; r < r1; r += rpi) {
+        const int64_t o = (base + r) * c + cl * 4;
+        f32x4 xv = *reinterpret_cast<const f32x4*>(x + o);
+        if (!BWD) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s[i] += (double)xv[i];
+                q[i] += (double)xv[i] * (double)xv[i];
+            }
+        } else {
+            f32x4 d = *reinterpret_cast<const f32x4*>(dy + o);
+            if (y) {
+                f32x4 yv = *reinterpret_cast<const f32x4*>(y + o);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d[i] = yv[i] > 0.f ? d[i] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s[i] += (double)d[i];
+                q[i] += (double)d[i] * (double)((xv[i] - mu[i]) * is[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        red[threadIdx.x * 8 + i] = s[i];
+        red[threadIdx.x * 8 + 4 + i] = q[i];
+    }
+    __syncthreads();
+    if (rl == 0) {
+        for (int k = 1; k < rpi; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s[i] += red[(k * c4 + cl) * 8 + i];
+                q[i] += red[(k * c4 + cl) * 8 + 4 + i];
+            }
+        double* o = ws + ((int64_t)(g * nblk + blk) * 2) * c + cl * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[i] = s[i];
+            o[c + i] = q[i];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const double* ws, int nblk, int c, int64_t rpg, const float* gamma,
+                                                              const float* beta, float* rmean, float* rvar, float momentum,
+                                                              float eps, float* mean, float* invstd, float* alpha,
+                                                              float* shift) {
+    const int g = blockIdx.y;
+    const int ch = blockIdx.x * 256 + threadIdx.x;
+    if (ch >= c) return;
+    double s = 0, q = 0;
+    for (int b = 0; b < nblk; ++b) {
+        const double* p = ws + ((int64_t)(g * nblk + b) * 2) * c;
+        s += p[ch];
+        q += p[c + ch];
+    }
+    const double n = (double)rpg;
+    const double m = s / n;
+    double var = q / n - m * m;
+    if (var < 0) var = 0;
+    const double is = 1.0 / sqrt(var + (double)eps);
+    const int o = g * c + ch;
+    mean[o] = (float)m;
+    invstd[o] = (float)is;
+    const float a = gamma[o] * (float)is;
+    alpha[o] = a;
+    shift[o] = beta[o] - (float)m * a;
+    if (rmean) {  // nn.BatchNorm2d buffer update: momentum blend, unbiased variance
+        const double unb = (rpg > 1) ? var * n / (n - 1.0) : var;
+        rmean[o] = (float)((1.0 - (double)momentum) * (double)rmean[o] + (double)momentum * m);
+        rvar[o] = (float)((1.0 - (double)momentum) * (double)rvar[o] + (double)momentum * unb);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const double* ws, int nblk, int c, float* dgamma, float* dbeta) {
+    const int g = blockIdx.y;
+    const int ch = blockIdx.x * 256 + threadIdx.x;
+    if (ch >= c) return;
+    double s = 0, q = 0;
+    for (int b = 0; b < nblk; ++b) {
+        const double* p = ws + ((int64_t)(g * nblk + b) * 2) * c;
+        s += p[ch];
+        q += p[c + ch];
+    }
+    dbeta[g * c + ch] = (float)s;
+    dgamma[g * c + ch] = (float)q;
+}
+
+__global__ __launch_bounds__(256) void scale_shift_kernel(const float* x, const float* alpha, const float* shift,
+                                                          const float* res, float* y, int64_t rpg, int c4, int64_t total4,
+                                                          int relu) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total4) return;
+    const int cq = (int)(idx % c4);
+    const int g = (int)((idx / c4) / rpg);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(alpha + (g * c4 + cq) * 4);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(shift + (g * c4 + cq) * 4);
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + idx * 4);
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = v[i] * a[i] + b[i];
+    if (res) {
+        const f32x4 r = *reinterpret_cast<const f32x4*>(res + idx * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] += r[i];
+    }
+    if (relu) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = o[i] > 0.f ? o[i] : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(y + idx * 4) = o;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, const float* y, const float* x, const float* mean,
+                                                           const float* invstd, const float* alpha, const float* dgamma,
+                                                           const float* dbeta, float* dx, float* dz_out, int64_t rpg, int c4,
+                                                           int64_t total4) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total4) return;
+    const int cq = (int)(idx % c4);
+    const int g = (int)((idx / c4) / rpg);
+    const int po = (g * c4 + cq) * 4;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + po), is = *reinterpret_cast<const f32x4*>(invstd + po);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(alpha + po);
+    const f32x4 dg = *reinterpret_cast<const f32x4*>(dgamma + po), db = *reinterpret_cast<const f32x4*>(dbeta + po);
+    const float inv_n = 1.0f / (float)rpg;
+    f32x4 d = *reinterpret_cast<const f32x4*>(dy + idx * 4);
+    if (y) {
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + idx * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = yv[i] > 0.f ? d[i] : 0.f;
+    }
+    if (dz_out) *reinterpret_cast<f32x4*>(dz_out + idx * 4) = d;
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + idx * 4);
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float xh = (xv[i] - mu[i]) * is[i];
+        o[i] = a[i] * (d[i] - db[i] * inv_n - xh * (dg[i] * inv_n));
+    }
+    *reinterpret_cast<f32x4*>(dx + idx * 4) = o;
+}
+
+// ------------------------------------------------------------------ element-wise
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* dy, const float* y, float* dx, int64_t n4) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n4) return;
+    f32x4 d = *reinterpret_cast<const f32x4*>(dy + idx * 4);
+    const f32x4 yv = *reinterpret_cast<const f32x4*>(y + idx * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = yv[i] > 0.f ? d[i] : 0.f;
+    *reinterpret_cast<f32x4*>(dx + idx * 4) = d;
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* a, const float* b, float* y, int64_t n4) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n4) return;
+    f32x4 u = *reinterpret_cast<const f32x4*>(a + idx * 4);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(b + idx * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] += v[i];
+    *reinterpret_cast<f32x4*>(y + idx * 4) = u;
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* x, float v, int64_t n4) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n4) return;
+    f32x4 o = {v, v, v, v};
+    *reinterpret_cast<f32x4*>(x + idx * 4) = o;
+}
+
+__global__ __launch_bounds__(256) void gelu_kernel(const float* z, float* h, int64_t n4) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n4) return;
+    f32x4 v = *reinterpret_cast<const f32x4*>(z + idx * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = egr_act(v[i], EGR_ACT_GELU);
+    *reinterpret_cast<f32x4*>(h + idx * 4) = v;
+}
+
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* dh, const float* z, float* dz, int64_t n4) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n4) return;
+    const f32x4 d = *reinterpret_cast<const f32x4*>(dh + idx * 4);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(z + idx * 4);
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // d/dz [0.5 z (1 + erf(z/sqrt2))] = Phi(z) + z phi(z)
+        const float cdf = 0.5f * (1.0f + erff(v[i] * 0.70710678118654752440f));
+        const float pdf = 0.39894228040143267794f * expf(-0.5f * v[i] * v[i]);
+        o[i] = d[i] * (cdf + v[i] * pdf);
+    }
+    *reinterpret_cast<f32x4*>(dz + idx * 4) = o;
+}
+
+__global__ __launch_bounds__(256) void rowmask_kernel(float* x, const uint8_t* mask, int64_t total4, int c4) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total4) return;
+    if (mask[idx / c4]) return;
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(x + idx * 4) = z;
+}
+
+// ------------------------------------------------------------------ MaxPool2d with recorded arg-max slot, and backward
+__global__ __launch_bounds__(256) void maxpool_train_kernel(const float* x, float* y, uint8_t* slot, int n, int h, int w, int c4,
+                                                            int ho, int wo, int k, int stride, int pad) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)n * ho * wo * c4;
+    if (idx >= total) return;
+    const int cq = (int)(idx % c4);
+    int64_t p = idx / c4;
+    const int ox = (int)(p % wo);
+    p /= wo;
+    const int oy = (int)(p % ho);
+    const int img = (int)(p / ho);
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bs[4] = {0, 0, 0, 0};
+    bool first = true;
+    for (int dy = 0; dy < k; ++dy) {
+        const int iy = oy * stride - pad + dy;
+        if (iy < 0 || iy >= h) continue;
+        for (int dx = 0; dx < k; ++dx) {
+            const int ix = ox * stride - pad + dx;
+            if (ix < 0 || ix >= w) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((int64_t)img * h + iy) * w + ix) * (c4 * 4) + cq * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (first || v[i] > best[i]) {  // first maximum in scan order (ATen max_pool2d)
+                    best[i] = v[i];
+                    bs[i] = dy * k + dx;
+                }
+            first = false;
+        }
+    }
+    *reinterpret_cast<f32x4*>(y + idx * 4) = best;
+    *reinterpret_cast<uint32_t*>(slot + idx * 4) = (uint32_t)bs[0] | ((uint32_t)bs[1] << 8) | ((uint32_t)bs[2] << 16) | ((uint32_t)bs[3] << 24);
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* dy, const uint8_t* slot, float* dx, int n, int h, int w,
+                                                          int c4, int ho, int wo, int k, int stride, int pad) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)n * h * w * c4;
+    if (idx >= total) return;
+    const int cq = (int)(idx % c4);
+    int64_t p = idx / c4;
+    const int ix = (int)(p % w);
+    p /= w;
+    const int iy = (int)(p % h);
+    const int img = (int)(p / h);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // windows (oy, ox) that contain (iy, ix): oy*stride - pad <= iy <= oy*stride - pad + k - 1
+    int oy0 = (iy + pad - k + 1 + stride - 1);
+    oy0 = oy0 <= 0 ? 0 : oy0 / stride;
+    int ox0 = (ix + pad - k + 1 + stride - 1);
+    ox0 = ox0 <= 0 ? 0 : ox0 / stride;
+    const int oy1 = min((iy + pad) / stride, ho - 1), ox1 = min((ix + pad) / stride, wo - 1);
+    for (int oy = oy0; oy <= oy1; ++oy)
+        for (int ox = ox0; ox <= ox1; ++ox) {
+            const int me = (iy - (oy * stride - pad)) * k + (ix - (ox * stride - pad));
+            const int64_t o = (((int64_t)img * ho + oy) * wo + ox) * c4 + cq;
+            const uint32_t s = *reinterpret_cast<const uint32_t*>(slot + o * 4);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dy + o * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if ((int)((s >> (8 * i)) & 255u) == me) acc[i] += d[i];
+        }
+    *reinterpret_cast<f32x4*>(dx + idx * 4) = acc;
+}
+
+// ------------------------------------------------------------------ bilinear x2 (align_corners=True) backward: exact adjoint
+// of upsample2x_kernel in gather form (no atomics): every source pixel collects the destination pixels whose (i0, i1)
+// pair - computed with the forward's own arithmetic - touches it.
+__device__ __forceinline__ float up_weight(int o, int i, int in, float scale) {
+    const float f = scale * (float)o;
+    const int i0 = (int)f;
+    const int i1 = min(i0 + 1, in - 1);
+    const float l1 = fminf(fmaxf(f - (float)i0, 0.f), 1.f);
+    float wgt = 0.f;
+    if (i0 == i) wgt += 1.f - l1;
+    if (i1 == i) wgt += l1;
+    return wgt;
+}
+
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* dy, const float* y, float* dx, int n, int h, int w,
+                                                             int c4) {
+    const int ho = 2 * h, wo = 2 * w;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)n * h * w * c4;
+    if (idx >= total) return;
+    const int cq = (int)(idx % c4);
+    int64_t p = idx / c4;
+    const int ix = (int)(p % w);
+    p /= w;
+    const int iy = (int)(p % h);
+    const int img = (int)(p / h);
+    const float sh = (ho > 1) ? (float)(h - 1) / (float)(ho - 1) : 0.f;
+    const float sw = (wo > 1) ? (float)(w - 1) / (float)(wo - 1) : 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int oy0 = max(0, 2 * iy - 2), oy1 = min(ho - 1, 2 * iy + 3);
+    const int ox0 = max(0, 2 * ix - 2), ox1 = min(wo - 1, 2 * ix + 3);
+    for (int oy = oy0; oy <= oy1; ++oy) {
+        const float wy = up_weight(oy, iy, h, sh);
+        if (wy == 0.f) continue;
+        for (int ox = ox0; ox <= ox1; ++ox) {
+            const float wx = up_weight(ox, ix, w, sw);
+            if (wx == 0.f) continue;
+            const int64_t o = ((((int64_t)img * ho + oy) * wo + ox) * c4 + cq) * 4;
+            f32x4 d = *reinterpret_cast<const f32x4*>(dy + o);
+            if (y) {
+                const f32x4 yv = *reinterpret_cast<const f32x4*>(y + o);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d[i] = yv[i] > 0.f ? d[i] : 0.f;
+            }
+            const float wgt = wy * wx;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = fmaf(wgt, d[i], acc[i]);
+        }
+    }
+    *reinterpret_cast<f32x4*>(dx + idx * 4) = acc;
+}
+
+// ------------------------------------------------------------------ boundary layouts
+__global__ __launch_bounds__(256) void planes_to_nhwc_kernel(const float* planes, egr_nmap map, float* y, int n, int c, int hw,
+                                                             int cpad) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)n * hw * cpad) return;
+    const int ch = (int)(idx % cpad);
+    const int64_t r = idx / cpad;
+    const int p = (int)(r % hw), img = (int)(r / hw);
+    y[idx] = ch < c ? planes[egr_map(map, img) + (int64_t)ch * hw + p] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const float* img, egr_nmap map, int n, int h, int w, float* cols) {
+    const int ho = h / 2, wo = w / 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)n * ho * wo * 160) return;
+    const int col = (int)(idx % 160);
+    int64_t r = idx / 160;
+    const int ox = (int)(r % wo);
+    r /= wo;
+    const int oy = (int)(r % ho);
+    const int im = (int)(r / ho);
+    float v = 0.f;
+    if (col < 147) {  // OIHW flatten order of the 7x7 weight: (c, ky, kx)
+        const int ch = col / 49, ky = (col % 49) / 7, kx = col % 7;
+        const int iy = 2 * oy - 3 + ky, ix = 2 * ox - 3 + kx;
+        if (iy >= 0 && iy < h && ix >= 0 && ix < w) v = img[egr_map(map, im) + ((int64_t)ch * h + iy) * w + ix];
+    }
+    cols[idx] = v;
+}
+
+// ------------------------------------------------------------------ LayerNorm backward
+template <int VPL>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* dy, const float* pre, const float* gamma, float* ds,
+                                                            float* rowstats, int rows, float eps, int rpg) {
+    const int c = VPL * 64;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    if (rpg > 0) gamma += (row / rpg) * c;
+    float v[VPL], gd[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        v[i] = pre[(int64_t)row * c + i * 64 + lane];
+        s += v[i];
+    }
+    const float mean = wave_sum(s) / (float)c;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const float dlt = v[i] - mean;
+        q += dlt * dlt;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)c + eps);
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int ch = i * 64 + lane;
+        v[i] = (v[i] - mean) * rstd;  // xhat
+        gd[i] = dy[(int64_t)row * c + ch] * gamma[ch];
+        m1 += gd[i];
+        m2 += gd[i] * v[i];
+    }
+    m1 = wave_sum(m1) / (float)c;
+    m2 = wave_sum(m2) / (float)c;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) ds[(int64_t)row * c + i * 64 + lane] = rstd * (gd[i] - m1 - v[i] * m2);
+    if (lane == 0) {
+        rowstats[row * 2 + 0] = mean;
+        rowstats[row * 2 + 1] = rstd;
+    }
+}
+
+__global__ __launch_bounds__(256) void layernorm_param_grad_kernel(const float* dy, const float* pre, const float* rowstats,
+                                                                   float* dgamma, float* dbeta, int rows_per_group, int c) {
+    const int g = blockIdx.y;
+    const int ch = blockIdx.x * 256 + threadIdx.x;
+    if (ch >= c) return;
+    float sg = 0.f, sb = 0.f;
+    for (int r = 0; r < rows_per_group; ++r) {
+        const int64_t row = (int64_t)g * rows_per_group + r;
+        const float d = dy[row * c + ch];
+        sg = fmaf(d, (pre[row * c + ch] - rowstats[row * 2]) * rowstats[row * 2 + 1], sg);
+        sb += d;
+    }
+    dgamma[g * c + ch] = sg;
+    dbeta[g * c + ch] = sb;
+}
+
+// ------------------------------------------------------------------ joint-attention core backward: one wave per (b, head)
+__global__ __launch_bounds__(64) void joint_mha_bwd_kernel(const float* qkv, const float* dout, float* dqkv, int J, int heads,
+                                                           int d, float scale) {
+    __shared__ float sq[16 * 64], sk[16 * 64], sv[16 * 64], sdo[16 * 64], sp[16 * 16], sds[16 * 16];
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int lane = threadIdx.x;
+    const int c = heads * d;
+    for (int i = lane; i < J * d; i += 64) {
+        const int t = i / d, dd = i % d;
+        const float* r = qkv + ((int64_t)b * J + t) * 3 * c + h * d + dd;
+        sq[t * d + dd] = r[0];
+        sk[t * d + dd] = r[c];
+        sv[t * d + dd] = r[2 * c];
+        sdo[t * d + dd] = dout[((int64_t)b * J + t) * c + h * d + dd];
+    }
+    __syncthreads();
+    const int i = lane >> 2, gq = lane & 3;
+    float s[4], dp[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int jj = gq + 4 * t;
+        float dot = 0.f, dpv = 0.f;
+        if (i < J && jj < J)
+            for (int dd = 0; dd < d; ++dd) {
+                dot = fmaf(sq[i * d + dd], sk[jj * d + dd], dot);
+                dpv = fmaf(sdo[i * d + dd], sv[jj * d + dd], dpv);   // dP = dO V^T
+            }
+        s[t] = (i < J && jj < J) ? dot * scale : -INFINITY;
+        dp[t] = dpv;
+        mx = fmaxf(mx, s[t]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        s[t] = (s[t] == -INFINITY) ? 0.f : expf(s[t] - mx);
+        sum += s[t];
+    }
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    float rowdot = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        s[t] = (i < J) ? s[t] / sum : 0.f;   // P
+        rowdot += s[t] * dp[t];
+    }
+    rowdot += __shfl_xor(rowdot, 1, 64);
+    rowdot += __shfl_xor(rowdot, 2, 64);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        sp[i * 16 + gq + 4 * t] = s[t];
+        sds[i * 16 + gq + 4 * t] = s[t] * (dp[t] - rowdot) * scale;   // dS (softmax backward), scale folded in
+    }
+    __syncthreads();
+    for (int idx = lane; idx < J * d; idx += 64) {
+        const int t = idx / d, dd = idx % d;
+        float dq = 0.f, dk = 0.f, dv = 0.f;
+        for (int jj = 0; jj < J; ++jj) {
+            dq = fmaf(sds[t * 16 + jj], sk[jj * d + dd], dq);    // dQ = dS K
+            dk = fmaf(sds[jj * 16 + t], sq[jj * d + dd], dk);    // dK = dS^T Q
+            dv = fmaf(sp[jj * 16 + t], sdo[jj * d + dd], dv);    // dV = P^T dO
+        }
+        float* o = dqkv + ((int64_t)b * J + t) * 3 * c + h * d + dd;
+        o[0] = dq;
+        o[c] = dk;
+        o[2 * c] = dv;
+    }
+}
+
+// ------------------------------------------------------------------ small reductions
+__global__ __launch_bounds__(256) void colsum_kernel(const float* x, int64_t ld, int64_t rows, int c, const float* scale,
+                                                     float* out, int accumulate, int64_t gx, int64_t gs) {
+    __shared__ float red[256];
+    const int g = blockIdx.y;
+    const int ch = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    x += (int64_t)g * gx;
+    if (scale) scale += (int64_t)g * gs;
+    float s = 0.f;
+    if (ch < c)
+        for (int64_t r = rl; r < rows; r += 4) s = fmaf(scale ? scale[r] : 1.f, x[r * ld + ch], s);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0 && ch < c) {
+        s = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+        float* o = out + (int64_t)g * c + ch;
+        *o = accumulate ? *o + s : s;
+    }
+}
+
+__global__ __launch_bounds__(256) void fold_rows_kernel(const float* x, float* y, int64_t total, int fold, int c) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int ch = (int)(idx % c);
+    const int64_t r = idx / c;
+    float s = 0.f;
+    for (int k = 0; k < fold; ++k) s += x[(r * fold + k) * c + ch];
+    y[idx] = s;
+}
+
+__global__ __launch_bounds__(256) void jqa_sum_bwd_kernel(const float* dx, float* d_embed, float* d_bfb, int b, int j, int c,
+                                                          int bpg) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int groups = b / bpg;
+    const int64_t n_embed = (int64_t)groups * j * c, n_bfb = (int64_t)b * c;
+    if (idx < n_embed) {
+        const int ch = (int)(idx % c);
+        const int64_t r = idx / c;
+        const int jj = (int)(r % j), g = (int)(r / j);
+        float s = 0.f;
+        for (int bb = 0; bb < bpg; ++bb) s += dx[(((int64_t)g * bpg + bb) * j + jj) * c + ch];
+        d_embed[idx] = s;
+    } else if (idx < n_embed + n_bfb) {
+        const int64_t k = idx - n_embed;
+        const int ch = (int)(k % c);
+        const int bb = (int)(k / c);
+        float s = 0.f;
+        for (int jj = 0; jj < j; ++jj) s += dx[((int64_t)bb * j + jj) * c + ch];
+        d_bfb[k] = s;
+    }
+}
+
+// ------------------------------------------------------------------ losses: one wave per row
+__global__ __launch_bounds__(256) void rownorm_loss_kernel(const float* pred, const float* gt, int64_t rows, int d, float coef,
+                                                           double* loss, float* dpred) {
+    __shared__ double part[4];
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    double mine = 0.0;
+    if (row < rows) {
+        float diff = 0.f;
+        if (lane < d) diff = pred[row * d + lane] - gt[row * d + lane];
+        const float nrm = sqrtf(wave_sum(diff * diff));
+        if (lane < d && dpred) dpred[row * d + lane] = nrm > 0.f ? coef * diff / nrm : 0.f;
+        mine = (double)nrm;
+    }
+    if (lane == 0) part[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (double)coef * ((part[0] + part[1]) + (part[2] + part[3])));
+}
+
+// ------------------------------------------------------------------ optimiser
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, int64_t n4, double* out) {
+    __shared__ double part[4];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(g + i * 4);
+        s += (double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2] + (double)v[3] * v[3];
+    }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+__global__ void zero_double_kernel(double* p) { *p = 0.0; }
+
+// torch.optim.AdamW single-tensor update: p *= 1 - lr*wd; m = lerp(m, g, 1-b1); v = b2 v + (1-b2) g^2;
+// p -= (lr / bc1) * m / (sqrt(v)/sqrt(bc2) + eps), with g pre-scaled by the clip_grad_norm_ coefficient.
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, int64_t n4, float lr, float b1,
+                                                    float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                    const double* sumsq, float clip) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n4) return;
+    float coef = 1.f;
+    if (sumsq) {
+        const float total = (float)sqrt(*sumsq);
+        coef = fminf(clip / (total + 1e-6f), 1.0f);
+    }
+    f32x4 pv = *reinterpret_cast<const f32x4*>(p + idx * 4);
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + idx * 4);
+    f32x4 mv = *reinterpret_cast<const f32x4*>(m + idx * 4);
+    f32x4 vv = *reinterpret_cast<const f32x4*>(v + idx * 4);
+    const float step_size = lr / bc1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float gi = gv[i] * coef;
+        pv[i] = pv[i] * (1.f - lr * wd);
+        mv[i] = mv[i] + (gi - mv[i]) * (1.f - b1);
+        vv[i] = vv[i] * b2 + (1.f - b2) * gi * gi;
+        const float denom = sqrtf(vv[i]) / bc2_sqrt + eps;
+        pv[i] = pv[i] - step_size * (mv[i] / denom);
+    }
+    *reinterpret_cast<f32x4*>(p + idx * 4) = pv;
+    *reinterpret_cast<f32x4*>(m + idx * 4) = mv;
+    *reinterpret_cast<f32x4*>(v + idx * 4) = vv;
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+}  // namespace
+
+extern "C" int32_t egr_bn_blocks(int64_t rows_per_group) {
+    int64_t n = rows_per_group / 512;
+    if (n < 1) n = 1;
+    if (n > 512) n = 512;
+    return (int32_t)n;
+}
+
+static int bn_shape_ok(int64_t rpg, int c, int groups) {
+    if (rpg <= 0 || groups <= 0 || groups > 65535 || c < 64 || c > 1024 || (c & (c - 1)) != 0) return 0;
+    return 1;
+}
+
+extern "C" int egr_bn_stats_f32(const float* x, int64_t rows_per_group, int32_t c, int32_t groups, const float* gamma,
+                                const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                float* mean, float* invstd, float* alpha, float* shift, double* workspace,
+                                size_t workspace_doubles, void* stream) {
+    if (!x || !gamma || !beta || !mean || !invstd || !alpha || !shift || !workspace) return EGR_ENULL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return EGR_ENULL;
+    if (!bn_shape_ok(rows_per_group, c, groups)) return EGR_EINVAL;
+    const int nblk = egr_bn_blocks(rows_per_group);
+    if (workspace_doubles < (size_t)groups * nblk * 2 * c) return EGR_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_partial_kernel<false>, dim3(nblk, groups), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr,
+                       rows_per_group, c, nblk, workspace);
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((c + 255) / 256, groups), dim3(256), 0, s, workspace, nblk, c,
+                       rows_per_group, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, alpha, shift);
+    return egr_launch_status();
+}
+
+extern "C" int egr_scale_shift_f32(const float* x, const float* alpha, const float* shift, const float* res, float* y,
+                                   int64_t rows_per_group, int32_t c, int32_t groups, int32_t relu, void* stream) {
+    if (!x || !alpha || !shift || !y) return EGR_ENULL;
+    if (rows_per_group <= 0 || groups <= 0 || c <= 0 || c % 4 != 0) return EGR_EINVAL;
+    const int64_t total4 = (int64_t)groups * rows_per_group * (c / 4);
+    hipLaunchKernelGGL(scale_shift_kernel, dim3(nblocks(total4)), dim3(256), 0, (hipStream_t)stream, x, alpha, shift, res, y,
+                       rows_per_group, c / 4, total4, relu);
+    return egr_launch_status();
+}
+
+extern "C" int egr_bn_backward_f32(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                                   const float* alpha, int64_t rows_per_group, int32_t c, int32_t groups, float* dgamma,
+                                   float* dbeta, float* dx, float* dz_out, double* workspace, size_t workspace_doubles,
+                                   void* stream) {
+    if (!dy || !x || !mean || !invstd || !alpha || !dgamma || !dbeta || !dx || !workspace) return EGR_ENULL;
+    if (!bn_shape_ok(rows_per_group, c, groups)) return EGR_EINVAL;
+    const int nblk = egr_bn_blocks(rows_per_group);
+    if (workspace_doubles < (size_t)groups * nblk * 2 * c) return EGR_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_partial_kernel<true>, dim3(nblk, groups), dim3(256), 0, s, x, dy, y, mean, invstd, rows_per_group, c,
+                       nblk, workspace);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((c + 255) / 256, groups), dim3(256), 0, s, workspace, nblk, c, dgamma,
+                       dbeta);
+    const int64_t total4 = (int64_t)groups * rows_per_group * (c / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks(total4)), dim3(256), 0, s, dy, y, x, mean, invstd, alpha, dgamma, dbeta,
+                       dx, dz_out, rows_per_group, c / 4, total4);
+    return egr_launch_status();
+}
+
+#define EGR_ELTWISE_CHECK(n, ...)                                         \
+    do {                                                                  \
+        const void* ptrs_[] = {__VA_ARGS__};                              \
+        for (const void* q_ : ptrs_) {                                    \
+            if (!q_) return EGR_ENULL;                                    \
+            if (!aligned16(q_)) return EGR_EINVAL;                        \
+        }                                                                 \
+        if ((n) <= 0 || (n) % 4 != 0) return EGR_EINVAL;                  \
+    } while (0)
+
+extern "C" int egr_relu_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, void* stream) {
+    EGR_ELTWISE_CHECK(n, dy, y, dx);
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(nblocks(n / 4)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n / 4);
+    return egr_launch_status();
+}
+
+extern "C" int egr_add_f32(const float* a, const float* b, float* y, int64_t n, void* stream) {
+    EGR_ELTWISE_CHECK(n, a, b, y);
+    hipLaunchKernelGGL(add_kernel, dim3(nblocks(n / 4)), dim3(256), 0, (hipStream_t)stream, a, b, y, n / 4);
+    return egr_launch_status();
+}
+
+extern "C" int egr_gelu_f32(const float* z, float* h, int64_t n, void* stream) {
+    EGR_ELTWISE_CHECK(n, z, h);
+    hipLaunchKernelGGL(gelu_kernel, dim3(nblocks(n / 4)), dim3(256), 0, (hipStream_t)stream, z, h, n / 4);
+    return egr_launch_status();
+}
+
+extern "C" int egr_gelu_bwd_f32(const float* dh, const float* z, float* dz, int64_t n, void* stream) {
+    EGR_ELTWISE_CHECK(n, dh, z, dz);
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(nblocks(n / 4)), dim3(256), 0, (hipStream_t)stream, dh, z, dz, n / 4);
+    return egr_launch_status();
+}
+
+extern "C" int egr_fill_f32(float* x, float v, int64_t n, void* stream) {
+    EGR_ELTWISE_CHECK(n, x);
+    hipLaunchKernelGGL(fill_kernel, dim3(nblocks(n / 4)), dim3(256), 0, (hipStream_t)stream, x, v, n / 4);
+    return egr_launch_status();
+}
+
+extern "C" int egr_rowmask_f32(float* x, const uint8_t* mask, int64_t rows, int32_t c, void* stream) {
+    if (!x || !mask) return EGR_ENULL;
+    if (rows <= 0 || c <= 0 || c % 4 != 0 || !aligned16(x)) return EGR_EINVAL;
+    const int64_t total4 = rows * (c / 4);
+    hipLaunchKernelGGL(rowmask_kernel, dim3(nblocks(total4)), dim3(256), 0, (hipStream_t)stream, x, mask, total4, c / 4);
+    return egr_launch_status();
+}
+
+extern "C" int egr_maxpool_train_f32(const float* x, float* y, uint8_t* slot, int32_t n, int32_t h, int32_t w, int32_t c,
+                                     int32_t k, int32_t stride, int32_t pad, void* stream) {
+    if (!x || !y || !slot) return EGR_ENULL;
+    if (n <= 0 || c % 4 != 0 || k <= 0 || k > 15 || stride <= 0 || pad < 0 || 2 * pad > k) return EGR_EINVAL;
+    const int ho = (h + 2 * pad - k) / stride + 1, wo = (w + 2 * pad - k) / stride + 1;
+    const int64_t total = (int64_t)n * ho * wo * (c / 4);
+    if (total <= 0) return EGR_EINVAL;
+    hipLaunchKernelGGL(maxpool_train_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, slot, n, h, w, c / 4,
+                       ho, wo, k, stride, pad);
+    return egr_launch_status();
+}
+
+extern "C" int egr_maxpool_bwd_f32(const float* dy, const uint8_t* slot, float* dx, int32_t n, int32_t h, int32_t w, int32_t c,
+                                   int32_t k, int32_t stride, int32_t pad, void* stream) {
+    if (!dy || !slot || !dx) return EGR_ENULL;
+    if (n <= 0 || c % 4 != 0 || k <= 0 || k > 15 || stride <= 0 || pad < 0 || 2 * pad > k) return EGR_EINVAL;
+    const int ho = (h + 2 * pad - k) / stride + 1, wo = (w + 2 * pad - k) / stride + 1;
+    const int64_t total = (int64_t)n * h * w * (c / 4);
+    if (total <= 0 || ho <= 0 || wo <= 0) return EGR_EINVAL;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, dy, slot, dx, n, h, w, c / 4,
+                       ho, wo, k, stride, pad);
+    return egr_launch_status();
+}
+
+extern "C" int egr_upsample2x_bwd_f32(const float* dy, const float* y, float* dx, int32_t n, int32_t h, int32_t w, int32_t c,
+                                      void* stream) {
+    if (!dy || !dx) return EGR_ENULL;
+    if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || c % 4 != 0) return EGR_EINVAL;
+    const int64_t total = (int64_t)n * h * w * (c / 4);
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n, h, w, c / 4);
+    return egr_launch_status();
+}
+
+extern "C" int egr_planes_to_nhwc_f32(const float* planes, int32_t n_inner, int64_t stride_inner, int64_t stride_outer, float* y,
+                                      int32_t n, int32_t c, int32_t hw, int32_t cpad, void* stream) {
+    if (!planes || !y) return EGR_ENULL;
+    if (n <= 0 || c <= 0 || hw <= 0 || cpad < c || n_inner <= 0) return EGR_EINVAL;
+    egr_nmap map{n_inner, stride_inner, stride_outer};
+    hipLaunchKernelGGL(planes_to_nhwc_kernel, dim3(nblocks((int64_t)n * hw * cpad)), dim3(256), 0, (hipStream_t)stream, planes,
+                       map, y, n, c, hw, cpad);
+    return egr_launch_status();
+}
+
+extern "C" int egr_stem_im2col_f32(const float* img, int32_t n_inner, int64_t stride_inner, int64_t stride_outer, int32_t n,
+                                   int32_t h, int32_t w, float* cols, void* stream) {
+    if (!img || !cols) return EGR_ENULL;
+    if (n <= 0 || h <= 0 || w <= 0 || (h & 1) || (w & 1) || n_inner <= 0) return EGR_EINVAL;
+    egr_nmap map{n_inner, stride_inner, stride_outer};
+    const int64_t total = (int64_t)n * (h / 2) * (w / 2) * 160;
+    if (total >= (1LL << 31) * 256) return EGR_EINVAL;
+    hipLaunchKernelGGL(stem_im2col_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, img, map, n, h, w, cols);
+    return egr_launch_status();
+}
+
+extern "C" int egr_layernorm_bwd_f32(const float* dy, const float* pre, const float* gamma, float* ds, float* dgamma,
+                                     float* dbeta, float* rowstats, int32_t rows, int32_t c, float eps, int32_t rows_per_group,
+                                     void* stream) {
+    if (!dy || !pre || !gamma || !ds || !dgamma || !dbeta || !rowstats) return EGR_ENULL;
+    if (rows <= 0) return EGR_EINVAL;
+    const int rpg = rows_per_group > 0 ? rows_per_group : rows;
+    if (rows % rpg != 0) return EGR_EINVAL;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (c) {
+        case 64: hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, block, 0, s, dy, pre, gamma, ds, rowstats, rows, eps, rows_per_group); break;
+        case 128: hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, block, 0, s, dy, pre, gamma, ds, rowstats, rows, eps, rows_per_group); break;
+        case 256: hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, 0, s, dy, pre, gamma, ds, rowstats, rows, eps, rows_per_group); break;
+        case 512: hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, block, 0, s, dy, pre, gamma, ds, rowstats, rows, eps, rows_per_group); break;
+        default: return EGR_EINVAL;
+    }
+    hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3((c + 255) / 256, rows / rpg), dim3(256), 0, s, dy, pre, rowstats, dgamma,
+                       dbeta, rpg, c);
+    return egr_launch_status();
+}
+
+extern "C" int egr_joint_mha_bwd_f32(const float* qkv, const float* dout, float* dqkv, int32_t b, int32_t j, int32_t heads,
+                                     int32_t d, float scale, void* stream) {
+    if (!qkv || !dout || !dqkv) return EGR_ENULL;
+    if (b <= 0 || j <= 0 || j > 16 || heads <= 0 || d <= 0 || d > 64) return EGR_EINVAL;
+    hipLaunchKernelGGL(joint_mha_bwd_kernel, dim3((unsigned)(b * heads)), dim3(64), 0, (hipStream_t)stream, qkv, dout, dqkv, j,
+                       heads, d, scale);
+    return egr_launch_status();
+}
+
+extern "C" int egr_colsum_f32(const float* x, int64_t ld, int64_t rows, int32_t c, const float* scale, float* out,
+                              int32_t accumulate, int32_t groups, int64_t gx, int64_t gs, void* stream) {
+    if (!x || !out) return EGR_ENULL;
+    if (rows <= 0 || c <= 0 || ld < c || groups <= 0 || groups > 65535) return EGR_EINVAL;
+    hipLaunchKernelGGL(colsum_kernel, dim3((c + 63) / 64, groups), dim3(256), 0, (hipStream_t)stream, x, ld, rows, c, scale, out,
+                       accumulate, gx, gs);
+    return egr_launch_status();
+}
+
+extern "C" int egr_fold_rows_f32(const float* x, float* y, int64_t rows_out, int32_t fold, int32_t c, void* stream) {
+    if (!x || !y) return EGR_ENULL;
+    if (rows_out <= 0 || fold <= 0 || c <= 0) return EGR_EINVAL;
+    hipLaunchKernelGGL(fold_rows_kernel, dim3(nblocks(rows_out * c)), dim3(256), 0, (hipStream_t)stream, x, y, rows_out * c, fold, c);
+    return egr_launch_status();
+}
+
+extern "C" int egr_jqa_sum_bwd_f32(const float* dx, float* d_embed, float* d_bfb, int32_t b, int32_t j, int32_t c,
+                                   int32_t b_per_group, void* stream) {
+    if (!dx || !d_embed || !d_bfb) return EGR_ENULL;
+    if (b <= 0 || j <= 0 || c <= 0 || b_per_group <= 0 || b % b_per_group != 0) return EGR_EINVAL;
+    const int64_t total = (int64_t)(b / b_per_group) * j * c + (int64_t)b * c;
+    hipLaunchKernelGGL(jqa_sum_bwd_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, dx, d_embed, d_bfb, b, j, c,
+                       b_per_group);
+    return egr_launch_status();
+}
+
+extern "C" int egr_rownorm_loss_f32(const float* pred, const float* gt, int64_t rows, int32_t d, float weight, double* loss,
+                                    float* dpred, void* stream) {
+    if (!pred || !gt || !loss) return EGR_ENULL;
+    if (rows <= 0 || d <= 0 || d > 64) return EGR_EINVAL;
+    const float coef = weight / (float)rows;
+    hipLaunchKernelGGL(rownorm_loss_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, pred, gt, rows, d,
+                       coef, loss, dpred);
+    return egr_launch_status();
+}
+
+extern "C" int egr_sumsq_f32(const float* g, int64_t n, double* out, int32_t accumulate, void* stream) {
+    if (!g || !out) return EGR_ENULL;
+    if (n <= 0 || n % 4 != 0 || !aligned16(g)) return EGR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate) hipLaunchKernelGGL(zero_double_kernel, dim3(1), dim3(1), 0, s, out);
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, n / 4, out);
+    return egr_launch_status();
+}
+
+extern "C" int egr_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, int32_t step, const double* grad_sumsq, float clip, void* stream) {
+    if (!p || !g || !m || !v) return EGR_ENULL;
+    if (n <= 0 || n % 4 != 0 || step <= 0 || !aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v)) return EGR_EINVAL;
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3(nblocks(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, lr, beta1, beta2,
+                       eps, weight_decay, bc1, bc2_sqrt, grad_sumsq, clip);
+    return egr_launch_status();
+}

@@ -1,0 +1,364 @@
+"""ctypes binding of the training-step entry points (include/egorear_train.h) of libegorear_hip.so.
+
+Same rules as egorear_amd.hip: torch only owns memory and streams, shapes are checked on the host before a pointer is
+handed to a kernel, and there is no fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import hip
+from .hip import Img, NMap, _check, _cont, _launch, _p, _stream, lib
+
+TRAIN_EXPORTS = [
+    "egr_bn_blocks", "egr_bn_stats_f32", "egr_scale_shift_f32", "egr_bn_backward_f32", "egr_relu_bwd_f32", "egr_add_f32",
+    "egr_gelu_f32", "egr_gelu_bwd_f32", "egr_rowmask_f32", "egr_fill_f32", "egr_maxpool_train_f32", "egr_maxpool_bwd_f32",
+    "egr_upsample2x_bwd_f32", "egr_planes_to_nhwc_f32", "egr_stem_im2col_f32", "egr_layernorm_bwd_f32", "egr_joint_mha_bwd_f32",
+    "egr_msda_gather_bwd_f32", "egr_colsum_f32", "egr_fold_rows_f32", "egr_jqa_sum_bwd_f32", "egr_rownorm_loss_f32",
+    "egr_sumsq_f32", "egr_adamw_f32",
+]
+
+
+def _bind():
+    vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+    lib.egr_bn_blocks.argtypes = [i64]
+    lib.egr_bn_stats_f32.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, sz, vp]
+    lib.egr_scale_shift_f32.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
+    lib.egr_bn_backward_f32.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, vp, sz, vp]
+    lib.egr_relu_bwd_f32.argtypes = [vp, vp, vp, i64, vp]
+    lib.egr_add_f32.argtypes = [vp, vp, vp, i64, vp]
+    lib.egr_gelu_f32.argtypes = [vp, vp, i64, vp]
+    lib.egr_gelu_bwd_f32.argtypes = [vp, vp, vp, i64, vp]
+    lib.egr_rowmask_f32.argtypes = [vp, vp, i64, i32, vp]
+    lib.egr_fill_f32.argtypes = [vp, f32, i64, vp]
+    lib.egr_maxpool_train_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.egr_maxpool_bwd_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.egr_upsample2x_bwd_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.egr_planes_to_nhwc_f32.argtypes = [vp, i32, i64, i64, vp, i32, i32, i32, i32, vp]
+    lib.egr_stem_im2col_f32.argtypes = [vp, i32, i64, i64, i32, i32, i32, vp, vp]
+    lib.egr_layernorm_bwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp]
+    lib.egr_joint_mha_bwd_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp]
+    lib.egr_msda_gather_bwd_f32.argtypes = [vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]
+    lib.egr_colsum_f32.argtypes = [vp, i64, i64, i32, vp, vp, i32, i32, i64, i64, vp]
+    lib.egr_fold_rows_f32.argtypes = [vp, vp, i64, i32, i32, vp]
+    lib.egr_jqa_sum_bwd_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.egr_rownorm_loss_f32.argtypes = [vp, vp, i64, i32, f32, vp, vp, vp]
+    lib.egr_sumsq_f32.argtypes = [vp, i64, vp, i32, vp]
+    lib.egr_adamw_f32.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, vp]
+    for name in TRAIN_EXPORTS:
+        getattr(lib, name).restype = C.c_int32 if name == "egr_bn_blocks" else C.c_int
+
+
+_bind()
+
+
+def _dense(t: torch.Tensor, what: str) -> torch.Tensor:
+    if not t.is_contiguous():
+        raise RuntimeError(f"egorear_amd.train: {what} must be contiguous")
+    return t
+
+
+def _same(a: torch.Tensor, b: torch.Tensor, what: str):
+    if a.shape != b.shape:
+        raise RuntimeError(f"egorear_amd.train: {what}: shapes {tuple(a.shape)} vs {tuple(b.shape)}")
+
+
+# --------------------------------------------------------------------------- BatchNorm (training mode)
+
+class BNCtx:
+    """What the backward of one grouped BatchNorm needs: raw conv output, batch statistics, alpha."""
+    __slots__ = ("x", "mean", "invstd", "alpha", "rpg", "c", "groups")
+
+
+def bn_workspace(device) -> torch.Tensor:
+    return torch.empty(2 * 512 * 2 * 1024 + 16, device=device, dtype=torch.float64)
+
+
+def bn_train(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, running_mean: Optional[torch.Tensor],
+             running_var: Optional[torch.Tensor], groups: int, ws: torch.Tensor, *, res: Optional[torch.Tensor] = None,
+             relu: bool = True, momentum: float = 0.1, eps: float = 1e-5, out: Optional[torch.Tensor] = None):
+    """x: dense (groups*n, h, w, c) raw conv output.  gamma/beta/running_*: (groups, c) contiguous (running_* updated in
+    place).  Returns (y, ctx)."""
+    _dense(x, "bn input")
+    c = x.shape[-1]
+    rows = x.numel() // c
+    if rows % groups:
+        raise RuntimeError("egorear_amd.train.bn_train: rows not divisible by groups")
+    rpg = rows // groups
+    for t in (gamma, beta, running_mean, running_var):
+        if t is not None and (t.numel() != groups * c or not t.is_contiguous()):
+            raise RuntimeError("egorear_amd.train.bn_train: per-channel arrays must be contiguous (groups, c)")
+    ctx = BNCtx()
+    ctx.x, ctx.rpg, ctx.c, ctx.groups = x, rpg, c, groups
+    st = torch.empty((4, groups, c), device=x.device, dtype=torch.float32)
+    ctx.mean, ctx.invstd, ctx.alpha, shift = st[0], st[1], st[2], st[3]
+    _launch("egr_bn_stats_f32", lib.egr_bn_stats_f32, _p(x), rpg, c, groups, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+            momentum, eps, _p(ctx.mean), _p(ctx.invstd), _p(ctx.alpha), _p(shift), _p(ws, torch.float64), ws.numel(), _stream(),
+            nbytes=4.0 * x.numel())
+    y = out if out is not None else torch.empty_like(x)
+    if res is not None:
+        _same(res, x, "bn residual")
+        _dense(res, "bn residual")
+    _launch("egr_scale_shift_f32", lib.egr_scale_shift_f32, _p(x), _p(ctx.alpha), _p(shift), _p(res), _p(_dense(y, "bn out")), rpg, c,
+            groups, 1 if relu else 0, _stream(), nbytes=4.0 * x.numel() * (3 if res is not None else 2))
+    return y, ctx
+
+
+def bn_backward(ctx: BNCtx, dy: torch.Tensor, y: Optional[torch.Tensor], ws: torch.Tensor, want_dz: bool = False):
+    """dy: gradient w.r.t. the BN(+res)(+ReLU) output y (pass y=None when no ReLU follows).  Returns
+    (dx, dgamma (groups,c), dbeta (groups,c), dz | None) with dz = dy*[y>0], the gradient of the residual branch."""
+    _same(dy, ctx.x, "bn backward dy")
+    _dense(dy, "bn backward dy")
+    if y is not None:
+        _same(y, ctx.x, "bn backward y")
+        _dense(y, "bn backward y")
+    dx = torch.empty_like(ctx.x)
+    dz = torch.empty_like(ctx.x) if want_dz else None
+    dgb = torch.empty((2, ctx.groups, ctx.c), device=dy.device, dtype=torch.float32)
+    _launch("egr_bn_backward_f32", lib.egr_bn_backward_f32, _p(dy), _p(y), _p(ctx.x), _p(ctx.mean), _p(ctx.invstd), _p(ctx.alpha),
+            ctx.rpg, ctx.c, ctx.groups, _p(dgb[0]), _p(dgb[1]), _p(dx), _p(dz), _p(ws, torch.float64), ws.numel(), _stream(),
+            nbytes=4.0 * dy.numel() * (7 if y is not None else 5))
+    return dx, dgb[0], dgb[1], dz
+
+
+# --------------------------------------------------------------------------- element-wise
+
+def _elt(name, cfunc, n, *ptrs, nbytes=0.0):
+    if n % 4:
+        raise RuntimeError(f"egorear_amd.train.{name}: element count must be a multiple of 4")
+    _launch(name, cfunc, *ptrs, n, _stream(), nbytes=nbytes)
+
+
+def relu_bwd(dy: torch.Tensor, y: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _same(dy, y, "relu_bwd")
+    out = out if out is not None else torch.empty_like(dy)
+    _elt("egr_relu_bwd_f32", lib.egr_relu_bwd_f32, dy.numel(), _p(_dense(dy, "dy")), _p(_dense(y, "y")), _p(_dense(out, "dx")),
+         nbytes=12.0 * dy.numel())
+    return out
+
+
+def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _same(a, b, "add")
+    out = out if out is not None else torch.empty_like(a)
+    _elt("egr_add_f32", lib.egr_add_f32, a.numel(), _p(_dense(a, "a")), _p(_dense(b, "b")), _p(_dense(out, "out")), nbytes=12.0 * a.numel())
+    return out
+
+
+def gelu(z: torch.Tensor) -> torch.Tensor:
+    h = torch.empty_like(z)
+    _elt("egr_gelu_f32", lib.egr_gelu_f32, z.numel(), _p(_dense(z, "z")), _p(h))
+    return h
+
+
+def gelu_bwd(dh: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+    _same(dh, z, "gelu_bwd")
+    dz = torch.empty_like(z)
+    _elt("egr_gelu_bwd_f32", lib.egr_gelu_bwd_f32, z.numel(), _p(_dense(dh, "dh")), _p(_dense(z, "z")), _p(dz))
+    return dz
+
+
+def fill(x: torch.Tensor, v: float = 0.0) -> torch.Tensor:
+    _dense(x, "fill target")
+    if x.numel() % 4:
+        raise RuntimeError("egorear_amd.train.fill: element count must be a multiple of 4")
+    _launch("egr_fill_f32", lib.egr_fill_f32, _p(x), float(v), x.numel(), _stream())
+    return x
+
+
+def zeros(shape, device) -> torch.Tensor:
+    return fill(torch.empty(shape, device=device, dtype=torch.float32))
+
+
+def rowmask_(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """x (rows, c) *= mask[rows] (uint8), in place."""
+    rows, c = x.shape
+    if mask.numel() != rows:
+        raise RuntimeError("egorear_amd.train.rowmask_: mask length")
+    _launch("egr_rowmask_f32", lib.egr_rowmask_f32, _p(_dense(x, "x")), _p(mask, torch.uint8), rows, c, _stream())
+    return x
+
+
+# --------------------------------------------------------------------------- pooling / resampling
+
+def maxpool_train(x: Img, k: int, stride: int, pad: int):
+    if not x.t.is_contiguous():
+        raise RuntimeError("egorear_amd.train.maxpool_train: contiguous NHWC input expected")
+    ho = (x.h + 2 * pad - k) // stride + 1
+    wo = (x.w + 2 * pad - k) // stride + 1
+    y = torch.empty((x.n, ho, wo, x.c), device=x.t.device, dtype=torch.float32)
+    slot = torch.empty((x.n, ho, wo, x.c), device=x.t.device, dtype=torch.uint8)
+    _launch("egr_maxpool_train_f32", lib.egr_maxpool_train_f32, _p(x.t), _p(y), _p(slot, torch.uint8), x.n, x.h, x.w, x.c, k, stride,
+            pad, _stream())
+    return Img(y), slot
+
+
+def maxpool_bwd(dy: torch.Tensor, slot: torch.Tensor, in_hw, k: int, stride: int, pad: int) -> torch.Tensor:
+    n, ho, wo, c = dy.shape
+    h, w = in_hw
+    if tuple(slot.shape) != (n, ho, wo, c) or (h + 2 * pad - k) // stride + 1 != ho or (w + 2 * pad - k) // stride + 1 != wo:
+        raise RuntimeError("egorear_amd.train.maxpool_bwd: geometry mismatch")
+    dx = torch.empty((n, h, w, c), device=dy.device, dtype=torch.float32)
+    _launch("egr_maxpool_bwd_f32", lib.egr_maxpool_bwd_f32, _p(_dense(dy, "dy")), _p(_dense(slot, "slot"), torch.uint8), _p(dx), n, h, w, c,
+            k, stride, pad, _stream())
+    return dx
+
+
+def upsample2x_bwd(dy: torch.Tensor, y: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dy (n, 2h, 2w, c) -> dx (n, h, w, c); with y given, dy is first masked by [y > 0] (fused up+ReLU forward)."""
+    n, ho, wo, c = dy.shape
+    if ho % 2 or wo % 2:
+        raise RuntimeError("egorear_amd.train.upsample2x_bwd: odd output size")
+    if y is not None:
+        _same(dy, y, "upsample2x_bwd")
+        _dense(y, "y")
+    dx = torch.empty((n, ho // 2, wo // 2, c), device=dy.device, dtype=torch.float32)
+    _launch("egr_upsample2x_bwd_f32", lib.egr_upsample2x_bwd_f32, _p(_dense(dy, "dy")), _p(y), _p(dx), n, ho // 2, wo // 2, c, _stream())
+    return dx
+
+
+def planes_to_nhwc(planes: torch.Tensor, nmap: NMap, n: int, c: int, hw: int, cpad: int, base_offset: int = 0) -> torch.Tensor:
+    """Channel-major planes (image n at nmap(n) floats from `base_offset`) -> (n, hw, cpad) channels-last, zero padded."""
+    flat = planes.reshape(-1)
+    last = (n - 1) // nmap.n_inner * nmap.stride_outer + (n - 1) % nmap.n_inner * nmap.stride_inner + c * hw
+    if not planes.is_contiguous() or base_offset + last > flat.numel():
+        raise RuntimeError("egorear_amd.train.planes_to_nhwc: map runs outside the tensor")
+    y = torch.empty((n, hw, cpad), device=planes.device, dtype=torch.float32)
+    _launch("egr_planes_to_nhwc_f32", lib.egr_planes_to_nhwc_f32, _p(flat[base_offset:]), nmap.n_inner, nmap.stride_inner,
+            nmap.stride_outer, _p(y), n, c, hw, cpad, _stream())
+    return y
+
+
+def stem_im2col(img: torch.Tensor, view0: int, nviews: int) -> torch.Tensor:
+    """img (B, V, 3, H, W) -> (nviews*B*H/2*W/2, 160) patch rows of views [view0, view0+nviews), view-major."""
+    B, V, Cc, H, W = img.shape
+    if Cc != 3 or view0 + nviews > V:
+        raise RuntimeError("egorear_amd.train.stem_im2col: bad views / channels")
+    _cont(img, "input image batch")
+    n = nviews * B
+    cols = torch.empty((n * (H // 2) * (W // 2), 160), device=img.device, dtype=torch.float32)
+    base = img.reshape(-1)[view0 * 3 * H * W:]
+    _launch("egr_stem_im2col_f32", lib.egr_stem_im2col_f32, _p(base), B, V * 3 * H * W, 3 * H * W, n, H, W, _p(cols), _stream())
+    return cols
+
+
+# --------------------------------------------------------------------------- LayerNorm / attention
+
+def layernorm_bwd(dy: torch.Tensor, pre: torch.Tensor, gamma: torch.Tensor, groups: int = 1, eps: float = 1e-5):
+    """-> (ds (rows,c), dgamma (groups*c), dbeta (groups*c))."""
+    rows, c = pre.shape
+    _same(dy, pre, "layernorm_bwd")
+    if gamma.numel() != groups * c or rows % groups:
+        raise RuntimeError("egorear_amd.train.layernorm_bwd: gamma / groups mismatch")
+    ds = torch.empty_like(pre)
+    dgb = torch.empty((2, groups * c), device=pre.device, dtype=torch.float32)
+    stats = torch.empty((rows, 2), device=pre.device, dtype=torch.float32)
+    _launch("egr_layernorm_bwd_f32", lib.egr_layernorm_bwd_f32, _p(_dense(dy, "dy")), _p(_dense(pre, "pre")), _p(_dense(gamma, "gamma")), _p(ds),
+            _p(dgb[0]), _p(dgb[1]), _p(stats), rows, c, eps, rows // groups if groups > 1 else 0, _stream())
+    return ds, dgb[0], dgb[1]
+
+
+def joint_mha_bwd(qkv: torch.Tensor, dout: torch.Tensor, b: int, j: int, heads: int, d: int, scale: float) -> torch.Tensor:
+    if tuple(qkv.shape) != (b * j, 3 * heads * d) or tuple(dout.shape) != (b * j, heads * d):
+        raise RuntimeError("egorear_amd.train.joint_mha_bwd: shape mismatch")
+    dqkv = torch.empty_like(qkv)
+    _launch("egr_joint_mha_bwd_f32", lib.egr_joint_mha_bwd_f32, _p(_dense(qkv, "qkv")), _p(_dense(dout, "dout")), _p(dqkv), b, j, heads, d,
+            scale, _stream())
+    return dqkv
+
+
+def msda_gather_bwd(feat: torch.Tensor, pos: Optional[torch.Tensor], offs_logits: torch.Tensor, anchors: torch.Tensor,
+                    valid: torch.Tensor, B: int, V: int, J: int, heads: int, dh: int, hgt: int, wid: int, dg: torch.Tensor,
+                    da: torch.Tensor, cfold: torch.Tensor, dfeat: Optional[torch.Tensor], dpos: Optional[torch.Tensor],
+                    groups: int = 1) -> torch.Tensor:
+    """Shapes as hip.msda_gather; dg (groups, rows, heads, cf), da (groups*rows, heads*dh), cfold (groups, heads*dh).
+    dfeat like feat / dpos like pos are accumulated into (zero them first).  Returns dol (groups*rows, heads*48)."""
+    cf = feat.shape[-1]
+    rows = B * J * V
+    C_ = heads * dh
+    if tuple(feat.shape) != (V, B, hgt * wid, cf) or offs_logits.shape != (groups * B * J, heads * 48):
+        raise RuntimeError("egorear_amd.train.msda_gather_bwd: feat / offs_logits shape")
+    if dg.numel() != groups * rows * heads * cf or da.numel() != groups * rows * C_ or cfold.numel() != groups * C_:
+        raise RuntimeError("egorear_amd.train.msda_gather_bwd: gradient shapes")
+    if pos is not None and tuple(pos.shape) != (groups, V, hgt * wid, C_):
+        raise RuntimeError("egorear_amd.train.msda_gather_bwd: pos shape")
+    if dfeat is not None:
+        _same(dfeat, feat, "dfeat")
+    if dpos is not None:
+        if pos is None:
+            raise RuntimeError("egorear_amd.train.msda_gather_bwd: dpos without pos")
+        _same(dpos, pos, "dpos")
+    if anchors.numel() != B * V * J * 2 or valid.numel() != B * V * J:
+        raise RuntimeError("egorear_amd.train.msda_gather_bwd: anchors / valid shape")
+    dol = torch.empty((groups * rows, heads * 48), device=feat.device, dtype=torch.float32)
+    _launch("egr_msda_gather_bwd_f32", lib.egr_msda_gather_bwd_f32, _p(_dense(feat, "feat")), cf, _p(pos), dh, _p(_dense(offs_logits, "ol")),
+            _p(_dense(anchors, "anchors")), _p(_dense(valid, "valid"), torch.uint8), B, V, J, heads, hgt, wid, _p(_dense(dg, "dg")),
+            _p(_dense(da, "da")), _p(_dense(cfold, "cfold")), _p(dol), _p(dfeat), _p(dpos), groups, _stream())
+    return dol
+
+
+# --------------------------------------------------------------------------- reductions
+
+def colsum(x: torch.Tensor, ld: int, rows: int, c: int, scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+           accumulate: bool = False, groups: int = 1, gx: int = 0, gs: int = 0) -> torch.Tensor:
+    """out[g, c] (+)= sum_r scale[g*gs + r] * x[g*gx + r*ld + c]; x is a storage-rooted view (first element = group 0 row 0)."""
+    need = (groups - 1) * gx + (rows - 1) * ld + c
+    if x.storage_offset() + need > x.untyped_storage().nbytes() // 4:
+        raise RuntimeError("egorear_amd.train.colsum: reads past the end of x")
+    if scale is not None and scale.numel() < (groups - 1) * gs + rows:
+        raise RuntimeError("egorear_amd.train.colsum: scale too short")
+    if out is None:
+        out = torch.empty((groups, c), device=x.device, dtype=torch.float32)
+    _launch("egr_colsum_f32", lib.egr_colsum_f32, _p(x), ld, rows, c, _p(scale), _p(out), 1 if accumulate else 0, groups, gx, gs, _stream())
+    return out
+
+
+def fold_rows(x: torch.Tensor, fold: int) -> torch.Tensor:
+    rows, c = x.shape
+    if rows % fold:
+        raise RuntimeError("egorear_amd.train.fold_rows: rows not divisible")
+    y = torch.empty((rows // fold, c), device=x.device, dtype=torch.float32)
+    _launch("egr_fold_rows_f32", lib.egr_fold_rows_f32, _p(_dense(x, "x")), _p(y), rows // fold, fold, c, _stream())
+    return y
+
+
+def jqa_sum_bwd(dx: torch.Tensor, b: int, j: int, c: int, groups: int):
+    if dx.numel() != b * j * c or b % groups:
+        raise RuntimeError("egorear_amd.train.jqa_sum_bwd: shape")
+    d_embed = torch.empty((groups, j, c), device=dx.device, dtype=torch.float32)
+    d_bfb = torch.empty((b, c), device=dx.device, dtype=torch.float32)
+    _launch("egr_jqa_sum_bwd_f32", lib.egr_jqa_sum_bwd_f32, _p(_dense(dx, "dx")), _p(d_embed), _p(d_bfb), b, j, c, b // groups, _stream())
+    return d_embed, d_bfb
+
+
+# --------------------------------------------------------------------------- loss / optimiser
+
+def rownorm_loss(pred: torch.Tensor, gt: torch.Tensor, d: int, weight: float, loss: torch.Tensor, want_grad: bool = True):
+    """loss (device float64 scalar) += weight * mean_rows ||gt - pred||_2 over rows of length d; returns dpred | None."""
+    _same(pred, gt, "rownorm_loss")
+    if pred.numel() % d or loss.dtype != torch.float64 or loss.numel() != 1:
+        raise RuntimeError("egorear_amd.train.rownorm_loss: bad shapes")
+    rows = pred.numel() // d
+    dpred = torch.empty_like(pred) if want_grad else None
+    _launch("egr_rownorm_loss_f32", lib.egr_rownorm_loss_f32, _p(_dense(pred, "pred")), _p(_dense(gt, "gt")), rows, d, float(weight),
+            _p(loss, torch.float64), _p(dpred), _stream())
+    return dpred
+
+
+def sumsq(g: torch.Tensor, out: torch.Tensor, accumulate: bool = False):
+    if out.dtype != torch.float64 or out.numel() != 1:
+        raise RuntimeError("egorear_amd.train.sumsq: out must be one float64")
+    _launch("egr_sumsq_f32", lib.egr_sumsq_f32, _p(_dense(g, "g")), g.numel(), _p(out, torch.float64), 1 if accumulate else 0, _stream())
+
+
+def adamw(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, beta1: float, beta2: float, eps: float,
+          weight_decay: float, step: int, grad_sumsq: Optional[torch.Tensor], clip: float):
+    n = p.numel()
+    if g.numel() != n or m.numel() != n or v.numel() != n:
+        raise RuntimeError("egorear_amd.train.adamw: size mismatch")
+    for t in (p, g, m, v):
+        _dense(t, "adamw operand")
+    _launch("egr_adamw_f32", lib.egr_adamw_f32, _p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, weight_decay, step,
+            _p(grad_sumsq, torch.float64) if grad_sumsq is not None else None, clip, _stream(), nbytes=28.0 * n)

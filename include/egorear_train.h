@@ -1,0 +1,114 @@
+/* egorear_train.h — C ABI of the training-step kernels (fwd + bwd + AdamW).
+ *
+ * Same conventions as egorear_hip.h: plain device pointers and sizes, fp32 channels-last activations, launch on the
+ * given stream, no allocation, no synchronisation, int return code (0 / positive hipError_t / negative EGR_E*).
+ * The convolution data / weight gradients are egr_conv2d_nhwc_f32 (transposed mode) and egr_conv2d_wgrad_f32 of
+ * egorear_hip.h; this header adds everything else a backward pass of the path needs.  Each entry cites the reference
+ * operator whose autograd it replaces (paths relative to /root/reference/pose_estimation/).
+ */
+#ifndef EGOREAR_TRAIN_H
+#define EGOREAR_TRAIN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- BatchNorm2d in training mode (torchvision BasicBlock bn1/bn2/downsample.1, resnet.py:33-39 after network.train(),
+ * pl_wrappers/egoposeformer/pose_3d_mvf_ex.py:115).  `groups` independent modules (the two stereo encoders) normalise
+ * rows_per_group consecutive pixels each; per-channel arrays are (groups, c).
+ * stats: batch mean / biased variance over the rows -> mean, invstd, and the affine pair (alpha = gamma*invstd,
+ * shift = beta - mean*alpha) consumed by egr_scale_shift_f32; running_mean / running_var are updated in place with
+ * `momentum` (unbiased variance), exactly what nn.BatchNorm2d writes.  workspace: >= groups*nblk*2*c doubles with
+ * nblk = egr_bn_blocks(rows_per_group). */
+int32_t egr_bn_blocks(int64_t rows_per_group);
+int egr_bn_stats_f32(const float* x, int64_t rows_per_group, int32_t c, int32_t groups, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                     float* alpha, float* shift, double* workspace, size_t workspace_doubles, void* stream);
+/* y = x*alpha[c] + shift[c] (+ res) (relu): the normalisation pass.  x, y, res dense (groups*rows_per_group, c). */
+int egr_scale_shift_f32(const float* x, const float* alpha, const float* shift, const float* res, float* y,
+                        int64_t rows_per_group, int32_t c, int32_t groups, int32_t relu, void* stream);
+/* backward: dz = dy * [y > 0] (y may be NULL: no ReLU behind the BN);  dgamma = sum dz*xhat, dbeta = sum dz;
+ * dx = alpha * (dz - dbeta/N - xhat*dgamma/N);  dz is also written to dz_out when given (the residual branch). */
+int egr_bn_backward_f32(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                        const float* alpha, int64_t rows_per_group, int32_t c, int32_t groups, float* dgamma, float* dbeta,
+                        float* dx, float* dz_out, double* workspace, size_t workspace_doubles, void* stream);
+
+/* ---- element-wise pieces.  n = number of floats (multiple of 4), 16-byte aligned pointers. */
+int egr_relu_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, void* stream);            /* dx = dy*[y>0]   */
+int egr_add_f32(const float* a, const float* b, float* y, int64_t n, void* stream);                   /* y = a + b       */
+int egr_gelu_f32(const float* z, float* h, int64_t n, void* stream);                                  /* exact-erf GELU  */
+int egr_gelu_bwd_f32(const float* dh, const float* z, float* dz, int64_t n, void* stream);
+int egr_rowmask_f32(float* x, const uint8_t* mask, int64_t rows, int32_t c, void* stream);            /* x[r,:] *= mask[r] */
+int egr_fill_f32(float* x, float v, int64_t n, void* stream);
+
+/* ---- pooling / resampling.  MaxPool2d with the arg-max window slot recorded (resnet.py:17, egoposeformer_mvf_ex.py:234)
+ * and its gather-form backward; Upsample(x2, bilinear, align_corners=True) backward = the exact adjoint of
+ * egr_upsample2x_nhwc_f32 (dy optionally masked by [y > 0] for the fused up+ReLU form). */
+int egr_maxpool_train_f32(const float* x, float* y, uint8_t* slot, int32_t n, int32_t h, int32_t w, int32_t c, int32_t k,
+                          int32_t stride, int32_t pad, void* stream);
+int egr_maxpool_bwd_f32(const float* dy, const uint8_t* slot, float* dx, int32_t n, int32_t h, int32_t w, int32_t c,
+                        int32_t k, int32_t stride, int32_t pad, void* stream);
+int egr_upsample2x_bwd_f32(const float* dy, const float* y, float* dx, int32_t n, int32_t h, int32_t w, int32_t c,
+                           void* stream);
+
+/* ---- layout changes at the boundary: (n, c, hw) channel-major planes <-> (n, hw, cpad) channels-last, zero padded.
+ * nmap places image n of the channel-major side (the (B,V,15,64,64) heat maps). */
+int egr_planes_to_nhwc_f32(const float* planes, int32_t n_inner, int64_t stride_inner, int64_t stride_outer, float* y,
+                           int32_t n, int32_t c, int32_t hw, int32_t cpad, void* stream);
+/* stem input patches: (B,V,3,H,W) images -> (n*H/2*W/2, 160) rows of the 7x7/s2/p3 receptive field, (ky,kx,c) order,
+ * columns 147..159 zero: turns the stem's weight gradient into a plain 1x1 egr_conv2d_wgrad_f32 (resnet.py:16,49). */
+int egr_stem_im2col_f32(const float* img, int32_t n_inner, int64_t stride_inner, int64_t stride_outer, int32_t n, int32_t h,
+                        int32_t w, float* cols, void* stream);
+
+/* ---- LayerNorm(x + res) backward (transformer.py / heatmap_mvf_ex.py:861-935 norms).  pre = the normalised input
+ * (x + res) saved by the forward; ds = gradient w.r.t. pre; dgamma/dbeta (groups, c) summed over each group's rows. */
+int egr_layernorm_bwd_f32(const float* dy, const float* pre, const float* gamma, float* ds, float* dgamma, float* dbeta,
+                          float* rowstats, int32_t rows, int32_t c, float eps, int32_t rows_per_group, void* stream);
+
+/* ---- joint-to-joint attention core backward (SpatialMHA, heatmap_mvf_ex.py:799-817): qkv (b*j, 3*heads*d),
+ * dout (b*j, heads*d) -> dqkv. */
+int egr_joint_mha_bwd_f32(const float* qkv, const float* dout, float* dqkv, int32_t b, int32_t j, int32_t heads, int32_t d,
+                          float scale, void* stream);
+
+/* ---- deformable sampling backward (mmcv ms_deform_attn backward in sample-then-project form, deform_attn.py:122-162).
+ * Inputs as egr_msda_gather_f32 plus dg (groups, rows, heads, cf): gradient w.r.t. the sampled un-projected rows,
+ * da (groups, rows, heads*dh): gradient w.r.t. the projected head outputs (drives the positional table and the bias
+ * mass sigma), cfold (groups, heads*dh): the folded bias.  Outputs: dol (groups, rows, heads*48) gradient w.r.t. the
+ * offsets/logits *per view row* (the caller sums the views), dfeat (views,b,hw,cf) and dpos (groups,views,hw,heads*dh)
+ * accumulated with atomics when given (must be zero-initialised by the caller). */
+int egr_msda_gather_bwd_f32(const float* feat, int32_t cf, const float* pos, int32_t dh, const float* offs_logits,
+                            const float* anchors, const uint8_t* valid, int32_t b, int32_t views, int32_t joints,
+                            int32_t heads, int32_t hgt, int32_t wid, const float* dg, const float* da, const float* cfold,
+                            float* dol, float* dfeat, float* dpos, int32_t groups, void* stream);
+
+/* ---- small reductions: out[c] (+)= sum_r scale[r] * x[r, c] over `rows` rows of leading dimension ld, per group
+ * (x group stride gx floats, scale group stride gs, out group stride c).  scale may be NULL. */
+int egr_colsum_f32(const float* x, int64_t ld, int64_t rows, int32_t c, const float* scale, float* out, int32_t accumulate,
+                   int32_t groups, int64_t gx, int64_t gs, void* stream);
+/* y[r, :] = sum_{k<fold} x[r*fold + k, :]  (sum the `fold` views of a query row). */
+int egr_fold_rows_f32(const float* x, float* y, int64_t rows_out, int32_t fold, int32_t c, void* stream);
+/* JQA sum backward (heatmap_mvf_ex.py:664-665): d_embed[g,j,:] = sum_b dx, d_bfb[b,:] = sum_j dx. */
+int egr_jqa_sum_bwd_f32(const float* dx, float* d_embed, float* d_bfb, int32_t b, int32_t j, int32_t c, int32_t b_per_group,
+                        void* stream);
+
+/* ---- losses of the wrapper's training_step (pose_3d_mvf_ex.py:133-145; MpjpeLoss, pose_metric.py:10-16):
+ * loss += weight/rows * sum_r ||gt[r,:] - pred[r,:]||_2 (accumulated into *loss, a device double), and
+ * dpred = weight/rows * (pred - gt)/||.|| (0 where the norm is 0).  d = 3 (poses) or 64 (heat-map rows). */
+int egr_rownorm_loss_f32(const float* pred, const float* gt, int64_t rows, int32_t d, float weight, double* loss,
+                         float* dpred, void* stream);
+
+/* ---- optimiser (pose_3d_mvf_ex.py:219-234 AdamW groups, yaml gradient_clip_val 5.0).
+ * sumsq: *out (+)= sum g^2 (device double).  adamw: one fused decoupled-weight-decay Adam update over a flat range;
+ * the clip coefficient min(1, clip/(sqrt(*sumsq)+1e-6)) is read from the device, so no host sync sits between backward
+ * and the update.  `step` is the 1-based update count. */
+int egr_sumsq_f32(const float* g, int64_t n, double* out, int32_t accumulate, void* stream);
+int egr_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int32_t step, const double* grad_sumsq, float clip, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

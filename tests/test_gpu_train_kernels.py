@@ -1,0 +1,277 @@
+"""Training-step kernels (include/egorear_train.h) against PyTorch-CPU autograd in fp64 — the per-op half of the §8(f)
+rank-2 parity bar; the assembled step is checked in test_gpu_train_step.py."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def close(got, ref, rel=2e-5, what=""):
+    ref = ref.detach().double()
+    tol = rel * max(float(ref.abs().max()), 1e-6)
+    err = float((got.double().cpu() - ref).abs().max())
+    assert err <= tol, f"{what} max err {err:.3e} > tol {tol:.3e}"
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("c,n,h,groups", [(64, 4, 32, 2), (128, 6, 16, 1), (512, 4, 8, 2), (64, 2, 128, 2)])
+def test_batchnorm_train_forward_backward(c, n, h, groups):
+    from egorear_amd import hip_train as T
+    ws = T.bn_workspace(DEV)
+    x = rnd(groups * n, c, h, h, seed=1) * 2 + 0.3
+    res = rnd(groups * n, c, h, h, seed=2)
+    gamma, beta = rnd(groups, c, seed=3) + 1.5, rnd(groups, c, seed=4)
+    rm, rv = rnd(groups, c, seed=5), rnd(groups, c, seed=6) + 2
+    dy = rnd(groups * n, c, h, h, seed=7)
+    # reference: each group is its own BatchNorm2d in training mode, followed by +res, ReLU
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rr = res.double().requires_grad_(True)
+    rms, rvs, ys = [], [], []
+    for g in range(groups):
+        m, v = rm[g].double().clone(), rv[g].double().clone()
+        ys.append(F.relu(F.batch_norm(xr[g * n:(g + 1) * n], m, v, gr[g], br[g], True, 0.1, 1e-5) + rr[g * n:(g + 1) * n]))
+        rms.append(m)
+        rvs.append(v)
+    yref = torch.cat(ys)
+    dx_ref, dg_ref, db_ref, dres_ref = torch.autograd.grad(yref, (xr, gr, br, rr), dy.double())
+    rm_d, rv_d = rm.to(DEV).contiguous(), rv.to(DEV).contiguous()
+    y, ctx = T.bn_train(nhwc(x).to(DEV), gamma.to(DEV), beta.to(DEV), rm_d, rv_d, groups, ws, res=nhwc(res).to(DEV), relu=True)
+    close(y.permute(0, 3, 1, 2), yref, what="y")
+    close(rm_d, torch.stack(rms), rel=1e-6, what="running_mean")
+    close(rv_d, torch.stack(rvs), rel=1e-6, what="running_var")
+    dx, dgam, dbet, dz = T.bn_backward(ctx, nhwc(dy).to(DEV), y, ws, want_dz=True)
+    close(dx.permute(0, 3, 1, 2), dx_ref, rel=1e-4, what="dx")
+    close(dgam, dg_ref, rel=1e-4, what="dgamma")
+    close(dbet, db_ref, rel=1e-4, what="dbeta")
+    close(dz.permute(0, 3, 1, 2), dres_ref, what="dres")
+    # no ReLU, no residual (the downsample branch)
+    y2, ctx2 = T.bn_train(nhwc(x).to(DEV), gamma.to(DEV), beta.to(DEV), None, None, groups, ws, relu=False)
+    y2ref = torch.cat([F.batch_norm(xr[g * n:(g + 1) * n], None, None, gr[g], br[g], True, 0.1, 1e-5) for g in range(groups)])
+    close(y2.permute(0, 3, 1, 2), y2ref, what="y2")
+    dx2_ref, = torch.autograd.grad(y2ref, xr, dy.double())
+    dx2, _, _, _ = T.bn_backward(ctx2, nhwc(dy).to(DEV), None, ws)
+    close(dx2.permute(0, 3, 1, 2), dx2_ref, rel=1e-4, what="dx2")
+
+
+def test_elementwise():
+    from egorear_amd import hip_train as T
+    a, b = rnd(3, 7, 16, seed=1), rnd(3, 7, 16, seed=2)
+    close(T.add(a.to(DEV), b.to(DEV)), a + b, rel=1e-7)
+    close(T.relu_bwd(a.to(DEV), b.to(DEV)), a * (b > 0), rel=1e-7)
+    z = (rnd(5, 64, seed=3) * 4).double().requires_grad_(True)
+    h = F.gelu(z)
+    dh = rnd(5, 64, seed=4)
+    dz_ref, = torch.autograd.grad(h, z, dh.double())
+    close(T.gelu(z.detach().float().to(DEV)), h.detach(), rel=2e-6)
+    close(T.gelu_bwd(dh.to(DEV), z.detach().float().to(DEV)), dz_ref, rel=2e-6)
+    x = rnd(9, 8, seed=5).to(DEV)
+    m = torch.tensor([1, 0, 1, 1, 0, 0, 1, 0, 1], dtype=torch.uint8)
+    close(T.rowmask_(x.clone(), m.to(DEV)), x.cpu() * m[:, None], rel=1e-7)
+    assert float(T.zeros((4, 4), DEV).abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("k,s,p,h", [(3, 2, 1, 32), (2, 2, 0, 32), (3, 2, 1, 13)])
+def test_maxpool_train_and_backward(k, s, p, h):
+    from egorear_amd import hip, hip_train as T
+    x = rnd(3, 8, h, h + 2, seed=1)
+    x[:, :, ::3, ::2] = 0.25  # ties inside windows: the first maximum in scan order must get the gradient
+    xr = x.double().requires_grad_(True)
+    y = F.max_pool2d(xr, k, s, p)
+    dy = rnd(*y.shape, seed=2)
+    dx_ref, = torch.autograd.grad(y, xr, dy.double())
+    yi, slot = T.maxpool_train(hip.Img(nhwc(x).to(DEV)), k, s, p)
+    close(yi.t.permute(0, 3, 1, 2), y.detach(), rel=1e-7)
+    dx = T.maxpool_bwd(nhwc(dy).to(DEV), slot, (h, h + 2), k, s, p)
+    close(dx.permute(0, 3, 1, 2), dx_ref, rel=1e-6)
+
+
+@pytest.mark.parametrize("h,w,relu", [(8, 8, False), (16, 12, True), (1, 5, False), (32, 32, True)])
+def test_upsample2x_backward(h, w, relu):
+    from egorear_amd import hip, hip_train as T
+    x = rnd(2, 8, h, w, seed=1)
+    xr = x.double().requires_grad_(True)
+    y = F.interpolate(xr, scale_factor=2, mode="bilinear", align_corners=True)
+    if relu:
+        y = F.relu(y)
+    dy = rnd(*y.shape, seed=2)
+    dx_ref, = torch.autograd.grad(y, xr, dy.double())
+    yd = hip.upsample2x(hip.Img(nhwc(x).to(DEV)), relu=relu).t
+    dx = T.upsample2x_bwd(nhwc(dy).to(DEV), yd if relu else None)
+    close(dx.permute(0, 3, 1, 2), dx_ref, rel=1e-5)
+
+
+def test_planes_to_nhwc_and_stem_im2col():
+    from egorear_amd import hip, hip_train as T
+    from egorear_amd.hip import NMap
+    B, V, J, hw = 3, 4, 15, 64
+    planes = rnd(B, V, J, hw, seed=1).to(DEV)
+    # view-major image order n = v*B + b over a (B,V,...) tensor
+    y = T.planes_to_nhwc(planes, NMap(B, V * J * hw, J * hw), V * B, J, hw, 32)
+    ref = torch.zeros(V * B, hw, 32)
+    ref[:, :, :J] = planes.cpu().permute(1, 0, 3, 2).reshape(V * B, hw, J)
+    close(y, ref, rel=1e-7)
+    # stem weight gradient through im2col + the 1x1 wgrad
+    img = rnd(2, 4, 3, 32, 32, seed=2)
+    w = rnd(64, 3, 7, 7, seed=3, scale=0.1).double().requires_grad_(True)
+    views = img[:, 1:3].permute(1, 0, 2, 3, 4).reshape(4, 3, 32, 32)   # view-major
+    yv = F.conv2d(views.double(), w, None, 2, 3)
+    dy = rnd(*yv.shape, seed=4)
+    dw_ref, = torch.autograd.grad(yv, w, dy.double())
+    cols = T.stem_im2col(img.to(DEV), 1, 2)
+    ws = torch.empty(1 << 22, device=DEV)
+    dw, _ = hip.conv2d_wgrad(hip.Img(cols.view(-1, 1, 1, 160)), hip.Img(nhwc(dy).reshape(-1, 1, 1, 64).to(DEV)), 1, 1, 1, 0, ws)
+    close(dw[:, :147].reshape(64, 3, 7, 7), dw_ref, rel=3e-5)
+    assert float(dw[:, 147:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("c,groups", [(256, 4), (128, 1)])
+def test_layernorm_backward(c, groups):
+    from egorear_amd import hip, hip_train as T
+    rows = groups * 30
+    x, res = rnd(rows, c, seed=1), rnd(rows, c, seed=2)
+    gamma, beta = rnd(groups, c, seed=3) + 1.2, rnd(groups, c, seed=4)
+    dy = rnd(rows, c, seed=5)
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    pre = xr + res.double()
+    y = torch.cat([F.layer_norm(pre[g * 30:(g + 1) * 30], (c,), gr[g], br[g], 1e-5) for g in range(groups)])
+    dx_ref, dg_ref, db_ref = torch.autograd.grad(y, (xr, gr, br), dy.double())
+    pre_d = T.add(x.to(DEV), res.to(DEV))
+    ds, dgam, dbet = T.layernorm_bwd(dy.to(DEV), pre_d, gamma.reshape(-1).to(DEV), groups)
+    close(ds, dx_ref, rel=2e-5)
+    close(dgam.view(groups, c), dg_ref, rel=2e-5)
+    close(dbet.view(groups, c), db_ref, rel=2e-5)
+    yk = hip.layernorm(x.to(DEV), gamma.reshape(-1).to(DEV), beta.reshape(-1).to(DEV), res=res.to(DEV), groups=groups)
+    close(yk, y.detach(), rel=2e-5)
+
+
+@pytest.mark.parametrize("J,heads,d", [(15, 4, 64), (16, 4, 32)])
+def test_joint_mha_backward(J, heads, d):
+    from egorear_amd import hip_train as T
+    B, C = 5, heads * d
+    qkv = rnd(B * J, 3 * C, seed=1)
+    dout = rnd(B * J, C, seed=2)
+    t = qkv.double().requires_grad_(True)
+    q, k, v = (t[:, i * C:(i + 1) * C].reshape(B, J, heads, d).permute(0, 2, 1, 3) for i in range(3))
+    att = ((q @ k.transpose(-2, -1)) * d ** -0.5).softmax(-1) @ v
+    out = att.permute(0, 2, 1, 3).reshape(B * J, C)
+    ref, = torch.autograd.grad(out, t, dout.double())
+    got = T.joint_mha_bwd(qkv.to(DEV), dout.to(DEV), B, J, heads, d, d ** -0.5)
+    close(got, ref, rel=3e-5)
+
+
+@pytest.mark.parametrize("with_pos,groups,C,cf", [(True, 2, 256, 128), (False, 1, 128, 128)])
+def test_msda_gather_backward(with_pos, groups, C, cf):
+    """Against autograd through the reference formulation (project every token, then mmcv-style sampling: oracle msda_core)."""
+    from egorear_amd import hip, hip_train as T
+    from oracle.egorear_oracle import msda_core
+    B, V, J, heads, H, W = 2, 4, 5, 4, 16, 16
+    dh = C // heads
+    feat = rnd(V, B, H * W, cf, seed=1)
+    pos = rnd(groups, V, H * W, C, seed=2) if with_pos else None
+    ol = rnd(groups * B * J, heads * 48, seed=3)
+    ol[:, :heads * 32] *= 6.0                              # offsets of several pixels: some samples leave the map
+    anchors = (rnd(B, V, J, 2, seed=4) * 0.5 + 0.5)
+    anchors[0, 0, 0] = torch.tensor([0.0, 0.0])            # corner anchor: out-of-bounds corners
+    anchors[1, 3, 2] = torch.tensor([63 / 64, 63 / 64])
+    valid = torch.ones(B, V, J, dtype=torch.uint8)
+    valid[1, 2, 3] = 0
+    Wfold = rnd(groups, C, cf, seed=5, scale=1 / math.sqrt(cf))
+    cfold = rnd(groups, C, seed=6)
+    da = rnd(groups, B * J * V, C, seed=7)                 # upstream gradient of a (rows (b,j,v), C)
+    featr = feat.double().requires_grad_(True)
+    posr = pos.double().requires_grad_(True) if with_pos else None
+    olr = ol.double().requires_grad_(True)
+    outs = []
+    for g in range(groups):
+        o_g = olr[g * B * J:(g + 1) * B * J]
+        off = o_g[:, :heads * 32].reshape(B, J, heads, 16, 2)
+        aw = o_g[:, heads * 32:].reshape(B, J, heads, 16).softmax(-1)
+        per_view = []
+        for v in range(V):
+            value = featr[v] @ Wfold[g].double().t() + cfold[g].double()
+            if with_pos:
+                value = value + posr[g, v]
+            loc = anchors[:, v].double()[:, :, None, None, :] + off / torch.tensor([W, H], dtype=torch.float64)
+            a = msda_core(value.reshape(B, H * W, heads, dh), H, W, loc, aw)               # (B, J, C)
+            per_view.append(a * valid[:, v, :, None].double())
+        outs.append(torch.stack(per_view, dim=2).reshape(B * J * V, C))                    # rows (b, j, v)
+    out = torch.stack(outs)
+    wanted = (olr, featr) + ((posr,) if with_pos else ())
+    grads = torch.autograd.grad(out, wanted, da.double())
+    dol_ref, dfeat_ref = grads[0], grads[1]
+    # kernel inputs: dg_h = Wfold_h^T da_h
+    da_m = da * valid.permute(0, 2, 1).reshape(1, B * J * V, 1).float()                    # masked rows carry no gradient
+    dg = torch.einsum("grhd,ghdc->grhc", da_m.reshape(groups, -1, heads, dh), Wfold.reshape(groups, heads, dh, cf))
+    dfeat = T.zeros(feat.shape, DEV)
+    dpos = T.zeros(pos.shape, DEV) if with_pos else None
+    dol = T.msda_gather_bwd(feat.to(DEV), pos.to(DEV) if with_pos else None, ol.to(DEV), anchors.to(DEV), valid.to(DEV), B, V, J,
+                            heads, dh, H, W, dg.contiguous().to(DEV), da_m.reshape(-1, C).contiguous().to(DEV), cfold.to(DEV),
+                            dfeat, dpos, groups)
+    dol_sum = T.fold_rows(dol, V)
+    close(dol_sum, dol_ref, rel=5e-5, what="d offsets/logits")
+    close(dfeat, dfeat_ref, rel=5e-5, what="d feat")
+    if with_pos:
+        close(dpos, grads[2], rel=5e-5, what="d pos")
+
+
+def test_small_reductions():
+    from egorear_amd import hip_train as T
+    x = rnd(2, 50, 96, seed=1)
+    sc = rnd(2, 50, seed=2)
+    got = T.colsum(x.to(DEV), 96, 50, 64, scale=sc.to(DEV), groups=2, gx=50 * 96, gs=50)
+    close(got, (x[:, :, :64] * sc[:, :, None]).sum(1), rel=1e-5)
+    got2 = T.colsum(x.to(DEV), 96, 100, 96)
+    close(got2, x.reshape(100, 96).sum(0, keepdim=True), rel=1e-5)
+    close(T.fold_rows(x.reshape(100, 96).to(DEV), 4), x.reshape(25, 4, 96).sum(1), rel=1e-6)
+    dx = rnd(8, 15, 32, seed=3)
+    de, db = T.jqa_sum_bwd(dx.to(DEV), 8, 15, 32, 4)
+    close(de, dx.reshape(4, 2, 15, 32).sum(1), rel=1e-6)
+    close(db, dx.sum(1), rel=1e-6)
+
+
+@pytest.mark.parametrize("d,rows", [(3, 32), (64, 960)])
+def test_rownorm_loss(d, rows):
+    from egorear_amd import hip_train as T
+    pred, gt = rnd(rows, d, seed=1), rnd(rows, d, seed=2)
+    gt[3] = pred[3]                                        # zero norm: torch's norm backward gives a zero subgradient
+    pr = pred.double().requires_grad_(True)
+    loss_ref = torch.mean(torch.linalg.norm(gt.double() - pr, dim=-1, ord=2)) * 10.0
+    g_ref, = torch.autograd.grad(loss_ref, pr)
+    loss = torch.zeros(1, dtype=torch.float64, device=DEV)
+    dp = T.rownorm_loss(pred.to(DEV), gt.to(DEV), d, 10.0, loss)
+    assert abs(float(loss) - float(loss_ref)) <= 1e-5 * abs(float(loss_ref))
+    close(dp, g_ref, rel=1e-5)
+
+
+def test_sumsq_and_adamw_match_torch():
+    from egorear_amd import hip_train as T
+    n = 4096 + 64
+    p0, g1, g2 = rnd(n, seed=1), rnd(n, seed=2) * 3, rnd(n, seed=3) * 0.01
+    for wd in (0.0, 5e-4):
+        ref = torch.nn.Parameter(p0.clone())
+        opt = torch.optim.AdamW([ref], lr=1e-3, weight_decay=wd)
+        p, m, v = p0.clone().to(DEV), T.zeros((n,), DEV), T.zeros((n,), DEV)
+        ss = torch.zeros(1, dtype=torch.float64, device=DEV)
+        for step, g in enumerate((g1, g2), 1):
+            ref.grad = g.clone()
+            total = torch.nn.utils.clip_grad_norm_([ref], 5.0)
+            opt.step()
+            gd = g.to(DEV)
+            T.sumsq(gd, ss)
+            assert abs(math.sqrt(float(ss)) - float(total)) <= 1e-5 * float(total)
+            T.adamw(p, gd, m, v, 1e-3, 0.9, 0.999, 1e-8, wd, step, ss, 5.0)
+            close(p, ref.detach(), rel=2e-6, what=f"wd {wd} step {step}")
