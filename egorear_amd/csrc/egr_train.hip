@@ -369,6 +369,16 @@ __global__ __launch_bounds__(256) void planes_to_nhwc_kernel(const float* planes
     y[idx] = ch < c ? planes[egr_map(map, img) + (int64_t)ch * hw + p] : 0.f;
 }
 
+__global__ __launch_bounds__(256) void nhwc_to_planes_kernel(const float* x, float* planes, egr_nmap map, int n, int c, int hw,
+                                                             int cpad) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)n * c * hw) return;
+    const int p = (int)(idx % hw);
+    const int64_t r = idx / hw;
+    const int ch = (int)(r % c), img = (int)(r / c);
+    planes[egr_map(map, img) + (int64_t)ch * hw + p] = x[((int64_t)img * hw + p) * cpad + ch];
+}
+
 __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* img, egr_nmap map, int n, int h, int w, float* cols) {
     const int ho = h / 2, wo = w / 2;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -572,17 +582,18 @@ __global__ __launch_bounds__(256) void jqa_sum_bwd_kernel(const float* dx, float
 }
 
 // ------------------------------------------------------------------ losses: one wave per row
-__global__ __launch_bounds__(256) void rownorm_loss_kernel(const float* pred, const float* gt, int64_t rows, int d, float coef,
-                                                           double* loss, float* dpred) {
+__global__ __launch_bounds__(256) void rownorm_loss_kernel(const float* pred, const float* gt, int64_t rows, int d, int inner,
+                                                           int64_t ldp, int64_t ldg, float coef, double* loss, float* dpred) {
     __shared__ double part[4];
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     double mine = 0.0;
     if (row < rows) {
+        const int64_t po = (row / inner) * ldp + (row % inner) * d, go = (row / inner) * ldg + (row % inner) * d;
         float diff = 0.f;
-        if (lane < d) diff = pred[row * d + lane] - gt[row * d + lane];
+        if (lane < d) diff = pred[po + lane] - gt[go + lane];
         const float nrm = sqrtf(wave_sum(diff * diff));
-        if (lane < d && dpred) dpred[row * d + lane] = nrm > 0.f ? coef * diff / nrm : 0.f;
+        if (lane < d && dpred) dpred[po + lane] = nrm > 0.f ? coef * diff / nrm : 0.f;
         mine = (double)nrm;
     }
     if (lane == 0) part[threadIdx.x >> 6] = mine;
@@ -790,6 +801,16 @@ extern "C" int egr_planes_to_nhwc_f32(const float* planes, int32_t n_inner, int6
     return egr_launch_status();
 }
 
+extern "C" int egr_nhwc_to_planes_f32(const float* x, float* planes, int32_t n_inner, int64_t stride_inner, int64_t stride_outer,
+                                      int32_t n, int32_t c, int32_t hw, int32_t cpad, void* stream) {
+    if (!planes || !x) return EGR_ENULL;
+    if (n <= 0 || c <= 0 || hw <= 0 || cpad < c || n_inner <= 0) return EGR_EINVAL;
+    egr_nmap map{n_inner, stride_inner, stride_outer};
+    hipLaunchKernelGGL(nhwc_to_planes_kernel, dim3(nblocks((int64_t)n * c * hw)), dim3(256), 0, (hipStream_t)stream, x, planes, map,
+                       n, c, hw, cpad);
+    return egr_launch_status();
+}
+
 extern "C" int egr_stem_im2col_f32(const float* img, int32_t n_inner, int64_t stride_inner, int64_t stride_outer, int32_t n,
                                    int32_t h, int32_t w, float* cols, void* stream) {
     if (!img || !cols) return EGR_ENULL;
@@ -857,13 +878,13 @@ extern "C" int egr_jqa_sum_bwd_f32(const float* dx, float* d_embed, float* d_bfb
     return egr_launch_status();
 }
 
-extern "C" int egr_rownorm_loss_f32(const float* pred, const float* gt, int64_t rows, int32_t d, float weight, double* loss,
-                                    float* dpred, void* stream) {
+extern "C" int egr_rownorm_loss_f32(const float* pred, const float* gt, int64_t rows, int32_t d, int32_t inner, int64_t ld_pred,
+                                    int64_t ld_gt, float weight, double* loss, float* dpred, void* stream) {
     if (!pred || !gt || !loss) return EGR_ENULL;
-    if (rows <= 0 || d <= 0 || d > 64) return EGR_EINVAL;
+    if (rows <= 0 || d <= 0 || d > 64 || inner <= 0 || ld_pred < (int64_t)inner * d || ld_gt < (int64_t)inner * d) return EGR_EINVAL;
     const float coef = weight / (float)rows;
     hipLaunchKernelGGL(rownorm_loss_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, pred, gt, rows, d,
-                       coef, loss, dpred);
+                       inner, ld_pred, ld_gt, coef, loss, dpred);
     return egr_launch_status();
 }
 

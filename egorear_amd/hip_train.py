@@ -16,7 +16,7 @@ from .hip import Img, NMap, _check, _cont, _launch, _p, _stream, lib
 TRAIN_EXPORTS = [
     "egr_bn_blocks", "egr_bn_stats_f32", "egr_scale_shift_f32", "egr_bn_backward_f32", "egr_relu_bwd_f32", "egr_add_f32",
     "egr_gelu_f32", "egr_gelu_bwd_f32", "egr_rowmask_f32", "egr_fill_f32", "egr_maxpool_train_f32", "egr_maxpool_bwd_f32",
-    "egr_upsample2x_bwd_f32", "egr_planes_to_nhwc_f32", "egr_stem_im2col_f32", "egr_layernorm_bwd_f32", "egr_joint_mha_bwd_f32",
+    "egr_upsample2x_bwd_f32", "egr_planes_to_nhwc_f32", "egr_nhwc_to_planes_f32", "egr_stem_im2col_f32", "egr_layernorm_bwd_f32", "egr_joint_mha_bwd_f32",
     "egr_msda_gather_bwd_f32", "egr_colsum_f32", "egr_fold_rows_f32", "egr_jqa_sum_bwd_f32", "egr_rownorm_loss_f32",
     "egr_sumsq_f32", "egr_adamw_f32",
 ]
@@ -38,6 +38,7 @@ def _bind():
     lib.egr_maxpool_bwd_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.egr_upsample2x_bwd_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
     lib.egr_planes_to_nhwc_f32.argtypes = [vp, i32, i64, i64, vp, i32, i32, i32, i32, vp]
+    lib.egr_nhwc_to_planes_f32.argtypes = [vp, vp, i32, i64, i64, i32, i32, i32, i32, vp]
     lib.egr_stem_im2col_f32.argtypes = [vp, i32, i64, i64, i32, i32, i32, vp, vp]
     lib.egr_layernorm_bwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp]
     lib.egr_joint_mha_bwd_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp]
@@ -45,7 +46,7 @@ def _bind():
     lib.egr_colsum_f32.argtypes = [vp, i64, i64, i32, vp, vp, i32, i32, i64, i64, vp]
     lib.egr_fold_rows_f32.argtypes = [vp, vp, i64, i32, i32, vp]
     lib.egr_jqa_sum_bwd_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
-    lib.egr_rownorm_loss_f32.argtypes = [vp, vp, i64, i32, f32, vp, vp, vp]
+    lib.egr_rownorm_loss_f32.argtypes = [vp, vp, i64, i32, i32, i64, i64, f32, vp, vp, vp]
     lib.egr_sumsq_f32.argtypes = [vp, i64, vp, i32, vp]
     lib.egr_adamw_f32.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, vp]
     for name in TRAIN_EXPORTS:
@@ -231,6 +232,18 @@ def planes_to_nhwc(planes: torch.Tensor, nmap: NMap, n: int, c: int, hw: int, cp
     return y
 
 
+def nhwc_to_planes(x: torch.Tensor, planes: torch.Tensor, nmap: NMap, c: int, base_offset: int = 0) -> torch.Tensor:
+    """x (n, hw, cpad) channels-last -> its first c channels as (c, hw) planes inside `planes` (image n at nmap(n))."""
+    n, hw, cpad = x.shape
+    flat = planes.reshape(-1)
+    last = (n - 1) // nmap.n_inner * nmap.stride_outer + (n - 1) % nmap.n_inner * nmap.stride_inner + c * hw
+    if not planes.is_contiguous() or base_offset + last > flat.numel() or c > cpad:
+        raise RuntimeError("egorear_amd.train.nhwc_to_planes: map runs outside the tensor")
+    _launch("egr_nhwc_to_planes_f32", lib.egr_nhwc_to_planes_f32, _p(_dense(x, "x")), _p(flat[base_offset:]), nmap.n_inner,
+            nmap.stride_inner, nmap.stride_outer, n, c, hw, cpad, _stream())
+    return planes
+
+
 def stem_im2col(img: torch.Tensor, view0: int, nviews: int) -> torch.Tensor:
     """img (B, V, 3, H, W) -> (nviews*B*H/2*W/2, 160) patch rows of views [view0, view0+nviews), view-major."""
     B, V, Cc, H, W = img.shape
@@ -335,15 +348,26 @@ def jqa_sum_bwd(dx: torch.Tensor, b: int, j: int, c: int, groups: int):
 
 # --------------------------------------------------------------------------- loss / optimiser
 
-def rownorm_loss(pred: torch.Tensor, gt: torch.Tensor, d: int, weight: float, loss: torch.Tensor, want_grad: bool = True):
-    """loss (device float64 scalar) += weight * mean_rows ||gt - pred||_2 over rows of length d; returns dpred | None."""
-    _same(pred, gt, "rownorm_loss")
-    if pred.numel() % d or loss.dtype != torch.float64 or loss.numel() != 1:
-        raise RuntimeError("egorear_amd.train.rownorm_loss: bad shapes")
-    rows = pred.numel() // d
-    dpred = torch.empty_like(pred) if want_grad else None
-    _launch("egr_rownorm_loss_f32", lib.egr_rownorm_loss_f32, _p(_dense(pred, "pred")), _p(_dense(gt, "gt")), rows, d, float(weight),
-            _p(loss, torch.float64), _p(dpred), _stream())
+def rownorm_loss(pred: torch.Tensor, gt: torch.Tensor, d: int, weight: float, loss: torch.Tensor, want_grad: bool = True,
+                 rows: Optional[int] = None, inner: int = 1, ld_pred: Optional[int] = None, ld_gt: Optional[int] = None):
+    """loss (device float64 scalar) += weight * mean_rows ||gt - pred||_2 over rows of length d; returns dpred | None.
+    Default: dense (rows, d) operands.  With inner / ld_*: row r starts at (r // inner)*ld + (r % inner)*d, which reads
+    channel-padded buffers in place; dpred then has pred's layout with the padding zeroed."""
+    if loss.dtype != torch.float64 or loss.numel() != 1:
+        raise RuntimeError("egorear_amd.train.rownorm_loss: loss must be one float64")
+    if rows is None:
+        _same(pred, gt, "rownorm_loss")
+        if pred.numel() % d:
+            raise RuntimeError("egorear_amd.train.rownorm_loss: bad shapes")
+        rows, inner, ld_pred, ld_gt = pred.numel() // d, 1, d, d
+    outer = (rows + inner - 1) // inner
+    if rows % inner or outer * ld_pred > pred.numel() + (ld_pred - inner * d) or outer * ld_gt > gt.numel() + (ld_gt - inner * d):
+        raise RuntimeError("egorear_amd.train.rownorm_loss: layout runs outside the operands")
+    dpred = None
+    if want_grad:
+        dpred = torch.empty_like(pred) if ld_pred == inner * d else fill(torch.empty_like(pred))
+    _launch("egr_rownorm_loss_f32", lib.egr_rownorm_loss_f32, _p(_dense(pred, "pred")), _p(_dense(gt, "gt")), rows, d, inner, ld_pred, ld_gt,
+            float(weight), _p(loss, torch.float64), _p(dpred), _stream())
     return dpred
 
 

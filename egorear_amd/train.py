@@ -1,0 +1,841 @@
+"""Training step of the hot path on the HIP kernels (BASELINE.json config 5).
+
+What the reference does per optimisation step (pl_wrappers/egoposeformer/pose_3d_mvf_ex.py:114-150, 212-248):
+`network.train()`, forward of EgoPoseFormerMVFEX, MPJPE loss on the four pose predictions + row-norm loss on the two
+heat-map sets, autograd backward, gradient-norm clipping, AdamW with two parameter groups.  Here the same step runs on
+hand-written kernels: the forward in training mode (BatchNorm batch statistics, intermediates kept), a hand-scheduled
+reverse pass over a small tape (conv data/weight gradients = egr_conv2d_nhwc_f32 transposed mode / egr_conv2d_wgrad_f32,
+everything else = include/egorear_train.h), loss kernels, and a fused clip + AdamW over flat parameter ranges.
+
+Gradient stops follow the reference's shipped pose3d configs (full_training, use_pred_heatmap_init, detach_heatmap_feat*):
+  * heat-map heads and refiners see *detached* encoder features (heatmap_mvf_ex.py:273-282), so the encoders are trained
+    only through the lifting head's deformable attention on feat_init (egoposeformer_mvf_ex.py:431);
+  * inside a refiner, `offset_pred + frame_feat.detach()` (:715) leaves frame_feat_proj_layers without any gradient
+    (torch leaves .grad = None and AdamW skips those tensors: so does this step), and conv_heatmap_layers see detached
+    refined features (:717-721);
+  * anchors (arg-max, reprojection) carry no gradient.
+
+torch is used for memory, streams, and *parameter-space* algebra only (re-packing weights into the kernels' layouts,
+folding W_v.W_pre of the sample-then-project attention and un-folding its gradient): activations never pass through
+a torch operator.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip
+from . import hip_train as T
+from .engine import _npad, _pad_rows, _pad_vec, _rows, pack_conv_weight, unpack_conv_weight
+from .hip import ACT_NONE, ACT_RELU, RES_BEFORE_ACT, RES_NONE, Img, NMap
+
+_WS_FLOATS = 72 << 20   # conv split-K / wgrad slab workspace (288 MB: one slab of mlp_pred.0's 2048 x 32768 gradient)
+
+
+def _ceil32(n: int) -> int:
+    return (n + 31) // 32 * 32
+
+
+# --------------------------------------------------------------------------- packed parameters for one step
+
+class TPack:
+    """`groups` same-shape conv / linear modules packed for the forward kernel (w, bias) and, when a data gradient is
+    needed, for the transposed launch (wt).  cin_pad / cout_pad: channel counts the kernels see (multiples of 32 on the
+    K side); names: state_dict keys of the weights / biases, one per group."""
+    __slots__ = ("w", "bias", "wt", "cout", "cin", "cin_pad", "cout_pad", "kh", "kw", "stride", "pad", "groups", "wnames",
+                 "bnames", "wshape")
+
+
+def _pack_dgrad(w4: torch.Tensor, cout_pad: int, cin_pad: int) -> torch.Tensor:
+    """OIHW (cout, cin, kh, kw) -> the data-gradient operand: in/out swapped, K order (cout_pad/32, taps, 32), rows padded."""
+    cout, cin, kh, kw = w4.shape
+    if cout_pad != cout:
+        w4 = torch.cat([w4, w4.new_zeros(cout_pad - cout, cin, kh, kw)], 0)
+    if kh * kw == 1:
+        wt = w4.reshape(cout_pad, cin).t().contiguous()               # linear: one transposed copy
+    else:
+        wt = pack_conv_weight(w4.transpose(0, 1).contiguous())        # (cin, cout_pad*taps)
+    return _pad_rows(wt) if cin_pad == cin else torch.cat([wt, wt.new_zeros(_npad(cin_pad) - cin, wt.shape[1])], 0)
+
+
+def make_pack(ws: Sequence[torch.Tensor], bs: Sequence[Optional[torch.Tensor]], wnames, bnames, stride=1, pad=0, need_dx=True) -> TPack:
+    """ws: OIHW conv weights or (N, K) linear weights, one per group."""
+    p = TPack()
+    w0 = ws[0]
+    if w0.dim() == 2:
+        w4s = [w.detach().float()[:, :, None, None] for w in ws]
+    else:
+        w4s = [w.detach().float() for w in ws]
+    p.cout, p.cin, p.kh, p.kw = w4s[0].shape
+    p.wshape = tuple(w0.shape)
+    p.cin_pad, p.cout_pad = _ceil32(p.cin), _ceil32(p.cout)
+    p.stride, p.pad, p.groups = stride, pad, len(ws)
+    p.wnames, p.bnames = list(wnames), list(bnames) if bs[0] is not None else None
+    if p.cin_pad != p.cin:   # K side padded with zero input channels (the 4- and 15-channel layers)
+        w4s = [torch.cat([w, w.new_zeros(p.cout, p.cin_pad - p.cin, p.kh, p.kw)], 1) for w in w4s]
+    lin = p.kh * p.kw == 1
+    fw = [_pad_rows(w.reshape(p.cout, p.cin_pad) if lin else pack_conv_weight(w)) for w in w4s]
+    p.w = torch.stack(fw).contiguous() if p.groups > 1 else fw[0]
+    if bs[0] is not None:
+        bb = [_pad_vec(b.detach(), p.cout) for b in bs]
+        p.bias = torch.stack(bb).contiguous() if p.groups > 1 else bb[0]
+    else:
+        p.bias = None
+    if need_dx:
+        tw = [_pack_dgrad(w, p.cout_pad, p.cin_pad) for w in w4s]
+        p.wt = torch.stack(tw).contiguous() if p.groups > 1 else tw[0]
+    else:
+        p.wt = None
+    return p
+
+
+# --------------------------------------------------------------------------- gradient store + tape
+
+class _Grads:
+    """Gradients of forward tensors, keyed by the identity of the tensor object the forward produced."""
+
+    def __init__(self):
+        self.g: Dict[int, torch.Tensor] = {}
+
+    def add(self, t: torch.Tensor, g: torch.Tensor):
+        if g.shape != t.shape:
+            g = g.view(t.shape)
+        k = id(t)
+        old = self.g.get(k)
+        self.g[k] = g if old is None else T.add(old, g)
+
+    def pop(self, t: torch.Tensor) -> Optional[torch.Tensor]:
+        return self.g.pop(id(t), None)
+
+    def peek(self, t: torch.Tensor) -> Optional[torch.Tensor]:
+        return self.g.get(id(t))
+
+
+class Step:
+    """One training forward/backward: the tape of backward closures, the activation-gradient store and the parameter
+    gradients (name -> tensor in the parameter's own shape)."""
+
+    def __init__(self, net: nn.Module, device):
+        self.net = net
+        self.dev = device
+        self.tape: List = []
+        self.G = _Grads()
+        self.pgrads: Dict[str, torch.Tensor] = {}
+        self.names = {id(p): k for k, p in net.named_parameters()}
+        self.bufnames = {id(b): k for k, b in net.named_buffers()}
+        st = net.__dict__.get("_egr_train_ws")
+        if st is None or st[0].device != device:
+            st = (torch.empty(_WS_FLOATS, device=device, dtype=torch.float32), T.bn_workspace(device))
+            net.__dict__["_egr_train_ws"] = st
+        self.ws, self.bnws = st
+        self.keep: List = []   # forward tensors whose identity keys the gradient store
+        self.record = True     # False: evaluate without taping (constant sub-graphs)
+        self.loss_terms = None
+
+    # ---- bookkeeping
+    def name(self, p: torch.Tensor) -> str:
+        return self.names[id(p)]
+
+    def pacc(self, name: str, g: torch.Tensor):
+        old = self.pgrads.get(name)
+        self.pgrads[name] = g if old is None else old + g   # parameter-space accumulation (feat_proj over 3 layers)
+
+    def backward(self):
+        for fn in reversed(self.tape):
+            fn()
+        self.tape = []
+
+    # ---- conv / linear ------------------------------------------------------------------------------------------
+    def pack(self, mods: Sequence[nn.Module], need_dx=True) -> TPack:
+        m0 = mods[0]
+        stride = m0.stride[0] if isinstance(m0, nn.Conv2d) else 1
+        pad = m0.padding[0] if isinstance(m0, nn.Conv2d) else 0
+        has_b = m0.bias is not None
+        return make_pack([m.weight for m in mods], [m.bias if has_b else None for m in mods], [self.name(m.weight) for m in mods],
+                         [self.name(m.bias) for m in mods] if has_b else [None] * len(mods), stride, pad, need_dx)
+
+    def _wgrad(self, p: TPack, x4: torch.Tensor, dz4: torch.Tensor, gx_rows: Optional[int] = None):
+        """Weight / bias gradients of every group.  x4 (G*n, h, w, cin_pad), dz4 (G*n, ho, wo, cout_pad) dense."""
+        n = x4.shape[0] // p.groups
+        for g in range(p.groups):
+            xi = Img(x4[g * n:(g + 1) * n])
+            dw, db = hip.conv2d_wgrad(xi, Img(dz4[g * n:(g + 1) * n]), p.kh, p.kw, p.stride, p.pad, self.ws, want_bias=p.bnames is not None)
+            if p.cout != p.cout_pad:       # narrow outputs travel channel-padded: drop the padding rows
+                dw, db = dw[:p.cout], (db[:p.cout] if db is not None else None)
+            if p.kh * p.kw == 1:
+                gw = dw[:, :p.cin].reshape(p.wshape) if p.cin != p.cin_pad else dw.view(p.wshape)
+            else:
+                gw = unpack_conv_weight(dw, p.cin_pad, p.kh, p.kw)
+                gw = gw[:, :p.cin] if p.cin != p.cin_pad else gw
+            self.pacc(p.wnames[g], gw)
+            if p.bnames is not None:
+                self.pacc(p.bnames[g], db)
+
+    def conv(self, x: torch.Tensor, p: TPack, act: int = ACT_NONE, res: Optional[torch.Tensor] = None, need_dx: bool = True,
+             out_pad: bool = False) -> torch.Tensor:
+        """x dense NHWC (G*n, h, w, cin_pad) -> y (G*n, ho, wo, cout) [cout_pad wide, zero padded, when out_pad].
+        res (same shape as y) is added before the activation.  ReLU is the only fused activation in training mode."""
+        assert act in (ACT_NONE, ACT_RELU) and x.shape[-1] == p.cin_pad, (x.shape, p.cin_pad)
+        n, h, w, _ = x.shape
+        ho = (h + 2 * p.pad - p.kh) // p.stride + 1
+        wo = (w + 2 * p.pad - p.kw) // p.stride + 1
+        cw = p.cout_pad if out_pad else p.cout
+        y = T.zeros((n, ho, wo, cw), self.dev) if (out_pad and cw != p.cout) else torch.empty((n, ho, wo, cw), device=self.dev)
+        yo = Img(y[..., :p.cout]) if cw != p.cout else Img(y)
+        hip.conv2d(Img(x), p.w, p.cout, p.kh, p.kw, p.stride, p.pad, shift=p.bias, act=act, res=Img(res) if res is not None else None,
+                   res_mode=RES_BEFORE_ACT if res is not None else RES_NONE, out=yo, workspace=self.ws, split_k=0, groups=p.groups)
+
+        def bwd():
+            dy = self.G.pop(y)
+            if dy is None:
+                return
+            dz = T.relu_bwd(dy, y) if act == ACT_RELU else dy
+            if res is not None:
+                self.G.add(res, dz)
+            if dz.shape[-1] != p.cout_pad:
+                raise RuntimeError("egorear_amd.train: gradient of a narrow conv output must arrive channel-padded")
+            self._wgrad(p, x, dz)
+            if need_dx:
+                prev = self.G.pop(x)
+                dx = hip.conv2d(Img(dz), p.wt, p.cin_pad, p.kh, p.kw, p.stride, p.pad, transposed_out_hw=(h, w), groups=p.groups,
+                                res=Img(prev) if prev is not None else None,
+                                res_mode=RES_BEFORE_ACT if prev is not None else RES_NONE, workspace=self.ws, split_k=0).t
+                self.G.g[id(x)] = dx
+        if self.record:
+            self.tape.append(bwd)
+        self.keep.append((x, y))
+        return y
+
+    def linear(self, x: torch.Tensor, p: TPack, act: int = ACT_NONE, need_dx: bool = True, out_pad: bool = False) -> torch.Tensor:
+        """x (G*rows, cin_pad) -> (G*rows, cout[_pad])."""
+        x4 = x.view(x.shape[0], 1, 1, x.shape[1])
+        self.alias(x, x4)                       # recorded before the conv: runs after it in the reverse pass
+        y4 = self.conv(x4, p, act, need_dx=need_dx, out_pad=out_pad)
+        y = y4.view(y4.shape[0], y4.shape[3])
+        self.alias(y4, y)                       # recorded after the conv: runs before it in the reverse pass
+        return y
+
+    def alias(self, base: torch.Tensor, view: torch.Tensor):
+        """`view` is a reshape of `base`: hand the gradient of the view over to the base.  Record it between the op that
+        produces `base` and the ops that consume `view` (the reverse pass runs the tape backwards)."""
+        def bwd():
+            g = self.G.pop(view)
+            if g is not None:
+                self.G.add(base, g.view(base.shape))
+        if self.record:
+            self.tape.append(bwd)
+        self.keep.append((base, view))
+
+    # ---- BatchNorm (training mode), grouped ----------------------------------------------------------------------
+    def bn(self, x: torch.Tensor, bns: Sequence[nn.BatchNorm2d], res: Optional[torch.Tensor] = None, relu: bool = True) -> torch.Tensor:
+        G = len(bns)
+        with torch.no_grad():
+            gamma = torch.stack([b.weight.detach().float() for b in bns]).contiguous()
+            beta = torch.stack([b.bias.detach().float() for b in bns]).contiguous()
+            rm = torch.stack([b.running_mean for b in bns]).contiguous()
+            rv = torch.stack([b.running_var for b in bns]).contiguous()
+        b0 = bns[0]
+        y, ctx = T.bn_train(x, gamma, beta, rm, rv, G, self.bnws, res=res, relu=relu, momentum=b0.momentum, eps=b0.eps)
+        with torch.no_grad():
+            for g, b in enumerate(bns):          # nn.BatchNorm2d buffer side effects of a training forward
+                b.running_mean.copy_(rm[g])
+                b.running_var.copy_(rv[g])
+                b.num_batches_tracked += 1
+
+        def bwd():
+            dy = self.G.pop(y)
+            if dy is None:
+                return
+            dx, dgam, dbet, dz = T.bn_backward(ctx, dy, y if relu else None, self.bnws, want_dz=res is not None)
+            for g, b in enumerate(bns):
+                self.pacc(self.name(b.weight), dgam[g])
+                self.pacc(self.name(b.bias), dbet[g])
+            if res is not None:
+                self.G.add(res, dz)
+            self.G.add(x, dx)
+        if self.record:
+            self.tape.append(bwd)
+        self.keep.append((x, y))
+        return y
+
+    # ---- pooling / resampling / element-wise -----------------------------------------------------------------------
+    def maxpool(self, x: torch.Tensor, k: int, s: int, pd: int) -> torch.Tensor:
+        yi, slot = T.maxpool_train(Img(x), k, s, pd)
+        y = yi.t
+
+        def bwd():
+            dy = self.G.pop(y)
+            if dy is not None:
+                self.G.add(x, T.maxpool_bwd(dy, slot, (x.shape[1], x.shape[2]), k, s, pd))
+        if self.record:
+            self.tape.append(bwd)
+        self.keep.append((x, y))
+        return y
+
+    def upsample(self, x: torch.Tensor, relu: bool = False) -> torch.Tensor:
+        y = hip.upsample2x(Img(x), relu=relu).t
+
+        def bwd():
+            dy = self.G.pop(y)
+            if dy is not None:
+                self.G.add(x, T.upsample2x_bwd(dy, y if relu else None))
+        if self.record:
+            self.tape.append(bwd)
+        self.keep.append((x, y))
+        return y
+
+    def add(self, a: torch.Tensor, b: Optional[torch.Tensor], b_const: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """a + b with gradient to both, or a + b_const with gradient to `a` only (a detached operand)."""
+        other = b if b is not None else b_const
+        y = T.add(a, other)
+
+        def bwd():
+            dy = self.G.pop(y)
+            if dy is None:
+                return
+            self.G.add(a, dy)
+            if b is not None:
+                self.G.add(b, dy)
+        if self.record:
+            self.tape.append(bwd)
+        self.keep.append((a, other, y))
+        return y
+
+    def gelu(self, z: torch.Tensor) -> torch.Tensor:
+        h = T.gelu(z)
+
+        def bwd():
+            dh = self.G.pop(h)
+            if dh is not None:
+                self.G.add(z, T.gelu_bwd(dh, z))
+        if self.record:
+            self.tape.append(bwd)
+        self.keep.append((z, h))
+        return h
+
+    def layernorm(self, x: torch.Tensor, lns: Sequence[nn.LayerNorm], res: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """LayerNorm(x + res) with per-group affine parameters; gradient flows to x and res alike."""
+        G = len(lns)
+        with torch.no_grad():
+            gamma = torch.cat([l.weight.detach().float() for l in lns]).contiguous()
+            beta = torch.cat([l.bias.detach().float() for l in lns]).contiguous()
+        pre = T.add(x, res) if res is not None else x
+        y = hip.layernorm(pre, gamma, beta, groups=G, eps=lns[0].eps)
+        c = x.shape[1]
+
+        def bwd():
+            dy = self.G.pop(y)
+            if dy is None:
+                return
+            ds, dgam, dbet = T.layernorm_bwd(dy, pre, gamma, G, lns[0].eps)
+            for g, l in enumerate(lns):
+                self.pacc(self.name(l.weight), dgam[g * c:(g + 1) * c])
+                self.pacc(self.name(l.bias), dbet[g * c:(g + 1) * c])
+            self.G.add(x, ds)
+            if res is not None:
+                self.G.add(res, ds)
+        if self.record:
+            self.tape.append(bwd)
+        self.keep.append((x, res, pre, y))
+        return y
+
+    def mha(self, qkv: torch.Tensor, b: int, j: int, heads: int, d: int) -> torch.Tensor:
+        att = hip.joint_mha(qkv, b, j, heads, d, d ** -0.5)
+
+        def bwd():
+            da = self.G.pop(att)
+            if da is not None:
+                self.G.add(qkv, T.joint_mha_bwd(qkv, da, b, j, heads, d, d ** -0.5))
+        if self.record:
+            self.tape.append(bwd)
+        self.keep.append((qkv, att))
+        return att
+
+
+# --------------------------------------------------------------------------- the network in training mode
+
+def _relu_after(seq: Sequence[nn.Module], i: int) -> bool:
+    return i + 1 < len(seq) and isinstance(seq[i + 1], nn.ReLU)
+
+
+def run_stack_train(S: Step, seqs: Sequence[nn.Sequential], x: torch.Tensor, need_dx_first: bool = True, out_pad_last: bool = False) -> torch.Tensor:
+    """tree.stack()s of `len(seqs)` groups in training mode (same evaluation order as engine.run_stack, including the
+    conv-before-upsample form, whose backward is the upsample adjoint followed by the 1x1 gradients on the coarse grid)."""
+    mods = [list(s) for s in seqs]
+    m0 = mods[0]
+    i = 0
+    first = True
+    while i < len(m0):
+        m = m0[i]
+        if isinstance(m, nn.Conv2d):
+            act = ACT_RELU if _relu_after(m0, i) else ACT_NONE
+            last = (i + (2 if act else 1)) >= len(m0)
+            p = S.pack([g[i] for g in mods], need_dx=(need_dx_first or not first))
+            x = S.conv(x, p, act, need_dx=(need_dx_first or not first), out_pad=(last and out_pad_last))
+            i += 2 if act else 1
+        elif isinstance(m, nn.Upsample):
+            nxt = m0[i + 1] if i + 1 < len(m0) else None
+            if isinstance(nxt, nn.Conv2d) and nxt.kernel_size == (1, 1) and nxt.stride == (1, 1) and i + 2 < len(m0) and isinstance(m0[i + 2], nn.ReLU):
+                p = S.pack([g[i + 1] for g in mods], need_dx=(need_dx_first or not first))
+                lo = S.conv(x, p, ACT_NONE, need_dx=(need_dx_first or not first))
+                x = S.upsample(lo, relu=True)
+                i += 3
+            else:
+                x = S.upsample(x)
+                i += 1
+        elif isinstance(m, nn.MaxPool2d):
+            k = m.kernel_size if isinstance(m.kernel_size, int) else m.kernel_size[0]
+            s = m.stride if isinstance(m.stride, int) else m.stride[0]
+            pd = m.padding if isinstance(m.padding, int) else m.padding[0]
+            x = S.maxpool(x, k, s, pd)
+            i += 1
+        else:
+            raise RuntimeError(f"egorear_amd.train: unexpected module {type(m).__name__}")
+        first = False
+    return x
+
+
+def _basic_block_train(S: Step, blks, x: torch.Tensor) -> torch.Tensor:
+    b0 = blks[0]
+    identity = x
+    if b0.downsample is not None:
+        pd = S.pack([b.downsample[0] for b in blks])
+        identity = S.bn(S.conv(x, pd), [b.downsample[1] for b in blks], relu=False)
+    y = S.bn(S.conv(x, S.pack([b.conv1 for b in blks])), [b.bn1 for b in blks], relu=True)
+    return S.bn(S.conv(y, S.pack([b.conv2 for b in blks])), [b.bn2 for b in blks], res=identity, relu=True)
+
+
+def backbone_train(S: Step, encs, img: torch.Tensor, view0: int, nviews: int):
+    """ResNet-18 trunk + FPN of len(encs) encoders (resnet.py:43-74, 121-137) in training mode.  Returns
+    (feat (G*nviews*B, 64, 64, 128), s32)."""
+    G = len(encs)
+    trunks, necks = [e.backbone for e in encs], [e.neck for e in encs]
+    B, V, _, H, W = img.shape
+    # stem as patches x (64, 160) matrix: the patch rows are kept and give the stem's weight gradient as a plain 1x1 wgrad
+    cols = T.stem_im2col(img, view0, G * nviews)          # view-major rows: group g = views [view0 + g*nviews, ...)
+    cols4 = cols.view(G * nviews * B, H // 2, W // 2, 160)
+    w7 = [t.layer_s2[0].weight for t in trunks]
+    pst = make_pack([w.detach().reshape(64, 147) for w in w7], [None] * G, [S.name(w) for w in w7], [None] * G, 1, 0, need_dx=False)
+    pst.wshape = tuple(w7[0].shape)
+    x = S.conv(cols4, pst, ACT_NONE, need_dx=False)
+    x = S.bn(x, [t.layer_s2[1] for t in trunks], relu=True)
+    x = S.maxpool(x, 3, 2, 1)
+    pyramid = []
+    stages = [(t.layer_s4[1], t.layer_s8, t.layer_s16, t.layer_s32) for t in trunks]
+    for si in range(4):
+        for bi in range(len(stages[0][si])):
+            x = _basic_block_train(S, [stages[g][si][bi] for g in range(G)], x)
+        pyramid.append(x)
+    # FPN, same split evaluation as engine.run_backbone; the two halves of each fuse conv are separate packs whose weight
+    # gradients are the two column blocks of fuse_convs[i].weight's gradient.
+    n0 = necks[0]
+    c = n0.out_channels
+    lat = S.conv(pyramid[3], S.pack([k.lateral_convs[3][0] for k in necks]), ACT_RELU)
+    for i in (3, 2, 1):
+        fine = S.conv(pyramid[i - 1], S.pack([k.lateral_convs[i - 1][0] for k in necks]), ACT_RELU)
+        fws = [k.fuse_convs[i - 1][0] for k in necks]
+        pa = make_pack([f.weight.detach()[:, :c] for f in fws], [f.bias for f in fws], [S.name(f.weight) + "@a" for f in fws],
+                       [S.name(f.bias) for f in fws])
+        pb = make_pack([f.weight.detach()[:, c:] for f in fws], [None] * G, [S.name(f.weight) + "@b" for f in fws], [None] * G)
+        coarse = S.upsample(S.conv(lat, pb, ACT_NONE))
+        fused = S.conv(fine, pa, ACT_RELU, res=coarse)
+        lat = S.conv(fused, S.pack([k.fpn_convs[i - 1][0] for k in necks]), ACT_RELU)
+    return lat, pyramid[3]
+
+
+def _merge_split_grads(S: Step):
+    """fuse_convs weights were used as two column blocks ('@a' | '@b'): join their gradients."""
+    for k in [k for k in S.pgrads if k.endswith("@a")]:
+        base = k[:-2]
+        S.pgrads[base] = torch.cat([S.pgrads.pop(k), S.pgrads.pop(base + "@b")], 1)
+
+
+# ---- deformable-attention transformer layer ----------------------------------------------------------------------
+
+class _LayerPack:
+    pass
+
+
+def _pack_layer(S: Step, layers, pres, poss) -> _LayerPack:
+    """Per-step packing of `len(layers)` same-shape transformer layers (cf. engine.pack_layers): the value path is folded
+    (fp64) for sample-then-project, and everything needed to un-fold the gradients is kept."""
+    L = _LayerPack()
+    ca0 = layers[0].cross_attn
+    L.heads, L.C, L.G = ca0.n_heads, ca0.d_model, len(layers)
+    L.dh = L.C // L.heads
+    L.layers, L.pres, L.poss = layers, pres, poss
+    with torch.no_grad():
+        Wv = [l.cross_attn.value_proj.weight.detach().double() for l in layers]
+        bv = [l.cross_attn.value_proj.bias.detach().double() for l in layers]
+        Wp = [w.detach().double().reshape(w.shape[0], -1) for w, _ in pres]
+        bp = [b.detach().double() for _, b in pres]
+        L.Wfold = torch.stack([(a @ b).float() for a, b in zip(Wv, Wp)]).contiguous()          # (G, C, cf)
+        L.cfold = torch.stack([(a @ b + c).float() for a, b, c in zip(Wv, bp, bv)]).contiguous()  # (G, C)
+        L.pos_proj = torch.stack([(p.detach()[0].double() @ w.t()).float() for p, w in zip(poss, Wv)]).contiguous() if poss[0] is not None else None
+        cf = L.Wfold.shape[2]
+        L.cf = cf
+        # per-head forward operand (G, dh_pad, cf) and data-gradient operand (G, cf, dh) of the folded projection
+        L.head_w = [torch.stack([_pad_rows(L.Wfold[g, h * L.dh:(h + 1) * L.dh].contiguous()) for g in range(L.G)]).contiguous() for h in range(L.heads)]
+        L.head_shift = [torch.stack([_pad_vec(L.cfold[g, h * L.dh:(h + 1) * L.dh], L.dh) for g in range(L.G)]).contiguous() for h in range(L.heads)]
+        L.head_wt = [torch.stack([L.Wfold[g, h * L.dh:(h + 1) * L.dh].t().contiguous() for g in range(L.G)]).contiguous() for h in range(L.heads)]
+    cas = [l.cross_attn for l in layers]
+    n = S.name
+    L.ol = make_pack([torch.cat([c.sampling_offsets.weight.detach(), c.attention_weights.weight.detach()], 0) for c in cas],
+                     [torch.cat([c.sampling_offsets.bias.detach(), c.attention_weights.bias.detach()], 0) for c in cas],
+                     [n(c.sampling_offsets.weight) + "|" + n(c.attention_weights.weight) for c in cas],
+                     [n(c.sampling_offsets.bias) + "|" + n(c.attention_weights.bias) for c in cas])
+    L.out_proj = S.pack([c.output_proj for c in cas])
+    L.fuse = S.pack([l.fuse_mlp for l in layers])
+    sas = [l.spatial_attn for l in layers]
+    L.qkv = make_pack([torch.cat([s.q_proj.weight.detach(), s.k_proj.weight.detach(), s.v_proj.weight.detach()], 0) for s in sas],
+                      [torch.cat([s.q_proj.bias.detach(), s.k_proj.bias.detach(), s.v_proj.bias.detach()], 0) for s in sas],
+                      ["|".join(n(getattr(s, k).weight) for k in ("q_proj", "k_proj", "v_proj")) for s in sas],
+                      ["|".join(n(getattr(s, k).bias) for k in ("q_proj", "k_proj", "v_proj")) for s in sas])
+    L.mha_out = S.pack([s.out_proj for s in sas])
+    L.ffn0 = S.pack([l.ffn.layers[0][0] for l in layers])
+    L.ffn1 = S.pack([l.ffn.layers[1] for l in layers])
+    return L
+
+
+def _split_cat_grads(S: Step):
+    """Layers evaluated as one concatenated matrix ('a|b|c' names): split the gradient rows back onto the parameters."""
+    shapes = {k: p.shape for k, p in S.net.named_parameters()}
+    for k in [k for k in S.pgrads if "|" in k]:
+        g = S.pgrads.pop(k)
+        r = 0
+        for part in k.split("|"):
+            rows = shapes[part][0]
+            S.pacc(part, g[r:r + rows])
+            r += rows
+
+
+def layer_train(S: Step, L: _LayerPack, x: torch.Tensor, memory: torch.Tensor, anchors, valid, B: int, V: int, J: int, hgt: int, wid: int,
+                dmem: Optional[torch.Tensor]) -> torch.Tensor:
+    """One MultiViewTransformerLayer / EgoPoseFormerTransformerLayer in training mode (cf. engine.run_layer).  memory
+    (V, B, hw, cf) un-projected features; when `dmem` is given the feature gradient of the sampling is accumulated into it
+    (the lifting head), otherwise the features are a constant (the refiners' detached memory)."""
+    G, C, heads, dh, cf = L.G, L.C, L.heads, L.dh, L.cf
+    rows = B * J * V
+    ol = S.linear(x, L.ol)
+    g, e, sigma, rowmask = hip.msda_gather(memory, L.pos_proj, ol, anchors, valid, B, V, J, heads, dh, hgt, wid, groups=G)
+    a = torch.empty((G * rows, C), device=S.dev, dtype=torch.float32)
+    g2 = g.view(G * rows, heads * cf)
+    e2 = e.view(G * rows, C) if e is not None else None
+    sig = sigma.view(G * heads * rows)
+    for h in range(heads):
+        hip.conv2d(_rows(g2[:rows, h * cf:(h + 1) * cf]), L.head_w[h] if G > 1 else L.head_w[h][0], dh, 1, 1, 1, 0,
+                   shift=L.head_shift[h] if G > 1 else L.head_shift[h][0], rowscale=sig[h * rows:], grs=heads * rows,
+                   res=_rows(e2[:rows, h * dh:(h + 1) * dh]) if e2 is not None else None,
+                   res_mode=hip.RES_AFTER_ACT if e2 is not None else RES_NONE, out=_rows(a[:rows, h * dh:(h + 1) * dh]),
+                   workspace=None, split_k=1, groups=G, gx=rows * heads * cf, gr=rows * C, gy=rows * C)
+
+    def bwd_sampling():
+        da = S.G.pop(a)
+        if da is None:
+            return
+        # folded projection: dWfold_h = da_h^T g_h, dcfold_h = sum_r sigma_h da_h, dg_h = da_h Wfold_h
+        dWfold = torch.empty((G, C, cf), device=S.dev, dtype=torch.float32)
+        dcfold = torch.empty((G, C), device=S.dev, dtype=torch.float32)
+        dg = torch.empty((G, rows, heads, cf), device=S.dev, dtype=torch.float32)
+        dg2 = dg.view(G * rows, heads * cf)
+        for h in range(heads):
+            for gi in range(G):
+                hip.conv2d_wgrad(_rows(g2[gi * rows:(gi + 1) * rows, h * cf:(h + 1) * cf]), _rows(da[gi * rows:(gi + 1) * rows, h * dh:(h + 1) * dh]),
+                                 1, 1, 1, 0, S.ws, dw=dWfold[gi, h * dh:(h + 1) * dh])
+            dcfold[:, h * dh:(h + 1) * dh] = T.colsum(da[:, h * dh:], C, rows, dh, scale=sig[h * rows:], groups=G, gx=rows * C, gs=heads * rows)
+            hip.conv2d(_rows(da[:rows, h * dh:(h + 1) * dh]), L.head_wt[h] if G > 1 else L.head_wt[h][0], cf, 1, 1, 1, 0,
+                       out=_rows(dg2[:rows, h * cf:(h + 1) * cf]), workspace=None, split_k=1, groups=G, gx=rows * C, gy=rows * heads * cf)
+        dpos = T.zeros(L.pos_proj.shape, S.dev) if L.pos_proj is not None else None
+        dol_v = T.msda_gather_bwd(memory, L.pos_proj, ol, anchors, valid, B, V, J, heads, dh, hgt, wid, dg, da, L.cfold, dmem, dpos, groups=G)
+        S.G.add(ol, T.fold_rows(dol_v, V))
+        # un-fold in parameter space (fp32 matmuls on (C, C)-sized operands)
+        with torch.no_grad():
+            for gi, layer in enumerate(L.layers):
+                ca = layer.cross_attn
+                Wv = ca.value_proj.weight.detach().float()
+                pw, pb = L.pres[gi]
+                Wp = pw.detach().float().reshape(pw.shape[0], -1)
+                dWv = dWfold[gi] @ Wp.t() + torch.outer(dcfold[gi], pb.detach().float())
+                if dpos is not None:
+                    pos = L.poss[gi].detach()[0].float()                               # (V, hw, C)
+                    dWv = dWv + torch.einsum("vpo,vpi->oi", dpos[gi], pos)
+                    S.pacc(S.name(L.poss[gi]), (dpos[gi] @ Wv).unsqueeze(0))
+                S.pacc(S.name(ca.value_proj.weight), dWv)
+                S.pacc(S.name(ca.value_proj.bias), dcfold[gi].clone())
+                S.pacc(S.name(pw), (Wv.t() @ dWfold[gi]).reshape(pw.shape))
+                S.pacc(S.name(pb), Wv.t() @ dcfold[gi])
+    S.tape.append(bwd_sampling)
+    S.keep.append((ol, g, e, sigma, a))
+    # masked_fill(~valid) after output_proj: rows of invalid anchors are zero and pass no gradient.  Forward and gradient
+    # are masked in place (the gradient tensor is the fresh output of fuse_mlp's data-gradient launch, nobody else holds it).
+    om = S.linear(a, L.out_proj)
+    mask_all = rowmask.repeat(G) if G > 1 else rowmask
+    T.rowmask_(om, mask_all)
+
+    def bwd_mask():
+        d = S.G.peek(om)
+        if d is not None:
+            T.rowmask_(d, mask_all)
+    S.tape.append(bwd_mask)
+    omv = om.view(G * B * J, V * C)
+    S.alias(om, omv)
+    f = S.linear(omv, L.fuse)
+    x = S.layernorm(f, [l.norm_cross for l in L.layers], res=x)
+    qkv = S.linear(x, L.qkv)
+    att = S.mha(qkv, G * B, J, heads, dh)
+    x = S.layernorm(S.linear(att, L.mha_out), [l.norm_spatial for l in L.layers], res=x)
+    h1 = S.gelu(S.linear(x, L.ffn0))
+    x = S.layernorm(S.linear(h1, L.ffn1), [l.norm_ffn for l in L.layers], res=x)
+    return x
+
+
+# ---- conv whose output is the (B, V, c, H, W) channel-major heat-map tensor ----------------------------------------
+
+def conv_to_planes(S: Step, x: torch.Tensor, p: TPack, planes: torch.Tensor, B: int, V: int, need_dx: bool = True):
+    """Final 1x1 conv of a heat-map head: writes planes[b, v] for the view-major images n = v*B + b held by x (all groups
+    stacked).  Its gradient arrives as a tensor shaped like `planes` (S.G.add(planes, d))."""
+    n, h, w, _ = x.shape
+    assert n == V * B and p.kh == 1 and p.stride == 1
+    plane = p.cout * h * w
+    per_group = n // p.groups
+    vpg = per_group // B                       # views per group
+    hip.conv2d(Img(x), p.w, p.cout, 1, 1, 1, 0, shift=p.bias, out_nchw=planes, ymap=NMap(B, V * plane, plane if vpg > 1 else 0),
+               gy=vpg * plane, groups=p.groups, workspace=S.ws, split_k=0)
+
+    def bwd():
+        d = S.G.pop(planes)
+        if d is None:
+            return
+        dz = T.planes_to_nhwc(d, NMap(B, V * plane, plane), n, p.cout, h * w, p.cout_pad).view(n, h, w, p.cout_pad)
+        S._wgrad(p, x, dz)
+        if need_dx:
+            prev = S.G.pop(x)
+            dx = hip.conv2d(Img(dz), p.wt, p.cin_pad, 1, 1, 1, 0, transposed_out_hw=(h, w), groups=p.groups, res=Img(prev) if prev is not None else None,
+                            res_mode=RES_BEFORE_ACT if prev is not None else RES_NONE, workspace=S.ws, split_k=0).t
+            S.G.g[id(x)] = dx
+    S.tape.append(bwd)
+    S.keep.append((x, planes))
+
+
+def heatmap_head_train(S: Step, seqs, x: torch.Tensor, planes: torch.Tensor, B: int, V: int):
+    """A heat-map head stack on *detached* features (heatmap_mvf_ex.py:273, :717-721): all layers but the last through
+    run_stack_train, the last 1x1 conv straight into the channel-major output."""
+    body = [nn.Sequential(*list(s)[:-1]) for s in seqs]
+    y = run_stack_train(S, body, x, need_dx_first=False)
+    conv_to_planes(S, y, S.pack([s[-1] for s in seqs]), planes, B, V)
+
+
+# ---- the four HeatmapMVF refiners ------------------------------------------------------------------------------------
+
+def refiners_train(S: Step, rs, B: int, V: int, hm_init: torch.Tensor, feat_all: torch.Tensor, s32_all: torch.Tensor, anchors, valid,
+                   hm_ref: torch.Tensor) -> torch.Tensor:
+    """heatmap_mvf_ex.py:652-731 for the G = V refiners in training mode.  hm_init, feat_all, s32_all are constants here
+    (detached in the reference).  Returns feat_ref (V*B, 64, 64, 128), which carries gradient back from the lifting head."""
+    G = len(rs)
+    r0 = rs[0]
+    J, C = r0.num_heatmap, r0.embed_dims
+    hgt, wid = r0.feat_shape
+    hw = hgt * wid
+    dev = S.dev
+    # --- JQA query: heatmap_proj.0 reads the (B, V, J, hw) heat maps in place, group g = view g
+    hp0 = S.pack([r.heatmap_proj[0] for r in rs], need_dx=False)
+    hm_rows = Img(hm_init.view(B * V, J, 1, hw)[0::V])
+    t4 = hip.conv2d(hm_rows, hp0.w, C, 1, 1, 1, 0, shift=hp0.bias, act=ACT_RELU, groups=G, gx=J * hw, workspace=S.ws, split_k=0).t   # (G*B, J, 1, C)
+    t = t4.view(G * B * J, C)
+
+    def bwd_hp0():
+        d = S.G.pop(t)
+        if d is None:
+            return
+        dz = T.relu_bwd(d, t).view(G * B, J, 1, C)
+        for g in range(G):
+            xg = Img(hm_init.view(B, V, J, 1, hw)[:, g])                        # (B, J, 1, hw) strided over the batch
+            dw, db = hip.conv2d_wgrad(xg, Img(dz[g * B:(g + 1) * B]), 1, 1, 1, 0, S.ws, want_bias=True)
+            S.pacc(hp0.wnames[g], dw)
+            S.pacc(hp0.bnames[g], db)
+    S.tape.append(bwd_hp0)
+    S.keep.append((t4, t))
+    hm_embed = S.linear(t, S.pack([r.heatmap_proj[2] for r in rs]))
+    bfb = S.linear(hip.avgpool(Img(s32_all)), S.pack([r.fc_bfb for r in rs], need_dx=False), need_dx=False)
+    with torch.no_grad():
+        embed = torch.stack([r.joint_query_embed.weight.detach().float() for r in rs]).contiguous()
+    xs = hip.jqa_sum(hm_embed, embed, bfb, G * B, J, C, groups=G)
+
+    def bwd_jqa():
+        d = S.G.pop(xs)
+        if d is None:
+            return
+        de, dbfb = T.jqa_sum_bwd(d, G * B, J, C, G)
+        for g, r in enumerate(rs):
+            S.pacc(S.name(r.joint_query_embed.weight), de[g])
+        S.G.add(bfb, dbfb)
+        S.G.add(hm_embed, d)
+    S.tape.append(bwd_jqa)
+    S.keep.append((xs,))
+    x = S.linear(xs, S.pack([r.fc_query[0] for r in rs]), ACT_RELU)
+    # --- own-view projection: a constant in this configuration (`offset_pred + frame_feat.detach()`, :715) - evaluated without tape
+    S.record = False
+    ff = run_stack_train(S, [r.frame_feat_proj_layers for r in rs], feat_all, need_dx_first=False)
+    S.record = True
+    # --- transformer layer over the (detached) 4-view memory
+    L = _pack_layer(S, [r.transformer_layers[0] for r in rs], [(r.frame_feat_multi_view_proj.weight, r.frame_feat_multi_view_proj.bias) for r in rs],
+                    [r.frame_feat_multi_view_pos_embed for r in rs])
+    x = layer_train(S, L, x, feat_all.view(V, B, hw, feat_all.shape[-1]), anchors, valid, B, V, J, hgt, wid, None)
+    xn = S.layernorm(x, [r.post_norm[0] for r in rs])
+    side = int(math.isqrt(C))
+    # (G*B, J, 256) tokens -> (G*B, 16, 16, 32) image with the 15 joints as (zero-padded) channels, and back
+    tok = T.planes_to_nhwc(xn, NMap(G * B, J * C, 0), G * B, J, C, 32).view(G * B, side, side, 32)
+
+    def bwd_tok():
+        d = S.G.pop(tok)
+        if d is not None:
+            dx = torch.empty_like(xn)
+            T.nhwc_to_planes(d.view(G * B, C, 32), dx, NMap(G * B, J * C, 0), J)
+            S.G.add(xn, dx)
+    S.tape.append(bwd_tok)
+    S.keep.append((tok,))
+    h0 = S.conv(tok, S.pack([r.head_layers[0].head[0] for r in rs]), ACT_RELU)
+    h0 = S.upsample(h0)
+    off = S.conv(h0, S.pack([r.head_layers[0].head[3] for r in rs]), ACT_RELU)
+    summed = S.add(off, None, b_const=ff)
+    feat_ref = run_stack_train(S, [r.frame_feat_refined_proj_layers[0] for r in rs], summed)
+    heatmap_head_train(S, [r.conv_heatmap_layers[0] for r in rs], feat_ref, hm_ref, B, V)
+    return feat_ref
+
+
+# ---- lifting head ------------------------------------------------------------------------------------------------------
+
+def pose3d_train(S: Step, p3, feat_init: torch.Tensor, feat_ref: torch.Tensor, B: int, V: int, ctm):
+    """EgoPoseFormerPose3D.forward (egoposeformer_mvf_ex.py:422-452) in training mode.  Returns the four predictions as
+    channel-padded buffers [(B, 64) proposal, 3 x (B*16, 32)] whose first 48 / 3 columns are the coordinates."""
+    from .engine import _pack_pose3d  # camera records only
+    dev = S.dev
+    J = p3.num_joints
+    hgt, wid = p3.feat_shape
+    C = p3.embed_dims
+    assert p3.use_pred_heatmap_init, "training path covers the shipped pose3d configs (use_pred_heatmap_init)"
+    memory = feat_init.view(V, B, hgt * wid, feat_init.shape[-1])
+    dmem = T.zeros(memory.shape, dev)
+
+    def bwd_mem():                      # runs after every layer's sampling backward has accumulated into dmem
+        S.G.add(feat_init, dmem.view(feat_init.shape))
+    S.tape.append(bwd_mem)
+    # --- proposal: conv stack on the refined features -> per-frame vector in the reference's (v, c, h, w) order
+    cf = run_stack_train(S, [p3.conv_frame_feat], feat_ref)                     # (V*B, 8, 8, 128)
+    flat = torch.empty((B, V * 128 * 64), device=dev, dtype=torch.float32)
+    T.nhwc_to_planes(cf.view(V * B, 64, 128), flat, NMap(B, V * 8192, 8192), 128)
+
+    def bwd_flat():
+        d = S.G.pop(flat)
+        if d is not None:
+            S.G.add(cf, T.planes_to_nhwc(d, NMap(B, V * 8192, 8192), V * B, 128, 64, 128).view(cf.shape))
+    S.tape.append(bwd_flat)
+    S.keep.append((flat,))
+    h = S.gelu(S.linear(flat, S.pack([p3.mlp_pred[0][0]])))
+    h = S.gelu(S.linear(h, S.pack([p3.mlp_pred[1][0]])))
+    mlp_pad = S.linear(h, S.pack([p3.mlp_pred[2]]), out_pad=True)             # (B, 64), 48 valid
+    anchors_3d = mlp_pad[:, :3 * J].contiguous().view(B, J, 3)                 # init_anchors_3d = mlp_pred.clone().detach()
+    ctm32 = None
+    if p3.camera_model.startswith("ego4view_rw"):
+        if ctm is None:
+            raise RuntimeError("egorear_amd: camera_model ego4view_rw needs coord_trans_mat (B,4,4,4)")
+        ctm32 = ctm.to(device=dev, dtype=torch.float32).contiguous()
+    cams = p3.__dict__.get("_egr_cams")
+    if cams is None or cams.device != dev:
+        cams = torch.from_numpy(np.stack([c.packed() for c in p3.cameras()])).to(dev)
+        p3.__dict__["_egr_cams"] = cams
+    anchors_2d, valid, q4 = hip.fisheye_project(anchors_3d, ctm32, cams)       # syn: anchors_3d mutated in place (F7)
+    a3_pad = T.planes_to_nhwc(anchors_3d, NMap(B * J, 3, 0), B * J, 3, 1, 32).view(B * J, 32)
+    q4p = T.planes_to_nhwc(q4, NMap(B * J, 4, 0), B * J, 4, 1, 32).view(B * J, 32)
+    qg = p3.query_gen_mlp
+    x = S.linear(q4p, S.pack([qg[0]], need_dx=False), ACT_RELU, need_dx=False)
+    x = S.linear(x, S.pack([qg[2]]), ACT_RELU)
+    x = S.linear(x, S.pack([qg[4]]))
+    fp = p3.feat_proj
+    preds = [mlp_pad]
+    for i, layer in enumerate(p3.layers):
+        L = _pack_layer(S, [layer], [(fp.weight, fp.bias)], [None])
+        x = layer_train(S, L, x, memory, anchors_2d, valid, B, V, J, hgt, wid, dmem)
+        xn = S.layernorm(x, [p3.post_norm[i]])
+        r = S.gelu(S.linear(xn, S.pack([p3.reg_mlp[i][0]])))
+        y = S.linear(r, S.pack([p3.reg_mlp[i][2]]), out_pad=True)               # (B*J, 32), 3 valid
+        preds.append(S.add(y, None, b_const=a3_pad))                            # offset + init_anchors_3d (detached)
+    aux = {"anchors_2d": anchors_2d, "anchors_valid": valid, "anchors_3d_after": anchors_3d}
+    return preds, aux
+
+
+# ---- whole network -------------------------------------------------------------------------------------------------------
+
+def forward_train(S: Step, net, img: torch.Tensor, ctm=None):
+    """EgoPoseFormerMVFEX.forward in training mode.  Returns (pred buffers, [hm_init, hm_ref] as (B,V,15,64,64), aux)."""
+    he, p3 = net.heatmap_estimator, net.pose3d_estimator
+    if not (he.full_training and he.use_pred_heatmap_init and he.detach_heatmap_feat and not he.no_detach_feat_init and not he.use_1by1_conv):
+        raise NotImplementedError("egorear_amd.train: the training path follows the shipped pose3d configs "
+                                  "(full_training, use_pred_heatmap_init, detach_heatmap_feat, non-1x1 heat-map heads)")
+    B, V = img.shape[:2]
+    img = img.contiguous()
+    H4, W4 = img.shape[3] // 4, img.shape[4] // 4
+    J = he.num_heatmap
+    dev = img.device
+    front, back = he.heatmap_estimator_stereo_front, he.heatmap_estimator_stereo_back
+    feat_all, s32_all = backbone_train(S, [front.encoder, back.encoder], img, 0, 2)
+    hm_init = torch.empty((B, V, J, H4, W4), device=dev, dtype=torch.float32)
+    heatmap_head_train(S, [he.conv_heatmap_layers_stereo_front, he.conv_heatmap_layers_stereo_back], feat_all, hm_init, B, V)
+    a, mv, vd, idx = hip.argmax_rows(hm_init, he.heatmap_threshold)
+    anchors, valid = a.view(B, V, J, 2), vd.view(B, V, J)
+    hm_ref = torch.empty_like(hm_init)
+    feat_ref = refiners_train(S, he.refiners(), B, V, hm_init, feat_all, s32_all, anchors, valid, hm_ref)
+    preds, aux_p = pose3d_train(S, p3, feat_all, feat_ref, B, V, ctm)
+    aux = {"heatmap": {"anchors_2d": anchors, "anchors_valid": valid, "argmax_idx": idx.view(B, V, J), "maxvals": mv.view(B, V, J)},
+           "pose3d": aux_p}
+    return preds, [hm_init, hm_ref], aux
+
+
+W_MPJPE, W_HEATMAP = 0.1, 10.0      # configs/*_pose3d.yaml: w_mpjpe, w_heatmap
+
+
+def loss_and_seed(S: Step, preds, hms, gt_pose: torch.Tensor, gt_heatmap: torch.Tensor, w_mpjpe: float = W_MPJPE, w_heatmap: float = W_HEATMAP):
+    """The wrapper's training loss (pose_3d_mvf_ex.py:133-145) and the gradients it sends into the network outputs.
+    Returns the device float64 total; per-term values in S.loss_terms (device float64 each)."""
+    B, J = gt_pose.shape[:2]
+    gt_pose = gt_pose.to(device=S.dev, dtype=torch.float32).contiguous()
+    gt_heatmap = gt_heatmap.to(device=S.dev, dtype=torch.float32).contiguous()
+    terms = torch.zeros(len(preds) + len(hms), dtype=torch.float64, device=S.dev)
+    for i, p in enumerate(preds):
+        if i == 0:    # (B, 64): 16 joints x 3 inside each padded row
+            d = T.rownorm_loss(p, gt_pose, 3, w_mpjpe, terms[i:i + 1], rows=B * J, inner=J, ld_pred=p.shape[1], ld_gt=3 * J)
+        else:         # (B*J, 32)
+            d = T.rownorm_loss(p, gt_pose, 3, w_mpjpe, terms[i:i + 1], rows=B * J, inner=1, ld_pred=p.shape[1], ld_gt=3)
+        S.G.add(p, d)
+    V = gt_heatmap.shape[1]
+    for i, h in enumerate(hms):   # sum over views of mean over (b, j, row) == V * mean over all rows
+        k = len(preds) + i
+        d = T.rownorm_loss(h, gt_heatmap, h.shape[-1], w_heatmap * V, terms[k:k + 1])
+        S.G.add(h, d)
+    S.loss_terms = terms
+    return terms
+
+
+def forward_backward(net, img, ctm, gt_pose, gt_heatmap):
+    """One training forward + backward.  Returns (Step with .pgrads / .loss_terms, outputs)."""
+    if not img.is_cuda:
+        raise RuntimeError("egorear_amd.train: HIP device tensors only (no CPU path)")
+    S = Step(net, img.device)
+    S.record = True
+    with torch.no_grad():
+        preds, hms, aux = forward_train(S, net, img, ctm)
+        loss_and_seed(S, preds, hms, gt_pose, gt_heatmap)
+        S.backward()
+        _merge_split_grads(S)
+        _split_cat_grads(S)
+    from .engine import invalidate
+    for m in (net, net.heatmap_estimator, net.pose3d_estimator):
+        invalidate(m)
+    B = img.shape[0]
+    J = net.pose3d_estimator.num_joints
+    outs = [preds[0][:, :3 * J].reshape(B, J, 3)] + [p[:, :3].reshape(B, J, 3) for p in preds[1:]]
+    return S, (outs, hms, aux)

@@ -58,6 +58,9 @@ int egr_upsample2x_bwd_f32(const float* dy, const float* y, float* dx, int32_t n
  * nmap places image n of the channel-major side (the (B,V,15,64,64) heat maps). */
 int egr_planes_to_nhwc_f32(const float* planes, int32_t n_inner, int64_t stride_inner, int64_t stride_outer, float* y,
                            int32_t n, int32_t c, int32_t hw, int32_t cpad, void* stream);
+/* the inverse: (n, hw, cpad) channels-last -> the first c channels as (c, hw) planes placed by nmap. */
+int egr_nhwc_to_planes_f32(const float* x, float* planes, int32_t n_inner, int64_t stride_inner, int64_t stride_outer,
+                           int32_t n, int32_t c, int32_t hw, int32_t cpad, void* stream);
 /* stem input patches: (B,V,3,H,W) images -> (n*H/2*W/2, 160) rows of the 7x7/s2/p3 receptive field, (ky,kx,c) order,
  * columns 147..159 zero: turns the stem's weight gradient into a plain 1x1 egr_conv2d_wgrad_f32 (resnet.py:16,49). */
 int egr_stem_im2col_f32(const float* img, int32_t n_inner, int64_t stride_inner, int64_t stride_outer, int32_t n, int32_t h,
@@ -96,9 +99,10 @@ int egr_jqa_sum_bwd_f32(const float* dx, float* d_embed, float* d_bfb, int32_t b
 
 /* ---- losses of the wrapper's training_step (pose_3d_mvf_ex.py:133-145; MpjpeLoss, pose_metric.py:10-16):
  * loss += weight/rows * sum_r ||gt[r,:] - pred[r,:]||_2 (accumulated into *loss, a device double), and
- * dpred = weight/rows * (pred - gt)/||.|| (0 where the norm is 0).  d = 3 (poses) or 64 (heat-map rows). */
-int egr_rownorm_loss_f32(const float* pred, const float* gt, int64_t rows, int32_t d, float weight, double* loss,
-                         float* dpred, void* stream);
+ * dpred = weight/rows * (pred - gt)/||.|| (0 where the norm is 0; same layout as pred).  d = 3 (poses) or 64
+ * (heat-map rows).  Row r starts at (r / inner)*ld + (r % inner)*d floats, so channel-padded buffers are read in place. */
+int egr_rownorm_loss_f32(const float* pred, const float* gt, int64_t rows, int32_t d, int32_t inner, int64_t ld_pred,
+                         int64_t ld_gt, float weight, double* loss, float* dpred, void* stream);
 
 /* ---- optimiser (pose_3d_mvf_ex.py:219-234 AdamW groups, yaml gradient_clip_val 5.0).
  * sumsq: *out (+)= sum g^2 (device double).  adamw: one fused decoupled-weight-decay Adam update over a flat range;

@@ -1,0 +1,69 @@
+"""The assembled training forward/backward on the HIP kernels against the REAL reference under autograd
+(tests/golden/train_rw_s0.npz, oracle/make_golden_train.py): loss terms, outputs, BatchNorm buffers, which parameters
+receive a gradient, and every parameter's gradient (norm + 16 samples)."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def step(golden_dir):
+    from egorear_amd import configs, synth, train
+    from egorear_amd.estimator import EgoPoseFormerMVFEX
+    from oracle import train_oracle as TO
+    net = EgoPoseFormerMVFEX(**copy.deepcopy(configs.pose3d_cfg("ego4view_rw")))
+    synth.load_synth(net, 42)
+    net = net.to(DEV)
+    B = 2
+    S, outs = train.forward_backward(net, synth.synth_images(B, 4, seed=0).to(DEV), synth.synth_coord_trans_mat(B).to(DEV),
+                                     synth.synth_gt_pose(B).to(DEV), TO.synth_gt_heatmap(B).to(DEV))
+    torch.cuda.synchronize()
+    return np.load(os.path.join(golden_dir, "train_rw_s0.npz")), net, S, outs
+
+
+def test_losses_and_outputs(step):
+    g, net, S, (preds, hms, aux) = step
+    terms = S.loss_terms.cpu().numpy()
+    names = ["mpjpe_loss_0", "mpjpe_loss_1", "mpjpe_loss_2", "mpjpe_loss_3", "heatmap_loss_0", "heatmap_loss_1"]
+    for k, v in zip(names, terms):
+        assert abs(v - float(g["loss_" + k])) <= 1e-4 * abs(float(g["loss_" + k])), (k, v, float(g["loss_" + k]))
+    np.testing.assert_allclose(torch.stack(preds).cpu().numpy(), g["pred_pose"], rtol=0, atol=1e-3)   # cm
+    for i, h in enumerate(hms):
+        assert abs(h.double().sum().item() - float(g[f"hm{i}_sum"])) <= 1e-4 * h.numel()
+
+
+def test_batchnorm_buffers_updated(step):
+    from oracle.train_oracle import sample
+    g, net, S, _ = step
+    bufs = dict(net.named_buffers())
+    for k, ref in zip(g["bn_names"], g["bn_samples"]):
+        np.testing.assert_allclose(sample(bufs[str(k)].float(), 8), ref, rtol=2e-5, atol=2e-6, err_msg=str(k))
+
+
+def test_gradients_match_reference_autograd(step):
+    from oracle.train_oracle import sample
+    g, net, S, _ = step
+    names = [k for k, _ in net.named_parameters()]
+    assert list(g["param_names"]) == names
+    present = np.array([k in S.pgrads for k in names])
+    assert (present == g["grad_present"]).all(), [n for n, a, b in zip(names, present, g["grad_present"]) if a != b]
+    shapes = {k: tuple(p.shape) for k, p in net.named_parameters()}
+    bad = []
+    for i, k in enumerate(names):
+        if not present[i]:
+            continue
+        gr = S.pgrads[k]
+        assert tuple(gr.shape) == shapes[k], (k, tuple(gr.shape), shapes[k])
+        gn = float(g["grad_norm"][i])
+        got_n = gr.double().norm().item()
+        err_s = np.abs(sample(gr) - g["grad_samples"][i]).max()
+        tol_s = 2e-3 * np.abs(g["grad_samples"][i]).max() + 4e-3 * max(gn, 1e-3) / np.sqrt(max(gr.numel(), 1))   # 0.2 % of the largest sample + 0.4 % of the RMS gradient
+        if abs(got_n - gn) > 1e-3 * gn + 1e-6 or err_s > tol_s:
+            bad.append((k, got_n, gn, float(err_s), float(tol_s)))
+    assert not bad, "\n".join(f"{k}: norm {a:.6g} vs {b:.6g}, sample err {e:.3g} (tol {t:.3g})" for k, a, b, e, t in bad[:40]) + f"\n{len(bad)} of {int(present.sum())} mismatched"
