@@ -798,9 +798,12 @@ def forward_train(S: Step, net, img: torch.Tensor, ctm=None):
 W_MPJPE, W_HEATMAP = 0.1, 10.0      # configs/*_pose3d.yaml: w_mpjpe, w_heatmap
 
 
-def loss_and_seed(S: Step, preds, hms, gt_pose: torch.Tensor, gt_heatmap: torch.Tensor, w_mpjpe: float = W_MPJPE, w_heatmap: float = W_HEATMAP):
+def loss_and_seed(S: Step, preds, hms, gt_pose: torch.Tensor, gt_heatmap: torch.Tensor, w_mpjpe: float = W_MPJPE, w_heatmap: float = W_HEATMAP,
+                  grad_scale: float = 1.0):
     """The wrapper's training loss (pose_3d_mvf_ex.py:133-145) and the gradients it sends into the network outputs.
-    Returns the device float64 total; per-term values in S.loss_terms (device float64 each)."""
+    Per-term values end up in S.loss_terms (6 device float64).  grad_scale multiplies the seeded gradients only (1/world_size
+    in data-parallel runs, so that a SUM all-reduce of the parameter gradients is DDP's average)."""
+    w_mpjpe, w_heatmap = w_mpjpe * grad_scale, w_heatmap * grad_scale
     B, J = gt_pose.shape[:2]
     gt_pose = gt_pose.to(device=S.dev, dtype=torch.float32).contiguous()
     gt_heatmap = gt_heatmap.to(device=S.dev, dtype=torch.float32).contiguous()
@@ -816,8 +819,8 @@ def loss_and_seed(S: Step, preds, hms, gt_pose: torch.Tensor, gt_heatmap: torch.
         k = len(preds) + i
         d = T.rownorm_loss(h, gt_heatmap, h.shape[-1], w_heatmap * V, terms[k:k + 1])
         S.G.add(h, d)
-    S.loss_terms = terms
-    return terms
+    S.loss_terms = terms if grad_scale == 1.0 else terms / grad_scale
+    return S.loss_terms
 
 
 def forward_backward(net, img, ctm, gt_pose, gt_heatmap):
@@ -839,3 +842,119 @@ def forward_backward(net, img, ctm, gt_pose, gt_heatmap):
     J = net.pose3d_estimator.num_joints
     outs = [preds[0][:, :3 * J].reshape(B, J, 3)] + [p[:, :3].reshape(B, J, 3) for p in preds[1:]]
     return S, (outs, hms, aux)
+
+
+# --------------------------------------------------------------------------- optimiser + the full step
+
+def is_no_decay(name: str) -> bool:
+    """Parameter-group rule of the reference's configure_optimizers (pose_3d_mvf_ex.py:223)."""
+    return ("norm" in name) or ("bn" in name) or ("ln" in name) or ("bias" in name)
+
+
+class FusedAdamW:
+    """AdamW over ONE flat fp32 buffer that the module's parameters are re-homed into (their .data become views), with
+    flat gradient / moment buffers of the same layout: [no-decay parameters | decayed parameters].  A step is a gradient
+    sum-of-squares, then one fused clip + AdamW launch per contiguous run of updated parameters (tensors that received no
+    gradient are skipped entirely, like torch's `grad is None`), and in multi-process runs ONE all-reduce of the flat
+    gradient over RCCL instead of one per tensor.
+
+    Matches torch.optim.AdamW(lr, betas=(0.9, 0.999), eps=1e-8, weight_decay) + clip_grad_norm_(clip) with the reference's
+    two parameter groups (pose_3d_mvf_ex.py:219-234) and its warm-up hook (:212-217: the rescale happens after the step,
+    so update 1 runs at the full lr and update t >= 2 at lr * min(1, t / warmup_iters))."""
+
+    def __init__(self, net: nn.Module, lr: float = 1e-3, weight_decay: float = 5e-4, clip: float = 5.0, warmup_iters: int = 500,
+                 betas=(0.9, 0.999), eps: float = 1e-8, process_group=None):
+        self.net, self.lr, self.wd, self.clip, self.warmup, self.betas, self.eps = net, lr, weight_decay, clip, warmup_iters, betas, eps
+        self.pg = process_group
+        named = list(net.named_parameters())
+        dev = named[0][1].device
+        if dev.type != "cuda":
+            raise RuntimeError("egorear_amd.train: parameters must live on the HIP device")
+        order = [(k, p) for k, p in named if is_no_decay(k)] + [(k, p) for k, p in named if not is_no_decay(k)]
+        self.slots = []                      # (name, offset, numel, decay)
+        off = 0
+        for k, p in order:
+            self.slots.append((k, off, p.numel(), not is_no_decay(k)))
+            off += (p.numel() + 3) // 4 * 4
+        self.total = off
+        self.flat_p = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.m = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.v = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.gviews: Dict[str, torch.Tensor] = {}
+        with torch.no_grad():
+            for (k, o, n, _), (_, p) in zip(self.slots, order):
+                self.flat_p[o:o + n].copy_(p.detach().reshape(-1))
+                p.data = self.flat_p[o:o + n].view(p.shape)
+                self.gviews[k] = self.flat_g[o:o + n].view(p.shape)
+        self.sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.steps = 0
+        self.lr_scale_epoch = 1.0            # MultiStepLR(lr_decay_epochs, 0.1) factor, set by the caller per epoch
+
+    def lr_at(self, t: int) -> float:
+        return self.lr * self.lr_scale_epoch * (1.0 if t <= 1 else min(1.0, float(t) / float(self.warmup)))
+
+    def _runs(self, have):
+        runs, cur = [], None
+        for k, o, n, decay in self.slots:
+            n4 = (n + 3) // 4 * 4
+            if k not in have:
+                cur = None
+                continue
+            if cur is not None and cur[2] == decay and cur[0] + cur[1] == o:
+                cur[1] += n4
+            else:
+                cur = [o, n4, decay]
+                runs.append(cur)
+        return runs
+
+    def step(self, have) -> None:
+        """`have`: names whose gradient views were written this step."""
+        self.steps += 1
+        world = 1
+        if self.pg is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            import torch.distributed as dist
+            world = dist.get_world_size(self.pg)
+            if world > 1:   # SUM: the 1/world of DDP's gradient average is already in the loss seed (Trainer.step)
+                dist.all_reduce(self.flat_g, group=self.pg)          # RCCL over xGMI: one 504 MB message
+        runs = self._runs(have)
+        for i, (o, n, _) in enumerate(runs):
+            T.sumsq(self.flat_g[o:o + n], self.sumsq, accumulate=i > 0)
+        lr = self.lr_at(self.steps)
+        for o, n, decay in runs:
+            T.adamw(self.flat_p[o:o + n], self.flat_g[o:o + n], self.m[o:o + n], self.v[o:o + n], lr, self.betas[0], self.betas[1], self.eps,
+                    self.wd if decay else 0.0, self.steps, self.sumsq, self.clip)
+
+    def grad_norm(self) -> float:
+        return float(torch.sqrt(self.sumsq))
+
+
+class Trainer:
+    """The native optimisation step of config 5: forward (training mode) + losses + backward + (all-reduce) + clip + AdamW."""
+
+    def __init__(self, net: nn.Module, lr: float = 1e-3, weight_decay: float = 5e-4, clip: float = 5.0, warmup_iters: int = 500,
+                 w_mpjpe: float = W_MPJPE, w_heatmap: float = W_HEATMAP, process_group=None):
+        self.net = net
+        self.opt = FusedAdamW(net, lr, weight_decay, clip, warmup_iters, process_group=process_group)
+        self.w_mpjpe, self.w_heatmap = w_mpjpe, w_heatmap
+
+    def step(self, img, ctm, gt_pose, gt_heatmap):
+        """Returns (loss terms (6,) float64 device tensor, outputs).  Parameters are updated in place."""
+        net = self.net
+        S = Step(net, img.device)
+        world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            world = torch.distributed.get_world_size(self.opt.pg)
+        with torch.no_grad():
+            preds, hms, aux = forward_train(S, net, img, ctm)
+            loss_and_seed(S, preds, hms, gt_pose, gt_heatmap, self.w_mpjpe, self.w_heatmap, grad_scale=1.0 / world)
+            S.backward()
+            _merge_split_grads(S)
+            _split_cat_grads(S)
+            for k, g in S.pgrads.items():
+                self.opt.gviews[k].copy_(g)
+            self.opt.step(S.pgrads.keys())
+        from .engine import invalidate
+        for m in (net, net.heatmap_estimator, net.pose3d_estimator):
+            invalidate(m)
+        return S.loss_terms, (preds, hms, aux)
