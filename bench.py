@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-iters", type=int, default=12)
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step leg (config 5)")
+    ap.add_argument("--train-batch", type=int, default=32, help="frames per GPU per optimisation step (config 5: 256 / 8)")
+    ap.add_argument("--train-steps", type=int, default=5)
     return ap.parse_args()
 
 
@@ -97,6 +100,62 @@ def cpu_baseline(state_dict, batch: int, iters: int):
     return {"value": round(batch * iters / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{iters} forwards of batch {batch} (config ego4view_syn_pose3d, eval/no_grad, torch-CPU fp32, "
                       f"{cores} threads), {dt:.1f} s"}
+
+
+def train_leg(args, dev, rank: int, world: int, backend: str):
+    """SURVEY.md §8(f) rank 2 / BASELINE.json config 5, timed separately (never part of `value`): one optimisation step =
+    training-mode forward + wrapper losses + backward + gradient all-reduce (RCCL, world > 1) + clip + AdamW, all on the
+    HIP kernels (egorear_amd.train.Trainer).  Every rank runs it (the all-reduce is collective); rank 0 reports."""
+    import torch
+    from egorear_amd import configs, hip, synth, train
+    from egorear_amd.dist import timed_steps
+    from egorear_amd.estimator import EgoPoseFormerMVFEX
+    from egorear_amd.metrics import generate_target
+    B = args.train_batch
+    net = EgoPoseFormerMVFEX(**copy.deepcopy(configs.pose3d_cfg("ego4view_rw")))
+    synth.load_synth(net, 42)
+    net = net.to(dev)
+    tr = train.Trainer(net)
+    img = synth.synth_images(B, 4, seed=4321 + rank).to(dev)
+    ctm = synth.synth_coord_trans_mat(B, seed=77 + rank).to(dev)
+    gt_pose = synth.synth_gt_pose(B, seed=99 + rank).to(dev)
+    gt_hm = generate_target(synth.synth_joint_px(B, seed=55 + rank).to(dev)).contiguous()
+    state = {}
+
+    def run():
+        state["terms"], _ = tr.step(img, ctm, gt_pose, gt_hm)
+
+    elapsed = timed_steps(run, args.train_steps, 2, torch.cuda.synchronize, dev if backend == "nccl" else None)
+    if rank != 0:
+        return None
+    kernels = {}
+    if world == 1:   # per-kernel breakdown of one more step (single process only: the step contains a collective otherwise)
+        hip.PROFILE = []
+        run()
+        torch.cuda.synchronize()
+        prof, hip.PROFILE = hip.PROFILE, None
+        for name, s, e, flops, nbytes, _tag in prof:
+            k = kernels.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            k["launches"] += 1
+            k["ms"] += s.elapsed_time(e)
+            k["flops"] += flops
+    leg = {"metric": "training 4-view frames/sec (fwd + bwd + grad all-reduce + clip + AdamW)",
+           "value": round(world * B * args.train_steps / elapsed, 2), "unit": "frames/s", "ms_per_step": round(1e3 * elapsed / args.train_steps, 3),
+           "steps": args.train_steps, "batch_per_gpu": B, "global_batch": B * world, "dtype": "f32", "data": "synthetic",
+           "workload": "ego4view_rw_pose3d fine-tune step (config 5): train-mode BatchNorm, MPJPE x4 + heat-map row-norm x2 losses, "
+                       "all 126 M parameters, gradient-norm clip 5.0, AdamW(1e-3, wd 5e-4, two groups)",
+           "parallelism": f"dp{world}: frames sharded, one flat-gradient all-reduce per step" if world > 1 else "single GPU",
+           "loss_total": round(float(state["terms"].sum()), 4)}
+    if kernels:
+        leg["kernel_ms"] = {n: round(v["ms"], 3) for n, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])[:12]}
+        dom = max(kernels, key=lambda n: kernels[n]["ms"])
+        k = kernels[dom]
+        if k["flops"] > 0:
+            ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
+            leg["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "launches_per_step": k["launches"],
+                               "kernel_ms_per_step": round(k["ms"], 3)}
+    return leg
 
 
 def main():
@@ -208,6 +267,15 @@ def main():
         pre_leg = {"frames_per_s": round(nfr / pms * 1e3, 1), "ms_per_batch": round(pms, 3), "batch": nfr,
                    "algorithmic_GBps": round(pbytes / pms / 1e6, 1), "bound": "hbm", "frac_of_8TBps": round(pbytes / pms / 1e6 / PEAK_HBM_GBS, 4),
                    "what": "uint8 (B,4,872,872,3) -> PIL-exact bicubic 256x256 + /255 + ImageNet normalise -> fp32 (B,4,3,256,256)"}
+    train = None
+    if not args.no_train:
+        _log("training-step leg")
+        try:
+            del graph
+            train = train_leg(args, dev, rank, world, backend)
+        except Exception as exc:  # the inference line must survive a failure here
+            train = {"error": f"{type(exc).__name__}: {exc}"}
+        _log("training-step leg done")
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         fps = world * B * args.steps / elapsed
@@ -223,6 +291,7 @@ def main():
             "path_frac_of_f32_mfma_peak": round(fps / world * GFLOP_PER_FRAME / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
             "roofline": roof,
             "preprocess": pre_leg,
+            "train": train,
         }
         if kernels:
             line["kernel_ms"] = {n: round(v["ms"], 3) for n, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])}

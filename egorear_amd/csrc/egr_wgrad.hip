@@ -201,14 +201,37 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a) {
     *o = s;
 }
 
-// per-channel sum over rows: bias gradient (and the building block of the BatchNorm reductions)
+// per-channel sum over rows (bias gradient).  256 threads = (256 / (c/4)) row lanes x (c/4) float4 column lanes over a
+// 1024-channel column block (blockIdx.y); four independent rows in flight per lane; LDS reduce over the row lanes.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* x, int64_t rows, int c, int ld, float* partial, int rows_per_block) {
-    // block handles rows [b*rpb, ...), thread t handles channels t, t+256, ...
-    int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-    for (int ch = threadIdx.x; ch < c; ch += 256) {
-        float s = 0.f;
-        for (int64_t r = r0; r < r1; ++r) s += x[r * ld + ch];
-        partial[(int64_t)blockIdx.x * c + ch] = s;
+    __shared__ f32x4 red[256];
+    const int c0 = blockIdx.y * 1024;
+    const int cw = min(1024, c - c0);              // channels of this column block (multiple of 4)
+    int c4 = cw >> 2;
+    int lanes = 1;
+    while (lanes < c4) lanes <<= 1;                // power of two >= c4, <= 256
+    const int rpi = 256 / lanes;
+    const int cl = threadIdx.x % lanes, rl = threadIdx.x / lanes;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if (cl < c4) {
+        const float* p = x + c0 + cl * 4;
+        int64_t r = r0 + rl;
+        for (; r + 3 * rpi < r1; r += 4 * rpi) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + r * ld);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (r + rpi) * ld);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (r + 2 * rpi) * ld);
+            const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (r + 3 * rpi) * ld);
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+        }
+        for (; r < r1; r += rpi) s0 += *reinterpret_cast<const f32x4*>(p + r * ld);
+    }
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rl == 0 && cl < c4) {
+        f32x4 t = red[cl];
+        for (int k = 1; k < rpi; ++k) t += red[k * lanes + cl];
+        *reinterpret_cast<f32x4*>(partial + (int64_t)blockIdx.x * c + c0 + cl * 4) = t;
     }
 }
 
@@ -268,10 +291,13 @@ extern "C" int egr_conv2d_wgrad_f32(const egr_conv_desc* dd, const float* x, con
     if (rc || !db) return rc;
     // bias gradient: column sums of dy (plain batch only)
     if (d.ymap.n_inner < d.n || d.ymap.stride_inner != (int64_t)d.ho * d.wo * d.ldy) return EGR_EINVAL;
-    const int rpb = 1024;
-    int nblk = (int)((M64 + rpb - 1) / rpb);
+    int nblk = (int)((M64 + 255) / 256);          // >= 256 rows per block, at most 256 blocks
+    if (nblk > 256) nblk = 256;
+    const int rpb = (int)((M64 + nblk - 1) / nblk);
+    nblk = (int)((M64 + rpb - 1) / rpb);
     if ((size_t)nblk * d.cout > workspace_floats) return EGR_EWORKSPACE;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)nblk), dim3(256), 0, s, dy, M64, d.cout, d.ldy, workspace, rpb);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)nblk, (unsigned)((d.cout + 1023) / 1024)), dim3(256), 0, s, dy, M64, d.cout,
+                       d.ldy, workspace, rpb);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((d.cout + 255) / 256)), dim3(256), 0, s, workspace, nblk, d.cout, db,
                        accumulate);
     return egr_launch_status();

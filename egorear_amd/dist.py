@@ -2,7 +2,13 @@
 
 Inference shards independent frames over ranks; weights are replicated and no data-path collective exists.
 torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" in CPU tests) is used only to fence the timed region and to
-take the max over ranks."""
+take the max over ranks.
+
+Training (config 5) has exactly one exchange step per optimisation step: the gradient average of data-parallel replicas
+(the reference runs Lightning DDP: pose_3d_mvf_ex.py:253-256 divides the batch by the process count).  Here every rank
+seeds its backward pass with loss weights scaled by 1/world (`grad_seed_scale`) and the parameter gradients, which live in
+ONE flat buffer (egorear_amd.train.FusedAdamW), are summed with a single all-reduce (`allreduce_gradients_`) - one
+504 MB RCCL message over xGMI instead of DDP's per-bucket traffic."""
 from __future__ import annotations
 
 import time
@@ -44,3 +50,17 @@ def timed_steps(run: Callable[[], object], steps: int, warmup: int, sync: Callab
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed
+
+
+def grad_seed_scale(group=None) -> float:
+    """Factor for the loss gradients seeded on this rank so that a SUM all-reduce yields DDP's gradient average."""
+    if dist.is_available() and dist.is_initialized():
+        return 1.0 / dist.get_world_size(group)
+    return 1.0
+
+
+def allreduce_gradients_(flat: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place SUM all-reduce of the flat gradient buffer over the data-parallel group (no-op for one process)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return flat

@@ -248,7 +248,7 @@ def conv2d(x: Img, w: torch.Tensor, cout: int, kh: int, kw: int, stride: int, pa
     _launch("egr_conv2d_nhwc_f32", lib.egr_conv2d_nhwc_f32, C.byref(d), _p(x.t), _p(w), _p(scale), _p(shift),
             _p(res.t) if res is not None else None, _p(rowscale), _p(rowmask, torch.uint8), yptr, ws_ptr, ws_n, _stream(),
             flops=2.0 * M * cout * K * groups, nbytes=4.0 * groups * (M * cout + x.n * x.h * x.w * x.c + cout * K),
-            tag=f"G{groups} M{M} N{cout} K{K} k{kh}s{stride} cin{x.c}" if PROFILE is not None else "")
+            tag=f"{'T ' if transposed_out_hw is not None else ''}G{groups} M{M} N{cout} K{K} k{kh}s{stride} cin{x.c}" if PROFILE is not None else "")
     return ret
 
 
@@ -270,7 +270,8 @@ def conv2d_wgrad(x: Img, dy: Img, kh: int, kw: int, stride: int, pad: int, works
     if want_bias and db is None:
         db = torch.empty((cout,), device=x.t.device, dtype=torch.float32)
     _launch("egr_conv2d_wgrad_f32", lib.egr_conv2d_wgrad_f32, C.byref(d), _p(x.t), _p(dy.t), _p(_cont(dw, "dw")), _p(db),
-            _p(workspace), workspace.numel(), 1 if accumulate else 0, _stream(), flops=2.0 * dy.n * dy.h * dy.w * cout * K)
+            _p(workspace), workspace.numel(), 1 if accumulate else 0, _stream(), flops=2.0 * dy.n * dy.h * dy.w * cout * K,
+            tag=f"M{dy.n * dy.h * dy.w} N{cout} K{K} k{kh}s{stride} cin{cin}" if PROFILE is not None else "")
     return dw, db
 
 

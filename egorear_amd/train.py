@@ -911,12 +911,8 @@ class FusedAdamW:
     def step(self, have) -> None:
         """`have`: names whose gradient views were written this step."""
         self.steps += 1
-        world = 1
-        if self.pg is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
-            import torch.distributed as dist
-            world = dist.get_world_size(self.pg)
-            if world > 1:   # SUM: the 1/world of DDP's gradient average is already in the loss seed (Trainer.step)
-                dist.all_reduce(self.flat_g, group=self.pg)          # RCCL over xGMI: one 504 MB message
+        from .dist import allreduce_gradients_
+        allreduce_gradients_(self.flat_g, self.pg)   # SUM; the 1/world of DDP's average is in the loss seed (Trainer.step)
         runs = self._runs(have)
         for i, (o, n, _) in enumerate(runs):
             T.sumsq(self.flat_g[o:o + n], self.sumsq, accumulate=i > 0)
@@ -942,12 +938,10 @@ class Trainer:
         """Returns (loss terms (6,) float64 device tensor, outputs).  Parameters are updated in place."""
         net = self.net
         S = Step(net, img.device)
-        world = 1
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            world = torch.distributed.get_world_size(self.opt.pg)
+        from .dist import grad_seed_scale
         with torch.no_grad():
             preds, hms, aux = forward_train(S, net, img, ctm)
-            loss_and_seed(S, preds, hms, gt_pose, gt_heatmap, self.w_mpjpe, self.w_heatmap, grad_scale=1.0 / world)
+            loss_and_seed(S, preds, hms, gt_pose, gt_heatmap, self.w_mpjpe, self.w_heatmap, grad_scale=grad_seed_scale(self.opt.pg))
             S.backward()
             _merge_split_grads(S)
             _split_cat_grads(S)

@@ -7,8 +7,8 @@ import re
 from conftest import REPO
 
 
-def _declared():
-    text = open(os.path.join(REPO, "include", "egorear_hip.h")).read()
+def _declared(header="egorear_hip.h"):
+    text = open(os.path.join(REPO, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(egr_[a-z0-9_]+)\s*\(", text)))
 
@@ -21,6 +21,16 @@ def test_header_symbols_are_exported():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(hip.EXPORTS) == names
+
+
+def test_training_header_symbols_are_exported():
+    from egorear_amd import hip, hip_train
+    names = _declared("egorear_train.h")
+    assert len(names) >= 20
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(hip_train.TRAIN_EXPORTS) == names
 
 
 def test_struct_layout_matches_header():
