@@ -237,5 +237,10 @@ class EgoPoseFormerMVFEX(nn.Module):
     @_no_dynamo
     def forward(self, img, coord_trans_mat=None, origin_3d=None):
         from . import engine
+        if self.training:
+            # network.train() (pl_wrappers/egoposeformer/pose_3d_mvf_ex.py:115): BatchNorm batch statistics, and under
+            # autograd the outputs carry a grad_fn whose backward is the hand-written reverse pass (egorear_amd.train)
+            from . import train
+            return train.mvfex_training_forward(self, img, coord_trans_mat)
         _require_inference(self)
         return engine.mvfex_forward_api(self, img, coord_trans_mat)

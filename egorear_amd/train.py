@@ -832,9 +832,7 @@ def forward_backward(net, img, ctm, gt_pose, gt_heatmap):
     with torch.no_grad():
         preds, hms, aux = forward_train(S, net, img, ctm)
         loss_and_seed(S, preds, hms, gt_pose, gt_heatmap)
-        S.backward()
-        _merge_split_grads(S)
-        _split_cat_grads(S)
+        _finish_backward(S)
     from .engine import invalidate
     for m in (net, net.heatmap_estimator, net.pose3d_estimator):
         invalidate(m)
@@ -942,9 +940,7 @@ class Trainer:
         with torch.no_grad():
             preds, hms, aux = forward_train(S, net, img, ctm)
             loss_and_seed(S, preds, hms, gt_pose, gt_heatmap, self.w_mpjpe, self.w_heatmap, grad_scale=grad_seed_scale(self.opt.pg))
-            S.backward()
-            _merge_split_grads(S)
-            _split_cat_grads(S)
+            _finish_backward(S)
             for k, g in S.pgrads.items():
                 self.opt.gviews[k].copy_(g)
             self.opt.step(S.pgrads.keys())
@@ -952,3 +948,68 @@ class Trainer:
         for m in (net, net.heatmap_estimator, net.pose3d_estimator):
             invalidate(m)
         return S.loss_terms, (preds, hms, aux)
+
+
+# --------------------------------------------------------------------------- autograd bridge (drop-in for the wrapper)
+
+def _finish_backward(S: Step):
+    S.backward()
+    _merge_split_grads(S)
+    _split_cat_grads(S)
+
+
+class _MVFEXTrainFn(torch.autograd.Function):
+    """One autograd node for the whole network: forward = training-mode forward on the HIP kernels, backward = the taped
+    reverse pass.  Inputs after `ctm` are the module's parameters (so autograd routes .grad to them; a tensor the
+    reverse pass never reaches gets None, exactly like the reference's untouched parameters)."""
+
+    @staticmethod
+    def forward(ctx, net, img, ctm, *params):
+        S = Step(net, img.device)
+        preds, hms, aux = forward_train(S, net, img, ctm)
+        B, J = img.shape[0], net.pose3d_estimator.num_joints
+        ctx.S, ctx.preds, ctx.hms, ctx.names, ctx.BJ = S, preds, hms, [S.name(p) for p in params], (B, J)
+        ctx.set_materialize_grads(False)
+        net.__dict__["_egr_last_aux"] = aux
+        outs = [preds[0][:, :3 * J].reshape(B, J, 3)] + [p[:, :3].reshape(B, J, 3) for p in preds[1:]]
+        return tuple(outs) + tuple(hms)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        S, (B, J) = ctx.S, ctx.BJ
+        n = len(ctx.preds)
+        for i, (buf, g) in enumerate(zip(ctx.preds, grads[:n])):
+            if g is None:
+                continue
+            g = g.to(torch.float32).contiguous()
+            c = 3 * J if i == 0 else 3
+            rows = B if i == 0 else B * J
+            S.G.add(buf, T.planes_to_nhwc(g, NMap(rows, c, 0), rows, c, 1, buf.shape[1]).view(buf.shape))
+        for h, g in zip(ctx.hms, grads[n:]):
+            if g is not None:
+                S.G.add(h, g.to(torch.float32).contiguous())
+        _finish_backward(S)
+        pg = S.pgrads
+        ctx.S = None
+        return (None, None, None) + tuple(pg.get(k) for k in ctx.names)
+
+
+def mvfex_training_forward(net, img, ctm=None):
+    """EgoPoseFormerMVFEX.forward in training mode -> (list_pred_pose3d, list_pred_heatmap) like the reference."""
+    from .engine import _check_input, invalidate
+    _check_input(img, net)
+    for m in (net, net.heatmap_estimator, net.pose3d_estimator):
+        invalidate(m)                      # parameters are about to change: drop the inference packs
+    params = [p for p in net.parameters()]
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        if not all(p.requires_grad for p in params):
+            raise NotImplementedError("egorear_amd.train: partially frozen parameter sets are not supported (the reference trains all of them)")
+        outs = _MVFEXTrainFn.apply(net, img, ctm, *params)
+        return list(outs[:4]), list(outs[4:])
+    with torch.no_grad():
+        S = Step(net, img.device)
+        S.record = False
+        preds, hms, aux = forward_train(S, net, img, ctm)
+        net.__dict__["_egr_last_aux"] = aux
+        B, J = img.shape[0], net.pose3d_estimator.num_joints
+        return [preds[0][:, :3 * J].reshape(B, J, 3)] + [p[:, :3].reshape(B, J, 3) for p in preds[1:]], hms

@@ -104,3 +104,45 @@ def test_optimizer_step_matches_reference_adamw(golden_dir):
     with torch.no_grad():
         preds, hms = net(synth.synth_images(B, 4, seed=0).to(DEV), synth.synth_coord_trans_mat(B).to(DEV))
     assert all(torch.isfinite(p).all() for p in preds)
+
+
+def test_dropin_autograd_flow_like_the_lightning_wrapper(golden_dir):
+    """What pl_wrappers/.../pose_3d_mvf_ex.py:114-150 + Lightning do with the module: network.train(), forward, torch
+    losses on the outputs, loss.backward(), clip_grad_norm_, torch.optim.AdamW.step().  The module's outputs carry a
+    grad_fn whose backward is the HIP reverse pass; .grad of every parameter must match the reference's."""
+    from egorear_amd import configs, synth
+    from egorear_amd.estimator import EgoPoseFormerMVFEX
+    from oracle import train_oracle as TO
+    g = np.load(os.path.join(golden_dir, "train_rw_s0.npz"))
+    net = EgoPoseFormerMVFEX(**copy.deepcopy(configs.pose3d_cfg("ego4view_rw")))
+    synth.load_synth(net, 42)
+    net = net.to(DEV)
+    net.train()
+    B = 2
+    preds, hms = net(synth.synth_images(B, 4, seed=0).to(DEV), synth.synth_coord_trans_mat(B).to(DEV), None)
+    losses = TO.training_loss(preds, hms, synth.synth_gt_pose(B).to(DEV), TO.synth_gt_heatmap(B).to(DEV))
+    total = sum(losses.values())
+    assert abs(float(total.detach()) - float(g["loss_total"])) <= 1e-4 * float(g["loss_total"])
+    total.backward()
+    names = [k for k, _ in net.named_parameters()]
+    present = np.array([p.grad is not None for _, p in net.named_parameters()])
+    assert (present == g["grad_present"]).all()
+    for i, (k, p) in enumerate(net.named_parameters()):
+        if p.grad is not None:
+            gn = float(g["grad_norm"][i])
+            assert abs(p.grad.double().norm().item() - gn) <= 1e-3 * gn + 1e-6, k
+    no_decay = [p for k, p in net.named_parameters() if TO.is_no_decay(k)]
+    other = [p for k, p in net.named_parameters() if not TO.is_no_decay(k)]
+    opt = torch.optim.AdamW([{"params": no_decay, "weight_decay": 0.0}, {"params": other, "weight_decay": TO.WEIGHT_DECAY}], lr=TO.LR)
+    tn = float(torch.nn.utils.clip_grad_norm_(net.parameters(), TO.CLIP_NORM))
+    assert abs(tn - float(g["grad_total_norm"])) <= 2e-4 * float(g["grad_total_norm"])
+    opt.step()
+    # second iteration runs on the updated weights (packs are rebuilt), and eval still works afterwards
+    opt.zero_grad(set_to_none=True)
+    preds2, hms2 = net(synth.synth_images(B, 4, seed=0).to(DEV), synth.synth_coord_trans_mat(B).to(DEV), None)
+    total2 = sum(TO.training_loss(preds2, hms2, synth.synth_gt_pose(B).to(DEV), TO.synth_gt_heatmap(B).to(DEV)).values())
+    assert torch.isfinite(total2) and float(total2.detach()) != float(total.detach())
+    net.eval()
+    with torch.no_grad():
+        p3, _ = net(synth.synth_images(B, 4, seed=0).to(DEV), synth.synth_coord_trans_mat(B).to(DEV))
+    assert all(torch.isfinite(t).all() for t in p3)
