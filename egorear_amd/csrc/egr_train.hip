@@ -443,18 +443,30 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* dy, con
 
 __global__ __launch_bounds__(256) void layernorm_param_grad_kernel(const float* dy, const float* pre, const float* rowstats,
                                                                    float* dgamma, float* dbeta, int rows_per_group, int c) {
+    // block = 16 channel lanes x 16 row lanes; every lane walks its rows with stride 16
+    __shared__ float rg[256], rb[256];
     const int g = blockIdx.y;
-    const int ch = blockIdx.x * 256 + threadIdx.x;
-    if (ch >= c) return;
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int ch = blockIdx.x * 16 + cl;
     float sg = 0.f, sb = 0.f;
-    for (int r = 0; r < rows_per_group; ++r) {
-        const int64_t row = (int64_t)g * rows_per_group + r;
-        const float d = dy[row * c + ch];
-        sg = fmaf(d, (pre[row * c + ch] - rowstats[row * 2]) * rowstats[row * 2 + 1], sg);
-        sb += d;
+    if (ch < c)
+        for (int r = rl; r < rows_per_group; r += 16) {
+            const int64_t row = (int64_t)g * rows_per_group + r;
+            const float d = dy[row * c + ch];
+            sg = fmaf(d, (pre[row * c + ch] - rowstats[row * 2]) * rowstats[row * 2 + 1], sg);
+            sb += d;
+        }
+    rg[threadIdx.x] = sg;
+    rb[threadIdx.x] = sb;
+    __syncthreads();
+    if (rl == 0 && ch < c) {
+        for (int k = 1; k < 16; ++k) {
+            sg += rg[k * 16 + cl];
+            sb += rb[k * 16 + cl];
+        }
+        dgamma[g * c + ch] = sg;
+        dbeta[g * c + ch] = sb;
     }
-    dgamma[g * c + ch] = sg;
-    dbeta[g * c + ch] = sb;
 }
 
 // ------------------------------------------------------------------ joint-attention core backward: one wave per (b, head)
@@ -533,17 +545,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* x, int64_t ld,
                                                      float* out, int accumulate, int64_t gx, int64_t gs) {
     __shared__ float red[256];
     const int g = blockIdx.y;
-    const int ch = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int rl = threadIdx.x >> 6;
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int ch = blockIdx.x * 16 + cl;
     x += (int64_t)g * gx;
     if (scale) scale += (int64_t)g * gs;
     float s = 0.f;
     if (ch < c)
-        for (int64_t r = rl; r < rows; r += 4) s = fmaf(scale ? scale[r] : 1.f, x[r * ld + ch], s);
+        for (int64_t r = rl; r < rows; r += 16) s = fmaf(scale ? scale[r] : 1.f, x[r * ld + ch], s);
     red[threadIdx.x] = s;
     __syncthreads();
     if (rl == 0 && ch < c) {
-        s = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+        for (int k = 1; k < 16; ++k) s += red[k * 16 + cl];
         float* o = out + (int64_t)g * c + ch;
         *o = accumulate ? *o + s : s;
     }
@@ -838,7 +850,7 @@ extern "C" int egr_layernorm_bwd_f32(const float* dy, const float* pre, const fl
         case 512: hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, block, 0, s, dy, pre, gamma, ds, rowstats, rows, eps, rows_per_group); break;
         default: return EGR_EINVAL;
     }
-    hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3((c + 255) / 256, rows / rpg), dim3(256), 0, s, dy, pre, rowstats, dgamma,
+    hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3((c + 15) / 16, rows / rpg), dim3(256), 0, s, dy, pre, rowstats, dgamma,
                        dbeta, rpg, c);
     return egr_launch_status();
 }
@@ -856,7 +868,7 @@ extern "C" int egr_colsum_f32(const float* x, int64_t ld, int64_t rows, int32_t 
                               int32_t accumulate, int32_t groups, int64_t gx, int64_t gs, void* stream) {
     if (!x || !out) return EGR_ENULL;
     if (rows <= 0 || c <= 0 || ld < c || groups <= 0 || groups > 65535) return EGR_EINVAL;
-    hipLaunchKernelGGL(colsum_kernel, dim3((c + 63) / 64, groups), dim3(256), 0, (hipStream_t)stream, x, ld, rows, c, scale, out,
+    hipLaunchKernelGGL(colsum_kernel, dim3((c + 15) / 16, groups), dim3(256), 0, (hipStream_t)stream, x, ld, rows, c, scale, out,
                        accumulate, gx, gs);
     return egr_launch_status();
 }

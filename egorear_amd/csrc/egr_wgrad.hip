@@ -29,6 +29,9 @@ struct WgradArgs {
     int splits, rows_per_split;
     int tilesCO, tilesK;
     int accumulate;  // dw += sum instead of dw = sum
+    int groups;      // same-shape problems (blockIdx.z): element strides below
+    int64_t gx, gy, gw, gb;
+    float* db;
 };
 
 __device__ __attribute__((aligned(16))) float egr_wg_zero16[4] = {0.f, 0.f, 0.f, 0.f};
@@ -55,6 +58,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    const float* xg = a.x + (int64_t)blockIdx.z * a.gx;
+    const float* dyg = a.dy + (int64_t)blockIdx.z * a.gy;
+    float* wsg = a.ws + (int64_t)blockIdx.z * a.splits * a.cout * a.K;
     const int l31 = lane & 31, half = lane >> 5;
     const int tk = blockIdx.x % a.tilesK, tco = blockIdx.x / a.tilesK;
     const int co0 = tco * BCO, chunk0 = tk * 4;
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
             const int piece = wave * (DY_PIECES / 4) + j;
             const int r = piece * DY_ROWS_PER_PIECE + d_rsub;
             const int yo = s_yoff[tb][r];
-            const float* p = (yo >= 0 && d_ok) ? a.dy + yo + co0 + d_seg * 4 : egr_wg_zero16;
+            const float* p = (yo >= 0 && d_ok) ? dyg + yo + co0 + d_seg * 4 : egr_wg_zero16;
             wg_glds16(p, sDy + piece * 256);
         }
 #pragma unroll
@@ -120,7 +126,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
             const int piece = wave * (A_PIECES / 4) + j;
             const int r = piece * 2 + a_rsub;
             const bool ok = chunk_ok && s_yoff[tb][r] >= 0 && ((s_mask[tb][r] >> a_tap) & 1u);
-            const float* p = ok ? a.x + (s_xoff[tb][r] + a_toff) : egr_wg_zero16;
+            const float* p = ok ? xg + (s_xoff[tb][r] + a_toff) : egr_wg_zero16;
             wg_glds16(p, sA + piece * 256);
         }
     };
@@ -182,29 +188,40 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (co < a.cout) a.ws[((int64_t)split * a.cout + co) * a.K + kcol] = acc[i][j][r];
+                if (co < a.cout) wsg[((int64_t)split * a.cout + co) * a.K + kcol] = acc[i][j][r];
             }
         }
 }
 
+// Sum of the split slabs in a fixed order (deterministic).  A block owns 16 float4 outputs; 16 split lanes walk the slabs
+// with stride 16 (independent loads in flight instead of one dependent chain of `splits` loads), then an LDS tree in
+// lane order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a) {
-    int64_t idx = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    __shared__ f32x4 red[256];
+    const int ol = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int64_t total = (int64_t)a.cout * a.K;
-    if (idx >= total) return;
+    const int64_t idx = ((int64_t)blockIdx.x * 16 + ol) * 4;
+    const float* wsg = a.ws + (int64_t)blockIdx.z * a.splits * total;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int sp = 0; sp < a.splits; ++sp) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(a.ws + (int64_t)sp * total + idx);
-        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    if (idx < total)
+        for (int sp = sl; sp < a.splits; sp += 16) s += *reinterpret_cast<const f32x4*>(wsg + (int64_t)sp * total + idx);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (sl == 0 && idx < total) {
+        for (int k = 1; k < 16; ++k) s += red[k * 16 + ol];
+        f32x4* o = reinterpret_cast<f32x4*>(a.dw + (int64_t)blockIdx.z * a.gw + idx);
+        if (a.accumulate) s += *o;
+        *o = s;
     }
-    f32x4* o = reinterpret_cast<f32x4*>(a.dw + idx);
-    if (a.accumulate) { f32x4 p = *o; s[0] += p[0]; s[1] += p[1]; s[2] += p[2]; s[3] += p[3]; }
-    *o = s;
 }
 
 // per-channel sum over rows (bias gradient).  256 threads = (256 / (c/4)) row lanes x (c/4) float4 column lanes over a
 // 1024-channel column block (blockIdx.y); four independent rows in flight per lane; LDS reduce over the row lanes.
-__global__ __launch_bounds__(256) void colsum_kernel(const float* x, int64_t rows, int c, int ld, float* partial, int rows_per_block) {
+__global__ __launch_bounds__(256) void colsum_kernel(const float* x, int64_t rows, int c, int ld, float* partial, int rows_per_block,
+                                                     int64_t gx) {
     __shared__ f32x4 red[256];
+    x += (int64_t)blockIdx.z * gx;
+    partial += (int64_t)blockIdx.z * gridDim.x * c;
     const int c0 = blockIdx.y * 1024;
     const int cw = min(1024, c - c0);              // channels of this column block (multiple of 4)
     int c4 = cw >> 2;
@@ -235,9 +252,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* x, int64_t row
     }
 }
 
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, int nblk, int c, float* out, int accumulate) {
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, int nblk, int c, float* out, int accumulate, int64_t gb) {
     int ch = blockIdx.x * 256 + threadIdx.x;
     if (ch >= c) return;
+    partial += (int64_t)blockIdx.y * nblk * c;
+    out += (int64_t)blockIdx.y * gb;
     double s = 0.0;
     for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * c + ch];
     out[ch] = (float)s + (accumulate ? out[ch] : 0.f);
@@ -249,7 +268,8 @@ extern "C" int egr_conv2d_wgrad_f32(const egr_conv_desc* dd, const float* x, con
                                     float* workspace, size_t workspace_floats, int32_t accumulate, void* stream) {
     if (!dd || !x || !dy || !dw || !workspace) return EGR_ENULL;
     const egr_conv_desc& d = *dd;
-    if (d.groups > 1 || d.transposed || d.out_nchw) return EGR_EINVAL;
+    if (d.groups < 1 || d.groups > 65535 || d.transposed || d.out_nchw) return EGR_EINVAL;
+    const int G = d.groups;
     if (d.cin <= 0 || d.cin % 32 != 0 || d.cout <= 0 || d.cout % 4 != 0 || d.kh * d.kw > 32 || d.kh <= 0 || d.kw <= 0) return EGR_EINVAL;
     if (d.ldx % 4 != 0 || d.ldy % 4 != 0 || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || ((uintptr_t)dw & 15) || ((uintptr_t)workspace & 15))
         return EGR_EINVAL;
@@ -266,27 +286,40 @@ extern "C" int egr_conv2d_wgrad_f32(const egr_conv_desc* dd, const float* x, con
     a.chunks = a.taps * (d.cin / 32);
     a.K = a.chunks * 32;
     a.accumulate = accumulate;
+    a.groups = G; a.gx = d.gx; a.gy = d.gy; a.gw = d.gw; a.gb = d.gp; a.db = db;
     const int bco = (d.cout > 64) ? 128 : 64;
     a.tilesCO = (d.cout + bco - 1) / bco;
     a.tilesK = (a.chunks + 3) / 4;
     const int tiles = a.tilesCO * a.tilesK;
-    int splits = (1024 + tiles - 1) / tiles;
-    int max_splits = (a.M + 4 * RS - 1) / (4 * RS);  // at least 4 stages per split
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
+    // Two workgroups fit a CU (64 KiB LDS each): 512 run at once, and equal-sized blocks finish in whole rounds.  Pick the
+    // split count that minimises rounds x (rows per block + a fixed per-block cost of ~4 stages: prologue, slab write).
+    const int max_splits = (a.M + 4 * RS - 1) / (4 * RS);  // at least 4 stages per split
+    int splits = 1;
+    {
+        double best = 1e30;
+        const int64_t tg = (int64_t)tiles * G;
+        for (int sp = 1; sp <= max_splits && sp <= 512; ++sp) {
+            const int64_t rounds = (tg * sp + 511) / 512;
+            const double cost = (double)rounds * ((double)((a.M + sp - 1) / sp) + 4.0 * RS);
+            if (cost < best * 0.97) { best = cost; splits = sp; }   // prefer fewer splits unless clearly better
+            if (tg * sp > 4096) break;
+        }
+    }
     const size_t per_split = (size_t)d.cout * a.K;
-    if ((size_t)splits * per_split > workspace_floats) splits = (int)(workspace_floats / per_split);
+    if ((size_t)splits * per_split * G > workspace_floats) splits = (int)(workspace_floats / (per_split * G));
     if (splits < 1) return EGR_EWORKSPACE;
     a.rows_per_split = ((a.M + splits - 1) / splits + RS - 1) / RS * RS;
     a.splits = (a.M + a.rows_per_split - 1) / a.rows_per_split;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((unsigned)tiles, (unsigned)a.splits);
+    const bool direct = (a.splits == 1 && !accumulate && d.gw == (int64_t)d.cout * a.K);   // the slab IS the result
+    if (direct) a.ws = dw;
+    dim3 grid((unsigned)tiles, (unsigned)a.splits, (unsigned)G);
     if (bco == 128) hipLaunchKernelGGL(conv_wgrad_kernel<128>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(conv_wgrad_kernel<64>, grid, dim3(256), 0, s, a);
     int rc = egr_launch_status();
     if (rc) return rc;
     const int64_t total = (int64_t)d.cout * a.K;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, a);
+    if (!direct) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total / 4 + 15) / 16), 1, (unsigned)G), dim3(256), 0, s, a);
     rc = egr_launch_status();
     if (rc || !db) return rc;
     // bias gradient: column sums of dy (plain batch only)
@@ -295,10 +328,10 @@ extern "C" int egr_conv2d_wgrad_f32(const egr_conv_desc* dd, const float* x, con
     if (nblk > 256) nblk = 256;
     const int rpb = (int)((M64 + nblk - 1) / nblk);
     nblk = (int)((M64 + rpb - 1) / rpb);
-    if ((size_t)nblk * d.cout > workspace_floats) return EGR_EWORKSPACE;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)nblk, (unsigned)((d.cout + 1023) / 1024)), dim3(256), 0, s, dy, M64, d.cout,
-                       d.ldy, workspace, rpb);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((d.cout + 255) / 256)), dim3(256), 0, s, workspace, nblk, d.cout, db,
-                       accumulate);
+    if ((size_t)nblk * d.cout * G > workspace_floats) return EGR_EWORKSPACE;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)nblk, (unsigned)((d.cout + 1023) / 1024), (unsigned)G), dim3(256), 0, s, dy, M64,
+                       d.cout, d.ldy, workspace, rpb, d.gy);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((d.cout + 255) / 256), (unsigned)G), dim3(256), 0, s, workspace, nblk,
+                       d.cout, db, accumulate, d.gp);
     return egr_launch_status();
 }

@@ -253,25 +253,33 @@ def conv2d(x: Img, w: torch.Tensor, cout: int, kh: int, kw: int, stride: int, pa
 
 
 def conv2d_wgrad(x: Img, dy: Img, kh: int, kw: int, stride: int, pad: int, workspace: torch.Tensor, *, want_bias: bool = False,
-                 dw: Optional[torch.Tensor] = None, db: Optional[torch.Tensor] = None, accumulate: bool = False):
-    """Weight (+ bias) gradient of the forward conv x -> y (training-row brick).  x, dy NHWC Imgs.  Returns (dw, db):
-    dw (cout, kh*kw*cin) in the packed K order of conv2d (engine.unpack_conv_weight turns it back into OIHW)."""
+                 dw: Optional[torch.Tensor] = None, db: Optional[torch.Tensor] = None, accumulate: bool = False, groups: int = 1):
+    """Weight (+ bias) gradient of the forward conv x -> y.  x, dy NHWC Imgs (all groups' images back to back when
+    groups > 1).  Returns (dw, db): dw ([groups,] cout, kh*kw*cin) in the packed K order of conv2d
+    (engine.unpack_conv_weight turns it back into OIHW), db ([groups,] cout)."""
     cin, cout = x.c, dy.c
-    if (x.n, (x.h + 2 * pad - kh) // stride + 1, (x.w + 2 * pad - kw) // stride + 1) != (dy.n, dy.h, dy.w):
+    if x.n % groups or dy.n != x.n:
+        raise RuntimeError("egorear_amd.conv2d_wgrad: image counts do not match / not divisible by groups")
+    ng = x.n // groups
+    if ((x.h + 2 * pad - kh) // stride + 1, (x.w + 2 * pad - kw) // stride + 1) != (dy.h, dy.w):
         raise RuntimeError("egorear_amd.conv2d_wgrad: dy does not match the forward output geometry")
     d = ConvDesc()
-    d.n, d.h, d.w, d.cin, d.cout = x.n, x.h, x.w, cin, cout
+    d.n, d.h, d.w, d.cin, d.cout = ng, x.h, x.w, cin, cout
     d.kh, d.kw, d.stride, d.pad, d.ho, d.wo = kh, kw, stride, pad, dy.h, dy.w
-    d.ldx, d.ldy, d.xmap, d.ymap, d.rmap = x.ld, dy.ld, x.nmap(), dy.nmap(), NMap(1, 0, 0)
-    d.groups = 1
+    d.ldx, d.ldy, d.rmap = x.ld, dy.ld, NMap(1, 0, 0)
+    d.xmap, d.ymap = NMap(ng, x.nstride, 0), NMap(ng, dy.nstride, 0)
     K = kh * kw * cin
+    d.groups, d.gx, d.gy, d.gw, d.gp = groups, ng * x.nstride, ng * dy.nstride, cout * K, cout
+    shape_w, shape_b = ((groups, cout, K), (groups, cout)) if groups > 1 else ((cout, K), (cout,))
     if dw is None:
-        dw = torch.empty((cout, K), device=x.t.device, dtype=torch.float32)
+        dw = torch.empty(shape_w, device=x.t.device, dtype=torch.float32)
+    elif dw.numel() != groups * cout * K:
+        raise RuntimeError("egorear_amd.conv2d_wgrad: dw has the wrong size")
     if want_bias and db is None:
-        db = torch.empty((cout,), device=x.t.device, dtype=torch.float32)
+        db = torch.empty(shape_b, device=x.t.device, dtype=torch.float32)
     _launch("egr_conv2d_wgrad_f32", lib.egr_conv2d_wgrad_f32, C.byref(d), _p(x.t), _p(dy.t), _p(_cont(dw, "dw")), _p(db),
             _p(workspace), workspace.numel(), 1 if accumulate else 0, _stream(), flops=2.0 * dy.n * dy.h * dy.w * cout * K,
-            tag=f"M{dy.n * dy.h * dy.w} N{cout} K{K} k{kh}s{stride} cin{cin}" if PROFILE is not None else "")
+            tag=f"G{groups} M{ng * dy.h * dy.w} N{cout} K{K} k{kh}s{stride} cin{cin}" if PROFILE is not None else "")
     return dw, db
 
 

@@ -160,10 +160,11 @@ class Step:
 
     def _wgrad(self, p: TPack, x4: torch.Tensor, dz4: torch.Tensor, gx_rows: Optional[int] = None):
         """Weight / bias gradients of every group.  x4 (G*n, h, w, cin_pad), dz4 (G*n, ho, wo, cout_pad) dense."""
-        n = x4.shape[0] // p.groups
+        dws, dbs = hip.conv2d_wgrad(Img(x4), Img(dz4), p.kh, p.kw, p.stride, p.pad, self.ws, want_bias=p.bnames is not None, groups=p.groups)
+        if p.groups == 1:
+            dws, dbs = dws[None], (dbs[None] if dbs is not None else None)
         for g in range(p.groups):
-            xi = Img(x4[g * n:(g + 1) * n])
-            dw, db = hip.conv2d_wgrad(xi, Img(dz4[g * n:(g + 1) * n]), p.kh, p.kw, p.stride, p.pad, self.ws, want_bias=p.bnames is not None)
+            dw, db = dws[g], (dbs[g] if dbs is not None else None)
             if p.cout != p.cout_pad:       # narrow outputs travel channel-padded: drop the padding rows
                 dw, db = dw[:p.cout], (db[:p.cout] if db is not None else None)
             if p.kh * p.kw == 1:
@@ -538,17 +539,16 @@ def layer_train(S: Step, L: _LayerPack, x: torch.Tensor, memory: torch.Tensor, a
         if da is None:
             return
         # folded projection: dWfold_h = da_h^T g_h, dcfold_h = sum_r sigma_h da_h, dg_h = da_h Wfold_h
-        dWfold = torch.empty((G, C, cf), device=S.dev, dtype=torch.float32)
+        dWh = torch.empty((heads, G, dh, cf), device=S.dev, dtype=torch.float32)
         dcfold = torch.empty((G, C), device=S.dev, dtype=torch.float32)
         dg = torch.empty((G, rows, heads, cf), device=S.dev, dtype=torch.float32)
         dg2 = dg.view(G * rows, heads * cf)
         for h in range(heads):
-            for gi in range(G):
-                hip.conv2d_wgrad(_rows(g2[gi * rows:(gi + 1) * rows, h * cf:(h + 1) * cf]), _rows(da[gi * rows:(gi + 1) * rows, h * dh:(h + 1) * dh]),
-                                 1, 1, 1, 0, S.ws, dw=dWfold[gi, h * dh:(h + 1) * dh])
+            hip.conv2d_wgrad(_rows(g2[:, h * cf:(h + 1) * cf]), _rows(da[:, h * dh:(h + 1) * dh]), 1, 1, 1, 0, S.ws, dw=dWh[h], groups=G)
             dcfold[:, h * dh:(h + 1) * dh] = T.colsum(da[:, h * dh:], C, rows, dh, scale=sig[h * rows:], groups=G, gx=rows * C, gs=heads * rows)
             hip.conv2d(_rows(da[:rows, h * dh:(h + 1) * dh]), L.head_wt[h] if G > 1 else L.head_wt[h][0], cf, 1, 1, 1, 0,
                        out=_rows(dg2[:rows, h * cf:(h + 1) * cf]), workspace=None, split_k=1, groups=G, gx=rows * C, gy=rows * heads * cf)
+        dWfold = dWh.permute(1, 0, 2, 3).reshape(G, C, cf)
         dpos = T.zeros(L.pos_proj.shape, S.dev) if L.pos_proj is not None else None
         dol_v = T.msda_gather_bwd(memory, L.pos_proj, ol, anchors, valid, B, V, J, heads, dh, hgt, wid, dg, da, L.cfold, dmem, dpos, groups=G)
         S.G.add(ol, T.fold_rows(dol_v, V))

@@ -88,8 +88,8 @@ int egr_conv2d_nhwc_f32(const egr_conv_desc* d, const float* x, const float* w,
                         const uint8_t* rowmask /* per m, NULL = keep; 0 -> row written as 0 */,
                         float* y, float* workspace, size_t workspace_floats, void* stream);
 
-/* Weight (and bias) gradient of the conv / linear layer described by `d` (forward geometry; groups = 1), a brick of the
- * training row: dw[co][(ci/32, kh, kw, ci%32)] (+)= sum over output pixels of dy[m][co] * im2col(x)[m][k],
+/* Weight (and bias) gradient of the conv / linear layer described by `d` (forward geometry; d->groups same-shape problems
+ * in one launch: x + g*gx, dy + g*gy, dw + g*gw, db + g*gp), the weight-side half of the training row: dw[co][(ci/32, kh, kw, ci%32)] (+)= sum over output pixels of dy[m][co] * im2col(x)[m][k],
  * db[co] (+)= sum_m dy[m][co] (db may be NULL).  dw is in the packed weight layout of egr_conv2d_nhwc_f32.  The pixels are
  * split over workgroups; partial tiles go through `workspace` and are summed in fixed order (deterministic).
  * Replaces autograd of nn.Conv2d / nn.Linear for config 5 (pl_wrappers/egoposeformer/pose_3d_mvf_ex.py:117-153). */

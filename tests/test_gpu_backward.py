@@ -98,3 +98,23 @@ def test_conv_wgrad_matches_autograd(case):
     hip.conv2d_wgrad(xi, dyi, k, k, s, pad, ws, want_bias=True, dw=dw2, db=db2, accumulate=True)
     close(dw2, 2 * dw.double().cpu(), rel=1e-6)
     close(db2, 2 * db.double().cpu(), rel=1e-6)
+
+
+def test_conv_wgrad_grouped_launch():
+    """Three same-shape layers with own inputs / gradients in one launch (the refiners' and encoders' grouped layers)."""
+    from egorear_amd import hip
+    from egorear_amd.engine import unpack_conv_weight
+    G, n, h, cin, cout, k = 3, 2, 16, 64, 96, 3
+    x = rnd(G * n, cin, h, h, seed=21)
+    dy = rnd(G * n, cout, h, h, seed=22)
+    ws = torch.empty(1 << 24, device=DEV)
+    dw, db = hip.conv2d_wgrad(hip.Img(x.permute(0, 2, 3, 1).contiguous().to(DEV)), hip.Img(dy.permute(0, 2, 3, 1).contiguous().to(DEV)),
+                              k, k, 1, 1, ws, want_bias=True, groups=G)
+    assert dw.shape == (G, cout, k * k * cin) and db.shape == (G, cout)
+    for g in range(G):
+        wt = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+        b = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(x[g * n:(g + 1) * n].double(), wt, b, 1, 1)
+        dw_ref, db_ref = torch.autograd.grad(y, (wt, b), dy[g * n:(g + 1) * n].double())
+        close(unpack_conv_weight(dw[g], cin, k, k), dw_ref, rel=3e-5)
+        close(db[g], db_ref, rel=3e-5)
