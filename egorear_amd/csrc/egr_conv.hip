@@ -73,6 +73,7 @@ struct ConvArgs {
     int x_plain, y_plain, r_plain;   // image map is a plain batch (n_inner >= n): offset = n * stride_inner
     unsigned long long* dbg;  // diagnostic only: per-block phase stamps (s_memtime), NULL in normal operation
     int vec_ok;   // NHWC output / residual addresses are 16-byte aligned for every (row, channel quad)
+    int cls_mode; // stride-2 data gradient split into the four output-parity classes (blockIdx.y): M, dHoWo, dWo, *_shift describe ONE class
 };
 
 constexpr int BK = 32;
@@ -136,10 +137,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
     const int tm = (a.tilesN == 1) ? bid : fdiv(bid, a.dTilesN);
     const int tn = bid - tm * a.tilesN;
-    const int split = blockIdx.y;
+    // Stride-2 data gradient: output pixel (ho, wo) only sees the taps with kh = (ho+pad) mod 2, kw = (wo+pad) mod 2, so the
+    // launch is split into the four output-parity classes (blockIdx.y).  A class enumerates its (ho/2, wo/2) sub-grid
+    // and walks only its own taps: no structurally-zero MFMA work (1 + 2 + 2 + 4 of the 9 taps of a 3x3 kernel).
+    const int cls = a.cls_mode ? (int)blockIdx.y : 0;
+    const int ph = cls >> 1, pw = cls & 1;
+    const int kstep = a.cls_mode ? 2 : 1;
+    const int kh0 = a.cls_mode ? ((ph + d.pad) & 1) : 0, kw0 = a.cls_mode ? ((pw + d.pad) & 1) : 0;
+    const int nkh = a.cls_mode ? max(0, (d.kh - kh0 + 1) >> 1) : d.kh, nkw = a.cls_mode ? max(0, (d.kw - kw0 + 1) >> 1) : d.kw;
+    const int taps_blk = nkh * nkw;
+    const int split = a.cls_mode ? 0 : (int)blockIdx.y;
     const int kt0 = split * a.ktiles_per_split;
-    const int kt1 = min(a.ktiles, kt0 + a.ktiles_per_split);
-    const int HoWo = d.ho * d.wo;
+    const int kt1 = a.cls_mode ? taps_blk * a.cblocks : min(a.ktiles, kt0 + a.ktiles_per_split);
+    const int HoWo = a.cls_mode ? (d.ho >> 1) * (d.wo >> 1) : d.ho * d.wo;   // pixels per image in the enumeration of m
+    const int Wenum = a.cls_mode ? (d.wo >> 1) : d.wo;
 
     // ---- per-lane staging roles: piece p covers tile rows p*32 + wave*8 + (lane>>3); physical segment lane&7.
     // Row geometry is decoded ONCE per row (thread r < BM handles row r) into a small LDS table: element offset of
@@ -161,8 +172,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             int n, pix, ho, wo;
             if (a.howo_shift >= 0) { n = m >> a.howo_shift; pix = m & (HoWo - 1); }
             else { n = fdiv(m, a.dHoWo); pix = m - n * HoWo; }
-            if (a.wo_shift >= 0) { ho = pix >> a.wo_shift; wo = pix & (d.wo - 1); }
-            else { ho = fdiv(pix, a.dWo); wo = pix - ho * d.wo; }
+            if (a.wo_shift >= 0) { ho = pix >> a.wo_shift; wo = pix & (Wenum - 1); }
+            else { ho = fdiv(pix, a.dWo); wo = pix - ho * Wenum; }
+            if (a.cls_mode) { ho = 2 * ho + ph; wo = 2 * wo + pw; pix = ho * d.wo + wo; }
             const int xbase = a.x_plain ? n * (int)d.xmap.stride_inner : (int)fmap(d.xmap, a.dXin, n);
             if (!d.transposed) {
                 const int hi0 = ho * d.stride - d.pad, wi0 = wo * d.stride - d.pad;
@@ -216,8 +228,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 
     // wave-uniform position of a chunk in K: (channel chunk cb, tap (kh, kw)); advanced incrementally
     struct KPos { int cb, kh, kw; };
-    auto kpos_of = [&](int kt) { KPos p; p.cb = kt / a.taps; int t = kt - p.cb * a.taps; p.kh = t / d.kw; p.kw = t - p.kh * d.kw; return p; };
-    auto kpos_next = [&](KPos p) { if (++p.kw == d.kw) { p.kw = 0; if (++p.kh == d.kh) { p.kh = 0; ++p.cb; } } return p; };
+    auto kpos_of = [&](int kt) {
+        KPos p;
+        const int tb = taps_blk > 0 ? taps_blk : 1, nw = nkw > 0 ? nkw : 1;
+        p.cb = kt / tb;
+        const int t = kt - p.cb * tb, th = t / nw;
+        p.kh = kh0 + kstep * th;
+        p.kw = kw0 + kstep * (t - th * nw);
+        return p;
+    };
+    auto kpos_next = [&](KPos p) {
+        p.kw += kstep;
+        if (p.kw >= d.kw) { p.kw = kw0; p.kh += kstep; if (p.kh >= d.kh) { p.kh = kh0; ++p.cb; } }
+        return p;
+    };
 
     // one 1-KiB DMA piece (8 rows x 128 B) of a stage: pieces [0, IA) are A rows, [IA, IA+IB) weight rows.
     // The stage buffer is a compile-time constant so LDS addresses fold into instruction immediates.
@@ -238,7 +262,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             glds16(reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo), sA + (piece * 32 + wave * 8) * BK);
         } else {
             const int i = piece - IA;
-            const float* p = wrow[i] ? wrow[i] + kt * BK : egr_zero16;
+            const float* p = wrow[i] ? wrow[i] + (kp.cb * a.taps + kp.kh * d.kw + kp.kw) * BK : egr_zero16;   // chunk index in K
             glds16(p, sA + BM * BK + (i * 32 + wave * 8) * BK);
         }
     };
@@ -534,7 +558,7 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
     a.tilesM = (a.M + BM - 1) / BM;
     a.tilesN = (a.Npad + BN - 1) / BN;
     a.dTilesN = make_fastdiv(a.tilesN);
-    dim3 grid((unsigned)(a.tilesM * a.tilesN), (unsigned)a.d.split_k, (unsigned)a.d.groups);
+    dim3 grid((unsigned)(a.tilesM * a.tilesN), (unsigned)(a.cls_mode ? 4 : a.d.split_k), (unsigned)a.d.groups);
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
     return egr_launch_status();
 }
@@ -594,13 +618,18 @@ extern "C" int egr_conv2d_nhwc_f32(const egr_conv_desc* dd, const float* x, cons
     a.Npad = (d.cout + 31) / 32 * 32;
     a.K = d.kh * d.kw * d.cin;
     auto log2_exact = [](int v) { int l = 0; while ((1 << l) < v) ++l; return ((1 << l) == v) ? l : -1; };
-    a.howo_shift = log2_exact(d.ho * d.wo);
-    a.wo_shift = log2_exact(d.wo);
+    // stride-2 data gradient with even output size: four parity classes, each enumerating a (ho/2, wo/2) grid
+    a.cls_mode = (d.transposed && d.stride == 2 && (d.ho % 2 == 0) && (d.wo % 2 == 0) && !d.out_nchw && !rowscale && !rowmask &&
+                  d.split_k <= 1) ? 1 : 0;
+    const int eho = a.cls_mode ? d.ho / 2 : d.ho, ewo = a.cls_mode ? d.wo / 2 : d.wo;
+    if (a.cls_mode) a.M = d.n * eho * ewo;
+    a.howo_shift = log2_exact(eho * ewo);
+    a.wo_shift = log2_exact(ewo);
     a.x_plain = d.xmap.n_inner >= d.n;
     a.y_plain = d.ymap.n_inner >= d.n;
     a.r_plain = d.res_mode ? (d.rmap.n_inner >= d.n) : 1;
-    a.dHoWo = make_fastdiv(d.ho * d.wo);
-    a.dWo = make_fastdiv(d.wo);
+    a.dHoWo = make_fastdiv(eho * ewo);
+    a.dWo = make_fastdiv(ewo);
     a.dXin = make_fastdiv(d.xmap.n_inner);
     a.dYin = make_fastdiv(d.ymap.n_inner);
     a.dRin = make_fastdiv(d.res_mode ? d.rmap.n_inner : 1);
@@ -627,6 +656,7 @@ extern "C" int egr_conv2d_nhwc_f32(const egr_conv_desc* dd, const float* x, cons
 
     // ---- split-K: auto (0) fills the chip for skinny GEMMs with long K
     int blocks = ((a.M + bm - 1) / bm) * ((a.Npad + bn - 1) / bn) * d.groups;
+    if (a.cls_mode) d.split_k = 1;
     if (d.split_k <= 0) {
         d.split_k = 1;
         if (blocks < 128 && a.ktiles >= 32 && workspace) {

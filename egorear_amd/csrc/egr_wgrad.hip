@@ -45,7 +45,7 @@ constexpr int RS = 32;    // rows (pixels) per stage
 constexpr int BKO = 128;  // K columns per tile = 4 chunks
 
 template <int BCO>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     constexpr int TM = BCO / 2, FM = TM / 32, FN = 2;        // waves 2 (co) x 2 (k); wave tile TM x 64
     constexpr int STAGE = RS * (BCO + BKO);                  // floats
     constexpr int DY_ROWS_PER_PIECE = 256 / BCO;             // 1 KiB = 256 floats
