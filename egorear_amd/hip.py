@@ -247,7 +247,7 @@ def conv2d(x: Img, w: torch.Tensor, cout: int, kh: int, kw: int, stride: int, pa
     ws_ptr, ws_n = (None, 0) if workspace is None else (_p(workspace), workspace.numel())
     _launch("egr_conv2d_nhwc_f32", lib.egr_conv2d_nhwc_f32, C.byref(d), _p(x.t), _p(w), _p(scale), _p(shift),
             _p(res.t) if res is not None else None, _p(rowscale), _p(rowmask, torch.uint8), yptr, ws_ptr, ws_n, _stream(),
-            flops=2.0 * M * cout * K * groups, nbytes=4.0 * groups * (M * cout + x.n * x.h * x.w * x.c + cout * K),
+            flops=2.0 * M * cout * K * groups / (stride * stride if transposed_out_hw is not None else 1), nbytes=4.0 * groups * (M * cout + x.n * x.h * x.w * x.c + cout * K),
             tag=f"{'T ' if transposed_out_hw is not None else ''}G{groups} M{M} N{cout} K{K} k{kh}s{stride} cin{x.c}" if PROFILE is not None else "")
     return ret
 
