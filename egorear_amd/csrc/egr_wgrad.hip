@@ -29,6 +29,7 @@ struct WgradArgs {
     int splits, rows_per_split;
     int tilesCO, tilesK;
     int accumulate;  // dw += sum instead of dw = sum
+    int howo_shift, wo_shift;  // >= 0: ho*wo / wo are powers of two (every layer of the path) -> shifts instead of divisions
     int groups;      // same-shape problems (blockIdx.z): element strides below
     int64_t gx, gy, gw, gb;
     float* db;
@@ -92,16 +93,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
             int xo = 0, yo = -1;
             unsigned mk = 0u;
             if (stage < nstages && m < m_end) {
-                int n = m / HoWo, pix = m - n * HoWo;
-                int ho = pix / a.wo, wo = pix - ho * a.wo;
-                int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
+                int n, pix, ho, wo;
+                if (a.howo_shift >= 0) { n = m >> a.howo_shift; pix = m & (HoWo - 1); }
+                else { n = m / HoWo; pix = m - n * HoWo; }
+                if (a.wo_shift >= 0) { ho = pix >> a.wo_shift; wo = pix & (a.wo - 1); }
+                else { ho = pix / a.wo; wo = pix - ho * a.wo; }
+                const int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
                 xo = (int)egr_map(a.xmap, n) + (hi0 * a.w + wi0) * a.ldx;
                 yo = (int)egr_map(a.ymap, n) + pix * a.ldy;
-                for (int kh = 0; kh < a.kh; ++kh)
-                    for (int kw = 0; kw < a.kw; ++kw) {
-                        int hi = hi0 + kh, wi = wi0 + kw;
-                        if (hi >= 0 && hi < a.h && wi >= 0 && wi < a.w) mk |= 1u << (kh * a.kw + kw);
-                    }
+                // taps inside the image: kh in [kh_lo, kh_hi), kw in [kw_lo, kw_hi)
+                const int kh_lo = max(0, -hi0), kh_hi = min(a.kh, a.h - hi0);
+                const int kw_lo = max(0, -wi0), kw_hi = min(a.kw, a.w - wi0);
+                const unsigned rowbits = (kw_hi > kw_lo) ? (((1u << (kw_hi - kw_lo)) - 1u) << kw_lo) : 0u;
+                for (int kh = kh_lo; kh < kh_hi; ++kh) mk |= rowbits << (kh * a.kw);
             }
             s_xoff[tb][r] = xo;
             s_yoff[tb][r] = yo;
@@ -139,6 +143,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Fragment i of a wave covers the channels co = wm*TM + l31*FM + i (interleaved), fragment j the K columns
+    // wn*64 + l31*2 + j: a lane's FM (2) operands are adjacent floats, fetched with ONE ds_read_b64 per operand side.
     auto compute = [&](auto buf_tag) {
         constexpr int BUF = decltype(buf_tag)::value;
         const float* sDy = lds + BUF * STAGE;
@@ -147,10 +153,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
         for (int ks = 0; ks < RS / 2; ++ks) {
             const int row = 2 * ks + half;
             float av[FM], bv[FN];
-#pragma unroll
-            for (int i = 0; i < FM; ++i) av[i] = sDy[row * BCO + wm * TM + i * 32 + l31];
-#pragma unroll
-            for (int j = 0; j < FN; ++j) bv[j] = sA[row * BKO + wn * 64 + j * 32 + l31];
+            if constexpr (FM == 2) {
+                const f32x2 t = *reinterpret_cast<const f32x2*>(&sDy[row * BCO + wm * TM + l31 * 2]);
+                av[0] = t[0]; av[1] = t[1];
+            } else {
+                av[0] = sDy[row * BCO + wm * TM + l31];
+            }
+            {
+                const f32x2 t = *reinterpret_cast<const f32x2*>(&sA[row * BKO + wn * 64 + l31 * 2]);
+                bv[0] = t[0]; bv[1] = t[1];
+            }
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -183,11 +195,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-            const int kcol = chunk0 * 32 + wn * 64 + j * 32 + l31;
+            const int kcol = chunk0 * 32 + wn * 64 + l31 * 2 + j;
             if (kcol >= a.K) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = co0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int co = co0 + wm * TM + ((r & 3) + 8 * (r >> 2) + 4 * half) * FM + i;
                 if (co < a.cout) wsg[((int64_t)split * a.cout + co) * a.K + kcol] = acc[i][j][r];
             }
         }
@@ -286,6 +298,8 @@ extern "C" int egr_conv2d_wgrad_f32(const egr_conv_desc* dd, const float* x, con
     a.chunks = a.taps * (d.cin / 32);
     a.K = a.chunks * 32;
     a.accumulate = accumulate;
+    { auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return ((1 << l) == v) ? l : -1; };
+      a.howo_shift = lg(d.ho * d.wo); a.wo_shift = lg(d.wo); }
     a.groups = G; a.gx = d.gx; a.gy = d.gy; a.gw = d.gw; a.gb = d.gp; a.db = db;
     const int bco = (d.cout > 64) ? 128 : 64;
     a.tilesCO = (d.cout + bco - 1) / bco;
