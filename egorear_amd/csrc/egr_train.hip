@@ -80,19 +80,37 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* x, const f
     }
 }
 
+// Sum of the per-slab partials: 16 channel lanes x 16 slab lanes per block (independent loads in flight), LDS reduce in
+// lane order (deterministic).
+__device__ __forceinline__ void bn_sum_partials(const double* ws, int nblk, int c, int g, int ch, int sl, double* red, double& s, double& q) {
+    s = 0;
+    q = 0;
+    if (ch < c)
+        for (int b = sl; b < nblk; b += 16) {
+            const double* p = ws + ((int64_t)(g * nblk + b) * 2) * c;
+            s += p[ch];
+            q += p[c + ch];
+        }
+    red[threadIdx.x * 2] = s;
+    red[threadIdx.x * 2 + 1] = q;
+    __syncthreads();
+    if (sl == 0)
+        for (int k = 1; k < 16; ++k) {
+            s += red[(k * 16 + (threadIdx.x & 15)) * 2];
+            q += red[(k * 16 + (threadIdx.x & 15)) * 2 + 1];
+        }
+}
+
 __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const double* ws, int nblk, int c, int64_t rpg, const float* gamma,
                                                               const float* beta, float* rmean, float* rvar, float momentum,
                                                               float eps, float* mean, float* invstd, float* alpha,
                                                               float* shift) {
+    __shared__ double red[512];
     const int g = blockIdx.y;
-    const int ch = blockIdx.x * 256 + threadIdx.x;
-    if (ch >= c) return;
-    double s = 0, q = 0;
-    for (int b = 0; b < nblk; ++b) {
-        const double* p = ws + ((int64_t)(g * nblk + b) * 2) * c;
-        s += p[ch];
-        q += p[c + ch];
-    }
+    const int ch = blockIdx.x * 16 + (threadIdx.x & 15), sl = threadIdx.x >> 4;
+    double s, q;
+    bn_sum_partials(ws, nblk, c, g, ch, sl, red, s, q);
+    if (sl != 0 || ch >= c) return;
     const double n = (double)rpg;
     const double m = s / n;
     double var = q / n - m * m;
@@ -112,15 +130,12 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const double* ws, 
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const double* ws, int nblk, int c, float* dgamma, float* dbeta) {
+    __shared__ double red[512];
     const int g = blockIdx.y;
-    const int ch = blockIdx.x * 256 + threadIdx.x;
-    if (ch >= c) return;
-    double s = 0, q = 0;
-    for (int b = 0; b < nblk; ++b) {
-        const double* p = ws + ((int64_t)(g * nblk + b) * 2) * c;
-        s += p[ch];
-        q += p[c + ch];
-    }
+    const int ch = blockIdx.x * 16 + (threadIdx.x & 15), sl = threadIdx.x >> 4;
+    double s, q;
+    bn_sum_partials(ws, nblk, c, g, ch, sl, red, s, q);
+    if (sl != 0 || ch >= c) return;
     dbeta[g * c + ch] = (float)s;
     dgamma[g * c + ch] = (float)q;
 }
@@ -597,16 +612,15 @@ __global__ __launch_bounds__(256) void jqa_sum_bwd_kernel(const float* dx, float
 __global__ __launch_bounds__(256) void rownorm_loss_kernel(const float* pred, const float* gt, int64_t rows, int d, int inner,
                                                            int64_t ldp, int64_t ldg, float coef, double* loss, float* dpred) {
     __shared__ double part[4];
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     double mine = 0.0;
-    if (row < rows) {
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
         const int64_t po = (row / inner) * ldp + (row % inner) * d, go = (row / inner) * ldg + (row % inner) * d;
         float diff = 0.f;
         if (lane < d) diff = pred[po + lane] - gt[go + lane];
         const float nrm = sqrtf(wave_sum(diff * diff));
         if (lane < d && dpred) dpred[po + lane] = nrm > 0.f ? coef * diff / nrm : 0.f;
-        mine = (double)nrm;
+        mine += (double)nrm;
     }
     if (lane == 0) part[threadIdx.x >> 6] = mine;
     __syncthreads();
@@ -688,7 +702,7 @@ extern "C" int egr_bn_stats_f32(const float* x, int64_t rows_per_group, int32_t 
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_partial_kernel<false>, dim3(nblk, groups), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr,
                        rows_per_group, c, nblk, workspace);
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((c + 255) / 256, groups), dim3(256), 0, s, workspace, nblk, c,
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((c + 15) / 16, groups), dim3(256), 0, s, workspace, nblk, c,
                        rows_per_group, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, alpha, shift);
     return egr_launch_status();
 }
@@ -714,7 +728,7 @@ extern "C" int egr_bn_backward_f32(const float* dy, const float* y, const float*
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_partial_kernel<true>, dim3(nblk, groups), dim3(256), 0, s, x, dy, y, mean, invstd, rows_per_group, c,
                        nblk, workspace);
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((c + 255) / 256, groups), dim3(256), 0, s, workspace, nblk, c, dgamma,
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((c + 15) / 16, groups), dim3(256), 0, s, workspace, nblk, c, dgamma,
                        dbeta);
     const int64_t total4 = (int64_t)groups * rows_per_group * (c / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks(total4)), dim3(256), 0, s, dy, y, x, mean, invstd, alpha, dgamma, dbeta,
@@ -895,7 +909,7 @@ extern "C" int egr_rownorm_loss_f32(const float* pred, const float* gt, int64_t 
     if (!pred || !gt || !loss) return EGR_ENULL;
     if (rows <= 0 || d <= 0 || d > 64 || inner <= 0 || ld_pred < (int64_t)inner * d || ld_gt < (int64_t)inner * d) return EGR_EINVAL;
     const float coef = weight / (float)rows;
-    hipLaunchKernelGGL(rownorm_loss_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, pred, gt, rows, d,
+    hipLaunchKernelGGL(rownorm_loss_kernel, dim3((unsigned)(((rows + 3) / 4) < 1024 ? ((rows + 3) / 4) : 1024)), dim3(256), 0, (hipStream_t)stream, pred, gt, rows, d,
                        inner, ld_pred, ld_gt, coef, loss, dpred);
     return egr_launch_status();
 }

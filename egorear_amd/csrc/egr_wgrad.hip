@@ -265,13 +265,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* x, int64_t row
 }
 
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, int nblk, int c, float* out, int accumulate, int64_t gb) {
-    int ch = blockIdx.x * 256 + threadIdx.x;
-    if (ch >= c) return;
+    __shared__ double red[256];
+    const int ch = blockIdx.x * 16 + (threadIdx.x & 15), sl = threadIdx.x >> 4;   // 16 channels x 16 slab lanes
     partial += (int64_t)blockIdx.y * nblk * c;
     out += (int64_t)blockIdx.y * gb;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * c + ch];
-    out[ch] = (float)s + (accumulate ? out[ch] : 0.f);
+    if (ch < c)
+        for (int b = sl; b < nblk; b += 16) s += partial[(int64_t)b * c + ch];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (sl == 0 && ch < c) {
+        for (int k = 1; k < 16; ++k) s += red[k * 16 + (threadIdx.x & 15)];
+        out[ch] = (float)s + (accumulate ? out[ch] : 0.f);
+    }
 }
 
 }  // namespace
@@ -345,7 +351,7 @@ extern "C" int egr_conv2d_wgrad_f32(const egr_conv_desc* dd, const float* x, con
     if ((size_t)nblk * d.cout * G > workspace_floats) return EGR_EWORKSPACE;
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)nblk, (unsigned)((d.cout + 1023) / 1024), (unsigned)G), dim3(256), 0, s, dy, M64,
                        d.cout, d.ldy, workspace, rpb, d.gy);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((d.cout + 255) / 256), (unsigned)G), dim3(256), 0, s, workspace, nblk,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((d.cout + 15) / 16), (unsigned)G), dim3(256), 0, s, workspace, nblk,
                        d.cout, db, accumulate, d.gp);
     return egr_launch_status();
 }
