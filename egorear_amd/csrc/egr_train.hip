@@ -674,9 +674,51 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
     *reinterpret_cast<f32x4*>(v + idx * 4) = vv;
 }
 
+// ------------------------------------------------------------------ multi-tensor re-packing
+__global__ __launch_bounds__(256) void repack_kernel(const egr_repack_desc* table, const int64_t* blocks) {
+    const egr_repack_desc d = table[blocks[2 * blockIdx.x]];
+    const int64_t first = blocks[2 * blockIdx.x + 1];
+    const int tk = d.taps * 32;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = first + u * 256 + threadIdx.x;
+        if (i >= d.total) return;
+        float v = 0.f;
+        if (d.kind == EGR_REPACK_COPYPAD) {
+            if (i < d.rows) v = d.src[i];
+            d.dst[i] = v;
+        } else if (d.kind == EGR_REPACK_FWD) {
+            const int Kp = d.cin_pad * d.taps;
+            const int row = (int)(i / Kp), k = (int)(i - (int64_t)row * Kp);
+            const int cb = k / tk, rem = k - cb * tk, tap = rem >> 5, ci = cb * 32 + (rem & 31);
+            if (row < d.rows && ci < d.cin) v = d.src[((int64_t)row * d.cin_tot + d.ci0 + ci) * d.taps + tap];
+            d.dst[i] = v;
+        } else if (d.kind == EGR_REPACK_DGRAD) {
+            const int Kt = d.rows_pad * d.taps;   // this descriptor's share of the K side (k_off is a multiple of 32 when taps > 1)
+            const int ci = (int)(i / Kt), k = (int)(i - (int64_t)ci * Kt);
+            const int cob = k / tk, rem = k - cob * tk, tap = rem >> 5, co = cob * 32 + (rem & 31);
+            if (ci < d.cin && co < d.rows) v = d.src[((int64_t)co * d.cin_tot + d.ci0 + ci) * d.taps + tap];
+            d.dst[((int64_t)ci * d.k_tot + d.k_off) * d.taps + k] = v;
+        } else {  // UNPACK: i enumerates the destination slice (row, ci, tap)
+            const int per_row = d.cin * d.taps;
+            const int row = (int)(i / per_row), r2 = (int)(i - (int64_t)row * per_row);
+            const int ci = r2 / d.taps, tap = r2 - ci * d.taps;
+            v = d.src[(int64_t)row * d.cin_pad * d.taps + ((ci >> 5) * d.taps + tap) * 32 + (ci & 31)];
+            d.dst[((int64_t)row * d.cin_tot + d.ci0 + ci) * d.taps + tap] = v;
+        }
+    }
+}
+
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
 }  // namespace
+
+extern "C" int egr_repack_f32(const egr_repack_desc* table, const int64_t* blocks, int32_t n_blocks, void* stream) {
+    if (!table || !blocks) return EGR_ENULL;
+    if (n_blocks <= 0) return EGR_EINVAL;
+    hipLaunchKernelGGL(repack_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, table, blocks);
+    return egr_launch_status();
+}
 
 extern "C" int32_t egr_bn_blocks(int64_t rows_per_group) {
     int64_t n = rows_per_group / 512;

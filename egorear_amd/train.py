@@ -30,6 +30,7 @@ import torch.nn as nn
 
 from . import hip
 from . import hip_train as T
+from . import repack
 from .engine import _npad, _pad_rows, _pad_vec, _rows, pack_conv_weight, unpack_conv_weight
 from .hip import ACT_NONE, ACT_RELU, RES_BEFORE_ACT, RES_NONE, Img, NMap
 
@@ -46,50 +47,121 @@ class TPack:
     """`groups` same-shape conv / linear modules packed for the forward kernel (w, bias) and, when a data gradient is
     needed, for the transposed launch (wt).  cin_pad / cout_pad: channel counts the kernels see (multiples of 32 on the
     K side); names: state_dict keys of the weights / biases, one per group."""
-    __slots__ = ("w", "bias", "wt", "cout", "cin", "cin_pad", "cout_pad", "kh", "kw", "stride", "pad", "groups", "wnames",
-                 "bnames", "wshape")
+    __slots__ = ("w", "bias", "wt", "cout", "cin", "cin_pad", "cout_pad", "kh", "kw", "stride", "pad", "groups", "wmeta", "bmeta")
 
 
-def _pack_dgrad(w4: torch.Tensor, cout_pad: int, cin_pad: int) -> torch.Tensor:
-    """OIHW (cout, cin, kh, kw) -> the data-gradient operand: in/out swapped, K order (cout_pad/32, taps, 32), rows padded."""
-    cout, cin, kh, kw = w4.shape
-    if cout_pad != cout:
-        w4 = torch.cat([w4, w4.new_zeros(cout_pad - cout, cin, kh, kw)], 0)
-    if kh * kw == 1:
-        wt = w4.reshape(cout_pad, cin).t().contiguous()               # linear: one transposed copy
-    else:
-        wt = pack_conv_weight(w4.transpose(0, 1).contiguous())        # (cin, cout_pad*taps)
-    return _pad_rows(wt) if cin_pad == cin else torch.cat([wt, wt.new_zeros(_npad(cin_pad) - cin, wt.shape[1])], 0)
+class PackCache:
+    """Persistent operand buffers of every conv / linear group of the network plus the descriptor table that refreshes
+    all of them from the current parameters in ONE egr_repack_f32 launch per step (a handful of very large transposes
+    go through one torch copy each).  Built lazily during the first training forward; rebuilt if a parameter's storage
+    moves (load_state_dict, .to(), re-homing into the optimiser's flat buffer)."""
+
+    def __init__(self, device):
+        self.dev = device
+        self.packs: Dict[object, TPack] = {}
+        self.table = repack.RepackTable(device)
+        self.torch_refresh: List = []        # (dst, src parameter): dst.copy_(src.t())
+        self.sources: Dict[int, tuple] = {}  # id(param) -> (param, data_ptr)
+        self.ready = False
+
+    def watch(self, p: torch.Tensor):
+        self.sources[id(p)] = (p, p.data_ptr())
+
+    def valid(self) -> bool:
+        return all(p.data_ptr() == ptr for p, ptr in self.sources.values())
+
+    def refresh(self):
+        self.table.run()
+        for dst, src in self.torch_refresh:
+            dst.copy_(src.detach().reshape(dst.shape[1], dst.shape[0]).t())
 
 
-def make_pack(ws: Sequence[torch.Tensor], bs: Sequence[Optional[torch.Tensor]], wnames, bnames, stride=1, pad=0, need_dx=True) -> TPack:
-    """ws: OIHW conv weights or (N, K) linear weights, one per group."""
+def _get_cache(net: nn.Module, device) -> PackCache:
+    c = net.__dict__.get("_egr_pack_cache")
+    if c is None or c.dev != device or not c.valid():
+        c = PackCache(device)
+        net.__dict__["_egr_pack_cache"] = c
+    return c
+
+
+_BIG_TRANSPOSE = 1 << 20   # linear data-gradient operands above this many elements are refreshed by one tiled torch transpose
+
+
+def make_pack(cache: PackCache, key, wparts, bparts, name_of, kh: int = 1, kw: int = 1, stride: int = 1, pad: int = 0,
+              need_dx: bool = True) -> TPack:
+    """One conv / linear group.  wparts[g]: list of (parameter, ci0, cin) whose rows are concatenated (ci0/cin select an
+    input-channel slice of the parameter); bparts[g]: list of bias parameters or None.  The operand buffers are
+    allocated once and (re)filled by repack descriptors; a plain, unpadded single linear aliases its parameter."""
+    hit = cache.packs.get(key)
+    if hit is not None:
+        return hit
+    dev = cache.dev
     p = TPack()
-    w0 = ws[0]
-    if w0.dim() == 2:
-        w4s = [w.detach().float()[:, :, None, None] for w in ws]
-    else:
-        w4s = [w.detach().float() for w in ws]
-    p.cout, p.cin, p.kh, p.kw = w4s[0].shape
-    p.wshape = tuple(w0.shape)
+    G = len(wparts)
+    taps = kh * kw
+    p.cout = sum(int(q.shape[0]) for q, _, _ in wparts[0])
+    p.cin = wparts[0][0][2]
+    p.kh, p.kw, p.stride, p.pad, p.groups = kh, kw, stride, pad, G
     p.cin_pad, p.cout_pad = _ceil32(p.cin), _ceil32(p.cout)
-    p.stride, p.pad, p.groups = stride, pad, len(ws)
-    p.wnames, p.bnames = list(wnames), list(bnames) if bs[0] is not None else None
-    if p.cin_pad != p.cin:   # K side padded with zero input channels (the 4- and 15-channel layers)
-        w4s = [torch.cat([w, w.new_zeros(p.cout, p.cin_pad - p.cin, p.kh, p.kw)], 1) for w in w4s]
-    lin = p.kh * p.kw == 1
-    fw = [_pad_rows(w.reshape(p.cout, p.cin_pad) if lin else pack_conv_weight(w)) for w in w4s]
-    p.w = torch.stack(fw).contiguous() if p.groups > 1 else fw[0]
-    if bs[0] is not None:
-        bb = [_pad_vec(b.detach(), p.cout) for b in bs]
-        p.bias = torch.stack(bb).contiguous() if p.groups > 1 else bb[0]
+    # where the gradient of every source goes: (parameter name, rows, first channel, channels per parameter row)
+    p.wmeta = [[(name_of(q), int(q.shape[0]), ci0, q.numel() // (int(q.shape[0]) * taps)) for q, ci0, _ in parts] for parts in wparts]
+    p.bmeta = [[(name_of(q), q.numel()) for q in parts] for parts in bparts] if bparts[0] is not None else None
+    rows_fwd, K = _npad(p.cout), p.cin_pad * taps
+    one = wparts[0][0]
+    tbl = repack.RepackTable(dev)          # this pack's descriptors, run once now; also appended to the cache's table
+
+    def add(*a, **k):
+        tbl.add(*a, **k)
+        cache.table.add(*a, **k)
+
+    alias = (G == 1 and len(wparts[0]) == 1 and taps == 1 and rows_fwd == p.cout and p.cin_pad == p.cin and one[1] == 0
+             and one[0].numel() == p.cout * p.cin)
+    if alias:
+        p.w = one[0].detach().view(p.cout, p.cin)        # the parameter already is the forward operand
+    else:
+        p.w = torch.empty((G, rows_fwd, K) if G > 1 else (rows_fwd, K), device=dev, dtype=torch.float32)
+        for g, parts in enumerate(wparts):
+            r0 = 0
+            for i, (q, ci0, cin) in enumerate(parts):
+                rows = int(q.shape[0])
+                rows_dst = (rows_fwd - r0) if i == len(parts) - 1 else rows
+                add(repack.FWD, q.detach(), p.w, (g * rows_fwd + r0) * K, rows=rows, cin=cin, cin_tot=q.numel() // (rows * taps), ci0=ci0,
+                    cin_pad=p.cin_pad, taps=taps, rows_pad=rows_dst, total=rows_dst * K)
+                r0 += rows
+    for parts in wparts:
+        for q, _, _ in parts:
+            cache.watch(q)
+    if bparts[0] is not None:
+        p.bias = torch.empty((G, rows_fwd) if G > 1 else (rows_fwd,), device=dev, dtype=torch.float32)
+        for g, parts in enumerate(bparts):
+            r0 = 0
+            for i, q in enumerate(parts):
+                n = q.numel()
+                n_dst = (rows_fwd - r0) if i == len(parts) - 1 else n
+                add(repack.COPYPAD, q.detach(), p.bias, g * rows_fwd + r0, rows=n, total=n_dst)
+                cache.watch(q)
+                r0 += n
     else:
         p.bias = None
+    p.wt = None
     if need_dx:
-        tw = [_pack_dgrad(w, p.cout_pad, p.cin_pad) for w in w4s]
-        p.wt = torch.stack(tw).contiguous() if p.groups > 1 else tw[0]
-    else:
-        p.wt = None
+        rows_t, Kt = _npad(p.cin_pad), p.cout_pad * taps
+        p.wt = torch.empty((G, rows_t, Kt) if G > 1 else (rows_t, Kt), device=dev, dtype=torch.float32)
+        big = alias and p.cout_pad == p.cout and rows_t == p.cin and p.w.numel() > _BIG_TRANSPOSE
+        if big:
+            cache.torch_refresh.append((p.wt, one[0]))
+            p.wt.copy_(one[0].detach().view(p.cout, p.cin).t())
+        else:
+            for g, parts in enumerate(wparts):
+                r0 = 0
+                for i, (q, ci0, cin) in enumerate(parts):
+                    rows = int(q.shape[0])
+                    rows_k = (p.cout_pad - r0) if i == len(parts) - 1 else rows
+                    add(repack.DGRAD, q.detach(), p.wt, g * rows_t * Kt, rows=rows, cin=cin, cin_tot=q.numel() // (rows * taps), ci0=ci0,
+                        cin_pad=p.cin_pad, taps=taps, rows_pad=rows_k, k_off=r0, k_tot=p.cout_pad, total=rows_t * rows_k * taps)
+                    r0 += rows
+    tbl.run()
+    cache.packs[key] = p
     return p
 
 
@@ -133,6 +205,13 @@ class Step:
             net.__dict__["_egr_train_ws"] = st
         self.ws, self.bnws = st
         self.keep: List = []   # forward tensors whose identity keys the gradient store
+        self.gviews: Optional[Dict[str, torch.Tensor]] = None   # flat-buffer views to write parameter gradients into (Trainer)
+        self.gtable = repack.RepackTable(device)                # packed / strided gradient pieces -> parameter layout, one launch
+        self.pextra: Dict[str, torch.Tensor] = {}               # gradients computed in parameter space (torch tensors)
+        self.pshapes = {k: p.shape for k, p in net.named_parameters()}
+        self.cache = _get_cache(net, device)
+        if self.cache.ready:
+            self.cache.refresh()   # every operand buffer of the step from the current parameters: one launch
         self.record = True     # False: evaluate without taping (constant sub-graphs)
         self.loss_terms = None
 
@@ -141,8 +220,24 @@ class Step:
         return self.names[id(p)]
 
     def pacc(self, name: str, g: torch.Tensor):
-        old = self.pgrads.get(name)
-        self.pgrads[name] = g if old is None else old + g   # parameter-space accumulation (feat_proj over 3 layers)
+        """A gradient (piece) that already has the parameter's layout; several contributions add up (feat_proj over the
+        three lifting layers)."""
+        old = self.pextra.get(name)
+        self.pextra[name] = g if old is None else old + g
+
+    def gdst(self, name: str) -> torch.Tensor:
+        """The tensor the gradient of `name` is assembled in: the optimiser's flat-buffer view, or a fresh tensor."""
+        t = self.pgrads.get(name)
+        if t is None:
+            t = self.gviews[name] if self.gviews is not None else torch.empty(self.pshapes[name], device=self.dev, dtype=torch.float32)
+            self.pgrads[name] = t
+        return t
+
+    def finish_param_grads(self):
+        self.gtable.run()
+        for name, g in self.pextra.items():
+            self.gdst(name).copy_(g.reshape(self.pshapes[name]))
+        self.pextra = {}
 
     def backward(self):
         for fn in reversed(self.tape):
@@ -152,29 +247,30 @@ class Step:
     # ---- conv / linear ------------------------------------------------------------------------------------------
     def pack(self, mods: Sequence[nn.Module], need_dx=True) -> TPack:
         m0 = mods[0]
-        stride = m0.stride[0] if isinstance(m0, nn.Conv2d) else 1
-        pad = m0.padding[0] if isinstance(m0, nn.Conv2d) else 0
+        conv = isinstance(m0, nn.Conv2d)
+        stride, pad = (m0.stride[0], m0.padding[0]) if conv else (1, 0)
+        kh, kw = (m0.kernel_size if conv else (1, 1))
         has_b = m0.bias is not None
-        return make_pack([m.weight for m in mods], [m.bias if has_b else None for m in mods], [self.name(m.weight) for m in mods],
-                         [self.name(m.bias) for m in mods] if has_b else [None] * len(mods), stride, pad, need_dx)
+        cin = m0.weight.shape[1]
+        return make_pack(self.cache, (tuple(id(m) for m in mods), need_dx), [[(m.weight, 0, cin)] for m in mods],
+                         [[m.bias] if has_b else None for m in mods], self.name, kh, kw, stride, pad, need_dx)
 
     def _wgrad(self, p: TPack, x4: torch.Tensor, dz4: torch.Tensor, gx_rows: Optional[int] = None):
         """Weight / bias gradients of every group.  x4 (G*n, h, w, cin_pad), dz4 (G*n, ho, wo, cout_pad) dense."""
-        dws, dbs = hip.conv2d_wgrad(Img(x4), Img(dz4), p.kh, p.kw, p.stride, p.pad, self.ws, want_bias=p.bnames is not None, groups=p.groups)
-        if p.groups == 1:
-            dws, dbs = dws[None], (dbs[None] if dbs is not None else None)
-        for g in range(p.groups):
-            dw, db = dws[g], (dbs[g] if dbs is not None else None)
-            if p.cout != p.cout_pad:       # narrow outputs travel channel-padded: drop the padding rows
-                dw, db = dw[:p.cout], (db[:p.cout] if db is not None else None)
-            if p.kh * p.kw == 1:
-                gw = dw[:, :p.cin].reshape(p.wshape) if p.cin != p.cin_pad else dw.view(p.wshape)
-            else:
-                gw = unpack_conv_weight(dw, p.cin_pad, p.kh, p.kw)
-                gw = gw[:, :p.cin] if p.cin != p.cin_pad else gw
-            self.pacc(p.wnames[g], gw)
-            if p.bnames is not None:
-                self.pacc(p.bnames[g], db)
+        dws, dbs = hip.conv2d_wgrad(Img(x4), Img(dz4), p.kh, p.kw, p.stride, p.pad, self.ws, want_bias=p.bmeta is not None, groups=p.groups)
+        taps = p.kh * p.kw
+        Kp = p.cin_pad * taps
+        for g in range(p.groups):       # packed (rows, cin_pad/32, taps, 32) pieces -> OIHW (column slices) of the parameters' gradients
+            r0 = 0
+            for name, rows, ci0, cin_tot in p.wmeta[g]:
+                self.gtable.add(repack.UNPACK, dws, self.gdst(name), 0, rows=rows, cin=p.cin, cin_tot=cin_tot, ci0=ci0, cin_pad=p.cin_pad,
+                                taps=taps, total=rows * p.cin * taps, src_off=(g * p.cout_pad + r0) * Kp)
+                r0 += rows
+            if p.bmeta is not None:
+                r0 = 0
+                for name, n in p.bmeta[g]:
+                    self.gtable.add(repack.COPYPAD, dbs, self.gdst(name), 0, rows=n, total=n, src_off=g * p.cout_pad + r0)
+                    r0 += n
 
     def conv(self, x: torch.Tensor, p: TPack, act: int = ACT_NONE, res: Optional[torch.Tensor] = None, need_dx: bool = True,
              out_pad: bool = False) -> torch.Tensor:
@@ -252,9 +348,10 @@ class Step:
             if dy is None:
                 return
             dx, dgam, dbet, dz = T.bn_backward(ctx, dy, y if relu else None, self.bnws, want_dz=res is not None)
+            c_ = dgam.shape[1]
             for g, b in enumerate(bns):
-                self.pacc(self.name(b.weight), dgam[g])
-                self.pacc(self.name(b.bias), dbet[g])
+                self.gtable.add(repack.COPYPAD, dgam, self.gdst(self.name(b.weight)), 0, rows=c_, total=c_, src_off=g * c_)
+                self.gtable.add(repack.COPYPAD, dbet, self.gdst(self.name(b.bias)), 0, rows=c_, total=c_, src_off=g * c_)
             if res is not None:
                 self.G.add(res, dz)
             self.G.add(x, dx)
@@ -334,8 +431,8 @@ class Step:
                 return
             ds, dgam, dbet = T.layernorm_bwd(dy, pre, gamma, G, lns[0].eps)
             for g, l in enumerate(lns):
-                self.pacc(self.name(l.weight), dgam[g * c:(g + 1) * c])
-                self.pacc(self.name(l.bias), dbet[g * c:(g + 1) * c])
+                self.gtable.add(repack.COPYPAD, dgam, self.gdst(self.name(l.weight)), 0, rows=c, total=c, src_off=g * c)
+                self.gtable.add(repack.COPYPAD, dbet, self.gdst(self.name(l.bias)), 0, rows=c, total=c, src_off=g * c)
             self.G.add(x, ds)
             if res is not None:
                 self.G.add(res, ds)
@@ -420,8 +517,8 @@ def backbone_train(S: Step, encs, img: torch.Tensor, view0: int, nviews: int):
     cols = T.stem_im2col(img, view0, G * nviews)          # view-major rows: group g = views [view0 + g*nviews, ...)
     cols4 = cols.view(G * nviews * B, H // 2, W // 2, 160)
     w7 = [t.layer_s2[0].weight for t in trunks]
-    pst = make_pack([w.detach().reshape(64, 147) for w in w7], [None] * G, [S.name(w) for w in w7], [None] * G, 1, 0, need_dx=False)
-    pst.wshape = tuple(w7[0].shape)
+    pst = make_pack(S.cache, ("stem", tuple(id(w) for w in w7)), [[(w, 0, 147)] for w in w7], [None] * G, S.name,
+                    need_dx=False)     # (64, 3, 7, 7) read as a (64, 147) matrix: OIHW flatten = im2col column order
     x = S.conv(cols4, pst, ACT_NONE, need_dx=False)
     x = S.bn(x, [t.layer_s2[1] for t in trunks], relu=True)
     x = S.maxpool(x, 3, 2, 1)
@@ -439,20 +536,12 @@ def backbone_train(S: Step, encs, img: torch.Tensor, view0: int, nviews: int):
     for i in (3, 2, 1):
         fine = S.conv(pyramid[i - 1], S.pack([k.lateral_convs[i - 1][0] for k in necks]), ACT_RELU)
         fws = [k.fuse_convs[i - 1][0] for k in necks]
-        pa = make_pack([f.weight.detach()[:, :c] for f in fws], [f.bias for f in fws], [S.name(f.weight) + "@a" for f in fws],
-                       [S.name(f.bias) for f in fws])
-        pb = make_pack([f.weight.detach()[:, c:] for f in fws], [None] * G, [S.name(f.weight) + "@b" for f in fws], [None] * G)
+        pa = make_pack(S.cache, ("fuse_a", tuple(id(f) for f in fws)), [[(f.weight, 0, c)] for f in fws], [[f.bias] for f in fws], S.name)
+        pb = make_pack(S.cache, ("fuse_b", tuple(id(f) for f in fws)), [[(f.weight, c, c)] for f in fws], [None] * G, S.name)
         coarse = S.upsample(S.conv(lat, pb, ACT_NONE))
         fused = S.conv(fine, pa, ACT_RELU, res=coarse)
         lat = S.conv(fused, S.pack([k.fpn_convs[i - 1][0] for k in necks]), ACT_RELU)
     return lat, pyramid[3]
-
-
-def _merge_split_grads(S: Step):
-    """fuse_convs weights were used as two column blocks ('@a' | '@b'): join their gradients."""
-    for k in [k for k in S.pgrads if k.endswith("@a")]:
-        base = k[:-2]
-        S.pgrads[base] = torch.cat([S.pgrads.pop(k), S.pgrads.pop(base + "@b")], 1)
 
 
 # ---- deformable-attention transformer layer ----------------------------------------------------------------------
@@ -484,34 +573,20 @@ def _pack_layer(S: Step, layers, pres, poss) -> _LayerPack:
         L.head_shift = [torch.stack([_pad_vec(L.cfold[g, h * L.dh:(h + 1) * L.dh], L.dh) for g in range(L.G)]).contiguous() for h in range(L.heads)]
         L.head_wt = [torch.stack([L.Wfold[g, h * L.dh:(h + 1) * L.dh].t().contiguous() for g in range(L.G)]).contiguous() for h in range(L.heads)]
     cas = [l.cross_attn for l in layers]
-    n = S.name
-    L.ol = make_pack([torch.cat([c.sampling_offsets.weight.detach(), c.attention_weights.weight.detach()], 0) for c in cas],
-                     [torch.cat([c.sampling_offsets.bias.detach(), c.attention_weights.bias.detach()], 0) for c in cas],
-                     [n(c.sampling_offsets.weight) + "|" + n(c.attention_weights.weight) for c in cas],
-                     [n(c.sampling_offsets.bias) + "|" + n(c.attention_weights.bias) for c in cas])
+    C_ = L.C
+    L.ol = make_pack(S.cache, ("ol", tuple(id(c) for c in cas)),
+                     [[(c.sampling_offsets.weight, 0, C_), (c.attention_weights.weight, 0, C_)] for c in cas],
+                     [[c.sampling_offsets.bias, c.attention_weights.bias] for c in cas], S.name)
     L.out_proj = S.pack([c.output_proj for c in cas])
     L.fuse = S.pack([l.fuse_mlp for l in layers])
     sas = [l.spatial_attn for l in layers]
-    L.qkv = make_pack([torch.cat([s.q_proj.weight.detach(), s.k_proj.weight.detach(), s.v_proj.weight.detach()], 0) for s in sas],
-                      [torch.cat([s.q_proj.bias.detach(), s.k_proj.bias.detach(), s.v_proj.bias.detach()], 0) for s in sas],
-                      ["|".join(n(getattr(s, k).weight) for k in ("q_proj", "k_proj", "v_proj")) for s in sas],
-                      ["|".join(n(getattr(s, k).bias) for k in ("q_proj", "k_proj", "v_proj")) for s in sas])
+    L.qkv = make_pack(S.cache, ("qkv", tuple(id(s) for s in sas)),
+                      [[(s.q_proj.weight, 0, C_), (s.k_proj.weight, 0, C_), (s.v_proj.weight, 0, C_)] for s in sas],
+                      [[s.q_proj.bias, s.k_proj.bias, s.v_proj.bias] for s in sas], S.name)
     L.mha_out = S.pack([s.out_proj for s in sas])
     L.ffn0 = S.pack([l.ffn.layers[0][0] for l in layers])
     L.ffn1 = S.pack([l.ffn.layers[1] for l in layers])
     return L
-
-
-def _split_cat_grads(S: Step):
-    """Layers evaluated as one concatenated matrix ('a|b|c' names): split the gradient rows back onto the parameters."""
-    shapes = {k: p.shape for k, p in S.net.named_parameters()}
-    for k in [k for k in S.pgrads if "|" in k]:
-        g = S.pgrads.pop(k)
-        r = 0
-        for part in k.split("|"):
-            rows = shapes[part][0]
-            S.pacc(part, g[r:r + rows])
-            r += rows
 
 
 def layer_train(S: Step, L: _LayerPack, x: torch.Tensor, memory: torch.Tensor, anchors, valid, B: int, V: int, J: int, hgt: int, wid: int,
@@ -655,8 +730,8 @@ def refiners_train(S: Step, rs, B: int, V: int, hm_init: torch.Tensor, feat_all:
         for g in range(G):
             xg = Img(hm_init.view(B, V, J, 1, hw)[:, g])                        # (B, J, 1, hw) strided over the batch
             dw, db = hip.conv2d_wgrad(xg, Img(dz[g * B:(g + 1) * B]), 1, 1, 1, 0, S.ws, want_bias=True)
-            S.pacc(hp0.wnames[g], dw)
-            S.pacc(hp0.bnames[g], db)
+            S.pacc(hp0.wmeta[g][0][0], dw)
+            S.pacc(hp0.bmeta[g][0][0], db)
     S.tape.append(bwd_hp0)
     S.keep.append((t4, t))
     hm_embed = S.linear(t, S.pack([r.heatmap_proj[2] for r in rs]))
@@ -936,13 +1011,12 @@ class Trainer:
         """Returns (loss terms (6,) float64 device tensor, outputs).  Parameters are updated in place."""
         net = self.net
         S = Step(net, img.device)
+        S.gviews = self.opt.gviews
         from .dist import grad_seed_scale
         with torch.no_grad():
             preds, hms, aux = forward_train(S, net, img, ctm)
             loss_and_seed(S, preds, hms, gt_pose, gt_heatmap, self.w_mpjpe, self.w_heatmap, grad_scale=grad_seed_scale(self.opt.pg))
             _finish_backward(S)
-            for k, g in S.pgrads.items():
-                self.opt.gviews[k].copy_(g)
             self.opt.step(S.pgrads.keys())
         from .engine import invalidate
         for m in (net, net.heatmap_estimator, net.pose3d_estimator):
@@ -953,9 +1027,9 @@ class Trainer:
 # --------------------------------------------------------------------------- autograd bridge (drop-in for the wrapper)
 
 def _finish_backward(S: Step):
+    S.cache.ready = True       # every pack of the network exists now: later steps refresh them with one launch
     S.backward()
-    _merge_split_grads(S)
-    _split_cat_grads(S)
+    S.finish_param_grads()
 
 
 class _MVFEXTrainFn(torch.autograd.Function):

@@ -112,6 +112,32 @@ int egr_sumsq_f32(const float* g, int64_t n, double* out, int32_t accumulate, vo
 int egr_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int32_t step, const double* grad_sumsq, float clip, void* stream);
 
+/* ---- parameter re-packing, all tensors of a step in ONE launch.  Every optimisation step the kernels' weight layouts
+ * (forward operand [cout_pad][cin_pad/32][taps][32], data-gradient operand [cin_pad32][cout_pad/32][taps][32], padded bias
+ * vectors, group stacks, row-concatenated projections) must be rebuilt from the nn.Parameters, and the weight gradients
+ * must be brought back from the packed K order to OIHW inside the flat gradient buffer.  A table of descriptors (device
+ * memory) drives one gather kernel; `blocks` maps every 1024-element block of work to (descriptor, first element). */
+typedef struct egr_repack_desc {
+    const float* src;
+    float* dst;
+    int32_t kind;      /* EGR_REPACK_* */
+    int32_t rows;      /* valid source rows (cout) */
+    int32_t cin;       /* valid input channels taken from the source */
+    int32_t cin_tot;   /* channels per source row (row pitch = cin_tot * taps) */
+    int32_t ci0;       /* first source channel */
+    int32_t cin_pad;   /* channels of the packed side (multiple of 32) */
+    int32_t taps;      /* kh * kw */
+    int32_t rows_pad;  /* FWD: destination rows; DGRAD: source rows incl. zero padding handled by this descriptor (K side) */
+    int32_t k_off;     /* DGRAD: first K-side channel written (row-concatenated sources) */
+    int32_t k_tot;     /* DGRAD: K-side channels of the whole destination row (multiple of 32) */
+    int64_t total;     /* elements enumerated by this descriptor */
+} egr_repack_desc;
+#define EGR_REPACK_COPYPAD 0 /* dst[i] = i < rows ? src[i] : 0                                     (bias / vector padding) */
+#define EGR_REPACK_FWD 1     /* OIHW (column slice) -> forward operand, zero padded rows / channels                        */
+#define EGR_REPACK_DGRAD 2   /* OIHW (column slice) -> data-gradient operand (in/out swapped)                               */
+#define EGR_REPACK_UNPACK 3  /* packed gradient [rows][cin_pad/32][taps][32] -> OIHW (column slice) at dst                  */
+int egr_repack_f32(const egr_repack_desc* table, const int64_t* blocks /* (desc, first) pairs */, int32_t n_blocks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

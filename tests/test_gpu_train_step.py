@@ -146,3 +146,37 @@ def test_dropin_autograd_flow_like_the_lightning_wrapper(golden_dir):
     with torch.no_grad():
         p3, _ = net(synth.synth_images(B, 4, seed=0).to(DEV), synth.synth_coord_trans_mat(B).to(DEV))
     assert all(torch.isfinite(t).all() for t in p3)
+
+
+def test_refreshed_operand_buffers_equal_rebuilt_ones():
+    """After an optimiser update, the one-launch refresh of every cached operand buffer (egr_repack_f32 descriptor table)
+    must give exactly what building the buffers from scratch gives."""
+    from egorear_amd import configs, synth, train
+    from egorear_amd.estimator import EgoPoseFormerMVFEX
+    from oracle import train_oracle as TO
+    net = EgoPoseFormerMVFEX(**copy.deepcopy(configs.pose3d_cfg("ego4view_rw")))
+    synth.load_synth(net, 42)
+    net = net.to(DEV)
+    tr = train.Trainer(net)
+    B = 1
+    args = (synth.synth_images(B, 4, seed=0).to(DEV), synth.synth_coord_trans_mat(B).to(DEV), synth.synth_gt_pose(B).to(DEV),
+            TO.synth_gt_heatmap(B).to(DEV))
+    tr.step(*args)                                   # builds the cache, then updates the parameters
+    cache = net.__dict__["_egr_pack_cache"]
+    assert cache.ready and len(cache.table) > 300
+    cache.refresh()
+    torch.cuda.synchronize()
+    snap = {k: (p.w.clone(), None if p.bias is None else p.bias.clone(), None if p.wt is None else p.wt.clone()) for k, p in cache.packs.items()}
+    net.__dict__.pop("_egr_pack_cache")
+    S = train.Step(net, torch.device(DEV))
+    S.record = False
+    with torch.no_grad():
+        train.forward_train(S, net, args[0], args[1])   # lazily rebuilds every pack from the current parameters
+    torch.cuda.synchronize()
+    fresh = net.__dict__["_egr_pack_cache"].packs
+    assert set(fresh) == set(snap)
+    for k, p in fresh.items():
+        w, b, wt = snap[k]
+        assert torch.equal(p.w, w), k
+        assert (b is None) == (p.bias is None) and (b is None or torch.equal(p.bias, b)), k
+        assert (wt is None) == (p.wt is None) and (wt is None or torch.equal(p.wt, wt)), k
