@@ -59,8 +59,21 @@ def grad_seed_scale(group=None) -> float:
     return 1.0
 
 
-def allreduce_gradients_(flat: torch.Tensor, group=None) -> torch.Tensor:
-    """In-place SUM all-reduce of the flat gradient buffer over the data-parallel group (no-op for one process)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    return flat
+def world_size(group=None) -> int:
+    return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def allreduce_gradients_(flat: torch.Tensor, group=None, async_op: bool = False):
+    """In-place SUM all-reduce of (a bucket of) the flat gradient buffer over the data-parallel group.  Returns `flat`, or
+    with async_op the work handle to wait on (None for one process).  RCCL runs it on its own stream, so a bucket started
+    when its stage of the reverse pass is finished overlaps with the remaining backward kernels.  With the gloo backend
+    (CPU tests, one-GPU rehearsals) device tensors are staged through the host."""
+    if world_size(group) <= 1:
+        return None if async_op else flat
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        host = flat.detach().cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host)
+        return None if async_op else flat
+    h = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return h if async_op else flat

@@ -205,6 +205,7 @@ class Step:
             net.__dict__["_egr_train_ws"] = st
         self.ws, self.bnws = st
         self.keep: List = []   # forward tensors whose identity keys the gradient store
+        self.stage_hook = None                                  # callable(stage) run when a gradient stage is complete (multi-process)
         self.gviews: Optional[Dict[str, torch.Tensor]] = None   # flat-buffer views to write parameter gradients into (Trainer)
         self.gtable = repack.RepackTable(device)                # packed / strided gradient pieces -> parameter layout, one launch
         self.pextra: Dict[str, torch.Tensor] = {}               # gradients computed in parameter space (torch tensors)
@@ -235,9 +236,20 @@ class Step:
 
     def finish_param_grads(self):
         self.gtable.run()
+        self.gtable = repack.RepackTable(self.dev)
         for name, g in self.pextra.items():
             self.gdst(name).copy_(g.reshape(self.pshapes[name]))
         self.pextra = {}
+
+    def mark_stage(self, stage: int):
+        """Record the end (in reverse-pass order) of a gradient stage: when the marker runs, the parameter gradients of the
+        stage are complete; they are flushed into their destination and handed to `stage_hook` (all-reduce start)."""
+        def bwd():
+            if self.stage_hook is not None:
+                self.finish_param_grads()
+                self.stage_hook(stage)
+        if self.record:
+            self.tape.append(bwd)
 
     def backward(self):
         for fn in reversed(self.tape):
@@ -716,6 +728,7 @@ def refiners_train(S: Step, rs, B: int, V: int, hm_init: torch.Tensor, feat_all:
     hgt, wid = r0.feat_shape
     hw = hgt * wid
     dev = S.dev
+    S.mark_stage(1)
     # --- JQA query: heatmap_proj.0 reads the (B, V, J, hw) heat maps in place, group g = view g
     hp0 = S.pack([r.heatmap_proj[0] for r in rs], need_dx=False)
     hm_rows = Img(hm_init.view(B * V, J, 1, hw)[0::V])
@@ -793,6 +806,7 @@ def pose3d_train(S: Step, p3, feat_init: torch.Tensor, feat_ref: torch.Tensor, B
     hgt, wid = p3.feat_shape
     C = p3.embed_dims
     assert p3.use_pred_heatmap_init, "training path covers the shipped pose3d configs (use_pred_heatmap_init)"
+    S.mark_stage(0)                     # reverse pass: everything recorded below is done when this marker runs
     memory = feat_init.view(V, B, hgt * wid, feat_init.shape[-1])
     dmem = T.zeros(memory.shape, dev)
 
@@ -859,6 +873,7 @@ def forward_train(S: Step, net, img: torch.Tensor, ctm=None):
     front, back = he.heatmap_estimator_stereo_front, he.heatmap_estimator_stereo_back
     feat_all, s32_all = backbone_train(S, [front.encoder, back.encoder], img, 0, 2)
     hm_init = torch.empty((B, V, J, H4, W4), device=dev, dtype=torch.float32)
+    S.mark_stage(2)
     heatmap_head_train(S, [he.conv_heatmap_layers_stereo_front, he.conv_heatmap_layers_stereo_back], feat_all, hm_init, B, V)
     a, mv, vd, idx = hip.argmax_rows(hm_init, he.heatmap_threshold)
     anchors, valid = a.view(B, V, J, 2), vd.view(B, V, J)
@@ -919,6 +934,21 @@ def forward_backward(net, img, ctm, gt_pose, gt_heatmap):
 
 # --------------------------------------------------------------------------- optimiser + the full step
 
+N_GRAD_STAGES = 4
+
+
+def grad_stage(name: str) -> int:
+    """Order in which the reverse pass completes parameter gradients: lifting head, refiners, initial heat-map heads,
+    encoders (the forward runs them the other way round)."""
+    if name.startswith("pose3d_estimator."):
+        return 0
+    if name.startswith("heatmap_estimator.heatmap_refiner_"):
+        return 1
+    if name.startswith("heatmap_estimator.conv_heatmap_layers_stereo_"):
+        return 2
+    return 3
+
+
 def is_no_decay(name: str) -> bool:
     """Parameter-group rule of the reference's configure_optimizers (pose_3d_mvf_ex.py:223)."""
     return ("norm" in name) or ("bn" in name) or ("ln" in name) or ("bias" in name)
@@ -943,13 +973,20 @@ class FusedAdamW:
         dev = named[0][1].device
         if dev.type != "cuda":
             raise RuntimeError("egorear_amd.train: parameters must live on the HIP device")
-        order = [(k, p) for k, p in named if is_no_decay(k)] + [(k, p) for k, p in named if not is_no_decay(k)]
+        # flat order: by the stage of the reverse pass that finishes a tensor's gradient (so a stage is one contiguous
+        # all-reduce bucket that can start while earlier layers are still being differentiated), then [no-decay | decayed]
+        order = sorted(named, key=lambda kp: (grad_stage(kp[0]), not is_no_decay(kp[0])))
         self.slots = []                      # (name, offset, numel, decay)
+        self.stage_range = {}                # stage -> [begin, end) in the flat buffers
         off = 0
         for k, p in order:
+            st = grad_stage(k)
+            rng = self.stage_range.setdefault(st, [off, off])
             self.slots.append((k, off, p.numel(), not is_no_decay(k)))
             off += (p.numel() + 3) // 4 * 4
+            rng[1] = off
         self.total = off
+        self.pending = []                    # async all-reduce handles of this step
         self.flat_p = torch.zeros(off, device=dev, dtype=torch.float32)
         self.flat_g = torch.zeros(off, device=dev, dtype=torch.float32)
         self.m = torch.zeros(off, device=dev, dtype=torch.float32)
@@ -981,11 +1018,21 @@ class FusedAdamW:
                 runs.append(cur)
         return runs
 
-    def step(self, have) -> None:
-        """`have`: names whose gradient views were written this step."""
-        self.steps += 1
+    def reduce_stage(self, stage: int):
+        """Start the gradient all-reduce of one finished stage (SUM; the 1/world of DDP's average is in the loss seed).
+        It runs on the communication stream of the process group while the reverse pass continues."""
         from .dist import allreduce_gradients_
-        allreduce_gradients_(self.flat_g, self.pg)   # SUM; the 1/world of DDP's average is in the loss seed (Trainer.step)
+        b, e = self.stage_range[stage]
+        h = allreduce_gradients_(self.flat_g[b:e], self.pg, async_op=True)
+        if h is not None:
+            self.pending.append(h)
+
+    def step(self, have) -> None:
+        """`have`: names whose gradient views were written this step.  Every stage must have been reduced (reduce_stage)."""
+        self.steps += 1
+        for h in self.pending:
+            h.wait()
+        self.pending = []
         runs = self._runs(have)
         for i, (o, n, _) in enumerate(runs):
             T.sumsq(self.flat_g[o:o + n], self.sumsq, accumulate=i > 0)
@@ -1012,7 +1059,9 @@ class Trainer:
         net = self.net
         S = Step(net, img.device)
         S.gviews = self.opt.gviews
-        from .dist import grad_seed_scale
+        from .dist import grad_seed_scale, world_size
+        if world_size(self.opt.pg) > 1:
+            S.stage_hook = self.opt.reduce_stage   # bucketed all-reduce overlapped with the rest of the reverse pass
         with torch.no_grad():
             preds, hms, aux = forward_train(S, net, img, ctm)
             loss_and_seed(S, preds, hms, gt_pose, gt_heatmap, self.w_mpjpe, self.w_heatmap, grad_scale=grad_seed_scale(self.opt.pg))
@@ -1030,6 +1079,8 @@ def _finish_backward(S: Step):
     S.cache.ready = True       # every pack of the network exists now: later steps refresh them with one launch
     S.backward()
     S.finish_param_grads()
+    if S.stage_hook is not None:
+        S.stage_hook(N_GRAD_STAGES - 1)    # the encoders finish last
 
 
 class _MVFEXTrainFn(torch.autograd.Function):

@@ -1,0 +1,93 @@
+"""Data-parallel training step rehearsed with two ranks sharing ONE GPU (gloo backend; the real runs use RCCL, one GPU per
+rank): the stage-bucketed, overlapped gradient exchange must leave every rank with the average of the per-rank gradients,
+and both ranks must apply the same update."""
+import copy
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _build():
+    from egorear_amd import configs, synth
+    from egorear_amd.estimator import EgoPoseFormerMVFEX
+    net = EgoPoseFormerMVFEX(**copy.deepcopy(configs.pose3d_cfg("ego4view_rw")))
+    synth.load_synth(net, 42)
+    return net.to(DEV)
+
+
+def _data(rank):
+    from egorear_amd import synth
+    from egorear_amd.metrics import generate_target
+    B = 1
+    return (synth.synth_images(B, 4, seed=10 + rank).to(DEV), synth.synth_coord_trans_mat(B, seed=20 + rank).to(DEV),
+            synth.synth_gt_pose(B, seed=30 + rank).to(DEV), generate_target(synth.synth_joint_px(B, seed=40 + rank).to(DEV)).contiguous())
+
+
+def _sample(t, n=16):
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    v = f[::step][:n].float().cpu().numpy()
+    return np.pad(v, (0, n - len(v)))
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from egorear_amd import train
+        torch.cuda.set_device(0)
+        net = _build()
+        tr = train.Trainer(net)
+        tr.step(*_data(rank))
+        torch.cuda.synchronize()
+        res = {k: (float(v.double().norm()), _sample(v)) for k, v in tr.opt.gviews.items()}
+        par = {k: _sample(p) for k, p in net.named_parameters()}
+        out.put((rank, res, par, tr.opt.grad_norm()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_average_gradients_and_stay_in_sync():
+    from egorear_amd import train
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(2):
+        rank, res, par, gn = out.get(timeout=600)
+        got[rank] = (res, par, gn)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # both ranks hold the same reduced gradient and made the same update
+    assert abs(got[0][2] - got[1][2]) <= 1e-6 * got[0][2]
+    for k in got[0][1]:
+        np.testing.assert_array_equal(got[0][1][k], got[1][1][k], err_msg=k)
+    # and it is the mean of the two single-process gradients
+    ref = []
+    for r in range(2):
+        S, _ = train.forward_backward(_build(), *_data(r))
+        ref.append(S.pgrads)
+    torch.cuda.synchronize()
+    for k, (norm, samp) in got[0][0].items():
+        if k not in ref[0]:
+            assert norm == 0.0, k
+            continue
+        avg = 0.5 * (ref[0][k] + ref[1][k])
+        n_ref = float(avg.double().norm())
+        assert abs(norm - n_ref) <= 1e-4 * n_ref + 1e-7, (k, norm, n_ref)
+        np.testing.assert_allclose(samp, _sample(avg), rtol=1e-3, atol=1e-5 * max(n_ref, 1e-6), err_msg=k)
