@@ -18,7 +18,7 @@ TRAIN_EXPORTS = [
     "egr_gelu_f32", "egr_gelu_bwd_f32", "egr_rowmask_f32", "egr_fill_f32", "egr_maxpool_train_f32", "egr_maxpool_bwd_f32",
     "egr_upsample2x_bwd_f32", "egr_planes_to_nhwc_f32", "egr_nhwc_to_planes_f32", "egr_stem_im2col_f32", "egr_layernorm_bwd_f32", "egr_joint_mha_bwd_f32",
     "egr_msda_gather_bwd_f32", "egr_colsum_f32", "egr_fold_rows_f32", "egr_jqa_sum_bwd_f32", "egr_rownorm_loss_f32",
-    "egr_sumsq_f32", "egr_adamw_f32",
+    "egr_sumsq_f32", "egr_adamw_f32", "egr_repack_f32",   # the last one is bound in egorear_amd.repack
 ]
 
 
@@ -50,7 +50,8 @@ def _bind():
     lib.egr_sumsq_f32.argtypes = [vp, i64, vp, i32, vp]
     lib.egr_adamw_f32.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, vp]
     for name in TRAIN_EXPORTS:
-        getattr(lib, name).restype = C.c_int32 if name == "egr_bn_blocks" else C.c_int
+        if name != "egr_repack_f32":
+            getattr(lib, name).restype = C.c_int32 if name == "egr_bn_blocks" else C.c_int
 
 
 _bind()
