@@ -26,6 +26,64 @@ OUT = os.path.join(REPO, "tests", "golden")
 BATCH = 2
 
 
+def _record(st, net, losses, total, outs, prefix=""):
+    st.update({"loss_" + k: np.float64(v.item()) for k, v in losses.items()})
+    st["loss_total"] = np.float64(total.item())
+    for i, h in enumerate(outs):
+        st[f"hm{i}_sum"] = np.float64(h.detach().double().sum().item())
+        st[f"hm{i}_sq"] = np.float64((h.detach().double() ** 2).sum().item())
+    names, has, norms, samples = [], [], [], []
+    for k, p in net.named_parameters():
+        names.append(k)
+        has.append(p.grad is not None)
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        norms.append(g.double().norm().item())
+        samples.append(T.sample(g))
+    st["param_names"] = np.array(names)
+    st["grad_present"] = np.array(has)
+    st["grad_norm"] = np.array(norms, dtype=np.float64)
+    st["grad_samples"] = np.stack(samples)
+    bn_names, bn_vals = [], []
+    for k, b in net.named_buffers():
+        if "running_" in k or "num_batches_tracked" in k:
+            bn_names.append(k)
+            bn_vals.append(T.sample(b.float(), 8))
+    st["bn_names"], st["bn_samples"] = np.array(bn_names), np.stack(bn_vals)
+
+
+def heatmap_cases():
+    """The two heat-map training stages (pl_wrappers/egoposeformer/heatmap.py:94-110, heatmap_mvf_ex.py:104-127): MSELoss."""
+    with reference_importable():
+        from pose_estimation.models.estimator import EgoPoseFormerHeatmap, EgoPoseFormerHeatmapMVFEX
+        crit = torch.nn.MSELoss(reduction="mean")
+        gt_hm = T.synth_gt_heatmap(BATCH)
+        # ---- stage 1: one stereo heat-map estimator
+        net = EgoPoseFormerHeatmap(**copy.deepcopy(configs.heatmap_cfg()))
+        synth.load_synth(net, 42)
+        net.train()
+        img = synth.synth_images(BATCH, 2, seed=0)
+        hm = net(img)
+        loss = sum(crit(hm[:, v], gt_hm[:, v]) * T.W_HEATMAP for v in range(2))
+        loss.backward()
+        st = {}
+        _record(st, net, {"heatmap_loss_0": loss}, loss, [hm])
+        np.savez_compressed(os.path.join(OUT, "train_heatmap_s0.npz"), **st)
+        print("heatmap stage:", float(loss), "params without grad:", int((~st["grad_present"]).sum()))
+        # ---- stage 2: multi-view refinement on frozen (no_grad, train-mode) encoders
+        net = EgoPoseFormerHeatmapMVFEX(**copy.deepcopy(configs.heatmap_mvfex_cfg()))
+        synth.load_synth(net, 42)
+        net.train()
+        img = synth.synth_images(BATCH, 4, seed=0)
+        hms, feats = net(img)
+        losses = {f"heatmap_loss_{i}": sum(crit(h[:, v], gt_hm[:, v]) * T.W_HEATMAP for v in range(4)) for i, h in enumerate(hms[0:])}
+        total = sum(losses.values())
+        total.backward()
+        st = {}
+        _record(st, net, losses, total, hms)
+        np.savez_compressed(os.path.join(OUT, "train_mvfex_s0.npz"), **st)
+        print("mvfex stage:", {k: float(v) for k, v in losses.items()}, "params without grad:", int((~st["grad_present"]).sum()))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -87,3 +145,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+    heatmap_cases()

@@ -85,6 +85,45 @@ def forward_backward(sd: Dict[str, torch.Tensor], cams, img, ctm, gt_pose, gt_he
     return {k: float(v.detach()) for k, v in losses.items()}, grads, dict(upd), (preds, hms)
 
 
+def mse_heatmap_losses(hms, gt_heatmap, w_heatmap: float = W_HEATMAP) -> "OrderedDict[str, torch.Tensor]":
+    """pl_wrappers/egoposeformer/heatmap.py:94-110 (one heat-map set) and heatmap_mvf_ex.py:104-127 (all sets, the initial
+    one included): per set, the sum over views of nn.MSELoss(reduction="mean") * w_heatmap (get_loss :215-218 / :258-261)."""
+    d = OrderedDict()
+    for i, h in enumerate(hms):
+        V = h.shape[1]          # the stage-1 model sees one stereo pair: views [0, V) of the ground truth
+        d["heatmap_loss_%d" % i] = sum(torch.nn.functional.mse_loss(h[:, v], gt_heatmap[:, v]) * w_heatmap for v in range(V))
+    return d
+
+
+def forward_backward_heatmap(sd: Dict[str, torch.Tensor], img, gt_heatmap, param_names):
+    """Training forward/backward of EgoPoseFormerHeatmap as PoseHeatmapLightningModel.training_step runs it."""
+    leaves = {k: sd[k].detach().clone().requires_grad_(True) for k in param_names}
+    work = {"m." + k: v for k, v in sd.items()}
+    work.update({"m." + k: v for k, v in leaves.items()})
+    with O.bn_train() as upd, torch.enable_grad():
+        hm = O.heatmap_forward(work, "m", img)
+        losses = mse_heatmap_losses([hm], gt_heatmap)
+        sum(losses.values()).backward()
+    return ({k: float(v.detach()) for k, v in losses.items()}, {k: v.grad for k, v in leaves.items()},
+            {k[2:]: v for k, v in upd.items()}, [hm])
+
+
+MVFEX_HEATMAP_FLAGS = dict(full_training=False, use_pred_heatmap_init=False, no_detach_feat_init=False, detach_heatmap_feat=False)
+
+
+def forward_backward_mvfex(sd: Dict[str, torch.Tensor], img, gt_heatmap, param_names):
+    """Training forward/backward of EgoPoseFormerHeatmapMVFEX with the constructor defaults of the shipped
+    *_heatmap_mvfex-n1_jqa.yaml configs (encoders under no_grad but in train() mode, nothing detached downstream)."""
+    leaves = {k: sd[k].detach().clone().requires_grad_(True) for k in param_names}
+    work = dict(sd)
+    work.update(leaves)
+    with O.bn_train() as upd, torch.enable_grad():
+        hms, feats, _ = O.heatmap_mvfex_forward(work, "", img, **MVFEX_HEATMAP_FLAGS)
+        losses = mse_heatmap_losses(hms, gt_heatmap)
+        sum(losses.values()).backward()
+    return {k: float(v.detach()) for k, v in losses.items()}, {k: v.grad for k, v in leaves.items()}, dict(upd), hms
+
+
 def optimizer_step(params: Dict[str, torch.Tensor], grads: Dict[str, Optional[torch.Tensor]], state: Optional[dict] = None,
                    lr: float = LR, weight_decay: float = WEIGHT_DECAY, clip: float = CLIP_NORM):
     """clip_grad_norm_ + AdamW.step with the reference's two parameter groups.  Mutates `params` in place; parameters

@@ -73,3 +73,41 @@ def test_optimizer_step(step):
         np.testing.assert_allclose(d[ok], g["param_delta_samples"][i][ok], rtol=0, atol=2e-5, err_msg=k)
         if not g["grad_present"][i]:
             assert (d == 0).all(), k
+
+
+def _check_case(g, names, losses, grads, upd, hms):
+    for k, v in losses.items():
+        assert abs(v - float(g["loss_" + k])) <= 2e-5 * abs(float(g["loss_" + k])), k
+    for i, h in enumerate(hms):
+        assert abs(h.detach().double().sum().item() - float(g[f"hm{i}_sum"])) <= 2e-5 * h.numel()
+    assert list(g["param_names"]) == names
+    present = np.array([grads[k] is not None for k in names])
+    assert (present == g["grad_present"]).all(), [n for n, a, b in zip(names, present, g["grad_present"]) if a != b]
+    scale = float(g["grad_norm"].max())
+    for i, k in enumerate(names):
+        if present[i]:
+            gn = float(g["grad_norm"][i])
+            assert abs(grads[k].double().norm().item() - gn) <= 2e-4 * gn + 1e-7 * scale, k
+            np.testing.assert_allclose(T.sample(grads[k]), g["grad_samples"][i], rtol=2e-3, atol=2e-5 * max(gn, 1e-3), err_msg=k)
+    for k, ref in zip(g["bn_names"], g["bn_samples"]):
+        np.testing.assert_allclose(T.sample(upd[str(k)].float(), 8), ref, rtol=1e-5, atol=1e-6, err_msg=str(k))
+
+
+def test_heatmap_stage_training_matches_reference(golden_dir):
+    """Stage 1 of the reference's schedule (pl_wrappers/egoposeformer/heatmap.py): one stereo estimator, MSE loss."""
+    from egorear_amd.estimator import EgoPoseFormerHeatmap
+    net = EgoPoseFormerHeatmap(**copy.deepcopy(configs.heatmap_cfg()))
+    sd = synth.synth_state_dict(synth.spec_of(net), 42)
+    names = [k for k, _ in net.named_parameters()]
+    losses, grads, upd, hms = T.forward_backward_heatmap(sd, synth.synth_images(2, 2, seed=0), T.synth_gt_heatmap(2), names)
+    _check_case(np.load(os.path.join(golden_dir, "train_heatmap_s0.npz")), names, losses, grads, upd, hms)
+
+
+def test_mvfex_stage_training_matches_reference(golden_dir):
+    """Stage 2 (heatmap_mvf_ex.py): refiners + initial heat-map heads on encoders that run under no_grad in train() mode."""
+    from egorear_amd.estimator import EgoPoseFormerHeatmapMVFEX
+    net = EgoPoseFormerHeatmapMVFEX(**copy.deepcopy(configs.heatmap_mvfex_cfg()))
+    sd = synth.synth_state_dict(synth.spec_of(net), 42)
+    names = [k for k, _ in net.named_parameters()]
+    losses, grads, upd, hms = T.forward_backward_mvfex(sd, synth.synth_images(2, 4, seed=0), T.synth_gt_heatmap(2), names)
+    _check_case(np.load(os.path.join(golden_dir, "train_mvfex_s0.npz")), names, losses, grads, upd, hms)
