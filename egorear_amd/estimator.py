@@ -59,6 +59,9 @@ class EgoPoseFormerHeatmap(nn.Module):
     @_no_dynamo
     def forward(self, img, return_feat=False):
         from . import engine
+        if self.training:   # network.train() in PoseHeatmapLightningModel.training_step (pl_wrappers/egoposeformer/heatmap.py:95)
+            from . import train
+            return train.heatmap_training_forward(self, img, return_feat)
         _require_inference(self)
         return engine.heatmap_forward_api(self, img, return_feat)
 
@@ -155,6 +158,9 @@ class EgoPoseFormerHeatmapMVFEX(nn.Module):
     @_no_dynamo
     def forward(self, img, heatmap_for_anchor=None):
         from . import engine
+        if self.training:   # PoseHeatmapMVFEXLightningModel.training_step (pl_wrappers/egoposeformer/heatmap_mvf_ex.py:105)
+            from . import train
+            return train.heatmap_mvfex_training_forward(self, img, heatmap_for_anchor)
         _require_inference(self)
         return engine.heatmap_mvfex_forward_api(self, img, heatmap_for_anchor)
 

@@ -708,20 +708,22 @@ def conv_to_planes(S: Step, x: torch.Tensor, p: TPack, planes: torch.Tensor, B: 
     S.keep.append((x, planes))
 
 
-def heatmap_head_train(S: Step, seqs, x: torch.Tensor, planes: torch.Tensor, B: int, V: int):
-    """A heat-map head stack on *detached* features (heatmap_mvf_ex.py:273, :717-721): all layers but the last through
-    run_stack_train, the last 1x1 conv straight into the channel-major output."""
+def heatmap_head_train(S: Step, seqs, x: torch.Tensor, planes: torch.Tensor, B: int, V: int, need_dx_first: bool = False):
+    """A heat-map head stack (on *detached* features unless need_dx_first: heatmap_mvf_ex.py:273, :717-721): all layers but
+    the last through run_stack_train, the last 1x1 conv straight into the channel-major output."""
     body = [nn.Sequential(*list(s)[:-1]) for s in seqs]
-    y = run_stack_train(S, body, x, need_dx_first=False)
+    y = run_stack_train(S, body, x, need_dx_first=need_dx_first)
     conv_to_planes(S, y, S.pack([s[-1] for s in seqs]), planes, B, V)
 
 
 # ---- the four HeatmapMVF refiners ------------------------------------------------------------------------------------
 
 def refiners_train(S: Step, rs, B: int, V: int, hm_init: torch.Tensor, feat_all: torch.Tensor, s32_all: torch.Tensor, anchors, valid,
-                   hm_ref: torch.Tensor) -> torch.Tensor:
-    """heatmap_mvf_ex.py:652-731 for the G = V refiners in training mode.  hm_init, feat_all, s32_all are constants here
-    (detached in the reference).  Returns feat_ref (V*B, 64, 64, 128), which carries gradient back from the lifting head."""
+                   hm_ref: torch.Tensor, hm_grad: bool = False, detach_heatmap_feat: bool = True) -> torch.Tensor:
+    """heatmap_mvf_ex.py:652-731 for the G = V refiners in training mode.  feat_all, s32_all are constants here (detached or
+    produced under no_grad in the reference); hm_init too unless hm_grad (stage-2 training: the initial heat maps feed
+    heatmap_proj with gradient).  detach_heatmap_feat: the refined heat-map head sees detached refined features (:717-721).
+    Returns feat_ref (V*B, 64, 64, 128), which carries gradient back from the lifting head / the refined head."""
     G = len(rs)
     r0 = rs[0]
     J, C = r0.num_heatmap, r0.embed_dims
@@ -730,7 +732,7 @@ def refiners_train(S: Step, rs, B: int, V: int, hm_init: torch.Tensor, feat_all:
     dev = S.dev
     S.mark_stage(1)
     # --- JQA query: heatmap_proj.0 reads the (B, V, J, hw) heat maps in place, group g = view g
-    hp0 = S.pack([r.heatmap_proj[0] for r in rs], need_dx=False)
+    hp0 = S.pack([r.heatmap_proj[0] for r in rs], need_dx=hm_grad)
     hm_rows = Img(hm_init.view(B * V, J, 1, hw)[0::V])
     t4 = hip.conv2d(hm_rows, hp0.w, C, 1, 1, 1, 0, shift=hp0.bias, act=ACT_RELU, groups=G, gx=J * hw, workspace=S.ws, split_k=0).t   # (G*B, J, 1, C)
     t = t4.view(G * B * J, C)
@@ -745,6 +747,11 @@ def refiners_train(S: Step, rs, B: int, V: int, hm_init: torch.Tensor, feat_all:
             dw, db = hip.conv2d_wgrad(xg, Img(dz[g * B:(g + 1) * B]), 1, 1, 1, 0, S.ws, want_bias=True)
             S.pacc(hp0.wmeta[g][0][0], dw)
             S.pacc(hp0.bmeta[g][0][0], db)
+        if hm_grad:     # gradient w.r.t. the heat-map rows, back into the (B, V, J, H, W) layout (group g = view g)
+            dxr = hip.conv2d(Img(dz), hp0.wt, hw, 1, 1, 1, 0, transposed_out_hw=(J, 1), groups=G, workspace=S.ws, split_k=0).t
+            dhm = torch.empty_like(hm_init)
+            T.nhwc_to_planes(dxr.view(G * B, 1, J * hw), dhm, NMap(B, V * J * hw, J * hw), J * hw)
+            S.G.add(hm_init, dhm)
     S.tape.append(bwd_hp0)
     S.keep.append((t4, t))
     hm_embed = S.linear(t, S.pack([r.heatmap_proj[2] for r in rs]))
@@ -791,7 +798,7 @@ def refiners_train(S: Step, rs, B: int, V: int, hm_init: torch.Tensor, feat_all:
     off = S.conv(h0, S.pack([r.head_layers[0].head[3] for r in rs]), ACT_RELU)
     summed = S.add(off, None, b_const=ff)
     feat_ref = run_stack_train(S, [r.frame_feat_refined_proj_layers[0] for r in rs], summed)
-    heatmap_head_train(S, [r.conv_heatmap_layers[0] for r in rs], feat_ref, hm_ref, B, V)
+    heatmap_head_train(S, [r.conv_heatmap_layers[0] for r in rs], feat_ref, hm_ref, B, V, need_dx_first=not detach_heatmap_feat)
     return feat_ref
 
 
@@ -1138,3 +1145,128 @@ def mvfex_training_forward(net, img, ctm=None):
         net.__dict__["_egr_last_aux"] = aux
         B, J = img.shape[0], net.pose3d_estimator.num_joints
         return [preds[0][:, :3 * J].reshape(B, J, 3)] + [p[:, :3].reshape(B, J, 3) for p in preds[1:]], hms
+
+
+# --------------------------------------------------------------------------- the two heat-map training stages
+
+_FLAGS_POSE3D = (True, True, True, False)     # full_training, use_pred_heatmap_init, detach_heatmap_feat, no_detach_feat_init
+_FLAGS_STAGE2 = (False, False, False, False)  # constructor defaults = configs/*_heatmap_mvfex-n1_jqa.yaml
+
+
+def heatmap_forward_train(S: Step, net, img: torch.Tensor) -> torch.Tensor:
+    """EgoPoseFormerHeatmap.forward in training mode (egoposeformer_heatmap.py:29-44; stage 1 of the reference's schedule)."""
+    B, V = img.shape[:2]
+    img = img.contiguous()
+    feat, _ = backbone_train(S, [net.encoder], img, 0, V)
+    hm = torch.empty((B, V, net.num_heatmap, feat.shape[1], feat.shape[2]), device=img.device, dtype=torch.float32)
+    conv_to_planes(S, feat, S.pack([net.conv_heatmap], need_dx=not net.detach_heatmap_feat_init), hm, B, V,
+                   need_dx=not net.detach_heatmap_feat_init)
+    return hm
+
+
+def mvfex_heatmap_forward_train(S: Step, he, img: torch.Tensor):
+    """EgoPoseFormerHeatmapMVFEX.forward in training mode for the stage-2 configuration (heatmap_mvf_ex.py:236-352 with the
+    constructor defaults): encoders under no_grad but with train()-mode BatchNorm, initial heads and refiners trained, the
+    initial heat maps feed the refiners' heatmap_proj WITH gradient, refined heads see un-detached refined features.
+    Returns ([hm_init, hm_ref], feat_all, feat_ref)."""
+    flags = (he.full_training, he.use_pred_heatmap_init, he.detach_heatmap_feat, he.no_detach_feat_init)
+    if flags != _FLAGS_STAGE2 or he.use_1by1_conv:
+        raise NotImplementedError("egorear_amd.train: EgoPoseFormerHeatmapMVFEX trains standalone with the shipped stage-2 flags only "
+                                  "(full_training / use_pred_heatmap_init / detach_heatmap_feat / no_detach_feat_init all False)")
+    B, V = img.shape[:2]
+    img = img.contiguous()
+    H4, W4 = img.shape[3] // 4, img.shape[4] // 4
+    J = he.num_heatmap
+    front, back = he.heatmap_estimator_stereo_front, he.heatmap_estimator_stereo_back
+    rec = S.record
+    S.record = False                     # `with torch.no_grad():` around the encoders (:267-268); BatchNorm still updates its buffers
+    feat_all, s32_all = backbone_train(S, [front.encoder, back.encoder], img, 0, 2)
+    S.record = rec
+    hm_init = torch.empty((B, V, J, H4, W4), device=img.device, dtype=torch.float32)
+    heatmap_head_train(S, [he.conv_heatmap_layers_stereo_front, he.conv_heatmap_layers_stereo_back], feat_all, hm_init, B, V)
+    a, mv, vd, idx = hip.argmax_rows(hm_init, he.heatmap_threshold)
+    hm_ref = torch.empty_like(hm_init)
+    feat_ref = refiners_train(S, he.refiners(), B, V, hm_init, feat_all, s32_all, a.view(B, V, J, 2), vd.view(B, V, J), hm_ref,
+                              hm_grad=True, detach_heatmap_feat=False)
+    he.__dict__["_egr_last_aux"] = {"anchors_2d": a.view(B, V, J, 2), "anchors_valid": vd.view(B, V, J), "argmax_idx": idx.view(B, V, J),
+                                    "maxvals": mv.view(B, V, J)}
+    return [hm_init, hm_ref], feat_all, feat_ref
+
+
+class _HeatmapTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, img, *params):
+        S = Step(net, img.device)
+        hm = heatmap_forward_train(S, net, img)
+        ctx.S, ctx.hm, ctx.names = S, hm, [S.name(p) for p in params]
+        return hm
+
+    @staticmethod
+    def backward(ctx, g):
+        S = ctx.S
+        S.G.add(ctx.hm, g.to(torch.float32).contiguous())
+        _finish_backward(S)
+        pg = S.pgrads
+        ctx.S = None
+        return (None, None) + tuple(pg.get(k) for k in ctx.names)
+
+
+class _HeatmapMVFEXTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, he, img, *params):
+        from .engine import _vb_view
+        S = Step(he, img.device)
+        hms, feat_all, feat_ref = mvfex_heatmap_forward_train(S, he, img)
+        B, V = img.shape[:2]
+        fa, fr = _vb_view(feat_all, V, B), _vb_view(feat_ref, V, B)
+        ctx.S, ctx.hms, ctx.names = S, hms, [S.name(p) for p in params]
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(fa, fr)      # the stage-2 wrapper trains on the heat maps only
+        return hms[0], hms[1], fa, fr
+
+    @staticmethod
+    def backward(ctx, g0, g1, *_):
+        S = ctx.S
+        for h, g in zip(ctx.hms, (g0, g1)):
+            if g is not None:
+                S.G.add(h, g.to(torch.float32).contiguous())
+        _finish_backward(S)
+        pg = S.pgrads
+        ctx.S = None
+        return (None, None) + tuple(pg.get(k) for k in ctx.names)
+
+
+def _training_entry(net, img, fn, eager):
+    from .engine import _check_input, invalidate
+    _check_input(img, net)
+    invalidate(net)
+    params = [p for p in net.parameters()]
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        if not all(p.requires_grad for p in params):
+            raise NotImplementedError("egorear_amd.train: partially frozen parameter sets are not supported")
+        return fn.apply(net, img, *params)
+    with torch.no_grad():
+        S = Step(net, img.device)
+        S.record = False
+        return eager(S)
+
+
+def heatmap_training_forward(net, img, return_feat=False):
+    """EgoPoseFormerHeatmap.forward in train() mode -> heat maps (B, V, 15, 64, 64)."""
+    if return_feat:
+        raise NotImplementedError("egorear_amd.train: return_feat is an inference-time option")
+    return _training_entry(net, img, _HeatmapTrainFn, lambda S: heatmap_forward_train(S, net, img))
+
+
+def heatmap_mvfex_training_forward(he, img, heatmap_for_anchor=None):
+    """EgoPoseFormerHeatmapMVFEX.forward in train() mode -> ([hm_init, hm_refined], [feat_init, feat_refined])."""
+    if heatmap_for_anchor is not None:
+        raise NotImplementedError("egorear_amd.train: heatmap_for_anchor is an inference-time option")
+    from .engine import _vb_view
+    B, V = img.shape[:2]
+
+    def eager(S):
+        hms, fa, fr = mvfex_heatmap_forward_train(S, he, img)
+        return hms[0], hms[1], _vb_view(fa, V, B), _vb_view(fr, V, B)
+    h0, h1, fa, fr = _training_entry(he, img, _HeatmapMVFEXTrainFn, eager)
+    return [h0, h1], [fa, fr]

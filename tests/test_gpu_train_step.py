@@ -180,3 +180,57 @@ def test_refreshed_operand_buffers_equal_rebuilt_ones():
         assert torch.equal(p.w, w), k
         assert (b is None) == (p.bias is None) and (b is None or torch.equal(p.bias, b)), k
         assert (wt is None) == (p.wt is None) and (wt is None or torch.equal(p.wt, wt)), k
+
+
+def _check_stage(g, net, losses, hms):
+    from oracle.train_oracle import sample
+    for k, v in losses.items():
+        assert abs(float(v.detach()) - float(g["loss_" + k])) <= 1e-4 * abs(float(g["loss_" + k])), k
+    for i, h in enumerate(hms):
+        assert abs(h.detach().double().sum().item() - float(g[f"hm{i}_sum"])) <= 1e-4 * h.numel()
+    names = [k for k, _ in net.named_parameters()]
+    assert list(g["param_names"]) == names
+    present = np.array([p.grad is not None for _, p in net.named_parameters()])
+    assert (present == g["grad_present"]).all(), [n for n, a, b in zip(names, present, g["grad_present"]) if a != b]
+    bad = []
+    for i, (k, p) in enumerate(net.named_parameters()):
+        if p.grad is None:
+            continue
+        gn = float(g["grad_norm"][i])
+        err_s = np.abs(sample(p.grad) - g["grad_samples"][i]).max()
+        tol_s = 2e-3 * np.abs(g["grad_samples"][i]).max() + 4e-3 * max(gn, 1e-6) / np.sqrt(max(p.numel(), 1))
+        if abs(p.grad.double().norm().item() - gn) > 1e-3 * gn + 1e-9 or err_s > tol_s:
+            bad.append((k, p.grad.double().norm().item(), gn, float(err_s), float(tol_s)))
+    assert not bad, "\n".join(f"{k}: norm {a:.6g} vs {b:.6g}, sample err {e:.3g} (tol {t:.3g})" for k, a, b, e, t in bad[:30]) + f"\n{len(bad)} mismatched"
+    bufs = dict(net.named_buffers())
+    for k, ref in zip(g["bn_names"], g["bn_samples"]):
+        np.testing.assert_allclose(sample(bufs[str(k)].float(), 8), ref, rtol=2e-5, atol=2e-6, err_msg=str(k))
+
+
+def test_stage1_heatmap_training_dropin(golden_dir):
+    """PoseHeatmapLightningModel.training_step (heatmap.py:94-110): network.train(), MSE loss on the heat maps, backward."""
+    from egorear_amd import configs, synth
+    from egorear_amd.estimator import EgoPoseFormerHeatmap
+    from oracle import train_oracle as TO
+    net = EgoPoseFormerHeatmap(**copy.deepcopy(configs.heatmap_cfg()))
+    synth.load_synth(net, 42)
+    net = net.to(DEV).train()
+    hm = net(synth.synth_images(2, 2, seed=0).to(DEV))
+    losses = TO.mse_heatmap_losses([hm], TO.synth_gt_heatmap(2).to(DEV))
+    sum(losses.values()).backward()
+    _check_stage(np.load(os.path.join(golden_dir, "train_heatmap_s0.npz")), net, losses, [hm])
+
+
+def test_stage2_mvfex_training_dropin(golden_dir):
+    """PoseHeatmapMVFEXLightningModel.training_step (heatmap_mvf_ex.py:104-127): both heat-map sets, encoders under no_grad."""
+    from egorear_amd import configs, synth
+    from egorear_amd.estimator import EgoPoseFormerHeatmapMVFEX
+    from oracle import train_oracle as TO
+    net = EgoPoseFormerHeatmapMVFEX(**copy.deepcopy(configs.heatmap_mvfex_cfg()))
+    synth.load_synth(net, 42)
+    net = net.to(DEV).train()
+    hms, feats = net(synth.synth_images(2, 4, seed=0).to(DEV))
+    assert feats[0].shape == (2, 4, 128, 64, 64) and not feats[1].requires_grad
+    losses = TO.mse_heatmap_losses(hms, TO.synth_gt_heatmap(2).to(DEV))
+    sum(losses.values()).backward()
+    _check_stage(np.load(os.path.join(golden_dir, "train_mvfex_s0.npz")), net, losses, hms)
