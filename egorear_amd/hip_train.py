@@ -10,8 +10,7 @@ from typing import Optional
 
 import torch
 
-from . import hip
-from .hip import Img, NMap, _check, _cont, _launch, _p, _stream, lib
+from .hip import Img, NMap, _cont, _launch, _p, _stream, lib
 
 TRAIN_EXPORTS = [
     "egr_bn_blocks", "egr_bn_stats_f32", "egr_scale_shift_f32", "egr_bn_backward_f32", "egr_relu_bwd_f32", "egr_add_f32",

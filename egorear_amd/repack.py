@@ -3,7 +3,7 @@ kernels' operand layouts of one training step in a single launch."""
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Tuple
+from typing import List
 
 import numpy as np
 import torch

@@ -31,7 +31,7 @@ import torch.nn as nn
 from . import hip
 from . import hip_train as T
 from . import repack
-from .engine import _npad, _pad_rows, _pad_vec, _rows, pack_conv_weight, unpack_conv_weight
+from .engine import _npad, _pad_rows, _pad_vec, _rows
 from .hip import ACT_NONE, ACT_RELU, RES_BEFORE_ACT, RES_NONE, Img, NMap
 
 _WS_FLOATS = 72 << 20   # conv split-K / wgrad slab workspace (288 MB: one slab of mlp_pred.0's 2048 x 32768 gradient)
@@ -807,7 +807,6 @@ def refiners_train(S: Step, rs, B: int, V: int, hm_init: torch.Tensor, feat_all:
 def pose3d_train(S: Step, p3, feat_init: torch.Tensor, feat_ref: torch.Tensor, B: int, V: int, ctm):
     """EgoPoseFormerPose3D.forward (egoposeformer_mvf_ex.py:422-452) in training mode.  Returns the four predictions as
     channel-padded buffers [(B, 64) proposal, 3 x (B*16, 32)] whose first 48 / 3 columns are the coordinates."""
-    from .engine import _pack_pose3d  # camera records only
     dev = S.dev
     J = p3.num_joints
     hgt, wid = p3.feat_shape
