@@ -191,18 +191,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     }
 
     // partial tile -> slab [split][co][k]; C/D map: col = lane&31 (k column), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (co)
+    // (a lane's two K columns are adjacent: one 8-byte store; K is a multiple of 32, so the pair is in range together)
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+    for (int i = 0; i < FM; ++i) {
+        const int kcol = chunk0 * 32 + wn * 64 + l31 * 2;
+        if (kcol >= a.K) continue;
 #pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int kcol = chunk0 * 32 + wn * 64 + l31 * 2 + j;
-            if (kcol >= a.K) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + wm * TM + ((r & 3) + 8 * (r >> 2) + 4 * half) * FM + i;
-                if (co < a.cout) wsg[((int64_t)split * a.cout + co) * a.K + kcol] = acc[i][j][r];
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm * TM + ((r & 3) + 8 * (r >> 2) + 4 * half) * FM + i;
+            if (co < a.cout) {
+                f32x2 v = {acc[i][0][r], acc[i][1][r]};
+                *reinterpret_cast<f32x2*>(&wsg[((int64_t)split * a.cout + co) * a.K + kcol]) = v;
             }
         }
+    }
 }
 
 // Sum of the split slabs in a fixed order (deterministic).  A block owns 16 float4 outputs; 16 split lanes walk the slabs

@@ -8,12 +8,15 @@ import collections, csv, glob, json, sys
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)[0]
 per = collections.defaultdict(lambda: collections.defaultdict(float)); dur = collections.defaultdict(float); seen = set()
 for r in csv.DictReader(open(f)):
-    k = "conv_igemm" if "conv_igemm" in r["Kernel_Name"] else ("stem" if "stem_kernel" in r["Kernel_Name"] else "other")
+    n = r["Kernel_Name"]
+    k = "conv_igemm" if "conv_igemm" in n else ("conv_wgrad" if "conv_wgrad" in n else ("stem" if "stem_kernel" in n else "other"))
     per[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if (r["Dispatch_Id"]) not in seen:
         seen.add(r["Dispatch_Id"]); dur[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 out = {}
-for k in ("conv_igemm", "stem"):
+for k in ("conv_igemm", "conv_wgrad", "stem"):
+    if k not in per:
+        continue
     busy, gui = per[k]["SQ_VALU_MFMA_BUSY_CYCLES"], per[k]["GRBM_GUI_ACTIVE"]
     cycles = gui / 8.0
     out[k] = {"mfma_busy_simd_cycles": busy, "elapsed_cycles": cycles, "mfma_util": busy / (cycles * 1024.0),
