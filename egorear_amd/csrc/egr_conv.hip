@@ -650,7 +650,7 @@ extern "C" int egr_conv2d_nhwc_f32(const egr_conv_desc* dd, const float* x, cons
         if (a.Npad == 32) cfg = CFG_128x32;
         else if (a.M <= 4096) cfg = CFG_64x64;
         else if (a.Npad % 128 == 0) cfg = CFG_128x128;
-        else cfg = CFG_64x64;  // N = 64 / 192: measured faster than 256x64 and 128x64 (tools/conv_micro.py)
+        else cfg = CFG_64x64;  // N = 64 / 192: 128x64 wins the isolated micro-benchmark (+15 %) but not the pipeline (26.2 vs 26.0 ms); 256x64 runs at 1 workgroup/CU
     }
     const int bm = kBM[cfg], bn = kBN[cfg];
 
