@@ -38,6 +38,9 @@ DGRAD_CASES = [
     (3, 16, 16, 64, 128, 1, 2),
     (2, 8, 8, 128, 32, 1, 1),
     (5, 64, 64, 32, 64, 3, 2),      # many rows: 128x128 / 64x64 tile paths with halo masks
+    (2, 15, 17, 32, 64, 3, 2),      # odd sizes: the stride-2 parity-class split does not apply, generic gather path
+    (2, 16, 16, 64, 64, 3, 1),      # (duplicate geometry on purpose: class mode must leave stride 1 untouched)
+    (1, 8, 8, 512, 256, 3, 2),      # deep K (16 channel chunks x class taps)
 ]
 
 

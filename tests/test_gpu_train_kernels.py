@@ -253,7 +253,7 @@ def test_rownorm_loss(d, rows):
     g_ref, = torch.autograd.grad(loss_ref, pr)
     loss = torch.zeros(1, dtype=torch.float64, device=DEV)
     dp = T.rownorm_loss(pred.to(DEV), gt.to(DEV), d, 10.0, loss)
-    assert abs(float(loss) - float(loss_ref)) <= 1e-5 * abs(float(loss_ref))
+    assert abs(float(loss) - float(loss_ref.detach())) <= 1e-5 * abs(float(loss_ref.detach()))
     close(dp, g_ref, rel=1e-5)
 
 
@@ -275,3 +275,44 @@ def test_sumsq_and_adamw_match_torch():
             assert abs(math.sqrt(float(ss)) - float(total)) <= 1e-5 * float(total)
             T.adamw(p, gd, m, v, 1e-3, 0.9, 0.999, 1e-8, wd, step, ss, 5.0)
             close(p, ref.detach(), rel=2e-6, what=f"wd {wd} step {step}")
+
+
+def test_repack_descriptor_kinds():
+    """egr_repack_f32: forward operand, data-gradient operand, padded vectors and gradient un-packing, incl. channel slices,
+    row-concatenated sources and zero padding, against plain torch indexing."""
+    from egorear_amd import repack
+    from egorear_amd.engine import pack_conv_weight, unpack_conv_weight
+    cout, cin_tot, ci0, cin, kh = 40, 48, 16, 20, 3           # a 20-channel slice of a 48-channel 3x3 weight; everything ragged
+    taps, cin_pad, cout_pad = kh * kh, 32, 64
+    w = rnd(cout, cin_tot, kh, kh, seed=1).to(DEV)
+    bias = rnd(cout, seed=2).to(DEV)
+    tbl = repack.RepackTable(torch.device(DEV))
+    K = cin_pad * taps
+    fwd = torch.full((cout_pad, K), 7.0, device=DEV)
+    tbl.add(repack.FWD, w, fwd, 0, rows=cout, cin=cin, cin_tot=cin_tot, ci0=ci0, cin_pad=cin_pad, taps=taps, rows_pad=cout_pad, total=cout_pad * K)
+    Kt = cout_pad * taps
+    dg = torch.full((cin_pad, Kt), 7.0, device=DEV)
+    tbl.add(repack.DGRAD, w, dg, 0, rows=cout, cin=cin, cin_tot=cin_tot, ci0=ci0, cin_pad=cin_pad, taps=taps, rows_pad=cout_pad, k_off=0,
+            k_tot=cout_pad, total=cin_pad * Kt)
+    bp = torch.full((cout_pad,), 7.0, device=DEV)
+    tbl.add(repack.COPYPAD, bias, bp, 0, rows=cout, total=cout_pad)
+    # gradient side: a packed (cout, cin_pad/32, taps, 32) tensor back into the channel slice of an OIHW gradient
+    gpk = rnd(cout, K, seed=3).to(DEV)
+    gdst = torch.zeros(cout, cin_tot, kh, kh, device=DEV)
+    tbl.add(repack.UNPACK, gpk, gdst, 0, rows=cout, cin=cin, cin_tot=cin_tot, ci0=ci0, cin_pad=cin_pad, taps=taps, total=cout * cin * taps)
+    # row-concatenated linear sources into one data-gradient operand (the q|k|v projection)
+    qa, qb = rnd(32, 64, seed=4).to(DEV), rnd(48, 64, seed=5).to(DEV)
+    cat_t = torch.full((64, 96), 7.0, device=DEV)
+    tbl.add(repack.DGRAD, qa, cat_t, 0, rows=32, cin=64, cin_tot=64, cin_pad=64, taps=1, rows_pad=32, k_off=0, k_tot=96, total=64 * 32)
+    tbl.add(repack.DGRAD, qb, cat_t, 0, rows=48, cin=64, cin_tot=64, cin_pad=64, taps=1, rows_pad=64, k_off=32, k_tot=96, total=64 * 64)
+    tbl.run()
+    torch.cuda.synchronize()
+    wsl = torch.zeros(cout_pad, cin_pad, kh, kh, device=DEV)
+    wsl[:cout, :cin] = w[:, ci0:ci0 + cin]
+    assert torch.equal(fwd, pack_conv_weight(wsl))
+    assert torch.equal(dg, pack_conv_weight(wsl.transpose(0, 1).contiguous()))
+    assert torch.equal(bp[:cout], bias) and float(bp[cout:].abs().max()) == 0.0
+    ref = torch.zeros_like(gdst)
+    ref[:, ci0:ci0 + cin] = unpack_conv_weight(gpk, cin_pad, kh, kh)[:, :cin]
+    assert torch.equal(gdst, ref)
+    assert torch.equal(cat_t[:, :80], torch.cat([qa, qb], 0).t()) and float(cat_t[:, 80:].abs().max()) == 0.0
