@@ -14,7 +14,7 @@ constexpr int TH = 8, TW = 32;           // output tile
 constexpr int PH = 2 * TH + 5;           // 21 input rows
 constexpr int PW = 2 * TW + 5;           // 69 input cols
 constexpr int PWS = 72;                  // padded patch row stride
-constexpr int KTOT = 147, KPAD = 148, WS = 149;  // weight row stride 149: conflict-free column reads
+constexpr int KTOT = 147, KPAD = 148;   // the filter bank is staged k-major: s_w[k][64 channels]
 
 struct StemArgs {
     const float* x;
@@ -35,80 +35,120 @@ __device__ __forceinline__ constexpr int patch_off(int k) {
     return ci * PH * PWS + (r / 7) * PWS + (r % 7);
 }
 
-__global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
-    __shared__ float s_patch[3 * PH * PWS];
-    __shared__ float s_w[64 * WS];
+constexpr int PATCH = 3 * PH * PWS;                       // floats per staged patch
+constexpr int PLOADS = (3 * PH * PW + 255) / 256;         // patch elements per thread (17)
+
+// Persistent workgroups: the 64 x 147 filter bank is staged once per workgroup, which then walks tiles with stride
+// gridDim.x.  The next tile's input patch is fetched into registers before the MFMA loop of the current tile and
+// parked in the other LDS buffer afterwards, so its global-load latency hides under 296 MFMAs.
+__global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
+    __shared__ float s_patch[2][PATCH];
+    __shared__ __attribute__((aligned(16))) float s_w[KPAD * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    int bid = blockIdx.x;
     const int grp = blockIdx.y;  // grouped launch (e.g. the two stereo estimators)
     const int tpi = a.tiles_x * a.tiles_y;
-    const int n = bid / tpi;
-    int t = bid - n * tpi;
-    const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
-    const int oy0 = ty * TH, ox0 = tx * TW;
-    const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
-    const float* img = a.x + grp * a.gx + egr_map(a.xmap, n);
+    const int total = a.n * tpi;
+    const float* xg = a.x + grp * a.gx;
     const float* wpack = a.wpack + grp * 64 * KPAD;
     const float* scale = a.scale + grp * 64;
     const float* shift = a.shift + grp * 64;
     float* y = a.y + (int64_t)grp * a.n * a.ho * a.wo * 64;
 
-    for (int i = tid; i < 3 * PH * PW; i += 256) {
-        int ci = i / (PH * PW);
-        int r = i - ci * PH * PW;
-        int py = r / PW, px = r - py * PW;
-        int iy = iy0 + py, ix = ix0 + px;
-        float v = 0.f;
-        if (iy >= 0 && iy < a.h && ix >= 0 && ix < a.w) v = img[((int64_t)ci * a.h + iy) * a.w + ix];
-        s_patch[ci * PH * PWS + py * PWS + px] = v;
+    // per-thread patch slots: element i = tid + 256*u -> (ci, py, px) and its LDS offset (tile independent)
+    int p_lds[PLOADS], p_ci[PLOADS], p_py[PLOADS], p_px[PLOADS];
+#pragma unroll
+    for (int u = 0; u < PLOADS; ++u) {
+        const int i = tid + 256 * u;
+        const int ci = i / (PH * PW);
+        const int r = i - ci * PH * PW;
+        p_ci[u] = ci; p_py[u] = r / PW; p_px[u] = r - p_py[u] * PW;
+        p_lds[u] = (i < 3 * PH * PW) ? ci * PH * PWS + p_py[u] * PWS + p_px[u] : -1;
     }
+    auto fetch = [&](int tile, float (&v)[PLOADS]) {
+        const int n = tile / tpi;
+        const int t = tile - n * tpi;
+        const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+        const int iy0 = 2 * ty * TH - 3, ix0 = 2 * tx * TW - 3;
+        const float* img = xg + egr_map(a.xmap, n);
+#pragma unroll
+        for (int u = 0; u < PLOADS; ++u) {
+            const int iy = iy0 + p_py[u], ix = ix0 + p_px[u];
+            const bool ok = p_lds[u] >= 0 && iy >= 0 && iy < a.h && ix >= 0 && ix < a.w;
+            v[u] = ok ? img[((int64_t)p_ci[u] * a.h + iy) * a.w + ix] : 0.f;
+        }
+    };
+    auto park = [&](int buf, const float (&v)[PLOADS]) {
+#pragma unroll
+        for (int u = 0; u < PLOADS; ++u)
+            if (p_lds[u] >= 0) s_patch[buf][p_lds[u]] = v[u];
+    };
+
     for (int i = tid; i < 64 * KPAD; i += 256) {
         int co = i / KPAD, k = i - co * KPAD;
-        s_w[co * WS + k] = wpack[i];
+        s_w[k * 64 + co] = wpack[i];
+    }
+    float pv[PLOADS];
+    int tile = blockIdx.x;
+    if (tile < total) {
+        fetch(tile, pv);
+        park(0, pv);
     }
     __syncthreads();
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // wave w owns tile rows 2w and 2w+1 (fm = 0/1), lane -> column
     const int abase0 = (2 * (2 * wave)) * PWS + 2 * l31;
     const int abase1 = (2 * (2 * wave + 1)) * PWS + 2 * l31;
-    const int bbase0 = l31 * WS, bbase1 = (32 + l31) * WS;
-
+    // fragment j covers the channels co = 2*l31 + j: a lane's two B operands are adjacent (one ds_read_b64), and so are
+    // its two outputs per pixel (one 8-byte store, 256 contiguous bytes per pixel and half-wave)
+    float sc[2], sh[2];
 #pragma unroll
-    for (int s = 0; s < KPAD / 2; ++s) {
-        const int ao = half ? patch_off(2 * s + 1) : patch_off(2 * s);
-        const int k = 2 * s + half;
-        float a0 = s_patch[abase0 + ao], a1 = s_patch[abase1 + ao];
-        float b0 = s_w[bbase0 + k], b1 = s_w[bbase1 + k];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-    }
+    for (int j = 0; j < 2; ++j) { sc[j] = scale[2 * l31 + j]; sh[j] = shift[2 * l31 + j]; }
 
+    int buf = 0;
+    for (; tile < total; tile += gridDim.x, buf ^= 1) {
+        const int next = tile + gridDim.x;
+        if (next < total) fetch(next, pv);        // in flight during the MFMA loop below
+        const float* sp = s_patch[buf];
+        f32x16 acc[2][2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        int co = j * 32 + l31;
-        float sc = scale[co], sh = shift[co];
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KPAD / 2; ++s) {
+            const int ao = half ? patch_off(2 * s + 1) : patch_off(2 * s);
+            const int k = 2 * s + half;
+            float a0 = sp[abase0 + ao], a1 = sp[abase1 + ao];
+            const f32x2 bb = *reinterpret_cast<const f32x2*>(&s_w[k * 64 + 2 * l31]);
+            const float b0 = bb[0], b1 = bb[1];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        const int n = tile / tpi;
+        const int t = tile - n * tpi;
+        const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+        const int oy0 = ty * TH, ox0 = tx * TW;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            int oy = oy0 + 2 * wave + i;
+            const int oy = oy0 + 2 * wave + i;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                float v = acc[i][j][r] * sc + sh;
-                v = v > 0.f ? v : 0.f;
-                y[(((int64_t)n * a.ho + oy) * a.wo + ox) * 64 + co] = v;
+                const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                f32x2 v;
+                v[0] = acc[i][0][r] * sc[0] + sh[0];
+                v[1] = acc[i][1][r] * sc[1] + sh[1];
+                v[0] = v[0] > 0.f ? v[0] : 0.f;
+                v[1] = v[1] > 0.f ? v[1] : 0.f;
+                *reinterpret_cast<f32x2*>(&y[(((int64_t)n * a.ho + oy) * a.wo + ox) * 64 + 2 * l31]) = v;
             }
         }
+        if (next < total) park(buf ^ 1, pv);
+        __syncthreads();                           // next patch visible; everybody is done reading the current one
     }
 }
 
@@ -125,8 +165,12 @@ extern "C" int egr_stem_conv7x7_f32(const float* x, egr_nmap xmap, int32_t n, in
     a.wpack = wpack; a.scale = scale; a.shift = shift; a.y = y;
     a.tiles_x = a.wo / TW; a.tiles_y = a.ho / TH;
     a.gx = gx;
-    int64_t blocks = (int64_t)n * a.tiles_x * a.tiles_y;
-    if (blocks >= (1LL << 31)) return EGR_EINVAL;
+    int64_t tiles = (int64_t)n * a.tiles_x * a.tiles_y;
+    if (tiles >= (1LL << 31)) return EGR_EINVAL;
+    // persistent: two workgroups per CU (74 KiB LDS each) across the 256 CUs, shared by the groups
+    int64_t blocks = 512 / groups;
+    if (blocks < 1) blocks = 1;
+    if (blocks > tiles) blocks = tiles;
     hipLaunchKernelGGL(stem_kernel, dim3((unsigned)blocks, (unsigned)groups), dim3(256), 0, (hipStream_t)stream, a);
     return egr_launch_status();
 }
