@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=12)
     ap.add_argument("--no-train", action="store_true", help="skip the training-step leg (config 5)")
     ap.add_argument("--train-batch", type=int, default=32, help="frames per GPU per optimisation step (config 5: 256 / 8)")
-    ap.add_argument("--train-steps", type=int, default=5)
+    ap.add_argument("--train-steps", type=int, default=10)
     return ap.parse_args()
 
 
@@ -125,7 +125,7 @@ def train_leg(args, dev, rank: int, world: int, backend: str):
     def run():
         state["terms"], _ = tr.step(img, ctm, gt_pose, gt_hm)
 
-    elapsed = timed_steps(run, args.train_steps, 2, torch.cuda.synchronize, dev if backend == "nccl" else None)
+    elapsed = timed_steps(run, args.train_steps, 3, torch.cuda.synchronize, dev if backend == "nccl" else None)
     if rank != 0:
         return None
     kernels = {}
@@ -271,7 +271,10 @@ def main():
     if not args.no_train:
         _log("training-step leg")
         try:
-            del graph
+            import gc
+            del graph, run, step, net, img     # hand the inference state (graph pool, weights, inputs) back before the step allocates
+            gc.collect()
+            torch.cuda.empty_cache()
             train = train_leg(args, dev, rank, world, backend)
         except Exception as exc:  # the inference line must survive a failure here
             train = {"error": f"{type(exc).__name__}: {exc}"}
