@@ -140,3 +140,35 @@ def optimizer_step(params: Dict[str, torch.Tensor], grads: Dict[str, Optional[to
     for k, p in ps.items():
         params[k] = p.data
     return float(total_norm), opt
+
+
+class OracleTrainer:
+    """Several optimisation steps of config 5 exactly as Lightning would run the reference: persistent torch.optim.AdamW
+    (two parameter groups), clip_grad_norm_, the warm-up hook of pose_3d_mvf_ex.py:212-217 (applied AFTER each step: update
+    t + 1 runs at lr * min(1, (t + 1) / warmup_iters)), and BatchNorm buffers carried from step to step."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], param_names, cams, lr: float = LR, weight_decay: float = WEIGHT_DECAY,
+                 clip: float = CLIP_NORM, warmup_iters: int = WARMUP_ITERS):
+        self.sd = {k: v.clone() for k, v in sd.items()}
+        self.names, self.cams, self.lr, self.clip, self.warmup = list(param_names), cams, lr, clip, warmup_iters
+        self.params = OrderedDict((k, torch.nn.Parameter(self.sd[k].clone())) for k in self.names)
+        no_decay = [p for k, p in self.params.items() if is_no_decay(k)]
+        other = [p for k, p in self.params.items() if not is_no_decay(k)]
+        self.opt = torch.optim.AdamW([{"params": no_decay, "weight_decay": 0.0}, {"params": other, "weight_decay": weight_decay}], lr=lr)
+        self.global_step = 0
+
+    def step(self, img, ctm, gt_pose, gt_heatmap):
+        for k, p in self.params.items():
+            self.sd[k] = p.data
+        losses, grads, upd, _ = forward_backward(self.sd, self.cams, img, ctm, gt_pose, gt_heatmap, self.names)
+        self.sd.update(upd)                                   # running statistics / num_batches_tracked of the training forward
+        for k, p in self.params.items():
+            p.grad = grads[k]
+        total_norm = float(torch.nn.utils.clip_grad_norm_(list(self.params.values()), self.clip))
+        self.opt.step()
+        self.global_step += 1
+        if self.global_step < self.warmup:                    # optimizer_step hook, after optimizer.step()
+            scale = min(1.0, float(self.global_step + 1) / float(self.warmup))
+            for pg in self.opt.param_groups:
+                pg["lr"] = scale * self.lr
+        return losses, total_norm

@@ -234,3 +234,44 @@ def test_stage2_mvfex_training_dropin(golden_dir):
     losses = TO.mse_heatmap_losses(hms, TO.synth_gt_heatmap(2).to(DEV))
     sum(losses.values()).backward()
     _check_stage(np.load(os.path.join(golden_dir, "train_mvfex_s0.npz")), net, losses, hms)
+
+
+def test_three_native_steps_track_the_reference_optimiser():
+    """Three consecutive native steps (operand refresh, BatchNorm buffers, AdamW moments, the warm-up rule: update 1 at the
+    full lr, update t >= 2 at lr * t / 500) against the oracle driving torch.optim.AdamW the way Lightning drives it."""
+    from egorear_amd import configs, synth, train
+    from egorear_amd.estimator import EgoPoseFormerMVFEX
+    from oracle import egorear_oracle as O
+    from oracle import train_oracle as TO
+    calib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "egorear_amd", "calib", "ego4view")
+    net = EgoPoseFormerMVFEX(**copy.deepcopy(configs.pose3d_cfg("ego4view_rw")))
+    sd = synth.load_synth(net, 42)
+    names = [k for k, _ in net.named_parameters()]
+    ref = TO.OracleTrainer({k: v.clone() for k, v in sd.items()}, names, O.make_cameras("ego4view_rw", calib))
+    net = net.to(DEV)
+    tr = train.Trainer(net)
+    B = 2
+    for t in range(3):
+        img, ctm = synth.synth_images(B, 4, seed=t), synth.synth_coord_trans_mat(B, seed=50 + t)
+        gp, gh = synth.synth_gt_pose(B, seed=60 + t), TO.synth_gt_heatmap(B)
+        o_losses, o_norm = ref.step(img, ctm, gp, gh)
+        terms, _ = tr.step(img.to(DEV), ctm.to(DEV), gp.to(DEV), gh.to(DEV))
+        total, o_total = float(terms.sum()), sum(o_losses.values())
+        assert abs(total - o_total) <= 5e-4 * o_total, (t, total, o_total)          # later steps see the earlier updates
+        assert abs(tr.opt.grad_norm() - o_norm) <= 2e-3 * o_norm, (t, tr.opt.grad_norm(), o_norm)
+    assert abs(tr.opt.lr_at(2) - 1e-3 * 2 / 500) < 1e-12 and tr.opt.lr_at(1) == 1e-3
+    # Adam's first update moves every element by ~lr * sign(g): where g is rounding noise (exactly-zero gradients such as
+    # k_proj.bias, weights that only ever see zero inputs) the sign is arbitrary, so compare the bulk, not the maximum
+    fr = []
+    for k, p in net.named_parameters():
+        r = ref.params[k].data
+        fr.append((float(((p.detach().cpu() - r).abs() > 2e-4).float().mean()), k))
+    fr.sort(reverse=True)
+    bad = [(f, k) for f, k in fr if f > 0.02 and "k_proj.bias" not in k]
+    assert not bad, bad[:10]
+    bufs = dict(net.named_buffers())
+    for k in ("heatmap_estimator.heatmap_estimator_stereo_front.encoder.backbone.layer_s2.1.running_var",
+              "heatmap_estimator.heatmap_estimator_stereo_back.encoder.backbone.layer_s32.1.bn2.running_mean"):
+        np.testing.assert_allclose(bufs[k].cpu().numpy(), ref.sd[k].numpy(), rtol=2e-3, atol=1e-5)
+    nbt = "heatmap_estimator.heatmap_estimator_stereo_front.encoder.backbone.layer_s2.1.num_batches_tracked"
+    assert int(bufs[nbt]) == int(ref.sd[nbt]) == int(sd[nbt]) + 3
