@@ -56,8 +56,11 @@ class RepackTable:
             blocks[k:k + n, 0] = i
             blocks[k:k + n, 1] = np.arange(n, dtype=np.int64) * _BLOCK
             k += n
-        self.table = torch.from_numpy(arr.view(np.uint8).copy()).to(self.dev)
-        self.blocks = torch.from_numpy(blocks).to(self.dev)
+        # pinned staging + asynchronous upload: a pageable copy would drain the stream (the host would wait for the whole
+        # reverse pass before it could enqueue the optimiser); the pinned tensors stay alive with the table
+        self._host = (torch.from_numpy(arr.view(np.uint8).copy()).pin_memory(), torch.from_numpy(blocks).pin_memory())
+        self.table = self._host[0].to(self.dev, non_blocking=True)
+        self.blocks = self._host[1].to(self.dev, non_blocking=True)
         self.n_blocks = int(blocks.shape[0])
 
     def run(self):

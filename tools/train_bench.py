@@ -37,10 +37,14 @@ def main():
         terms, _ = tr.step(img, ctm, gt_pose, gt_hm)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    host = 0.0
     for _ in range(a.steps):
+        h0 = time.perf_counter()
         terms, _ = tr.step(img, ctm, gt_pose, gt_hm)
+        host += time.perf_counter() - h0          # time the host needs to ENQUEUE a step (no sync inside)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
+    print(f"host enqueue time {host / a.steps * 1e3:.2f} ms/step")
     print(f"batch {B}: {dt * 1e3:.2f} ms/step, {B / dt:.1f} frames/s, loss {float(terms.sum()):.4f}, mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     # per-kernel breakdown of one step
     hip.PROFILE = []
