@@ -115,7 +115,7 @@ def train_leg(args, dev, rank: int, world: int, backend: str):
     net = EgoPoseFormerMVFEX(**copy.deepcopy(configs.pose3d_cfg("ego4view_rw")))
     synth.load_synth(net, 42)
     net = net.to(dev)
-    tr = train.Trainer(net)
+    tr = train.Trainer(net, use_graph=(world == 1))   # one process: the whole step replays as one hipGraph after two eager steps
     img = synth.synth_images(B, 4, seed=4321 + rank).to(dev)
     ctm = synth.synth_coord_trans_mat(B, seed=77 + rank).to(dev)
     gt_pose = synth.synth_gt_pose(B, seed=99 + rank).to(dev)
@@ -129,9 +129,9 @@ def train_leg(args, dev, rank: int, world: int, backend: str):
     if rank != 0:
         return None
     kernels = {}
-    if world == 1:   # per-kernel breakdown of one more step (single process only: the step contains a collective otherwise)
+    if world == 1:   # per-kernel breakdown of one more (eager, instrumented) step; single process only: no collective inside
         hip.PROFILE = []
-        run()
+        tr._run(img, ctm, gt_pose, gt_hm, update=True)
         torch.cuda.synchronize()
         prof, hip.PROFILE = hip.PROFILE, None
         for name, s, e, flops, nbytes, _tag in prof:
@@ -144,7 +144,8 @@ def train_leg(args, dev, rank: int, world: int, backend: str):
            "steps": args.train_steps, "batch_per_gpu": B, "global_batch": B * world, "dtype": "f32", "data": "synthetic",
            "workload": "ego4view_rw_pose3d fine-tune step (config 5): train-mode BatchNorm, MPJPE x4 + heat-map row-norm x2 losses, "
                        "all 126 M parameters, gradient-norm clip 5.0, AdamW(1e-3, wd 5e-4, two groups)",
-           "parallelism": f"dp{world}: frames sharded, one flat-gradient all-reduce per step" if world > 1 else "single GPU",
+           "parallelism": f"dp{world}: frames sharded, stage-bucketed gradient all-reduce overlapped with backward" if world > 1 else "single GPU",
+           "launch": "hipGraph replay" if tr.graph is not None else "eager",
            "loss_total": round(float(state["terms"].sum()), 4)}
     if kernels:
         leg["kernel_ms"] = {n: round(v["ms"], 3) for n, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])[:12]}

@@ -642,14 +642,16 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* g, int64_t n4, 
 }
 
 __global__ void zero_double_kernel(double* p) { *p = 0.0; }
+__global__ void set4_kernel(float* dst, float a, float b, float c, float d) { dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d; }
 
 // torch.optim.AdamW single-tensor update: p *= 1 - lr*wd; m = lerp(m, g, 1-b1); v = b2 v + (1-b2) g^2;
 // p -= (lr / bc1) * m / (sqrt(v)/sqrt(bc2) + eps), with g pre-scaled by the clip_grad_norm_ coefficient.
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, int64_t n4, float lr, float b1,
                                                     float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                                                    const double* sumsq, float clip) {
+                                                    const double* sumsq, float clip, const float* hyper) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n4) return;
+    if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2_sqrt = hyper[2]; }
     float coef = 1.f;
     if (sumsq) {
         const float total = (float)sqrt(*sumsq);
@@ -974,6 +976,21 @@ extern "C" int egr_adamw_f32(float* p, const float* g, float* m, float* v, int64
     const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
     const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     hipLaunchKernelGGL(adamw_kernel, dim3(nblocks(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, lr, beta1, beta2,
-                       eps, weight_decay, bc1, bc2_sqrt, grad_sumsq, clip);
+                       eps, weight_decay, bc1, bc2_sqrt, grad_sumsq, clip, (const float*)nullptr);
+    return egr_launch_status();
+}
+
+extern "C" int egr_set4_f32(float* dst, float a, float b, float c, float d, void* stream) {
+    if (!dst) return EGR_ENULL;
+    hipLaunchKernelGGL(set4_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dst, a, b, c, d);
+    return egr_launch_status();
+}
+
+extern "C" int egr_adamw_dev_f32(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float beta1,
+                                 float beta2, float eps, float weight_decay, const double* grad_sumsq, float clip, void* stream) {
+    if (!p || !g || !m || !v || !hyper) return EGR_ENULL;
+    if (n <= 0 || n % 4 != 0 || !aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v)) return EGR_EINVAL;
+    hipLaunchKernelGGL(adamw_kernel, dim3(nblocks(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, 0.f, beta1, beta2,
+                       eps, weight_decay, 1.f, 1.f, grad_sumsq, clip, hyper);
     return egr_launch_status();
 }

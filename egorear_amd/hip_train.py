@@ -17,7 +17,7 @@ TRAIN_EXPORTS = [
     "egr_gelu_f32", "egr_gelu_bwd_f32", "egr_rowmask_f32", "egr_fill_f32", "egr_maxpool_train_f32", "egr_maxpool_bwd_f32",
     "egr_upsample2x_bwd_f32", "egr_planes_to_nhwc_f32", "egr_nhwc_to_planes_f32", "egr_stem_im2col_f32", "egr_layernorm_bwd_f32", "egr_joint_mha_bwd_f32",
     "egr_msda_gather_bwd_f32", "egr_colsum_f32", "egr_fold_rows_f32", "egr_jqa_sum_bwd_f32", "egr_rownorm_loss_f32",
-    "egr_sumsq_f32", "egr_adamw_f32", "egr_repack_f32",   # the last one is bound in egorear_amd.repack
+    "egr_sumsq_f32", "egr_adamw_f32", "egr_adamw_dev_f32", "egr_set4_f32", "egr_repack_f32",   # the last one is bound in egorear_amd.repack
 ]
 
 
@@ -48,6 +48,8 @@ def _bind():
     lib.egr_rownorm_loss_f32.argtypes = [vp, vp, i64, i32, i32, i64, i64, f32, vp, vp, vp]
     lib.egr_sumsq_f32.argtypes = [vp, i64, vp, i32, vp]
     lib.egr_adamw_f32.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, vp]
+    lib.egr_set4_f32.argtypes = [vp, f32, f32, f32, f32, vp]
+    lib.egr_adamw_dev_f32.argtypes = [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp, f32, vp]
     for name in TRAIN_EXPORTS:
         if name != "egr_repack_f32":
             getattr(lib, name).restype = C.c_int32 if name == "egr_bn_blocks" else C.c_int
@@ -386,3 +388,21 @@ def adamw(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr
         _dense(t, "adamw operand")
     _launch("egr_adamw_f32", lib.egr_adamw_f32, _p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, weight_decay, step,
             _p(grad_sumsq, torch.float64) if grad_sumsq is not None else None, clip, _stream(), nbytes=28.0 * n)
+
+
+def adamw_dev(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, hyper: torch.Tensor, beta1: float, beta2: float,
+              eps: float, weight_decay: float, grad_sumsq: Optional[torch.Tensor], clip: float):
+    """adamw() with {lr, 1 - beta1^t, sqrt(1 - beta2^t)} read from the 3-float device tensor `hyper`."""
+    n = p.numel()
+    if g.numel() != n or m.numel() != n or v.numel() != n or hyper.numel() < 3 or hyper.dtype != torch.float32:
+        raise RuntimeError("egorear_amd.train.adamw_dev: size mismatch")
+    for t in (p, g, m, v, hyper):
+        _dense(t, "adamw operand")
+    _launch("egr_adamw_dev_f32", lib.egr_adamw_dev_f32, _p(p), _p(g), _p(m), _p(v), n, _p(hyper), beta1, beta2, eps, weight_decay,
+            _p(grad_sumsq, torch.float64) if grad_sumsq is not None else None, clip, _stream(), nbytes=28.0 * n)
+
+
+def set4(dst: torch.Tensor, a: float, b: float, c: float, d: float = 0.0):
+    if dst.numel() < 4 or dst.dtype != torch.float32:
+        raise RuntimeError("egorear_amd.train.set4: a 4-float device tensor expected")
+    _launch("egr_set4_f32", lib.egr_set4_f32, _p(_dense(dst, "dst")), float(a), float(b), float(c), float(d), _stream())

@@ -236,6 +236,7 @@ class Step:
 
     def finish_param_grads(self):
         self.gtable.run()
+        self.keep.append(self.gtable)       # a captured step replays the table's pinned upload: it must outlive this call
         self.gtable = repack.RepackTable(self.dev)
         for name, g in self.pextra.items():
             self.gdst(name).copy_(g.reshape(self.pshapes[name]))
@@ -1004,6 +1005,7 @@ class FusedAdamW:
                 p.data = self.flat_p[o:o + n].view(p.shape)
                 self.gviews[k] = self.flat_g[o:o + n].view(p.shape)
         self.sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)        # {lr, 1 - b1^t, sqrt(1 - b2^t)} of the coming update
         self.steps = 0
         self.lr_scale_epoch = 1.0            # MultiStepLR(lr_decay_epochs, 0.1) factor, set by the caller per epoch
 
@@ -1033,35 +1035,55 @@ class FusedAdamW:
         if h is not None:
             self.pending.append(h)
 
-    def step(self, have) -> None:
-        """`have`: names whose gradient views were written this step.  Every stage must have been reduced (reduce_stage)."""
+    def begin_update(self):
+        """Count the coming update and put its step-dependent scalars where the kernels read them (device memory, so the
+        same enqueued / captured launches serve every step)."""
         self.steps += 1
+        t = self.steps
+        # by kernel argument, not by a pinned-buffer copy: the host may be several replays ahead of the device
+        T.set4(self.hyper, self.lr_at(t), 1.0 - self.betas[0] ** t, math.sqrt(1.0 - self.betas[1] ** t))
+
+    def enqueue_update(self, have) -> None:
+        """sumsq + clip + AdamW launches for the names whose gradient views were written (every stage already reduced)."""
         for h in self.pending:
             h.wait()
         self.pending = []
         runs = self._runs(have)
         for i, (o, n, _) in enumerate(runs):
             T.sumsq(self.flat_g[o:o + n], self.sumsq, accumulate=i > 0)
-        lr = self.lr_at(self.steps)
         for o, n, decay in runs:
-            T.adamw(self.flat_p[o:o + n], self.flat_g[o:o + n], self.m[o:o + n], self.v[o:o + n], lr, self.betas[0], self.betas[1], self.eps,
-                    self.wd if decay else 0.0, self.steps, self.sumsq, self.clip)
+            T.adamw_dev(self.flat_p[o:o + n], self.flat_g[o:o + n], self.m[o:o + n], self.v[o:o + n], self.hyper, self.betas[0], self.betas[1],
+                        self.eps, self.wd if decay else 0.0, self.sumsq, self.clip)
+
+    def step(self, have) -> None:
+        """`have`: names whose gradient views were written this step.  Every stage must have been reduced (reduce_stage)."""
+        self.begin_update()
+        self.enqueue_update(have)
 
     def grad_norm(self) -> float:
         return float(torch.sqrt(self.sumsq))
 
 
 class Trainer:
-    """The native optimisation step of config 5: forward (training mode) + losses + backward + (all-reduce) + clip + AdamW."""
+    """The native optimisation step of config 5: forward (training mode) + losses + backward + (all-reduce) + clip + AdamW.
+
+    use_graph: after two eager steps the whole step (~2600 kernel launches and copies) is captured into ONE hipGraph on
+    static input buffers and replayed, which takes the host out of the loop (eager: ~40 ms of enqueue work per 56 ms
+    step).  Single-process only; with a process group the step stays eager (the all-reduce is not captured)."""
 
     def __init__(self, net: nn.Module, lr: float = 1e-3, weight_decay: float = 5e-4, clip: float = 5.0, warmup_iters: int = 500,
-                 w_mpjpe: float = W_MPJPE, w_heatmap: float = W_HEATMAP, process_group=None):
+                 w_mpjpe: float = W_MPJPE, w_heatmap: float = W_HEATMAP, process_group=None, use_graph: bool = False):
         self.net = net
         self.opt = FusedAdamW(net, lr, weight_decay, clip, warmup_iters, process_group=process_group)
         self.w_mpjpe, self.w_heatmap = w_mpjpe, w_heatmap
+        self.use_graph = use_graph
+        self.graph = None
+        self._eager_done = 0
+        self._static = None
+        self._graph_out = None
+        self._graph_step = None     # keeps the captured step's tensors / pinned tables alive
 
-    def step(self, img, ctm, gt_pose, gt_heatmap):
-        """Returns (loss terms (6,) float64 device tensor, outputs).  Parameters are updated in place."""
+    def _run(self, img, ctm, gt_pose, gt_heatmap, update: bool):
         net = self.net
         S = Step(net, img.device)
         S.gviews = self.opt.gviews
@@ -1072,11 +1094,49 @@ class Trainer:
             preds, hms, aux = forward_train(S, net, img, ctm)
             loss_and_seed(S, preds, hms, gt_pose, gt_heatmap, self.w_mpjpe, self.w_heatmap, grad_scale=grad_seed_scale(self.opt.pg))
             _finish_backward(S)
-            self.opt.step(S.pgrads.keys())
+            if update:
+                self.opt.begin_update()
+            self.opt.enqueue_update(S.pgrads.keys())
+        return S, (preds, hms, aux)
+
+    def _invalidate(self):
         from .engine import invalidate
-        for m in (net, net.heatmap_estimator, net.pose3d_estimator):
+        for m in (self.net, self.net.heatmap_estimator, self.net.pose3d_estimator):
             invalidate(m)
-        return S.loss_terms, (preds, hms, aux)
+
+    def step(self, img, ctm, gt_pose, gt_heatmap):
+        """Returns (loss terms (6,) float64 device tensor, outputs).  Parameters are updated in place."""
+        from .dist import world_size
+        if self.graph is not None:
+            same = all(a.shape == b.shape for a, b in zip(self._static, (img, ctm, gt_pose, gt_heatmap)))
+            if same:
+                for dst, src in zip(self._static, (img, ctm, gt_pose, gt_heatmap)):
+                    dst.copy_(src, non_blocking=True)
+                self.opt.begin_update()
+                self.graph.replay()
+                self._invalidate()
+                return self._graph_out
+        if self.use_graph and self.graph is None and self._eager_done >= 2 and world_size(self.opt.pg) == 1 and ctm is not None:
+            try:
+                self._capture(img, ctm, gt_pose, gt_heatmap)
+            except Exception:      # capture is an optimisation: any refusal leaves the eager path in charge
+                self.graph, self.use_graph = None, False
+                torch.cuda.synchronize()
+            else:
+                return self.step(img, ctm, gt_pose, gt_heatmap)
+        S, outs = self._run(img, ctm, gt_pose, gt_heatmap, update=True)
+        self._eager_done += 1
+        self._invalidate()
+        return S.loss_terms, outs
+
+    def _capture(self, img, ctm, gt_pose, gt_heatmap):
+        dev = img.device
+        self._static = [t.detach().to(device=dev, dtype=torch.float32).clone().contiguous() for t in (img, ctm, gt_pose, gt_heatmap)]
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="relaxed"):
+            S, outs = self._run(*self._static, update=False)       # recorded, not executed: no update is counted
+        self.graph, self._graph_step, self._graph_out = g, S, (S.loss_terms, outs)
 
 
 # --------------------------------------------------------------------------- autograd bridge (drop-in for the wrapper)

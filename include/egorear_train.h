@@ -109,6 +109,13 @@ int egr_rownorm_loss_f32(const float* pred, const float* gt, int64_t rows, int32
  * the clip coefficient min(1, clip/(sqrt(*sumsq)+1e-6)) is read from the device, so no host sync sits between backward
  * and the update.  `step` is the 1-based update count. */
 int egr_sumsq_f32(const float* g, int64_t n, double* out, int32_t accumulate, void* stream);
+/* dst[0..3] = {a, b, c, d}: scalars travel as kernel arguments, so a host that runs many steps ahead of the device cannot
+ * overwrite a value before it is consumed (a pinned-buffer copy could). */
+int egr_set4_f32(float* dst, float a, float b, float c, float d, void* stream);
+/* as egr_adamw_f32 with the step-dependent scalars read from device memory: hyper = {lr, 1 - beta1^t, sqrt(1 - beta2^t)}
+ * (a captured hipGraph of the whole step replays with fresh values written into that buffer). */
+int egr_adamw_dev_f32(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float beta1, float beta2,
+                      float eps, float weight_decay, const double* grad_sumsq, float clip, void* stream);
 int egr_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int32_t step, const double* grad_sumsq, float clip, void* stream);
 

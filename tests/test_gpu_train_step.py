@@ -275,3 +275,31 @@ def test_three_native_steps_track_the_reference_optimiser():
         np.testing.assert_allclose(bufs[k].cpu().numpy(), ref.sd[k].numpy(), rtol=2e-3, atol=1e-5)
     nbt = "heatmap_estimator.heatmap_estimator_stereo_front.encoder.backbone.layer_s2.1.num_batches_tracked"
     assert int(bufs[nbt]) == int(ref.sd[nbt]) == int(sd[nbt]) + 3
+
+
+def test_graphed_training_step_follows_the_eager_trajectory():
+    """Trainer(use_graph=True) captures the whole step into one hipGraph after two eager steps; replayed steps must follow
+    the eager trainer's trajectory (same data, same initial weights), including the step-dependent AdamW scalars that are
+    read from device memory."""
+    from egorear_amd import configs, synth, train
+    from egorear_amd.estimator import EgoPoseFormerMVFEX
+    from oracle import train_oracle as TO
+
+    def make(use_graph):
+        net = EgoPoseFormerMVFEX(**copy.deepcopy(configs.pose3d_cfg("ego4view_rw")))
+        synth.load_synth(net, 42)
+        return train.Trainer(net.to(DEV), use_graph=use_graph)
+    eager, graphed = make(False), make(True)
+    B = 2
+    gh = TO.synth_gt_heatmap(B).to(DEV)
+    for t in range(5):
+        args = (synth.synth_images(B, 4, seed=t).to(DEV), synth.synth_coord_trans_mat(B, seed=50 + t).to(DEV), synth.synth_gt_pose(B, seed=60 + t).to(DEV), gh)
+        le, _ = eager.step(*args)
+        lg, _ = graphed.step(*args)
+        torch.cuda.synchronize()
+        assert abs(float(le.sum()) - float(lg.sum())) <= 1e-5 * abs(float(le.sum())), (t, float(le.sum()), float(lg.sum()))
+    assert graphed.graph is not None, "capture was refused"
+    assert graphed.opt.steps == eager.opt.steps == 5
+    for (k, p), (_, q) in zip(eager.net.named_parameters(), graphed.net.named_parameters()):
+        if "k_proj.bias" not in k:
+            assert float(((p - q).abs() > 2e-4).float().mean()) < 0.02, k

@@ -21,13 +21,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph")
     a = ap.parse_args()
     dev = "cuda:0"
     net = EgoPoseFormerMVFEX(**copy.deepcopy(configs.pose3d_cfg("ego4view_rw")))
     synth.load_synth(net, 42)
     net = net.to(dev)
-    tr = train.Trainer(net)
+    tr = train.Trainer(net, use_graph=a.graph)
     B = a.batch
     img = synth.synth_images(B, 4, seed=1234).to(dev)
     ctm = synth.synth_coord_trans_mat(B).to(dev)
@@ -48,7 +49,7 @@ def main():
     print(f"batch {B}: {dt * 1e3:.2f} ms/step, {B / dt:.1f} frames/s, loss {float(terms.sum()):.4f}, mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     # per-kernel breakdown of one step
     hip.PROFILE = []
-    tr.step(img, ctm, gt_pose, gt_hm)
+    tr._run(img, ctm, gt_pose, gt_hm, update=True)      # eager and instrumented even when the timed steps were graph replays
     torch.cuda.synchronize()
     prof, hip.PROFILE = hip.PROFILE, None
     agg = collections.OrderedDict()
