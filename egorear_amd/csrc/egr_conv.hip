@@ -61,6 +61,7 @@ struct ConvArgs {
     const float* res;
     const float* rowscale;
     const uint8_t* rowmask;
+    const float* mask;   // data gradient behind a ReLU: output *= [mask > 0]; same layout / offsets as y (NULL = off)
     float* y;
     float* ws;
     int M, Npad, K;
@@ -439,6 +440,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             if (shg) sh[e] = shg[co + e];
         }
 
+    if (a.mask) {  // dx = (acc [+ res]) * [mask > 0]  (the host guarantees the 16-byte path, no scale/shift/activation)
+        const float* const maskg = a.mask + grp * d.gy;
+#pragma unroll 8
+        for (int it = 0; it < BM / RPI; ++it) {
+            const int row = row0 + it * RPI;
+            const int yo = s_yoff[row];
+            if (yo < 0) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(&sC[row * P::CS + cq * 4]);
+            if (d.res_mode) v += *reinterpret_cast<const f32x4*>(resg + (int64_t)s_roff[row] + co);
+            const f32x4 mk = *reinterpret_cast<const f32x4*>(maskg + (int64_t)yo + co);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+            *reinterpret_cast<f32x4*>(yg + (int64_t)yo + co) = v;
+        }
+        return;
+    }
+
     if (vec && !rsg && !rmg) {
         // fast path (every conv of the CNN stages): 16-byte accesses, activation / residual mode resolved at compile
         // time so the row loop is branch-free straight-line code
@@ -582,10 +600,9 @@ extern "C" int egr_conv_force_config(int cfg) {
     return 0;
 }
 
-extern "C" int egr_conv2d_nhwc_f32(const egr_conv_desc* dd, const float* x, const float* w, const float* scale,
-                                   const float* shift, const float* res, const float* rowscale,
-                                   const uint8_t* rowmask, float* y, float* workspace, size_t workspace_floats,
-                                   void* stream) {
+static int conv_run(const egr_conv_desc* dd, const float* x, const float* w, const float* scale, const float* shift, const float* res,
+                    const float* rowscale, const uint8_t* rowmask, const float* mask, float* y, float* workspace,
+                    size_t workspace_floats, void* stream) {
     if (!dd || !x || !w || !y) return EGR_ENULL;
     ConvArgs a;
     a.d = *dd;
@@ -613,6 +630,7 @@ extern "C" int egr_conv2d_nhwc_f32(const egr_conv_desc* dd, const float* x, cons
 
     a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.res = res; a.rowscale = rowscale; a.rowmask = rowmask;
     a.y = y; a.ws = workspace;
+    a.mask = mask;
     a.dbg = g_dbg;
     a.M = (int)M64;
     a.Npad = (d.cout + 31) / 32 * 32;
@@ -643,6 +661,12 @@ extern "C" int egr_conv2d_nhwc_f32(const egr_conv_desc* dd, const float* x, cons
     if (d.res_mode)
         a.vec_ok = a.vec_ok && (d.ldr % 4 == 0) && (((uintptr_t)res & 15) == 0) &&
                    ((d.rmap.stride_inner | d.rmap.stride_outer) % 4 == 0);
+    if (mask) {  // masked data gradient: plain 16-byte epilogue only
+        if (!a.vec_ok || d.cout % 4 != 0 || scale || shift || rowscale || rowmask || d.act != EGR_ACT_NONE || d.out_nchw ||
+            d.res_mode == EGR_RES_AFTER_ACT || ((uintptr_t)mask & 15))
+            return EGR_EINVAL;
+        d.split_k = 1;   // the mask is applied in the tile epilogue, not in the split-K reduction
+    }
 
     // ---- tile configuration
     int cfg = g_force_cfg;
@@ -692,4 +716,17 @@ extern "C" int egr_conv2d_nhwc_f32(const egr_conv_desc* dd, const float* x, cons
         rc = egr_launch_status();
     }
     return rc;
+}
+
+extern "C" int egr_conv2d_nhwc_f32(const egr_conv_desc* dd, const float* x, const float* w, const float* scale,
+                                   const float* shift, const float* res, const float* rowscale,
+                                   const uint8_t* rowmask, float* y, float* workspace, size_t workspace_floats,
+                                   void* stream) {
+    return conv_run(dd, x, w, scale, shift, res, rowscale, rowmask, nullptr, y, workspace, workspace_floats, stream);
+}
+
+extern "C" int egr_conv2d_masked_f32(const egr_conv_desc* dd, const float* x, const float* w, const float* res, const float* mask,
+                                     float* y, float* workspace, size_t workspace_floats, void* stream) {
+    if (!mask) return EGR_ENULL;
+    return conv_run(dd, x, w, nullptr, nullptr, res, nullptr, nullptr, mask, y, workspace, workspace_floats, stream);
 }

@@ -23,7 +23,7 @@ EXPORTS = [
     "egr_conv2d_nhwc_f32", "egr_stem_conv7x7_f32", "egr_maxpool_nhwc_f32", "egr_upsample2x_nhwc_f32",
     "egr_avgpool_nhwc_f32", "egr_argmax_rows_f32", "egr_layernorm_f32", "egr_joint_mha_f32", "egr_msda_gather_f32",
     "egr_fisheye_project_f32", "egr_linear_smallk_f32", "egr_jqa_sum_f32", "egr_tokens_to_nhwc_f32", "egr_version",
-    "egr_device_arch", "egr_conv_force_config", "egr_preprocess_u8_f32", "egr_pose_metrics_f32", "egr_gt_heatmap_f32", "egr_conv_debug_stamps", "egr_conv2d_wgrad_f32",
+    "egr_device_arch", "egr_conv_force_config", "egr_preprocess_u8_f32", "egr_pose_metrics_f32", "egr_gt_heatmap_f32", "egr_conv_debug_stamps", "egr_conv2d_wgrad_f32", "egr_conv2d_masked_f32",
 ]
 
 
@@ -68,6 +68,7 @@ def _load() -> C.CDLL:
     lib.egr_version.restype = C.c_char_p
     lib.egr_device_arch.argtypes = [C.c_char_p, i32]
     lib.egr_conv_force_config.argtypes = [i32]
+    lib.egr_conv2d_masked_f32.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.egr_conv2d_wgrad_f32.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, C.c_size_t, i32, vp]
     lib.egr_gt_heatmap_f32.argtypes = [vp, i32, C.c_double, i32, i32, vp, vp, vp]
     lib.egr_pose_metrics_f32.argtypes = [vp, vp, i32, i32, f32, i32, vp, vp, vp]
@@ -168,7 +169,8 @@ def conv2d(x: Img, w: torch.Tensor, cout: int, kh: int, kw: int, stride: int, pa
            out: Optional[Img] = None, out_nchw: Optional[torch.Tensor] = None, ymap: Optional[NMap] = None,
            xmap: Optional[NMap] = None, rmap: Optional[NMap] = None, workspace: Optional[torch.Tensor] = None,
            split_k: int = 1, groups: int = 1, gx: Optional[int] = None, gy: Optional[int] = None,
-           gr: Optional[int] = None, grs: int = 0, grm: int = 0, transposed_out_hw: Optional[tuple] = None) -> Optional[Img]:
+           gr: Optional[int] = None, grs: int = 0, grm: int = 0, transposed_out_hw: Optional[tuple] = None,
+           mask: Optional[Img] = None) -> Optional[Img]:
     """Implicit-GEMM conv / linear.  Output goes to `out` (NHWC Img, maybe a channel slice), or to the raw
     tensor `out_nchw` (channel-major planes placed by `ymap`), or to a fresh NHWC tensor.
 
@@ -245,6 +247,17 @@ def conv2d(x: Img, w: torch.Tensor, cout: int, kh: int, kw: int, stride: int, pa
     if rowscale is not None and rowscale.numel() < (groups - 1) * grs + M or rowmask is not None and rowmask.numel() < (groups - 1) * grm + M:
         raise RuntimeError("egorear_amd.conv2d: rowscale/rowmask shorter than M")
     ws_ptr, ws_n = (None, 0) if workspace is None else (_p(workspace), workspace.numel())
+    if mask is not None:   # output *= [mask > 0]; mask has the output's dense layout
+        if out_nchw is not None or scale is not None or shift is not None or rowscale is not None or rowmask is not None or act != ACT_NONE:
+            raise RuntimeError("egorear_amd.conv2d: mask goes with a plain NHWC data gradient only")
+        if (mask.n, mask.h, mask.w, mask.c) != (groups * x.n, ho, wo, cout) or not mask.t.is_contiguous() or ret is None or not ret.t.is_contiguous():
+            raise RuntimeError("egorear_amd.conv2d: mask must be dense and shaped like the output")
+        _launch("egr_conv2d_nhwc_f32", lib.egr_conv2d_masked_f32, C.byref(d), _p(x.t), _p(w), _p(res.t) if res is not None else None,
+                _p(mask.t), yptr, ws_ptr, ws_n, _stream(),
+                flops=2.0 * M * cout * K * groups / (stride * stride if transposed_out_hw is not None else 1),
+                nbytes=4.0 * groups * (2 * M * cout + x.n * x.h * x.w * x.c + cout * K),
+                tag=f"{'T ' if transposed_out_hw is not None else ''}masked G{groups} M{M} N{cout} K{K} k{kh}s{stride} cin{x.c}" if PROFILE is not None else "")
+        return ret
     _launch("egr_conv2d_nhwc_f32", lib.egr_conv2d_nhwc_f32, C.byref(d), _p(x.t), _p(w), _p(scale), _p(shift),
             _p(res.t) if res is not None else None, _p(rowscale), _p(rowmask, torch.uint8), yptr, ws_ptr, ws_n, _stream(),
             flops=2.0 * M * cout * K * groups / (stride * stride if transposed_out_hw is not None else 1), nbytes=4.0 * groups * (M * cout + x.n * x.h * x.w * x.c + cout * K),

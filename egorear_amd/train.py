@@ -172,6 +172,15 @@ class _Grads:
 
     def __init__(self):
         self.g: Dict[int, torch.Tensor] = {}
+        self.gm: Dict[int, torch.Tensor] = {}   # contributions to post-ReLU tensors that already carry the [y > 0] mask
+
+    def add_masked(self, t: torch.Tensor, g: torch.Tensor):
+        k = id(t)
+        old = self.gm.get(k)
+        self.gm[k] = g if old is None else T.add(old, g)
+
+    def pop_masked(self, t: torch.Tensor) -> Optional[torch.Tensor]:
+        return self.gm.pop(id(t), None)
 
     def add(self, t: torch.Tensor, g: torch.Tensor):
         if g.shape != t.shape:
@@ -213,6 +222,7 @@ class Step:
         self.cache = _get_cache(net, device)
         if self.cache.ready:
             self.cache.refresh()   # every operand buffer of the step from the current parameters: one launch
+        self.relu_out = set()  # ids of tensors produced by a fused ReLU: conv data gradients into them apply the mask themselves
         self.record = True     # False: evaluate without taping (constant sub-graphs)
         self.loss_terms = None
 
@@ -257,6 +267,27 @@ class Step:
             fn()
         self.tape = []
 
+    def grad_behind_relu(self, y: torch.Tensor) -> Optional[torch.Tensor]:
+        """Total gradient w.r.t. the pre-activation of a ReLU output y: the contributions that were masked at their source
+        (conv data gradients, see _dgrad) plus the [y > 0]-masked rest."""
+        dy, dzm = self.G.pop(y), self.G.pop_masked(y)
+        if dy is None:
+            return dzm
+        dz = T.relu_bwd(dy, y)
+        return dz if dzm is None else T.add(dz, dzm)
+
+    def _dgrad(self, p: "TPack", x: torch.Tensor, dz: torch.Tensor, h: int, w: int):
+        """Data gradient of a conv into its input x, accumulated with what x has received so far.  When x came out of a
+        fused ReLU the launch applies that ReLU's mask itself (egr_conv2d_masked_f32) and the result goes to the masked store."""
+        prev = self.G.pop(x)
+        kw = dict(transposed_out_hw=(h, w), groups=p.groups, res=Img(prev) if prev is not None else None,
+                  res_mode=RES_BEFORE_ACT if prev is not None else RES_NONE, workspace=self.ws, split_k=0)
+        if id(x) in self.relu_out:
+            dx = hip.conv2d(Img(dz), p.wt, p.cin_pad, p.kh, p.kw, p.stride, p.pad, mask=Img(x), **kw).t
+            self.G.add_masked(x, dx)
+        else:
+            self.G.g[id(x)] = hip.conv2d(Img(dz), p.wt, p.cin_pad, p.kh, p.kw, p.stride, p.pad, **kw).t
+
     # ---- conv / linear ------------------------------------------------------------------------------------------
     def pack(self, mods: Sequence[nn.Module], need_dx=True) -> TPack:
         m0 = mods[0]
@@ -299,22 +330,20 @@ class Step:
         hip.conv2d(Img(x), p.w, p.cout, p.kh, p.kw, p.stride, p.pad, shift=p.bias, act=act, res=Img(res) if res is not None else None,
                    res_mode=RES_BEFORE_ACT if res is not None else RES_NONE, out=yo, workspace=self.ws, split_k=0, groups=p.groups)
 
+        if act == ACT_RELU and cw == p.cout:
+            self.relu_out.add(id(y))
+
         def bwd():
-            dy = self.G.pop(y)
-            if dy is None:
+            dz = self.grad_behind_relu(y) if act == ACT_RELU else self.G.pop(y)
+            if dz is None:
                 return
-            dz = T.relu_bwd(dy, y) if act == ACT_RELU else dy
             if res is not None:
                 self.G.add(res, dz)
             if dz.shape[-1] != p.cout_pad:
                 raise RuntimeError("egorear_amd.train: gradient of a narrow conv output must arrive channel-padded")
             self._wgrad(p, x, dz)
             if need_dx:
-                prev = self.G.pop(x)
-                dx = hip.conv2d(Img(dz), p.wt, p.cin_pad, p.kh, p.kw, p.stride, p.pad, transposed_out_hw=(h, w), groups=p.groups,
-                                res=Img(prev) if prev is not None else None,
-                                res_mode=RES_BEFORE_ACT if prev is not None else RES_NONE, workspace=self.ws, split_k=0).t
-                self.G.g[id(x)] = dx
+                self._dgrad(p, x, dz, h, w)
         if self.record:
             self.tape.append(bwd)
         self.keep.append((x, y))
@@ -356,11 +385,21 @@ class Step:
                 b.running_var.copy_(rv[g])
                 b.num_batches_tracked += 1
 
+        if relu:
+            self.relu_out.add(id(y))
+
         def bwd():
             dy = self.G.pop(y)
-            if dy is None:
+            dzm = self.G.pop_masked(y) if relu else None
+            if dy is None and dzm is None:
                 return
-            dx, dgam, dbet, dz = T.bn_backward(ctx, dy, y if relu else None, self.bnws, want_dz=res is not None)
+            if dzm is not None:      # (part of) the gradient arrived already masked: finish the sum, no mask inside the kernels
+                if dy is not None:
+                    dzm = T.add(dzm, T.relu_bwd(dy, y))
+                dx, dgam, dbet, _ = T.bn_backward(ctx, dzm, None, self.bnws, want_dz=False)
+                dz = dzm
+            else:
+                dx, dgam, dbet, dz = T.bn_backward(ctx, dy, y if relu else None, self.bnws, want_dz=res is not None)
             c_ = dgam.shape[1]
             for g, b in enumerate(bns):
                 self.gtable.add(repack.COPYPAD, dgam, self.gdst(self.name(b.weight)), 0, rows=c_, total=c_, src_off=g * c_)
@@ -389,11 +428,19 @@ class Step:
 
     def upsample(self, x: torch.Tensor, relu: bool = False) -> torch.Tensor:
         y = hip.upsample2x(Img(x), relu=relu).t
+        if relu:
+            self.relu_out.add(id(y))
 
         def bwd():
             dy = self.G.pop(y)
+            dzm = self.G.pop_masked(y) if relu else None
+            if dzm is None:
+                if dy is not None:
+                    self.G.add(x, T.upsample2x_bwd(dy, y if relu else None))   # the ReLU mask is applied inside the adjoint
+                return
             if dy is not None:
-                self.G.add(x, T.upsample2x_bwd(dy, y if relu else None))
+                dzm = T.add(dzm, T.relu_bwd(dy, y))
+            self.G.add(x, T.upsample2x_bwd(dzm, None))
         if self.record:
             self.tape.append(bwd)
         self.keep.append((x, y))
@@ -701,10 +748,7 @@ def conv_to_planes(S: Step, x: torch.Tensor, p: TPack, planes: torch.Tensor, B: 
         dz = T.planes_to_nhwc(d, NMap(B, V * plane, plane), n, p.cout, h * w, p.cout_pad).view(n, h, w, p.cout_pad)
         S._wgrad(p, x, dz)
         if need_dx:
-            prev = S.G.pop(x)
-            dx = hip.conv2d(Img(dz), p.wt, p.cin_pad, 1, 1, 1, 0, transposed_out_hw=(h, w), groups=p.groups, res=Img(prev) if prev is not None else None,
-                            res_mode=RES_BEFORE_ACT if prev is not None else RES_NONE, workspace=S.ws, split_k=0).t
-            S.G.g[id(x)] = dx
+            S._dgrad(p, x, dz, h, w)
     S.tape.append(bwd)
     S.keep.append((x, planes))
 

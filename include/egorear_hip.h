@@ -88,6 +88,12 @@ int egr_conv2d_nhwc_f32(const egr_conv_desc* d, const float* x, const float* w,
                         const uint8_t* rowmask /* per m, NULL = keep; 0 -> row written as 0 */,
                         float* y, float* workspace, size_t workspace_floats, void* stream);
 
+/* Data gradient behind a ReLU (training row): the conv of `d` (normally in transposed mode) with y = (conv [+ res]) * [mask > 0],
+ * mask laid out exactly like y (the forward activation the ReLU produced).  Fuses torch's threshold_backward into the
+ * data-gradient launch of the layer above.  No scale / shift / activation; res (may be NULL) is added before the mask. */
+int egr_conv2d_masked_f32(const egr_conv_desc* d, const float* x, const float* w, const float* res, const float* mask, float* y,
+                          float* workspace, size_t workspace_floats, void* stream);
+
 /* Weight (and bias) gradient of the conv / linear layer described by `d` (forward geometry; d->groups same-shape problems
  * in one launch: x + g*gx, dy + g*gy, dw + g*gw, db + g*gp), the weight-side half of the training row: dw[co][(ci/32, kh, kw, ci%32)] (+)= sum over output pixels of dy[m][co] * im2col(x)[m][k],
  * db[co] (+)= sum_m dy[m][co] (db may be NULL).  dw is in the packed weight layout of egr_conv2d_nhwc_f32.  The pixels are

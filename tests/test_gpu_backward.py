@@ -121,3 +121,24 @@ def test_conv_wgrad_grouped_launch():
         dw_ref, db_ref = torch.autograd.grad(y, (wt, b), dy[g * n:(g + 1) * n].double())
         close(unpack_conv_weight(dw[g], cin, k, k), dw_ref, rel=3e-5)
         close(db[g], db_ref, rel=3e-5)
+
+
+def test_masked_data_gradient_fuses_the_relu_backward():
+    """egr_conv2d_masked_f32: dx = (dgrad(dy) + prev) * [x > 0] in one launch (stride 1 and the stride-2 parity classes, grouped)."""
+    from egorear_amd import hip
+    for (G, n, h, cin, cout, k, s) in ((1, 2, 16, 64, 128, 3, 1), (2, 2, 32, 64, 64, 3, 2), (1, 3, 8, 128, 32, 1, 1)):
+        pad = k // 2
+        ho = (h + 2 * pad - k) // s + 1
+        xs = rnd(G * n, h, h, cin, seed=31)                      # the forward activation (post-ReLU: about half non-positive)
+        prev = rnd(G * n, h, h, cin, seed=32)
+        dy = rnd(G * n, ho, ho, cout, seed=33)
+        wts = [rnd(cout, cin, k, k, seed=34 + g, scale=1.0 / math.sqrt(cin * k * k)) for g in range(G)]
+        wt = torch.stack([pack_w_dgrad(w) for w in wts]) if G > 1 else pack_w_dgrad(wts[0])
+        out = hip.conv2d(hip.Img(dy.to(DEV)), wt.to(DEV), cin, k, k, s, pad, transposed_out_hw=(h, h), groups=G,
+                         res=hip.Img(prev.to(DEV)), res_mode=hip.RES_BEFORE_ACT, mask=hip.Img(xs.to(DEV)))
+        for g in range(G):
+            xr = torch.zeros(n, cin, h, h, dtype=torch.float64, requires_grad=True)
+            y = F.conv2d(xr, wts[g].double(), None, s, pad)
+            (dx_ref,) = torch.autograd.grad(y, xr, dy[g * n:(g + 1) * n].permute(0, 3, 1, 2).double())
+            ref = (dx_ref.permute(0, 2, 3, 1) + prev[g * n:(g + 1) * n].double()) * (xs[g * n:(g + 1) * n] > 0)
+            close(out.t[g * n:(g + 1) * n], ref)
