@@ -303,7 +303,8 @@ def stem(img: torch.Tensor, view0: int, nviews: int, wpack, scale, shift, groups
     if Cc != 3:
         raise RuntimeError("egorear_amd.stem: 3-channel input expected")
     _cont(img, "input image batch")
-    if view0 + groups * nviews > V or wpack.numel() != groups * 64 * 148 or scale.numel() != groups * 64 or shift.numel() != groups * 64:
+    raw = scale is None and shift is None          # training mode: bare convolution
+    if view0 + groups * nviews > V or wpack.numel() != groups * 64 * 148 or (not raw and (scale.numel() != groups * 64 or shift.numel() != groups * 64)):
         raise RuntimeError("egorear_amd.stem: views / weights mismatch")
     n = nviews * B
     y = torch.empty((groups * n, H // 2, W // 2, 64), device=img.device, dtype=torch.float32)

@@ -15,7 +15,7 @@ from .hip import Img, NMap, _cont, _launch, _p, _stream, lib
 TRAIN_EXPORTS = [
     "egr_bn_blocks", "egr_bn_stats_f32", "egr_scale_shift_f32", "egr_bn_backward_f32", "egr_relu_bwd_f32", "egr_add_f32",
     "egr_gelu_f32", "egr_gelu_bwd_f32", "egr_rowmask_f32", "egr_fill_f32", "egr_maxpool_train_f32", "egr_maxpool_bwd_f32",
-    "egr_upsample2x_bwd_f32", "egr_planes_to_nhwc_f32", "egr_nhwc_to_planes_f32", "egr_stem_im2col_f32", "egr_layernorm_bwd_f32", "egr_joint_mha_bwd_f32",
+    "egr_upsample2x_bwd_f32", "egr_stem_wgrad_f32", "egr_planes_to_nhwc_f32", "egr_nhwc_to_planes_f32", "egr_stem_im2col_f32", "egr_layernorm_bwd_f32", "egr_joint_mha_bwd_f32",
     "egr_msda_gather_bwd_f32", "egr_colsum_f32", "egr_fold_rows_f32", "egr_jqa_sum_bwd_f32", "egr_rownorm_loss_f32",
     "egr_sumsq_f32", "egr_adamw_f32", "egr_adamw_dev_f32", "egr_set4_f32", "egr_repack_f32",   # the last one is bound in egorear_amd.repack
 ]
@@ -38,6 +38,7 @@ def _bind():
     lib.egr_upsample2x_bwd_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
     lib.egr_planes_to_nhwc_f32.argtypes = [vp, i32, i64, i64, vp, i32, i32, i32, i32, vp]
     lib.egr_nhwc_to_planes_f32.argtypes = [vp, vp, i32, i64, i64, i32, i32, i32, i32, vp]
+    lib.egr_stem_wgrad_f32.argtypes = [vp, i32, i64, i64, i32, i32, i32, vp, vp, vp, sz, i32, i64, vp]
     lib.egr_stem_im2col_f32.argtypes = [vp, i32, i64, i64, i32, i32, i32, vp, vp]
     lib.egr_layernorm_bwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp]
     lib.egr_joint_mha_bwd_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp]
@@ -244,6 +245,21 @@ def nhwc_to_planes(x: torch.Tensor, planes: torch.Tensor, nmap: NMap, c: int, ba
     _launch("egr_nhwc_to_planes_f32", lib.egr_nhwc_to_planes_f32, _p(_dense(x, "x")), _p(flat[base_offset:]), nmap.n_inner,
             nmap.stride_inner, nmap.stride_outer, n, c, hw, cpad, _stream())
     return planes
+
+
+def stem_wgrad(img: torch.Tensor, view0: int, nviews: int, dy: torch.Tensor, workspace: torch.Tensor, groups: int = 1) -> torch.Tensor:
+    """Weight gradient of the stem conv for `groups` encoders (group g = views [view0 + g*nviews, ...)): img (B, V, 3, H, W),
+    dy (groups*nviews*B, H/2, W/2, 64) view-major NHWC -> (groups, 64, 3, 7, 7)."""
+    B, V, Cc, H, W = img.shape
+    n = nviews * B
+    if Cc != 3 or view0 + groups * nviews > V or tuple(dy.shape) != (groups * n, H // 2, W // 2, 64):
+        raise RuntimeError("egorear_amd.train.stem_wgrad: shapes do not match")
+    _cont(img, "input image batch")
+    dw = torch.empty((groups, 64, 3, 7, 7), device=img.device, dtype=torch.float32)
+    base = img.reshape(-1)[view0 * 3 * H * W:]
+    _launch("egr_stem_wgrad_f32", lib.egr_stem_wgrad_f32, _p(base), B, V * 3 * H * W, 3 * H * W, n, H, W, _p(_dense(dy, "dy")), _p(dw),
+            _p(workspace), workspace.numel(), groups, nviews * 3 * H * W, _stream(), flops=2.0 * groups * n * (H // 2) * (W // 2) * 64 * 147)
+    return dw
 
 
 def stem_im2col(img: torch.Tensor, view0: int, nviews: int) -> torch.Tensor:

@@ -573,13 +573,33 @@ def backbone_train(S: Step, encs, img: torch.Tensor, view0: int, nviews: int):
     G = len(encs)
     trunks, necks = [e.backbone for e in encs], [e.neck for e in encs]
     B, V, _, H, W = img.shape
-    # stem as patches x (64, 160) matrix: the patch rows are kept and give the stem's weight gradient as a plain 1x1 wgrad
-    cols = T.stem_im2col(img, view0, G * nviews)          # view-major rows: group g = views [view0 + g*nviews, ...)
-    cols4 = cols.view(G * nviews * B, H // 2, W // 2, 160)
+    # stem: the inference kernel in raw mode (bare conv; BatchNorm on batch statistics follows); its weight gradient comes
+    # from egr_stem_wgrad_f32, which re-stages the same input patches (no im2col buffer)
     w7 = [t.layer_s2[0].weight for t in trunks]
-    pst = make_pack(S.cache, ("stem", tuple(id(w) for w in w7)), [[(w, 0, 147)] for w in w7], [None] * G, S.name,
-                    need_dx=False)     # (64, 3, 7, 7) read as a (64, 147) matrix: OIHW flatten = im2col column order
-    x = S.conv(cols4, pst, ACT_NONE, need_dx=False)
+    key = ("stem", tuple(id(w) for w in w7))
+    wp = S.cache.packs.get(key)
+    if wp is None:
+        wp = torch.empty((G, 64, 148), device=S.dev, dtype=torch.float32)
+        tbl = repack.RepackTable(S.dev)
+        for g, w in enumerate(w7):       # (64, 3, 7, 7) -> (64, 148): OIHW flattening + one zero column
+            for t_ in (tbl, S.cache.table):
+                t_.add(repack.FWD, w.detach(), wp, g * 64 * 148, rows=64, cin=147, cin_tot=147, cin_pad=148, taps=1, rows_pad=64, total=64 * 148)
+            S.cache.watch(w)
+        tbl.run()
+        S.cache.packs[key] = wp
+    x = hip.stem(img, view0, nviews, wp, None, None, groups=G).t
+    wnames = [S.name(w) for w in w7]
+
+    def bwd_stem(x=x):
+        dy = S.G.pop(x)
+        if dy is None:
+            return
+        dw = T.stem_wgrad(img, view0, nviews, dy, S.ws, groups=G)
+        for g, nme in enumerate(wnames):
+            S.gtable.add(repack.COPYPAD, dw, S.gdst(nme), 0, rows=64 * 147, total=64 * 147, src_off=g * 64 * 147)
+    if S.record:
+        S.tape.append(bwd_stem)
+    S.keep.append((x,))
     x = S.bn(x, [t.layer_s2[1] for t in trunks], relu=True)
     x = S.maxpool(x, 3, 2, 1)
     pyramid = []

@@ -113,7 +113,8 @@ int egr_conv_debug_stamps(unsigned long long* buf);
 
 /* ResNet stem: conv 7x7 stride 2 pad 3 (3 -> 64) + BatchNorm(eval) + ReLU, NCHW fp32 input
  * (h, w multiples of 64) -> NHWC output (n, h/2, w/2, 64).  w: [64][148] rows = (ci,kh,kw), last col 0.
- * Replaces layer_s2 of models/backbones/resnet.py:16,49. */
+ * Replaces layer_s2 of models/backbones/resnet.py:16,49.  scale == shift == NULL: the bare convolution (training mode,
+ * BatchNorm on batch statistics follows as its own pass). */
 int egr_stem_conv7x7_f32(const float* x, egr_nmap xmap, int32_t n, int32_t h, int32_t w,
                          const float* wpack, const float* scale, const float* shift, float* y,
                          int32_t groups /* group g: x + g*gx, wpack + g*64*148, scale/shift + g*64, y + g*n*(h/2)*(w/2)*64 */,

@@ -66,6 +66,13 @@ int egr_nhwc_to_planes_f32(const float* x, float* planes, int32_t n_inner, int64
 int egr_stem_im2col_f32(const float* img, int32_t n_inner, int64_t stride_inner, int64_t stride_outer, int32_t n, int32_t h,
                         int32_t w, float* cols, void* stream);
 
+/* stem (conv 7x7 / s2 / p3, 3 -> 64) weight gradient straight from the (B,V,3,H,W) images and dy (groups*n, H/2, W/2, 64) NHWC:
+ * dw (groups, 64, 147) in the OIHW flattening (ci, kh, kw).  Same patch staging as egr_stem_conv7x7_f32; the pixel is the
+ * MFMA reduction index; persistent workgroups write one partial slab each (workspace >= groups*512*64*160 floats), summed in
+ * fixed order.  xmap / gx as in egr_stem_conv7x7_f32.  Replaces autograd of resnet.py:16,49's conv1. */
+int egr_stem_wgrad_f32(const float* x, int32_t n_inner, int64_t stride_inner, int64_t stride_outer, int32_t n, int32_t h, int32_t w,
+                       const float* dy, float* dw, float* workspace, size_t workspace_floats, int32_t groups, int64_t gx, void* stream);
+
 /* ---- LayerNorm(x + res) backward (transformer.py / heatmap_mvf_ex.py:861-935 norms).  pre = the normalised input
  * (x + res) saved by the forward; ds = gradient w.r.t. pre; dgamma/dbeta (groups, c) summed over each group's rows. */
 int egr_layernorm_bwd_f32(const float* dy, const float* pre, const float* gamma, float* ds, float* dgamma, float* dbeta,

@@ -316,3 +316,26 @@ def test_repack_descriptor_kinds():
     ref[:, ci0:ci0 + cin] = unpack_conv_weight(gpk, cin_pad, kh, kh)[:, :cin]
     assert torch.equal(gdst, ref)
     assert torch.equal(cat_t[:, :80], torch.cat([qa, qb], 0).t()) and float(cat_t[:, 80:].abs().max()) == 0.0
+
+
+def test_stem_forward_raw_and_weight_gradient():
+    """Training-mode stem: the inference kernel without BatchNorm / ReLU, and egr_stem_wgrad_f32 against autograd (two groups)."""
+    from egorear_amd import hip, hip_train as T
+    B, V, H = 3, 4, 64
+    img = rnd(B, V, 3, H, H, seed=1)
+    ws = [rnd(64, 3, 7, 7, seed=2 + g, scale=0.1) for g in range(2)]
+    wp = torch.zeros(2, 64, 148)
+    for g in range(2):
+        wp[g, :, :147] = ws[g].reshape(64, 147)
+    y = hip.stem(img.to(DEV), 0, 2, wp.to(DEV), None, None, groups=2).t          # group g = views 2g, 2g+1
+    dy = rnd(*y.shape, seed=5)
+    wsb = torch.empty(2 * 512 * 64 * 160, device=DEV)
+    dw = T.stem_wgrad(img.to(DEV), 0, 2, dy.to(DEV), wsb, groups=2)
+    n = 2 * B
+    for g in range(2):
+        views = img[:, 2 * g:2 * g + 2].permute(1, 0, 2, 3, 4).reshape(n, 3, H, H)
+        w = ws[g].double().requires_grad_(True)
+        ref = F.conv2d(views.double(), w, None, 2, 3)
+        close(y[g * n:(g + 1) * n].permute(0, 3, 1, 2), ref.detach(), rel=2e-5, what="raw stem")
+        dref, = torch.autograd.grad(ref, w, dy[g * n:(g + 1) * n].permute(0, 3, 1, 2).double())
+        close(dw[g], dref, rel=3e-5, what="stem wgrad")

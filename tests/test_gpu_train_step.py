@@ -96,8 +96,11 @@ def test_optimizer_step_matches_reference_adamw(golden_dir):
             assert (d == 0).all(), k
             continue
         ok = np.abs(g["grad_samples"][i]) > 1e-6 * max(float(g["grad_norm"][i]), 1e-12)   # first Adam step ~ lr*sign(g): skip g ~ 0
-        if np.abs(d[ok] - g["param_delta_samples"][i][ok]).max(initial=0.0) > 2e-5:
-            bad.append((k, d[ok], g["param_delta_samples"][i][ok]))
+        ref_d = g["param_delta_samples"][i]
+        # |update| < 0.9 lr means |g| is down at Adam's eps (1e-8): those elements amplify rounding noise of the gradient
+        tol = np.where(np.abs(ref_d) >= 0.9e-3, 2e-5, 1e-4)
+        if (np.abs(d - ref_d)[ok] > tol[ok]).any():
+            bad.append((k, d[ok], ref_d[ok]))
     assert not bad, f"{len(bad)} parameters moved differently, e.g. {bad[0]}"
     # the module still works as the drop-in inference module after the update (packed weights are rebuilt)
     net.eval()
@@ -166,7 +169,9 @@ def test_refreshed_operand_buffers_equal_rebuilt_ones():
     assert cache.ready and len(cache.table) > 300
     cache.refresh()
     torch.cuda.synchronize()
-    snap = {k: (p.w.clone(), None if p.bias is None else p.bias.clone(), None if p.wt is None else p.wt.clone()) for k, p in cache.packs.items()}
+    def parts(p):     # a pack, or (the stem) a bare operand tensor
+        return (p, None, None) if isinstance(p, torch.Tensor) else (p.w, p.bias, p.wt)
+    snap = {k: tuple(None if t is None else t.clone() for t in parts(p)) for k, p in cache.packs.items()}
     net.__dict__.pop("_egr_pack_cache")
     S = train.Step(net, torch.device(DEV))
     S.record = False
@@ -176,10 +181,8 @@ def test_refreshed_operand_buffers_equal_rebuilt_ones():
     fresh = net.__dict__["_egr_pack_cache"].packs
     assert set(fresh) == set(snap)
     for k, p in fresh.items():
-        w, b, wt = snap[k]
-        assert torch.equal(p.w, w), k
-        assert (b is None) == (p.bias is None) and (b is None or torch.equal(p.bias, b)), k
-        assert (wt is None) == (p.wt is None) and (wt is None or torch.equal(p.wt, wt)), k
+        for old, new in zip(snap[k], parts(p)):
+            assert (old is None) == (new is None) and (old is None or torch.equal(old, new)), k
 
 
 def _check_stage(g, net, losses, hms):
