@@ -557,13 +557,13 @@ __global__ __launch_bounds__(64) void joint_mha_bwd_kernel(const float* qkv, con
 
 // ------------------------------------------------------------------ small reductions
 __global__ __launch_bounds__(256) void colsum_kernel(const float* x, int64_t ld, int64_t rows, int c, const float* scale,
-                                                     float* out, int accumulate, int64_t gx, int64_t gs) {
+                                                     float* out, int accumulate, int64_t gx, int64_t gs, int cps, int64_t sstride) {
     __shared__ float red[256];
     const int g = blockIdx.y;
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int ch = blockIdx.x * 16 + cl;
     x += (int64_t)g * gx;
-    if (scale) scale += (int64_t)g * gs;
+    if (scale) scale += (int64_t)g * gs + (cps > 0 ? (int64_t)(min(ch, c - 1) / cps) * sstride : 0);
     float s = 0.f;
     if (ch < c)
         for (int64_t r = rl; r < rows; r += 16) s = fmaf(scale ? scale[r] : 1.f, x[r * ld + ch], s);
@@ -923,11 +923,12 @@ extern "C" int egr_joint_mha_bwd_f32(const float* qkv, const float* dout, float*
 }
 
 extern "C" int egr_colsum_f32(const float* x, int64_t ld, int64_t rows, int32_t c, const float* scale, float* out,
-                              int32_t accumulate, int32_t groups, int64_t gx, int64_t gs, void* stream) {
+                              int32_t accumulate, int32_t groups, int64_t gx, int64_t gs, int32_t cols_per_scale, int64_t scale_stride,
+                              void* stream) {
     if (!x || !out) return EGR_ENULL;
     if (rows <= 0 || c <= 0 || ld < c || groups <= 0 || groups > 65535) return EGR_EINVAL;
     hipLaunchKernelGGL(colsum_kernel, dim3((c + 15) / 16, groups), dim3(256), 0, (hipStream_t)stream, x, ld, rows, c, scale, out,
-                       accumulate, gx, gs);
+                       accumulate, gx, gs, cols_per_scale, scale_stride);
     return egr_launch_status();
 }
 

@@ -43,7 +43,7 @@ def _bind():
     lib.egr_layernorm_bwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp]
     lib.egr_joint_mha_bwd_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp]
     lib.egr_msda_gather_bwd_f32.argtypes = [vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]
-    lib.egr_colsum_f32.argtypes = [vp, i64, i64, i32, vp, vp, i32, i32, i64, i64, vp]
+    lib.egr_colsum_f32.argtypes = [vp, i64, i64, i32, vp, vp, i32, i32, i64, i64, i32, i64, vp]
     lib.egr_fold_rows_f32.argtypes = [vp, vp, i64, i32, i32, vp]
     lib.egr_jqa_sum_bwd_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
     lib.egr_rownorm_loss_f32.argtypes = [vp, vp, i64, i32, i32, i64, i64, f32, vp, vp, vp]
@@ -333,16 +333,19 @@ def msda_gather_bwd(feat: torch.Tensor, pos: Optional[torch.Tensor], offs_logits
 # --------------------------------------------------------------------------- reductions
 
 def colsum(x: torch.Tensor, ld: int, rows: int, c: int, scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-           accumulate: bool = False, groups: int = 1, gx: int = 0, gs: int = 0) -> torch.Tensor:
-    """out[g, c] (+)= sum_r scale[g*gs + r] * x[g*gx + r*ld + c]; x is a storage-rooted view (first element = group 0 row 0)."""
+           accumulate: bool = False, groups: int = 1, gx: int = 0, gs: int = 0, cols_per_scale: int = 0, scale_stride: int = 0) -> torch.Tensor:
+    """out[g, c] (+)= sum_r scale[g*gs + r] * x[g*gx + r*ld + c]; x is a storage-rooted view (first element = group 0 row 0).
+    cols_per_scale > 0: column ch uses the scale vector at scale + (ch // cols_per_scale) * scale_stride (one per head)."""
     need = (groups - 1) * gx + (rows - 1) * ld + c
     if x.storage_offset() + need > x.untyped_storage().nbytes() // 4:
         raise RuntimeError("egorear_amd.train.colsum: reads past the end of x")
-    if scale is not None and scale.numel() < (groups - 1) * gs + rows:
+    nvec = (c + cols_per_scale - 1) // cols_per_scale if cols_per_scale > 0 else 1
+    if scale is not None and scale.numel() < (groups - 1) * gs + (nvec - 1) * scale_stride + rows:
         raise RuntimeError("egorear_amd.train.colsum: scale too short")
     if out is None:
         out = torch.empty((groups, c), device=x.device, dtype=torch.float32)
-    _launch("egr_colsum_f32", lib.egr_colsum_f32, _p(x), ld, rows, c, _p(scale), _p(out), 1 if accumulate else 0, groups, gx, gs, _stream())
+    _launch("egr_colsum_f32", lib.egr_colsum_f32, _p(x), ld, rows, c, _p(scale), _p(out), 1 if accumulate else 0, groups, gx, gs,
+            cols_per_scale, scale_stride, _stream())
     return out
 
 

@@ -700,10 +700,11 @@ def layer_train(S: Step, L: _LayerPack, x: torch.Tensor, memory: torch.Tensor, a
         dg2 = dg.view(G * rows, heads * cf)
         for h in range(heads):
             hip.conv2d_wgrad(_rows(g2[:, h * cf:(h + 1) * cf]), _rows(da[:, h * dh:(h + 1) * dh]), 1, 1, 1, 0, S.ws, dw=dWh[h], groups=G)
-            dcfold[:, h * dh:(h + 1) * dh] = T.colsum(da[:, h * dh:], C, rows, dh, scale=sig[h * rows:], groups=G, gx=rows * C, gs=heads * rows)
             hip.conv2d(_rows(da[:rows, h * dh:(h + 1) * dh]), L.head_wt[h] if G > 1 else L.head_wt[h][0], cf, 1, 1, 1, 0,
                        out=_rows(dg2[:rows, h * cf:(h + 1) * cf]), workspace=None, split_k=1, groups=G, gx=rows * C, gy=rows * heads * cf)
         dWfold = dWh.permute(1, 0, 2, 3).reshape(G, C, cf)
+        # dcfold[g, h*dh + d] = sum_r sigma[g, h, r] * da[g, r, h*dh + d]: all heads in one launch
+        T.colsum(da, C, rows, C, scale=sig, out=dcfold, groups=G, gx=rows * C, gs=heads * rows, cols_per_scale=dh, scale_stride=rows)
         dpos = T.zeros(L.pos_proj.shape, S.dev) if L.pos_proj is not None else None
         dol_v = T.msda_gather_bwd(memory, L.pos_proj, ol, anchors, valid, B, V, J, heads, dh, hgt, wid, dg, da, L.cfold, dmem, dpos, groups=G)
         S.G.add(ol, T.fold_rows(dol_v, V))

@@ -97,7 +97,8 @@ int egr_msda_gather_bwd_f32(const float* feat, int32_t cf, const float* pos, int
 /* ---- small reductions: out[c] (+)= sum_r scale[r] * x[r, c] over `rows` rows of leading dimension ld, per group
  * (x group stride gx floats, scale group stride gs, out group stride c).  scale may be NULL. */
 int egr_colsum_f32(const float* x, int64_t ld, int64_t rows, int32_t c, const float* scale, float* out, int32_t accumulate,
-                   int32_t groups, int64_t gx, int64_t gs, void* stream);
+                   int32_t groups, int64_t gx, int64_t gs, int32_t cols_per_scale, int64_t scale_stride, void* stream);
+/* cols_per_scale > 0: column ch uses the scale vector scale + (ch / cols_per_scale) * scale_stride (one vector per attention head) */
 /* y[r, :] = sum_{k<fold} x[r*fold + k, :]  (sum the `fold` views of a query row). */
 int egr_fold_rows_f32(const float* x, float* y, int64_t rows_out, int32_t fold, int32_t c, void* stream);
 /* JQA sum backward (heatmap_mvf_ex.py:664-665): d_embed[g,j,:] = sum_b dx, d_bfb[b,:] = sum_j dx. */
