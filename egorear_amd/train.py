@@ -899,7 +899,8 @@ def pose3d_train(S: Step, p3, feat_init: torch.Tensor, feat_ref: torch.Tensor, B
     h = S.gelu(S.linear(flat, S.pack([p3.mlp_pred[0][0]])))
     h = S.gelu(S.linear(h, S.pack([p3.mlp_pred[1][0]])))
     mlp_pad = S.linear(h, S.pack([p3.mlp_pred[2]]), out_pad=True)             # (B, 64), 48 valid
-    anchors_3d = mlp_pad[:, :3 * J].contiguous().view(B, J, 3)                 # init_anchors_3d = mlp_pred.clone().detach()
+    anchors_3d = mlp_pad[:, :3 * J].clone().view(B, J, 3)                      # init_anchors_3d = mlp_pred.clone().detach(): a real copy
+    # (syn mode mutates the anchors in place, F7; for B = 1 the slice is contiguous and .contiguous() would alias mlp_pad)
     ctm32 = None
     if p3.camera_model.startswith("ego4view_rw"):
         if ctm is None:
@@ -1173,15 +1174,16 @@ class Trainer:
         """Returns (loss terms (6,) float64 device tensor, outputs).  Parameters are updated in place."""
         from .dist import world_size
         if self.graph is not None:
-            same = all(a.shape == b.shape for a, b in zip(self._static, (img, ctm, gt_pose, gt_heatmap)))
+            same = all((a is None) == (b is None) and (a is None or a.shape == b.shape) for a, b in zip(self._static, (img, ctm, gt_pose, gt_heatmap)))
             if same:
                 for dst, src in zip(self._static, (img, ctm, gt_pose, gt_heatmap)):
-                    dst.copy_(src, non_blocking=True)
+                    if dst is not None:
+                        dst.copy_(src, non_blocking=True)
                 self.opt.begin_update()
                 self.graph.replay()
                 self._invalidate()
                 return self._graph_out
-        if self.use_graph and self.graph is None and self._eager_done >= 2 and world_size(self.opt.pg) == 1 and ctm is not None:
+        if self.use_graph and self.graph is None and self._eager_done >= 2 and world_size(self.opt.pg) == 1:
             try:
                 self._capture(img, ctm, gt_pose, gt_heatmap)
             except Exception:      # capture is an optimisation: any refusal leaves the eager path in charge
@@ -1196,7 +1198,8 @@ class Trainer:
 
     def _capture(self, img, ctm, gt_pose, gt_heatmap):
         dev = img.device
-        self._static = [t.detach().to(device=dev, dtype=torch.float32).clone().contiguous() for t in (img, ctm, gt_pose, gt_heatmap)]
+        self._static = [None if t is None else t.detach().to(device=dev, dtype=torch.float32).clone().contiguous()
+                        for t in (img, ctm, gt_pose, gt_heatmap)]
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="relaxed"):

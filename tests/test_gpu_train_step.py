@@ -306,3 +306,35 @@ def test_graphed_training_step_follows_the_eager_trajectory():
     for (k, p), (_, q) in zip(eager.net.named_parameters(), graphed.net.named_parameters()):
         if "k_proj.bias" not in k:
             assert float(((p - q).abs() > 2e-4).float().mean()) < 0.02, k
+
+
+def test_training_step_syn_camera_against_the_oracle():
+    """ego4view_syn training (no coord_trans_mat; the reprojection mutates the 3-D anchors in place): losses and
+    every gradient against the oracle's autograd, eager and replayed as a hipGraph."""
+    from egorear_amd import configs, synth, train
+    from egorear_amd.estimator import EgoPoseFormerMVFEX
+    from oracle import egorear_oracle as O
+    from oracle import train_oracle as TO
+    calib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "egorear_amd", "calib", "ego4view")
+    net = EgoPoseFormerMVFEX(**copy.deepcopy(configs.pose3d_cfg("ego4view_syn")))
+    sd = synth.load_synth(net, 42)
+    names = [k for k, _ in net.named_parameters()]
+    B = 1
+    img, gp, gh = synth.synth_images(B, 4, seed=3), synth.synth_gt_pose(B), TO.synth_gt_heatmap(B)
+    o_losses, o_grads, _, _ = TO.forward_backward({k: v.clone() for k, v in sd.items()}, O.make_cameras("ego4view_syn", calib), img, None, gp, gh, names)
+    net = net.to(DEV)
+    S, _ = train.forward_backward(net, img.to(DEV), None, gp.to(DEV), gh.to(DEV))
+    torch.cuda.synchronize()
+    total = sum(o_losses.values())
+    assert abs(float(S.loss_terms.sum()) - total) <= 1e-4 * total
+    gmax = max(float(g.double().norm()) for g in o_grads.values() if g is not None)
+    for k in names:
+        assert (k in S.pgrads) == (o_grads[k] is not None), k
+        if o_grads[k] is not None:
+            ref = o_grads[k].double()
+            assert float((S.pgrads[k].double().cpu() - ref).norm()) <= 5e-3 * float(ref.norm()) + 5e-6 * gmax, k
+    tr = train.Trainer(net, use_graph=True)       # and the graphed trainer accepts ctm = None
+    for _ in range(4):
+        terms, _ = tr.step(img.to(DEV), None, gp.to(DEV), gh.to(DEV))
+    torch.cuda.synchronize()
+    assert tr.graph is not None and torch.isfinite(terms).all()
