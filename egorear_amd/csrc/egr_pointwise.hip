@@ -196,6 +196,85 @@ __global__ __launch_bounds__(256) void tokens_to_nhwc_kernel(const float* x, flo
     y[idx] = x[((int64_t)bb * j + jj) * hw + p];
 }
 
+
+// ------------------------------------------------------------------ heat-map head tail: up x2 (+ReLU) -> 1x1 conv (cin -> <=16) -> planes
+// The last two steps of every heat-map head (heatmap_mvf_ex.py:101-126, 570-584) in one pass: the 128-channel tensor at
+// 64 x 64 that would sit between them (written by the upsample, read back by a 15-output conv that is pure HBM traffic)
+// never exists.  A workgroup owns 8 x 32 output pixels and stages their (<= 6 x 18) low-resolution source pixels in LDS
+// (pixel stride cin + 4 floats: the 16 pixels of an MFMA group hit different banks).  The 1x1 conv runs on
+// v_mfma_f32_16x16x4_f32 with N = 16 output channels: lane l supplies a[pixel l%16][channel 4s + l/16], computed on the
+// fly (four source reads, the upsample kernel's interpolation arithmetic, ReLU), and b from registers (the filter,
+// 32 floats per lane, loaded once); D[pixel][co] leaves as one 16-byte store of 4 consecutive pixels per lane.
+constexpr int HT_H = 8, HT_W = 32, HT_SRC_H = 6, HT_SRC_W = 18, HT_MAXCO = 16, HT_MAXCIN = 128;
+typedef float f32x4_mfma __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void up2_relu_head_kernel(const float* lo, int h, int w, int cin, const float* wgt, const float* bias,
+                                                            int cout, float* planes, egr_nmap map, int npg, int64_t gy) {
+    extern __shared__ __attribute__((aligned(16))) float s_src[];   // [HT_SRC_H * HT_SRC_W][cin + 4]
+    const int ld = cin + 4;
+    const int ho = 2 * h, wo = 2 * w;
+    const int tiles_x = wo / HT_W, tiles_y = ho / HT_H;
+    int t = blockIdx.x;
+    const int img = t / (tiles_x * tiles_y);
+    t -= img * tiles_x * tiles_y;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int oy0 = ty * HT_H, ox0 = tx * HT_W;
+    const int grp = img / npg;
+    const float sh = (ho > 1) ? (float)(h - 1) / (float)(ho - 1) : 0.f;
+    const float sw = (wo > 1) ? (float)(w - 1) / (float)(wo - 1) : 0.f;
+    const int sy0 = (int)(sh * (float)oy0), sx0 = (int)(sw * (float)ox0);   // first source row / column of the tile
+    const int c4n = cin >> 2;
+    const float* src = lo + (int64_t)img * h * w * cin;
+    for (int i = threadIdx.x; i < HT_SRC_H * HT_SRC_W * c4n; i += 256) {
+        const int cq = i % c4n, p = i / c4n;
+        const int py = p / HT_SRC_W, px = p - py * HT_SRC_W;
+        const int iy = min(sy0 + py, h - 1), ix = min(sx0 + px, w - 1);
+        *reinterpret_cast<f32x4*>(&s_src[p * ld + cq * 4]) = *reinterpret_cast<const f32x4*>(src + ((int64_t)iy * w + ix) * cin + cq * 4);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pj = lane & 15, kq = lane >> 4;                   // MFMA roles: A row / B column pj, k index kq
+    // filter: b[s] = W[co = pj][channel 4s + kq] (zero rows above cout)
+    const float* wg = wgt + (int64_t)grp * cout * cin;
+    float bw[HT_MAXCIN / 4];
+    const int ksteps = cin >> 2;
+#pragma unroll
+    for (int s_ = 0; s_ < HT_MAXCIN / 4; ++s_) bw[s_] = (s_ < ksteps && pj < cout) ? wg[pj * cin + 4 * s_ + kq] : 0.f;
+    __syncthreads();
+
+    const float* bg = bias ? bias + grp * cout : nullptr;
+    const float bco = (bg && pj < cout) ? bg[pj] : 0.f;        // D column = co = pj
+    float* outg = planes + grp * gy + egr_map(map, img - grp * npg);
+#pragma unroll 1
+    for (int mg = 0; mg < 4; ++mg) {                            // wave: rows 2*wave, 2*wave+1; 2 groups of 16 columns per row
+        const int oy = oy0 + 2 * wave + (mg >> 1);
+        const int oxg = ox0 + (mg & 1) * 16;
+        const int ox = oxg + pj;                                // this lane's A-row pixel
+        // ATen's align_corners=True source index / weights, as in upsample2x_kernel
+        const float fy = sh * (float)oy, fx = sw * (float)ox;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+        const float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f);
+        const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const float* p00 = s_src + ((y0 - sy0) * HT_SRC_W + (x0 - sx0)) * ld + kq;
+        const float* p01 = s_src + ((y0 - sy0) * HT_SRC_W + (x1 - sx0)) * ld + kq;
+        const float* p10 = s_src + ((y1 - sy0) * HT_SRC_W + (x0 - sx0)) * ld + kq;
+        const float* p11 = s_src + ((y1 - sy0) * HT_SRC_W + (x1 - sx0)) * ld + kq;
+        f32x4_mfma acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s_ = 0; s_ < HT_MAXCIN / 4; ++s_) {
+            if (s_ < ksteps) {
+                const float u = ly0 * (lx0 * p00[4 * s_] + lx1 * p01[4 * s_]) + ly1 * (lx0 * p10[4 * s_] + lx1 * p11[4 * s_]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(u < 0.f ? 0.f : u, bw[s_], acc, 0, 0, 0);
+            }
+        }
+        // D[row = 4*kq + r][col = pj]: rows are the pixels oxg + 4*kq + r (contiguous in a plane), col the output channel
+        if (pj < cout) {
+            f32x4 v = {acc[0] + bco, acc[1] + bco, acc[2] + bco, acc[3] + bco};
+            *reinterpret_cast<f32x4*>(outg + (int64_t)pj * ho * wo + (int64_t)oy * wo + oxg + 4 * kq) = v;
+        }
+    }
+}
+
 inline unsigned nblocks(int64_t total) { return (unsigned)((total + 255) / 256); }
 
 }  // namespace
@@ -219,6 +298,23 @@ extern "C" int egr_upsample2x_nhwc_f32(const float* x, int32_t ldx, float* y, in
     int64_t total = (int64_t)n * 4 * h * w * (c / 4);
     hipLaunchKernelGGL(upsample2x_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, n, h,
                        w, c / 4, relu);
+    return egr_launch_status();
+}
+
+extern "C" int egr_up2_relu_head_f32(const float* lo, int32_t n, int32_t h, int32_t w, int32_t cin, const float* wgt, const float* bias,
+                                     int32_t cout, float* planes, int32_t n_inner, int64_t stride_inner, int64_t stride_outer,
+                                     int32_t groups, int64_t gy, void* stream) {
+    if (!lo || !wgt || !planes) return EGR_ENULL;
+    if (n <= 0 || groups <= 0 || n % groups != 0 || h <= 0 || w <= 0 || cin <= 0 || cin % 4 != 0 || cin > HT_MAXCIN || cout <= 0 ||
+        cout > HT_MAXCO || (2 * h) % HT_H != 0 || (2 * w) % HT_W != 0 || n_inner <= 0 || ((uintptr_t)planes & 15) ||
+        ((stride_inner | stride_outer | gy) % 4 != 0))
+        return EGR_EINVAL;
+    egr_nmap map{n_inner, stride_inner, stride_outer};
+    const size_t lds = (size_t)(HT_SRC_H * HT_SRC_W * (cin + 4)) * sizeof(float);
+    const int64_t blocks = (int64_t)n * ((2 * h) / HT_H) * ((2 * w) / HT_W);
+    if (blocks >= (1LL << 31) || lds > 64 * 1024) return EGR_EINVAL;
+    hipLaunchKernelGGL(up2_relu_head_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, lo, h, w, cin, wgt, bias, cout,
+                       planes, map, n / groups, gy);
     return egr_launch_status();
 }
 

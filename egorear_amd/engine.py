@@ -230,6 +230,17 @@ def run_stack(st: State, seqs: Sequence[nn.Sequential], x: Img, out: Optional[Im
                     and isinstance(m0[i + 2], nn.ReLU)):
                 p = st.get(nxt, lambda i=i: pack_convs([g[i + 1] for g in mods]))
                 lo = conv(st, x, p, ACT_NONE)
+                fin = m0[i + 3] if i + 4 == len(m0) else None
+                if (isinstance(fin, nn.Conv2d) and fin.kernel_size == (1, 1) and fin.stride == (1, 1) and fin.out_channels <= 16
+                        and fin.in_channels <= 128 and last_kw is not None and "out_nchw" in last_kw and (2 * lo.h) % 8 == 0
+                        and (2 * lo.w) % 32 == 0):
+                    # tail of a heat-map head: up x2 + ReLU + the final narrow 1x1 conv in one pass, straight into the
+                    # (B, V, 15, H, W) planes; the 128-channel full-resolution tensor in between is never written
+                    wf = st.get((id(fin), "plain"), lambda i=i: (
+                        torch.stack([g[i + 3].weight.detach().float().reshape(fin.out_channels, fin.in_channels) for g in mods]).contiguous(),
+                        torch.stack([g[i + 3].bias.detach().float() for g in mods]).contiguous() if fin.bias is not None else None))
+                    hip.up2_relu_head(lo, wf[0], wf[1], last_kw["out_nchw"], last_kw["ymap"], last_kw.get("gy", 0), groups=len(mods))
+                    return None
                 last = (i + 3) >= len(m0)
                 x = hip.upsample2x(lo, out=out if last else None, relu=True)
                 i += 3

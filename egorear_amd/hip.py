@@ -23,7 +23,7 @@ EXPORTS = [
     "egr_conv2d_nhwc_f32", "egr_stem_conv7x7_f32", "egr_maxpool_nhwc_f32", "egr_upsample2x_nhwc_f32",
     "egr_avgpool_nhwc_f32", "egr_argmax_rows_f32", "egr_layernorm_f32", "egr_joint_mha_f32", "egr_msda_gather_f32",
     "egr_fisheye_project_f32", "egr_linear_smallk_f32", "egr_jqa_sum_f32", "egr_tokens_to_nhwc_f32", "egr_version",
-    "egr_device_arch", "egr_conv_force_config", "egr_preprocess_u8_f32", "egr_pose_metrics_f32", "egr_gt_heatmap_f32", "egr_conv_debug_stamps", "egr_conv2d_wgrad_f32", "egr_conv2d_masked_f32",
+    "egr_device_arch", "egr_conv_force_config", "egr_preprocess_u8_f32", "egr_pose_metrics_f32", "egr_gt_heatmap_f32", "egr_conv_debug_stamps", "egr_conv2d_wgrad_f32", "egr_conv2d_masked_f32", "egr_up2_relu_head_f32",
 ]
 
 
@@ -68,6 +68,7 @@ def _load() -> C.CDLL:
     lib.egr_version.restype = C.c_char_p
     lib.egr_device_arch.argtypes = [C.c_char_p, i32]
     lib.egr_conv_force_config.argtypes = [i32]
+    lib.egr_up2_relu_head_f32.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, i64, i64, i32, i64, vp]
     lib.egr_conv2d_masked_f32.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.egr_conv2d_wgrad_f32.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, C.c_size_t, i32, vp]
     lib.egr_gt_heatmap_f32.argtypes = [vp, i32, C.c_double, i32, i32, vp, vp, vp]
@@ -336,6 +337,24 @@ def upsample2x(x: Img, out: Optional[Img] = None, relu: bool = False) -> Img:
     _launch("egr_upsample2x_nhwc_f32", lib.egr_upsample2x_nhwc_f32, _p(x.t), x.ld, _p(out.t), out.ld, x.n, x.h, x.w, x.c, 1 if relu else 0, _stream(),
             nbytes=4.0 * 5 * x.n * x.h * x.w * x.c)
     return out
+
+
+def up2_relu_head(lo: Img, wgt: torch.Tensor, bias: Optional[torch.Tensor], planes: torch.Tensor, ymap: NMap, gy: int, groups: int = 1):
+    """Upsample x2 + ReLU + final 1x1 conv of a heat-map head, straight into channel-major planes (see egorear_hip.h).
+    lo: dense (groups*n, h, w, cin); wgt (groups, cout, cin) contiguous; image i of group g lands at planes.flat[g*gy + ymap(i)]."""
+    if not lo.t.is_contiguous() or lo.n % groups:
+        raise RuntimeError("egorear_amd.up2_relu_head: dense NHWC input with groups | n expected")
+    cout, cin = wgt.shape[-2], wgt.shape[-1]
+    npg = lo.n // groups
+    if cin != lo.c or wgt.numel() != groups * cout * cin or (bias is not None and bias.numel() != groups * cout):
+        raise RuntimeError("egorear_amd.up2_relu_head: weight / bias shape")
+    ho, wo = 2 * lo.h, 2 * lo.w
+    last = (groups - 1) * gy + (npg - 1) // ymap.n_inner * ymap.stride_outer + min(npg - 1, ymap.n_inner - 1) * ymap.stride_inner + cout * ho * wo
+    if not planes.is_contiguous() or last > planes.numel():
+        raise RuntimeError("egorear_amd.up2_relu_head: output map runs outside the tensor")
+    _launch("egr_up2_relu_head_f32", lib.egr_up2_relu_head_f32, _p(lo.t), lo.n, lo.h, lo.w, cin, _p(_cont(wgt, "weight")), _p(bias), cout,
+            _p(planes), ymap.n_inner, ymap.stride_inner, ymap.stride_outer, groups, gy, _stream(),
+            flops=2.0 * lo.n * ho * wo * cout * cin, nbytes=4.0 * lo.n * (lo.h * lo.w * cin + cout * ho * wo))
 
 
 def avgpool(x: Img) -> torch.Tensor:

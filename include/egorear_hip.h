@@ -106,6 +106,15 @@ int egr_conv2d_wgrad_f32(const egr_conv_desc* d, const float* x, const float* dy
  * (-1 auto, 0 128x128, 1 256x64, 2 64x64, 3 128x32, 4 128x64).  Process-wide; results do not depend on it. */
 int egr_conv_force_config(int cfg);
 
+/* Tail of a heat-map head in one pass: Upsample(x2, bilinear, align_corners=True) + ReLU, then the final 1x1 conv
+ * (cin <= 128 -> cout <= 16, with bias) written as channel-major planes: lo (n, h, w, cin) NHWC, all groups' images back to back;
+ * wgt (groups, cout, cin) plain row-major; image i of group g goes to planes + g*gy + nmap(i).  The cin-channel tensor at the
+ * doubled resolution is never materialised.  Replaces `nn.Upsample -> ... -> ReLU -> Conv2d(128, 15, 1)` of
+ * egoposeformer_heatmap_mvf_ex.py:101-126 (indices 6-9) and :570-584 (indices 4-7); 2h % 8 == 0, 2w % 32 == 0. */
+int egr_up2_relu_head_f32(const float* lo, int32_t n, int32_t h, int32_t w, int32_t cin, const float* wgt, const float* bias,
+                          int32_t cout, float* planes, int32_t n_inner, int64_t stride_inner, int64_t stride_outer,
+                          int32_t groups, int64_t gy, void* stream);
+
 /* Diagnostic only (tools/conv_stamps.py): when `buf` is non-NULL every conv workgroup writes 8 x uint64 — s_memtime at
  * [0] start, [1] row decode done, [2] first chunk landed, [3] K loop done, [4] accumulators staged, [5] stores issued, and
  * [6] its physical placement (XCC id << 16 | HW_ID) — to buf[8 * workgroup].  NULL (the default) disables it. */

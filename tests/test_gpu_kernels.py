@@ -356,3 +356,27 @@ def test_fisheye_matches_oracle_and_f7_chain(hip, calib_dir):
         q = q4.cpu().view(B, J, 4)
         assert torch.allclose(q[..., 0], (torch.arange(1, J + 1) / J).expand(B, J))
         assert torch.equal(q[..., 1:], dpts.cpu())
+
+
+@pytest.mark.parametrize("groups,cout,h,w", [(2, 15, 32, 32), (1, 16, 4, 16), (4, 3, 8, 32)])
+def test_up2_relu_head_matches_torch(groups, cout, h, w):
+    """Fused tail of a heat-map head: bilinear x2 (align_corners=True) + ReLU + 1x1 conv into channel-major planes, grouped,
+    view-major images scattered into a (B, V, cout, 2h, 2w) tensor through the image map."""
+    import torch.nn.functional as F
+    from egorear_amd import hip
+    from egorear_amd.hip import NMap
+    B, cin = 3, 128
+    V = groups
+    g = torch.Generator().manual_seed(7)
+    lo = torch.randn(V * B, h, w, cin, generator=g)
+    wt = torch.randn(groups, cout, cin, generator=g) / 11.0
+    bias = torch.randn(groups, cout, generator=g)
+    planes = torch.zeros(B, V, cout, 2 * h, 2 * w, device=DEV)
+    plane = cout * 4 * h * w
+    hip.up2_relu_head(hip.Img(lo.to(DEV)), wt.to(DEV), bias.to(DEV), planes, NMap(B, V * plane, 0), plane, groups=groups)   # group g = view g
+    for v in range(V):
+        x = lo[v * B:(v + 1) * B].permute(0, 3, 1, 2).double()
+        up = F.relu(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True))
+        ref = F.conv2d(up, wt[v].double()[:, :, None, None], bias[v].double())
+        err = float((planes[:, v].cpu().double() - ref).abs().max())
+        assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (v, err)
