@@ -102,6 +102,32 @@ def cpu_baseline(state_dict, batch: int, iters: int):
                       f"{cores} threads), {dt:.1f} s"}
 
 
+def cpu_train_baseline(batch: int = 4, iters: int = 4):
+    """The training oracle (oracle/train_oracle.py: the reference's step restated on PyTorch-CPU autograd, kind 'port') timed on
+    the host cores on a bounded sample: `iters` forward + backward + clip + AdamW steps of `batch` frames (after one warm-up)."""
+    import torch
+    from egorear_amd import configs, synth
+    from egorear_amd.estimator import EgoPoseFormerMVFEX
+    from oracle import egorear_oracle as O
+    from oracle import train_oracle as TO
+    cores = _host_cores()
+    torch.set_num_threads(cores)
+    net = EgoPoseFormerMVFEX(**copy.deepcopy(configs.pose3d_cfg("ego4view_rw")))
+    sd = synth.load_synth(net, 42)
+    names = [k for k, _ in net.named_parameters()]
+    ref = TO.OracleTrainer(sd, names, O.make_cameras("ego4view_rw", os.path.join(REPO, "egorear_amd", "calib", "ego4view")))
+    args_ = (synth.synth_images(batch, 4, seed=5), synth.synth_coord_trans_mat(batch), synth.synth_gt_pose(batch), TO.synth_gt_heatmap(batch))
+    _log(f"cpu training baseline: warm-up step, batch {batch}, {cores} threads")
+    ref.step(*args_)
+    _log("cpu training baseline: timing")
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        ref.step(*args_)
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * iters / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{iters} optimisation steps of batch {batch} (train-mode forward, autograd backward, clip, torch AdamW; torch-CPU fp32, {cores} threads), {dt:.1f} s"}
+
+
 def train_leg(args, dev, rank: int, world: int, backend: str):
     """SURVEY.md §8(f) rank 2 / BASELINE.json config 5, timed separately (never part of `value`): one optimisation step =
     training-mode forward + wrapper losses + backward + gradient all-reduce (RCCL, world > 1) + clip + AdamW, all on the
@@ -147,6 +173,8 @@ def train_leg(args, dev, rank: int, world: int, backend: str):
            "parallelism": f"dp{world}: frames sharded, stage-bucketed gradient all-reduce overlapped with backward" if world > 1 else "single GPU",
            "launch": "hipGraph replay" if tr.graph is not None else "eager",
            "loss_total": round(float(state["terms"].sum()), 4)}
+    if world == 1 and not args.no_cpu_baseline:
+        leg["cpu_baseline"] = cpu_train_baseline()
     if kernels:
         leg["kernel_ms"] = {n: round(v["ms"], 3) for n, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])[:12]}
         dom = max(kernels, key=lambda n: kernels[n]["ms"])
