@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             }
             mk &= fullmask;
             yo = (a.y_plain ? n * (int)d.ymap.stride_inner : (int)fmap(d.ymap, a.dYin, n)) + (d.out_nchw ? pix : pix * d.ldy);
-            if (d.res_mode) ro = (a.r_plain ? n * (int)d.rmap.stride_inner : (int)fmap(d.rmap, a.dRin, n)) + pix * d.ldr;
+            if (d.res_mode == EGR_RES_BEFORE_ACT || d.res_mode == EGR_RES_AFTER_ACT) ro = (a.r_plain ? n * (int)d.rmap.stride_inner : (int)fmap(d.rmap, a.dRin, n)) + pix * d.ldr;
         }
         s_xoff[r] = xo;
         s_mask[r] = mk;
@@ -440,6 +440,45 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             if (shg) sh[e] = shg[co + e];
         }
 
+    if (d.res_mode == EGR_RES_UP2_BEFORE_ACT) {
+        // residual = bilinear x2 upsampling (align_corners=True, ATen arithmetic as in upsample2x_kernel) of a HALF-resolution
+        // tensor, evaluated here instead of being materialised by a separate pass (the FPN top-down path): 4 gathers per output
+        const int hl = d.ho >> 1, wl = d.wo >> 1;
+        const float shh = (d.ho > 1) ? (float)(hl - 1) / (float)(d.ho - 1) : 0.f;
+        const float sww = (d.wo > 1) ? (float)(wl - 1) / (float)(d.wo - 1) : 0.f;
+#pragma unroll 4
+        for (int it = 0; it < BM / RPI; ++it) {
+            const int row = row0 + it * RPI;
+            const int yo = s_yoff[row];
+            if (yo < 0) continue;
+            const int m = tm * BM + row;
+            int n, pix, oy, ox;
+            if (a.howo_shift >= 0) { n = m >> a.howo_shift; pix = m & (HoWo - 1); }
+            else { n = fdiv(m, a.dHoWo); pix = m - n * HoWo; }
+            if (a.wo_shift >= 0) { oy = pix >> a.wo_shift; ox = pix & (d.wo - 1); }
+            else { oy = fdiv(pix, a.dWo); ox = pix - oy * d.wo; }
+            const float fy = shh * (float)oy, fx = sww * (float)ox;
+            const int y0 = (int)fy, x0 = (int)fx;
+            const int y1 = min(y0 + 1, hl - 1), x1 = min(x0 + 1, wl - 1);
+            const float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f);
+            const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+            const float* rb = resg + (a.r_plain ? (int64_t)n * d.rmap.stride_inner : (int64_t)fmap(d.rmap, a.dRin, n)) + co;
+            const f32x4 v00 = *reinterpret_cast<const f32x4*>(rb + (int64_t)(y0 * wl + x0) * d.ldr);
+            const f32x4 v01 = *reinterpret_cast<const f32x4*>(rb + (int64_t)(y0 * wl + x1) * d.ldr);
+            const f32x4 v10 = *reinterpret_cast<const f32x4*>(rb + (int64_t)(y1 * wl + x0) * d.ldr);
+            const f32x4 v11 = *reinterpret_cast<const f32x4*>(rb + (int64_t)(y1 * wl + x1) * d.ldr);
+            f32x4 v = *reinterpret_cast<const f32x4*>(&sC[row * P::CS + cq * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = v[e] * sc[e] + sh[e];
+                t += ly0 * (lx0 * v00[e] + lx1 * v01[e]) + ly1 * (lx0 * v10[e] + lx1 * v11[e]);
+                v[e] = (d.act == EGR_ACT_RELU) ? (t > 0.f ? t : 0.f) : t;
+            }
+            *reinterpret_cast<f32x4*>(yg + (int64_t)yo + co) = v;
+        }
+        return;
+    }
+
     if (a.mask) {  // dx = (acc [+ res]) * [mask > 0]  (the host guarantees the 16-byte path, no scale/shift/activation)
         const float* const maskg = a.mask + grp * d.gy;
 #pragma unroll 8
@@ -626,7 +665,7 @@ static int conv_run(const egr_conv_desc* dd, const float* x, const float* w, con
     if (span(d.xmap, d.n) + (int64_t)d.h * d.w * d.ldx >= (1LL << 31)) return EGR_EINVAL;
     int64_t ypix = d.out_nchw ? (int64_t)d.cout * d.ho * d.wo : (int64_t)d.ho * d.wo * d.ldy;
     if (span(d.ymap, d.n) + ypix >= (1LL << 31)) return EGR_EINVAL;
-    if (d.res_mode && span(d.rmap, d.n) + (int64_t)d.ho * d.wo * d.ldr >= (1LL << 31)) return EGR_EINVAL;
+    if (d.res_mode && span(d.rmap, d.n) + (int64_t)d.ho * d.wo * d.ldr >= (1LL << 31)) return EGR_EINVAL;   // (upper bound for the half-size mode too)
 
     a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.res = res; a.rowscale = rowscale; a.rowmask = rowmask;
     a.y = y; a.ws = workspace;
@@ -661,6 +700,12 @@ static int conv_run(const egr_conv_desc* dd, const float* x, const float* w, con
     if (d.res_mode)
         a.vec_ok = a.vec_ok && (d.ldr % 4 == 0) && (((uintptr_t)res & 15) == 0) &&
                    ((d.rmap.stride_inner | d.rmap.stride_outer) % 4 == 0);
+    if (d.res_mode == EGR_RES_UP2_BEFORE_ACT) {  // residual upsampled on the fly: 16-byte path, even output size, ReLU / none
+        if (!a.vec_ok || d.cout % 4 != 0 || rowscale || rowmask || mask || d.out_nchw || d.transposed || (d.ho & 1) || (d.wo & 1) ||
+            d.act == EGR_ACT_GELU)
+            return EGR_EINVAL;
+        d.split_k = 1;
+    }
     if (mask) {  // masked data gradient: plain 16-byte epilogue only
         if (!a.vec_ok || d.cout % 4 != 0 || scale || shift || rowscale || rowmask || d.act != EGR_ACT_NONE || d.out_nchw ||
             d.res_mode == EGR_RES_AFTER_ACT || ((uintptr_t)mask & 15))

@@ -32,7 +32,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .hip import ACT_GELU, ACT_NONE, ACT_RELU, RES_AFTER_ACT, RES_BEFORE_ACT, RES_NONE, Img, NMap
+from .hip import ACT_GELU, ACT_NONE, ACT_RELU, RES_AFTER_ACT, RES_BEFORE_ACT, RES_NONE, RES_UP2_BEFORE_ACT, Img, NMap
 
 _WORKSPACE_FLOATS = 16 << 20  # split-K partial slabs (64 MB)
 
@@ -306,8 +306,9 @@ def run_backbone(st: State, encs, img: torch.Tensor, view0: int, nviews: int, fe
         pyramid.append(x)
     # FPN top-down (resnet.py:121-137).  The fuse conv over cat(lateral, up2(coarser)) is split by linearity:
     #   W . cat(a, up2(b)) + bias = W_a . a + bias + up2(W_b . b)
-    # so the W_b half runs on the coarse grid (a quarter of the pixels), is upsampled, and enters the W_a conv as a
-    # pre-activation residual; the 256-wide concat buffer is never materialised.
+    # so the W_b half runs on the coarse grid (a quarter of the pixels) and enters the W_a conv as a pre-activation residual
+    # that the epilogue interpolates itself (EGR_RES_UP2_BEFORE_ACT); neither the 256-wide concat buffer nor the upsampled
+    # tensor is ever materialised.
     c = n0.out_channels
     lat = conv(st, pyramid[3], st.get(n0.lateral_convs[3], lambda: pack_convs([k.lateral_convs[3][0] for k in necks])), ACT_RELU)
     for i in (3, 2, 1):
@@ -316,8 +317,8 @@ def run_backbone(st: State, encs, img: torch.Tensor, view0: int, nviews: int, fe
         fuse = n0.fuse_convs[i - 1]
         pa = st.get((id(fuse), "a"), lambda i=i: pack_convs_cin_slice([k.fuse_convs[i - 1][0] for k in necks], 0, c, True))
         pb = st.get((id(fuse), "b"), lambda i=i: pack_convs_cin_slice([k.fuse_convs[i - 1][0] for k in necks], c, 2 * c, False))
-        coarse = hip.upsample2x(conv(st, lat, pb, ACT_NONE))
-        fused = conv(st, fine, pa, ACT_RELU, res=coarse, res_mode=RES_BEFORE_ACT)
+        coarse_lo = conv(st, lat, pb, ACT_NONE)          # stays at the coarse resolution: the fuse conv's epilogue upsamples it on the fly
+        fused = conv(st, fine, pa, ACT_RELU, res=coarse_lo, res_mode=RES_UP2_BEFORE_ACT)
         lat = conv(st, fused, st.get(n0.fpn_convs[i - 1], lambda i=i: pack_convs([k.fpn_convs[i - 1][0] for k in necks])), ACT_RELU,
                    out=feat_out if i == 1 else None)
     return pyramid

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libegorear_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
-RES_NONE, RES_BEFORE_ACT, RES_AFTER_ACT = 0, 1, 2
+RES_NONE, RES_BEFORE_ACT, RES_AFTER_ACT, RES_UP2_BEFORE_ACT = 0, 1, 2, 3
 
 EXPORTS = [
     "egr_conv2d_nhwc_f32", "egr_stem_conv7x7_f32", "egr_maxpool_nhwc_f32", "egr_upsample2x_nhwc_f32",
@@ -237,6 +237,8 @@ def conv2d(x: Img, w: torch.Tensor, cout: int, kh: int, kw: int, stride: int, pa
                 raise RuntimeError("egorear_amd.conv2d: grouped residual must hold groups x n images")
             gr = x.n * res.nstride
             res = Img(res.t[:x.n])
+        if res_mode == RES_UP2_BEFORE_ACT and (2 * res.h != ho or 2 * res.w != wo or res.c < cout):
+            raise RuntimeError("egorear_amd.conv2d: the upsampled residual must be exactly half the output resolution")
         d.ldr, d.gr = res.ld, (gr or 0)
         d.rmap = rmap if rmap is not None else res.nmap()
     else:

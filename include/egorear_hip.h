@@ -38,7 +38,8 @@ extern "C" {
 #define EGR_EWORKSPACE (-3) /* workspace too small */
 
 enum { EGR_ACT_NONE = 0, EGR_ACT_RELU = 1, EGR_ACT_GELU = 2 };           /* GELU = exact erf form */
-enum { EGR_RES_NONE = 0, EGR_RES_BEFORE_ACT = 1, EGR_RES_AFTER_ACT = 2 };
+enum { EGR_RES_NONE = 0, EGR_RES_BEFORE_ACT = 1, EGR_RES_AFTER_ACT = 2,
+       EGR_RES_UP2_BEFORE_ACT = 3 /* res is a (ho/2, wo/2) tensor: its bilinear x2 upsampling (align_corners=True) is added before the activation */ };
 
 /* image-index -> offset mapping (floats) */
 typedef struct {

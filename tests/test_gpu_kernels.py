@@ -380,3 +380,27 @@ def test_up2_relu_head_matches_torch(groups, cout, h, w):
         ref = F.conv2d(up, wt[v].double()[:, :, None, None], bias[v].double())
         err = float((planes[:, v].cpu().double() - ref).abs().max())
         assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (v, err)
+
+
+@pytest.mark.parametrize("groups,k", [(1, 1), (2, 3)])
+def test_conv_with_residual_upsampled_in_the_epilogue(groups, k):
+    """EGR_RES_UP2_BEFORE_ACT: y = relu(conv(x) + bias + up2_bilinear_ac(lo)) with lo at half resolution (the FPN top-down add)."""
+    import torch.nn.functional as F
+    from egorear_amd import hip
+    from egorear_amd.engine import pack_conv_weight
+    n, h, w, cin, cout = 2, 16, 32, 64, 128
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(groups * n, h, w, cin, generator=g)
+    lo = torch.randn(groups * n, h // 2, w // 2, cout, generator=g)
+    wt = torch.randn(groups, cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    bias = torch.randn(groups, cout, generator=g)
+    wp = torch.stack([pack_conv_weight(wt[i]) for i in range(groups)])
+    y = hip.conv2d(hip.Img(x.to(DEV)), (wp if groups > 1 else wp[0]).contiguous().to(DEV), cout, k, k, 1, k // 2,
+                   shift=(bias if groups > 1 else bias[0]).contiguous().to(DEV), act=hip.ACT_RELU, res=hip.Img(lo.to(DEV)),
+                   res_mode=hip.RES_UP2_BEFORE_ACT, groups=groups)
+    for i in range(groups):
+        xs = x[i * n:(i + 1) * n].permute(0, 3, 1, 2).double()
+        up = F.interpolate(lo[i * n:(i + 1) * n].permute(0, 3, 1, 2).double(), scale_factor=2, mode="bilinear", align_corners=True)
+        ref = F.relu(F.conv2d(xs, wt[i].double(), bias[i].double(), 1, k // 2) + up)
+        err = float((y.t[i * n:(i + 1) * n].permute(0, 3, 1, 2).cpu().double() - ref).abs().max())
+        assert err <= 3e-5 * max(1.0, float(ref.abs().max())), (i, err)
