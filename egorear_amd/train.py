@@ -1115,8 +1115,7 @@ class FusedAdamW:
             h.wait()
         self.pending = []
         runs = self._runs(have)
-        for i, (o, n, _) in enumerate(runs):
-            T.sumsq(self.flat_g[o:o + n], self.sumsq, accumulate=i > 0)
+        T.sumsq(self.flat_g, self.sumsq)       # one pass over the whole flat buffer: slots that never receive a gradient stay zero
         for o, n, decay in runs:
             T.adamw_dev(self.flat_p[o:o + n], self.flat_g[o:o + n], self.m[o:o + n], self.v[o:o + n], self.hyper, self.betas[0], self.betas[1],
                         self.eps, self.wd if decay else 0.0, self.sumsq, self.clip)
