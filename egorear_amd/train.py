@@ -317,7 +317,7 @@ class Step:
                     r0 += n
 
     def conv(self, x: torch.Tensor, p: TPack, act: int = ACT_NONE, res: Optional[torch.Tensor] = None, need_dx: bool = True,
-             out_pad: bool = False) -> torch.Tensor:
+             out_pad: bool = False, res_up2: bool = False) -> torch.Tensor:
         """x dense NHWC (G*n, h, w, cin_pad) -> y (G*n, ho, wo, cout) [cout_pad wide, zero padded, when out_pad].
         res (same shape as y) is added before the activation.  ReLU is the only fused activation in training mode."""
         assert act in (ACT_NONE, ACT_RELU) and x.shape[-1] == p.cin_pad, (x.shape, p.cin_pad)
@@ -327,8 +327,10 @@ class Step:
         cw = p.cout_pad if out_pad else p.cout
         y = T.zeros((n, ho, wo, cw), self.dev) if (out_pad and cw != p.cout) else torch.empty((n, ho, wo, cw), device=self.dev)
         yo = Img(y[..., :p.cout]) if cw != p.cout else Img(y)
+        # res_up2: `res` is a half-resolution tensor that the epilogue up-samples itself (the FPN top-down add)
         hip.conv2d(Img(x), p.w, p.cout, p.kh, p.kw, p.stride, p.pad, shift=p.bias, act=act, res=Img(res) if res is not None else None,
-                   res_mode=RES_BEFORE_ACT if res is not None else RES_NONE, out=yo, workspace=self.ws, split_k=0, groups=p.groups)
+                   res_mode=(hip.RES_UP2_BEFORE_ACT if res_up2 else RES_BEFORE_ACT) if res is not None else RES_NONE, out=yo,
+                   workspace=self.ws, split_k=0, groups=p.groups)
 
         if act == ACT_RELU and cw == p.cout:
             self.relu_out.add(id(y))
@@ -338,7 +340,7 @@ class Step:
             if dz is None:
                 return
             if res is not None:
-                self.G.add(res, dz)
+                self.G.add(res, T.upsample2x_bwd(dz, None) if res_up2 else dz)
             if dz.shape[-1] != p.cout_pad:
                 raise RuntimeError("egorear_amd.train: gradient of a narrow conv output must arrive channel-padded")
             self._wgrad(p, x, dz)
@@ -618,8 +620,8 @@ def backbone_train(S: Step, encs, img: torch.Tensor, view0: int, nviews: int):
         fws = [k.fuse_convs[i - 1][0] for k in necks]
         pa = make_pack(S.cache, ("fuse_a", tuple(id(f) for f in fws)), [[(f.weight, 0, c)] for f in fws], [[f.bias] for f in fws], S.name)
         pb = make_pack(S.cache, ("fuse_b", tuple(id(f) for f in fws)), [[(f.weight, c, c)] for f in fws], [None] * G, S.name)
-        coarse = S.upsample(S.conv(lat, pb, ACT_NONE))
-        fused = S.conv(fine, pa, ACT_RELU, res=coarse)
+        coarse_lo = S.conv(lat, pb, ACT_NONE)
+        fused = S.conv(fine, pa, ACT_RELU, res=coarse_lo, res_up2=True)
         lat = S.conv(fused, S.pack([k.fpn_convs[i - 1][0] for k in necks]), ACT_RELU)
     return lat, pyramid[3]
 
