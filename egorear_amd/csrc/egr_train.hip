@@ -723,7 +723,8 @@ extern "C" int egr_repack_f32(const egr_repack_desc* table, const int64_t* block
 }
 
 extern "C" int32_t egr_bn_blocks(int64_t rows_per_group) {
-    int64_t n = rows_per_group / 512;
+    // >= 32 rows per slab: the deep layers (4096 rows per group) still spread over 128 workgroups per group instead of 8
+    int64_t n = rows_per_group / 32;
     if (n < 1) n = 1;
     if (n > 512) n = 512;
     return (int32_t)n;
