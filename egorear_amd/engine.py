@@ -366,7 +366,7 @@ def heatmap_forward_api(mod, img, return_feat=False):
 # --------------------------------------------------------------------------- deformable-attention layer (a12-a15, a24)
 
 class PLayer:
-    __slots__ = ("offs_logits", "head_w", "head_shift", "pos_proj", "out_proj", "fuse", "ln_cross", "qkv", "mha_out",
+    __slots__ = ("offs_logits", "head_w", "head_shift", "head_w_all", "head_shift_all", "pos_proj", "out_proj", "fuse", "ln_cross", "qkv", "mha_out",
                  "ln_spatial", "ffn0", "ffn1", "ln_ffn", "heads", "dh", "C", "groups")
 
 
@@ -397,6 +397,9 @@ def pack_layers(layers, pres, poss) -> PLayer:
             pos_proj.append((pos.detach()[0].double() @ Wv.t()).float())
     P.head_w = [_stack(w) for w in head_w]
     P.head_shift = [_stack(s) for s in head_shift]
+    # one query set (the lifting head): the heads themselves become the groups of a single launch
+    P.head_w_all = torch.stack([w[0] for w in head_w]).contiguous() if P.groups == 1 else None
+    P.head_shift_all = torch.stack([s[0] for s in head_shift]).contiguous() if P.groups == 1 else None
     P.pos_proj = torch.stack(pos_proj).contiguous() if pos_proj else None
     cas = [l.cross_attn for l in layers]
     P.offs_logits = pack_linears([(torch.cat([c.sampling_offsets.weight.detach(), c.attention_weights.weight.detach()], 0),
@@ -431,7 +434,11 @@ def run_layer(st: State, P: PLayer, x: torch.Tensor, memory: torch.Tensor, ancho
     g2 = g.view(G * rows, heads * cf)
     e2 = e.view(G * rows, C) if e is not None else None
     sig = sigma.view(G * heads * rows)
-    for h in range(heads):                                              # per-head folded value projection, all groups
+    if G == 1 and P.head_w_all is not None:                             # heads as groups: one launch for the whole projection
+        hip.conv2d(_rows(g2[:rows, :cf]), P.head_w_all, dh, 1, 1, 1, 0, shift=P.head_shift_all, rowscale=sig, grs=rows,
+                   res=_rows(e2[:rows, :dh]) if e2 is not None else None, res_mode=RES_AFTER_ACT if e2 is not None else RES_NONE,
+                   out=_rows(a[:rows, :dh]), workspace=None, split_k=1, groups=heads, gx=cf, gr=dh, gy=dh)
+    for h in range(heads if not (G == 1 and P.head_w_all is not None) else 0):   # per-head folded value projection, all groups
         hip.conv2d(_rows(g2[:rows, h * cf:(h + 1) * cf]), P.head_w[h], dh, 1, 1, 1, 0, shift=P.head_shift[h],
                    rowscale=sig[h * rows:], grs=heads * rows,
                    res=_rows(e2[:rows, h * dh:(h + 1) * dh]) if e2 is not None else None,
