@@ -729,7 +729,9 @@ static int conv_run(const egr_conv_desc* dd, const float* x, const float* w, con
     if (d.split_k <= 0) {
         d.split_k = 1;
         if (blocks < 128 && a.ktiles >= 32 && workspace) {
-            int s = 256 / blocks;
+            // skinny GEMM streaming a long weight matrix (mlp_pred.0: 268 MB): a block's two-stage pipeline moves ~8 GB/s,
+            // so the HBM rate is set by how many blocks stream at once -> aim at 4 per CU
+            int s = 1024 / blocks;
             if (s > a.ktiles / 8) s = a.ktiles / 8;
             if (s > 32) s = 32;
             while (s > 1 && (size_t)s * a.M * a.Npad * d.groups > workspace_floats) --s;
