@@ -24,6 +24,8 @@
 // sense (no reduced-precision path exists on gfx950, and none is wanted: argmax indices must match).
 #include <type_traits>
 
+#include <cstdlib>
+
 #include "egr_common.h"
 
 namespace {
@@ -731,7 +733,8 @@ static int conv_run(const egr_conv_desc* dd, const float* x, const float* w, con
         if (blocks < 128 && a.ktiles >= 32 && workspace) {
             // skinny GEMM streaming a long weight matrix (mlp_pred.0: 268 MB): a block's two-stage pipeline moves ~8 GB/s,
             // so the HBM rate is set by how many blocks stream at once -> aim at 4 per CU
-            int s = 1024 / blocks;
+            static const int target = getenv("EGR_SPLITK_TARGET") ? atoi(getenv("EGR_SPLITK_TARGET")) : 1024;   // tuning knob
+            int s = target / blocks;
             if (s > a.ktiles / 8) s = a.ktiles / 8;
             if (s > 32) s = 32;
             while (s > 1 && (size_t)s * a.M * a.Npad * d.groups > workspace_floats) --s;
