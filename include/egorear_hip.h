@@ -227,6 +227,26 @@ int egr_pose_metrics_f32(const float* pred, const float* gt, int32_t b, int32_t 
 int egr_gt_heatmap_f32(const double* joints, int32_t maps, double image_size, int32_t heatmap_size, int32_t tmp_size,
                        const float* gauss, float* out, void* stream);
 
+/* The reference's only native call, in its own operand layout: mmcv==2.2.0 MultiScaleDeformableAttnFunction.apply
+ * (models/utils/deform_attn.py:155-162; third-party, un-vendored, pin README.md:134).
+ *   value (n, lin, heads, d) fp32, spatial_shapes i64 (levels, 2) = (H_l, W_l), level_start_index i64 (levels) — both
+ *   device arrays —, sampling_loc (n, lq, heads, levels, points, 2) normalised (x, y), attn_weight (n, lq, heads, levels,
+ *   points)  ->  out (n, lq, heads*d).
+ * pixel = loc*size - 0.5; a point contributes iff -1 < pixel < size on both axes; corners outside the map read as 0.
+ * im2col_step of the reference only chunks the batch and has no counterpart here.  Corner tokens >= lin are skipped, so
+ * inconsistent shapes cannot fault.  The model path itself uses egr_msda_gather_f32 (sample-then-project); these two
+ * entries serve a maintainer who replaces only the mmcv extension (egorear_amd/msda.py). */
+int egr_msda_fwd_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                     const float* sampling_loc, const float* attn_weight, int32_t n, int64_t lin, int32_t heads, int32_t d,
+                     int32_t lq, int32_t levels, int32_t points, float* out, void* stream);
+/* Backward of the above: grad_value (n, lin, heads, d) is zeroed on the stream and then accumulated with atomics (the
+ * summation order, and so the last bits, vary run to run — as in mmcv); grad_sampling_loc and grad_attn_weight are
+ * written for every point (zeros for points outside the map). */
+int egr_msda_bwd_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                     const float* sampling_loc, const float* attn_weight, const float* grad_out, int32_t n, int64_t lin,
+                     int32_t heads, int32_t d, int32_t lq, int32_t levels, int32_t points, float* grad_value,
+                     float* grad_sampling_loc, float* grad_attn_weight, void* stream);
+
 /* Library / device identification. */
 const char* egr_version(void);
 int egr_device_arch(char* buf, int32_t buflen); /* gcnArchName of the current device */

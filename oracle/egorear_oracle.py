@@ -201,6 +201,19 @@ def msda_core(value: torch.Tensor, H: int, W: int, loc: torch.Tensor, attn: torc
     return out.permute(0, 2, 1, 3).reshape(N, Lq, nh * D)
 
 
+def msda_levels(value: torch.Tensor, spatial_shapes, level_start_index, loc: torch.Tensor, attn: torch.Tensor) -> torch.Tensor:
+    """mmcv 2.2.0 MultiScaleDeformableAttnFunction.apply in its own operand layout (call site
+    models/utils/deform_attn.py:155-162): value (N, Lin, nh, D); spatial_shapes (L, 2) = (H, W); level_start_index (L,);
+    loc (N, Lq, nh, L, P, 2); attn (N, Lq, nh, L, P) -> (N, Lq, nh*D).  The sum over levels of msda_core on each level's
+    token range; differentiable by autograd in value, loc and attn (floor and the inside tests carry no gradient, as in
+    mmcv's col2im kernels)."""
+    out = None
+    for lvl, ((H, W), st) in enumerate(zip(torch.as_tensor(spatial_shapes).tolist(), torch.as_tensor(level_start_index).tolist())):
+        o = msda_core(value[:, st : st + H * W], int(H), int(W), loc[:, :, :, lvl], attn[:, :, :, lvl])
+        out = o if out is None else out + o
+    return out
+
+
 def ms_deform_attn(sd: SD, p: str, query, ref_pts, memory, H: int, W: int, n_heads: int = 4, n_points: int = 16):
     """models/utils/deform_attn.py:90-168 (MSDeformAttn.forward, one level, 2-d reference points)."""
     N, Lq, C = query.shape
