@@ -15,6 +15,11 @@ Extra objects on the line:
                  instrumented pass right after the timed region; peak = 157.3 TFLOP/s (fp32 MFMA, gfx950).
   cpu_baseline — the CPU oracle (oracle/egorear_oracle.py, a PyTorch-CPU port of the reference path)
                  timed on this box's host cores on a bounded sample of the same workload.
+  parity_vs_cpu_oracle — the metric's "MPJPE vs ref" half: the oracle's warm-up forward of that sample checks the HIP
+                 path's output on the same frames (arg-max indices equal, largest 3-D joint deviation in cm,
+                 MPJPE of both against the seeded synthetic ground truth).
+  preprocess, train — the SURVEY.md §8(f) legs (raw 872x872 uint8 -> model input; the config-5 optimisation step),
+                 timed separately, never part of `value`.
 """
 from __future__ import annotations
 
@@ -80,8 +85,10 @@ def _log(msg: str):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(state_dict, batch: int, iters: int):
-    """Time the CPU oracle (kind 'port') on a bounded sample: `iters` forwards of `batch` frames."""
+def cpu_baseline(state_dict, batch: int, iters: int, gpu_out=None):
+    """Time the CPU oracle (kind 'port') on a bounded sample: `iters` forwards of `batch` frames.  `gpu_out` = the HIP path's
+    (poses, heat maps) on the same frames: the oracle's warm-up forward doubles as the checker for the metric's
+    "MPJPE vs ref" half (returned as the second value)."""
     import torch
     from egorear_amd import synth
     from oracle import egorear_oracle as O
@@ -91,7 +98,18 @@ def cpu_baseline(state_dict, batch: int, iters: int):
     img = synth.synth_images(batch, 4, seed=1234)
     with torch.no_grad():
         _log(f"cpu baseline: warm-up forward, batch {batch}, {cores} threads")
-        O.mvfex_forward(state_dict, cams, img)  # warm-up
+        ref_pose, ref_hm, _ = O.mvfex_forward(state_dict, cams, img)  # warm-up
+        parity = None
+        if gpu_out is not None:
+            gt = synth.synth_gt_pose(batch, seed=1235)
+            pose, hm = gpu_out
+            am_g = hm.flatten(-2).argmax(-1)
+            am_c = ref_hm[-1].flatten(-2).argmax(-1)
+            parity = {"frames": batch, "argmax_equal": bool((am_g == am_c).all()), "argmax_compared": int(am_c.numel()),
+                      "max_joint_err_cm": float((pose - ref_pose[-1]).abs().max()),
+                      "mpjpe_mm_hip": float(O.compute_mpjpe_batch(pose, gt).mean() * 10),
+                      "mpjpe_mm_cpu_oracle": float(O.compute_mpjpe_batch(ref_pose[-1], gt).mean() * 10),
+                      "tolerance_cm": 1e-3}
         _log("cpu baseline: timing")
         t0 = time.perf_counter()
         for _ in range(iters):
@@ -99,7 +117,7 @@ def cpu_baseline(state_dict, batch: int, iters: int):
         dt = time.perf_counter() - t0
     return {"value": round(batch * iters / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{iters} forwards of batch {batch} (config ego4view_syn_pose3d, eval/no_grad, torch-CPU fp32, "
-                      f"{cores} threads), {dt:.1f} s"}
+                      f"{cores} threads), {dt:.1f} s"}, parity
 
 
 def cpu_train_baseline(batch: int = 4, iters: int = 4):
@@ -274,6 +292,11 @@ def main():
                     "kernel_ms_per_step": round(k["ms"], 3),
                     "all_kernels_ms_per_step": round(sum(v["ms"] for v in kernels.values()), 3)}
 
+    parity_out = None
+    if cpu_sd is not None:  # the HIP path on the frames the CPU oracle will see (checked inside the cpu_baseline leg)
+        with torch.no_grad():
+            poses, hms = net(synth.synth_images(args.cpu_batch, 4, seed=1234).to(dev))
+        parity_out = (poses[-1].cpu(), hms[-1].cpu())
     pre_leg = None
     if rank == 0:
         # §8(f) rank 1, timed separately (never part of `value`): raw uint8 872x872 frames -> model input, on the GPU
@@ -328,7 +351,7 @@ def main():
         if kernels:
             line["kernel_ms"] = {n: round(v["ms"], 3) for n, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])}
         if cpu_sd is not None:
-            line["cpu_baseline"] = cpu_baseline(cpu_sd, args.cpu_batch, args.cpu_iters)
+            line["cpu_baseline"], line["parity_vs_cpu_oracle"] = cpu_baseline(cpu_sd, args.cpu_batch, args.cpu_iters, parity_out)
         elif world == 1:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
