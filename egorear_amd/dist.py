@@ -63,12 +63,13 @@ def world_size(group=None) -> int:
     return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
 
 
-def allreduce_gradients_(flat: torch.Tensor, group=None, async_op: bool = False):
+def allreduce_gradients_(flat: torch.Tensor, group=None, async_op: bool = False, force: bool = False):
     """In-place SUM all-reduce of (a bucket of) the flat gradient buffer over the data-parallel group.  Returns `flat`, or
     with async_op the work handle to wait on (None for one process).  RCCL runs it on its own stream, so a bucket started
     when its stage of the reverse pass is finished overlaps with the remaining backward kernels.  With the gloo backend
-    (CPU tests, one-GPU rehearsals) device tensors are staged through the host."""
-    if world_size(group) <= 1:
+    (CPU tests, one-GPU rehearsals) device tensors are staged through the host.  `force` issues the collective for a
+    one-rank group too (an identity; the RCCL stream / work-handle semantics can then be exercised on a one-GPU box)."""
+    if world_size(group) <= 1 and not (force and dist.is_available() and dist.is_initialized()):
         return None if async_op else flat
     if flat.is_cuda and dist.get_backend(group) == "gloo":
         host = flat.detach().cpu()

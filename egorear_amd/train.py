@@ -1044,6 +1044,7 @@ class FusedAdamW:
                  betas=(0.9, 0.999), eps: float = 1e-8, process_group=None):
         self.net, self.lr, self.wd, self.clip, self.warmup, self.betas, self.eps = net, lr, weight_decay, clip, warmup_iters, betas, eps
         self.pg = process_group
+        self.force_collective = False        # issue the stage all-reduces for a one-rank group too (RCCL rehearsal on one GPU)
         named = list(net.named_parameters())
         dev = named[0][1].device
         if dev.type != "cuda":
@@ -1099,7 +1100,7 @@ class FusedAdamW:
         It runs on the communication stream of the process group while the reverse pass continues."""
         from .dist import allreduce_gradients_
         b, e = self.stage_range[stage]
-        h = allreduce_gradients_(self.flat_g[b:e], self.pg, async_op=True)
+        h = allreduce_gradients_(self.flat_g[b:e], self.pg, async_op=True, force=self.force_collective)
         if h is not None:
             self.pending.append(h)
 
@@ -1155,7 +1156,7 @@ class Trainer:
         S = Step(net, img.device)
         S.gviews = self.opt.gviews
         from .dist import grad_seed_scale, world_size
-        if world_size(self.opt.pg) > 1:
+        if world_size(self.opt.pg) > 1 or self.opt.force_collective:
             S.stage_hook = self.opt.reduce_stage   # bucketed all-reduce overlapped with the rest of the reverse pass
         with torch.no_grad():
             preds, hms, aux = forward_train(S, net, img, ctm)
@@ -1184,7 +1185,7 @@ class Trainer:
                 self.graph.replay()
                 self._invalidate()
                 return self._graph_out
-        if self.use_graph and self.graph is None and self._eager_done >= 2 and world_size(self.opt.pg) == 1:
+        if self.use_graph and self.graph is None and self._eager_done >= 2 and world_size(self.opt.pg) == 1 and not self.opt.force_collective:
             try:
                 self._capture(img, ctm, gt_pose, gt_heatmap)
             except Exception:      # capture is an optimisation: any refusal leaves the eager path in charge

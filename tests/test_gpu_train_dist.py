@@ -91,3 +91,50 @@ def test_two_ranks_average_gradients_and_stay_in_sync():
         n_ref = float(avg.double().norm())
         assert abs(norm - n_ref) <= 1e-4 * n_ref + 1e-7, (k, norm, n_ref)
         np.testing.assert_allclose(samp, _sample(avg), rtol=1e-3, atol=1e-5 * max(n_ref, 1e-6), err_msg=k)
+
+
+def _rccl_worker(port, out):
+    """One rank, backend "nccl" (= RCCL): the stage all-reduces are identities, but they run on RCCL's own stream through the
+    same async work handles as the 8-GPU job — the update must wait for them and the trajectory must not change."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from egorear_amd import train
+        plain, forced = train.Trainer(_build()), train.Trainer(_build())
+        forced.opt.force_collective = True
+        losses = []
+        for t in range(3):
+            args = _data(t)
+            a, _ = plain.step(*args)
+            b, _ = forced.step(*args)
+            torch.cuda.synchronize()
+            losses.append((float(a.sum()), float(b.sum())))
+        assert not forced.opt.pending
+        worst = 0.0
+        for (k, p), (_, q) in zip(plain.net.named_parameters(), forced.net.named_parameters()):
+            if "k_proj.bias" not in k:
+                worst = max(worst, float(((p - q).abs() > 2e-4).float().mean()))
+        out.put((losses, worst, forced.opt.steps, None))
+    except Exception as exc:  # noqa: BLE001 - reported to the parent
+        out.put((None, None, None, f"{type(exc).__name__}: {exc}"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_rccl_group_runs_the_overlapped_exchange():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(port, out))
+    p.start()
+    losses, worst, steps, err = out.get(timeout=600)
+    p.join(timeout=120)
+    assert err is None, err
+    assert p.exitcode == 0 and steps == 3
+    for a, b in losses:
+        assert abs(a - b) <= 1e-5 * abs(a), losses
+    assert worst < 0.02, worst
