@@ -88,22 +88,36 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool X6 = false>
 struct LdsPlan {
-    static constexpr int TILE = (BM + BN) * BK;             // floats per stage
+    // floats per stage.  fp32 path: BK = 32 deep rows of both operands.  Split-bf16 path: one k16 step of (hi, mid, lo) bf16
+    // planes in fragment order, 1 KiB per (32-row fragment, plane)
+    static constexpr int TILE = X6 ? (BM / 32 + BN / 32) * 3 * 256 : (BM + BN) * BK;
     static constexpr int CS = BN + 4;                       // epilogue staging row stride
     static constexpr int ROWOFF = (2 * TILE > BM * CS) ? 2 * TILE : BM * CS;  // row offsets (y, res) live past both
     static constexpr int FLOATS = ROWOFF + 4 * BM;                            // + per-row input offset and tap mask
 };
 
-template <int BM, int BN, int WM, int WN>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// two fp32 -> packed bf16 (round to nearest even); element 0 in the low half
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float bf16_hi_f32(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
+__device__ __forceinline__ float bf16_lo_f32(unsigned p) { return __uint_as_float(p << 16); }
+
+template <int BM, int BN, int WM, int WN, bool X6 = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     static_assert(WM * WN == 4, "four waves per workgroup");
     constexpr int NT = 256;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 32, FN = TN / 32;
     constexpr int IA = BM / 32, IB = BN / 32;  // 32 rows per load pass (8 rows per wave-instruction)
-    using P = LdsPlan<BM, BN>;
+    using P = LdsPlan<BM, BN, X6>;
     static_assert(FM >= 1 && FN >= 1, "wave tile must be >= 32x32");
 
     __shared__ __attribute__((aligned(16))) float lds[P::FLOATS];
@@ -219,16 +233,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         s_yoff[r] = yo;
         s_roff[r] = ro;
     }
-    const float* wrow[IB];
-#pragma unroll
-    for (int i = 0; i < IB; ++i) {
-        int r = i * 32 + rsub;
-        int co = tn * BN + r;
-        wrow[i] = (co < a.Npad) ? wg + (int64_t)co * a.K + (pseg ^ ((r >> 1) & 7)) * 4 : nullptr;
-    }
-    const float* arow[IA];
-    unsigned amask[IA];
-
     // wave-uniform position of a chunk in K: (channel chunk cb, tap (kh, kw)); advanced incrementally
     struct KPos { int cb, kh, kw; };
     auto kpos_of = [&](int kt) {
@@ -246,30 +250,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         return p;
     };
 
-    // one 1-KiB DMA piece (8 rows x 128 B) of a stage: pieces [0, IA) are A rows, [IA, IA+IB) weight rows.
-    // The stage buffer is a compile-time constant so LDS addresses fold into instruction immediates.
-    const uint32_t zlo = (uint32_t)(uint64_t)egr_zero16, zhi = (uint32_t)((uint64_t)egr_zero16 >> 32);
-    auto issue_piece = [&](int kt, KPos kp, auto buf_tag, int piece) {
-        constexpr int BUF = decltype(buf_tag)::value;
-        float* sA = lds + BUF * P::TILE;
-        if (piece < IA) {
-            const int tap = kp.kh * d.kw + kp.kw;
-            // wave-uniform, 32-bit.  Transposed mode: th - kh = stride*(bh - kh/stride) + (th%stride - kh%stride), and the mask
-            // bit is set only where the remainders agree, so the source pixel is (bh - kh/stride, bw - kw/stride).
-            const int toff = d.transposed ? -((kp.kh / d.stride) * d.w + (kp.kw / d.stride)) * d.ldx + kp.cb * BK
-                                          : (kp.kh * d.w + kp.kw) * d.ldx + kp.cb * BK;
-            const uint64_t pa = (uint64_t)(arow[piece] + toff);
-            const bool ok = (amask[piece] >> tap) & 1u;
-            // select between the pixel row and the zero buffer with two 32-bit v_cndmask (no branch, no 64-bit logic)
-            const uint32_t lo = ok ? (uint32_t)pa : zlo, hi = ok ? (uint32_t)(pa >> 32) : zhi;
-            glds16(reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo), sA + (piece * 32 + wave * 8) * BK);
-        } else {
-            const int i = piece - IA;
-            const float* p = wrow[i] ? wrow[i] + (kp.cb * a.taps + kp.kh * d.kw + kp.kw) * BK : egr_zero16;   // chunk index in K
-            glds16(p, sA + BM * BK + (i * 32 + wave * 8) * BK);
-        }
-    };
-
     f32x16 acc[FM][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -278,104 +258,283 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // fragment read offsets (floats) inside a stage for the four k-groups of a chunk, computed once:
-    // row * 32 + ((q ^ swz(row)) * 4) with q = 2*g + half
-    int afo[FM][4], bfo[FN][4];
+    if constexpr (!X6) {
+        const float* wrow[IB];
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        const int r = wm * TM + i * 32 + l31;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) afo[i][g] = r * BK + (((2 * g + half) ^ ((r >> 1) & 7)) << 2);
-    }
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-        const int r = wn * TN + j * 32 + l31;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bfo[j][g] = BM * BK + r * BK + (((2 * g + half) ^ ((r >> 1) & 7)) << 2);
-    }
+        for (int i = 0; i < IB; ++i) {
+            int r = i * 32 + rsub;
+            int co = tn * BN + r;
+            wrow[i] = (co < a.Npad) ? wg + (int64_t)co * a.K + (pseg ^ ((r >> 1) & 7)) * 4 : nullptr;
+        }
+        const float* arow[IA];
+        unsigned amask[IA];
 
-    constexpr int NPIECE = IA + IB;
-    constexpr int DMA_EVERY = (FM * FN >= 4) ? 2 : 1;  // big tiles: one DMA piece behind every 2nd MFMA (measured +2.5 %)
-    using B0 = std::integral_constant<int, 0>;
-    using B1 = std::integral_constant<int, 1>;
-
-    // multiply one staged chunk; when ISSUE, the next chunk's DMA pieces go out one per MFMA behind the first
-    // matrix instructions (pinned with sched_barrier), so their issue slots hide under the 64-cycle MFMAs
-    auto chunk = [&](int kt, auto buf_tag, KPos kp_next, auto issue_tag) {
-        constexpr int BUF = decltype(buf_tag)::value;
-        constexpr bool ISSUE = decltype(issue_tag)::value;
-        using NB = std::integral_constant<int, BUF ^ 1>;
-        const float* st = lds + BUF * P::TILE;
-        f32x4 av[2][FM], bv[2][FN];
-#pragma unroll
-        for (int i = 0; i < FM; ++i) av[0][i] = *reinterpret_cast<const f32x4*>(&st[afo[i][0]]);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) bv[0][j] = *reinterpret_cast<const f32x4*>(&st[bfo[j][0]]);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int cur = g & 1, nxt = cur ^ 1;
-            if (g < 3) {  // fragments of the next k-group are fetched under this group's MFMAs
-#pragma unroll
-                for (int i = 0; i < FM; ++i) av[nxt][i] = *reinterpret_cast<const f32x4*>(&st[afo[i][g + 1]]);
-#pragma unroll
-                for (int j = 0; j < FN; ++j) bv[nxt][j] = *reinterpret_cast<const f32x4*>(&st[bfo[j][g + 1]]);
+        // one 1-KiB DMA piece (8 rows x 128 B) of a stage: pieces [0, IA) are A rows, [IA, IA+IB) weight rows.
+        // The stage buffer is a compile-time constant so LDS addresses fold into instruction immediates.
+        const uint32_t zlo = (uint32_t)(uint64_t)egr_zero16, zhi = (uint32_t)((uint64_t)egr_zero16 >> 32);
+        auto issue_piece = [&](int kt, KPos kp, auto buf_tag, int piece) {
+            constexpr int BUF = decltype(buf_tag)::value;
+            float* sA = lds + BUF * P::TILE;
+            if (piece < IA) {
+                const int tap = kp.kh * d.kw + kp.kw;
+                // wave-uniform, 32-bit.  Transposed mode: th - kh = stride*(bh - kh/stride) + (th%stride - kh%stride), and the mask
+                // bit is set only where the remainders agree, so the source pixel is (bh - kh/stride, bw - kw/stride).
+                const int toff = d.transposed ? -((kp.kh / d.stride) * d.w + (kp.kw / d.stride)) * d.ldx + kp.cb * BK
+                                              : (kp.kh * d.w + kp.kw) * d.ldx + kp.cb * BK;
+                const uint64_t pa = (uint64_t)(arow[piece] + toff);
+                const bool ok = (amask[piece] >> tap) & 1u;
+                // select between the pixel row and the zero buffer with two 32-bit v_cndmask (no branch, no 64-bit logic)
+                const uint32_t lo = ok ? (uint32_t)pa : zlo, hi = ok ? (uint32_t)(pa >> 32) : zhi;
+                glds16(reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo), sA + (piece * 32 + wave * 8) * BK);
+            } else {
+                const int i = piece - IA;
+                const float* p = wrow[i] ? wrow[i] + (kp.cb * a.taps + kp.kh * d.kw + kp.kw) * BK : egr_zero16;   // chunk index in K
+                glds16(p, sA + BM * BK + (i * 32 + wave * 8) * BK);
             }
+        };
+
+        // fragment read offsets (floats) inside a stage for the four k-groups of a chunk, computed once:
+        // row * 32 + ((q ^ swz(row)) * 4) with q = 2*g + half
+        int afo[FM][4], bfo[FN][4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+        for (int i = 0; i < FM; ++i) {
+            const int r = wm * TM + i * 32 + l31;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) afo[i][g] = r * BK + (((2 * g + half) ^ ((r >> 1) & 7)) << 2);
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int r = wn * TN + j * 32 + l31;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bfo[j][g] = BM * BK + r * BK + (((2 * g + half) ^ ((r >> 1) & 7)) << 2);
+        }
+
+        constexpr int NPIECE = IA + IB;
+        constexpr int DMA_EVERY = (FM * FN >= 4) ? 2 : 1;  // big tiles: one DMA piece behind every 2nd MFMA (measured +2.5 %)
+        using B0 = std::integral_constant<int, 0>;
+        using B1 = std::integral_constant<int, 1>;
+
+        // multiply one staged chunk; when ISSUE, the next chunk's DMA pieces go out one per MFMA behind the first
+        // matrix instructions (pinned with sched_barrier), so their issue slots hide under the 64-cycle MFMAs
+        auto chunk = [&](int kt, auto buf_tag, KPos kp_next, auto issue_tag) {
+            constexpr int BUF = decltype(buf_tag)::value;
+            constexpr bool ISSUE = decltype(issue_tag)::value;
+            using NB = std::integral_constant<int, BUF ^ 1>;
+            const float* st = lds + BUF * P::TILE;
+            f32x4 av[2][FM], bv[2][FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) av[0][i] = *reinterpret_cast<const f32x4*>(&st[afo[i][0]]);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bv[0][j] = *reinterpret_cast<const f32x4*>(&st[bfo[j][0]]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cur = g & 1, nxt = cur ^ 1;
+                if (g < 3) {  // fragments of the next k-group are fetched under this group's MFMAs
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) av[nxt][i] = *reinterpret_cast<const f32x4*>(&st[afo[i][g + 1]]);
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) bv[nxt][j] = *reinterpret_cast<const f32x4*>(&st[bfo[j][g + 1]]);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i][t], bv[cur][j][t], acc[i][j], 0, 0, 0);
+                            if constexpr (ISSUE) {
+                                const int n = ((g * 4 + t) * FM + i) * FN + j;
+                                if ((n % DMA_EVERY) == 0 && (n / DMA_EVERY) < NPIECE) {
+                                    issue_piece(kt + 1, kp_next, NB{}, n / DMA_EVERY);
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                            }
+                        }
+            }
+        };
+
+        KPos kp = kpos_of(kt0);
+        if (kt0 < kt1) {  // weight pieces of the first chunk need no row geometry: their latency overlaps the decode
+#pragma unroll
+            for (int pc = IA; pc < NPIECE; ++pc) issue_piece(kt0, kp, B0{}, pc);
+        }
+        __syncthreads();  // row table visible (also drains the weight DMA; it had the whole decode to land)
+#pragma unroll
+        for (int i = 0; i < IA; ++i) {
+            const int r = i * 32 + rsub;
+            arow[i] = xg + (s_xoff[r] + (pseg ^ ((r >> 1) & 7)) * 4);
+            amask[i] = s_mask[r];
+        }
+        stamp(1);  // row decode done
+        if (kt0 < kt1) {
+#pragma unroll
+            for (int pc = 0; pc < IA; ++pc) issue_piece(kt0, kp, B0{}, pc);
+        }
+        __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes stage 0
+        stamp(2);  // first chunk landed
+        int kt = kt0;
+        for (; kt + 2 < kt1; kt += 2) {  // two chunks per trip: stage indices are compile-time constants
+            KPos k1 = kpos_next(kp);
+            chunk(kt, B0{}, k1, std::true_type{});
+            __syncthreads();
+            KPos k2 = kpos_next(k1);
+            chunk(kt + 1, B1{}, k2, std::true_type{});
+            __syncthreads();
+            kp = k2;
+        }
+        if (kt + 1 < kt1) {  // two chunks left
+            KPos k1 = kpos_next(kp);
+            chunk(kt, B0{}, k1, std::true_type{});
+            __syncthreads();
+            chunk(kt + 1, B1{}, k1, std::false_type{});
+            __syncthreads();
+        } else if (kt < kt1) {  // one chunk left
+            chunk(kt, B0{}, kp, std::false_type{});
+            __syncthreads();
+        }
+    } else {
+        // ---- split-bf16 main loop: fp32 operands as exact sums of three bf16 (hi, mid, lo); the six partial products of order
+        // <= 2 on v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  The dropped ones are ~2^-26 relative, below fp32 rounding.
+        // A stage is ONE k16 step: a chunk (tap x 32 channels) is two stages, stage s of a chunk lives in LDS buffer s.
+        //   A: a thread owns `unit` = (tile row, 8-channel group); its 32 bytes are loaded into registers one stage ahead,
+        //      split by VALU work pinned into the gaps behind the MFMAs, and written in fragment order (ds_write_b128 x 3);
+        //   B: the weights were split once (egr_pack_w6_f32) into the same fragment order: LDS-DMA, 1 KiB per wave-instruction.
+        constexpr int AU = 2 * BM;                    // staging units per stage
+        constexpr int NU = (AU + NT - 1) / NT;        // per thread
+        constexpr int NFA = BM / 32, NFB = BN / 32;
+        constexpr int A_BYTES = NFA * 3 * 1024;
+        constexpr int STB = P::TILE * 4;              // bytes per stage
+        constexpr int NPB = NFB * 3;                  // weight pieces per stage
+        uint8_t* const lb = reinterpret_cast<uint8_t*>(lds);
+        const uint8_t* const wimg = reinterpret_cast<const uint8_t*>(a.w) + (int64_t)grp * d.gw * 2;
+        __syncthreads();  // row table visible
+        const float* ubase[NU];
+        unsigned umask[NU];
+        int uwo[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int u = tid + NT * i, r = (u >> 1) % BM, g = u & 1;
+            const bool live = u < AU;
+            ubase[i] = xg + (live ? s_xoff[r] : 0) + g * 8;
+            umask[i] = live ? s_mask[r] : 0u;
+            uwo[i] = ((r >> 5) * 3) * 1024 + ((r & 31) + 32 * g) * 16;
+        }
+        f32x4 xr[2][NU][2];
+        auto load_a = [&](KPos kp, int sidx, auto set_tag) {
+            constexpr int SET = decltype(set_tag)::value;
+            const int tap = kp.kh * d.kw + kp.kw;
+            const int toff = (d.transposed ? -((kp.kh / d.stride) * d.w + (kp.kw / d.stride)) * d.ldx + kp.cb * BK
+                                           : (kp.kh * d.w + kp.kw) * d.ldx + kp.cb * BK) + sidx * 16;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                const bool ok = (umask[i] >> tap) & 1u;
+                const float* p0 = ok ? ubase[i] + toff : egr_zero16;
+                const float* p1 = ok ? ubase[i] + toff + 4 : egr_zero16;
+                xr[SET][i][0] = *reinterpret_cast<const f32x4*>(p0);
+                xr[SET][i][1] = *reinterpret_cast<const f32x4*>(p1);
+            }
+        };
+        auto dma_b = [&](KPos kp, int sidx, auto buf_tag) {
+            constexpr int BUF = decltype(buf_tag)::value;
+            const int64_t kc = (int64_t)(kp.cb * a.taps + kp.kh * d.kw + kp.kw);
+#pragma unroll
+            for (int j = 0; j < (NPB + 3) / 4; ++j) {
+                const int pc = wave + 4 * j;
+                if (pc < NPB) {
+                    const int cf = tn * NFB + pc / 3, pl = pc % 3;
+                    glds16(reinterpret_cast<const float*>(wimg + (((int64_t)cf * a.ktiles + kc) * 6 + sidx * 3 + pl) * 1024 + lane * 16),
+                           reinterpret_cast<float*>(lb + BUF * STB + A_BYTES + pc * 1024));
+                }
+            }
+        };
+        // one slice of the split of a unit: 0-3 hi halves + first residuals of pair k, 4-7 mid / lo halves, 8 the three writes
+        u32x4 sh_[NU], sm_[NU], sl_[NU];
+        float ra_[NU][4], rb_[NU][4];
+        auto slice = [&](auto set_tag, auto buf_tag, int k) {
+            constexpr int SET = decltype(set_tag)::value;
+            constexpr int BUF = decltype(buf_tag)::value;
+            const int i = k / 9, q = k % 9;
+            if (q < 4) {
+                const float v0 = xr[SET][i][q >> 1][(q & 1) * 2], v1 = xr[SET][i][q >> 1][(q & 1) * 2 + 1];
+                sh_[i][q] = cvt_pk_bf16(v0, v1);
+                ra_[i][q] = v0 - bf16_lo_f32(sh_[i][q]);
+                rb_[i][q] = v1 - bf16_hi_f32(sh_[i][q]);
+            } else if (q < 8) {
+                const int t = q - 4;
+                sm_[i][t] = cvt_pk_bf16(ra_[i][t], rb_[i][t]);
+                sl_[i][t] = cvt_pk_bf16(ra_[i][t] - bf16_lo_f32(sm_[i][t]), rb_[i][t] - bf16_hi_f32(sm_[i][t]));
+            } else if (AU >= NT * (i + 1) || tid + NT * i < AU) {
+                uint8_t* dst = lb + BUF * STB + uwo[i];
+                *reinterpret_cast<u32x4*>(dst) = sh_[i];
+                *reinterpret_cast<u32x4*>(dst + 1024) = sm_[i];
+                *reinterpret_cast<u32x4*>(dst + 2048) = sl_[i];
+            }
+        };
+        constexpr int NS = 9 * NU;          // slices per stage
+        constexpr int NM = 6 * FM * FN;     // MFMAs per stage
+        // MFMAs of the stage in buffer BUF; when `conv`, the registers of set BUF^1 are split into buffer BUF^1 behind them
+        auto stage = [&](auto buf_tag, bool conv) {
+            constexpr int BUF = decltype(buf_tag)::value;
+            using NB = std::integral_constant<int, BUF ^ 1>;
+            const uint8_t* st = lb + BUF * STB;
+            bf16x8 af[FM][3], bf[FN][3];
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) af[i][pl] = *reinterpret_cast<const bf16x8*>(st + ((wm * FM + i) * 3 + pl) * 1024 + lane * 16);
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8*>(st + A_BYTES + ((wn * FN + j) * 3 + pl) * 1024 + lane * 16);
+            // smallest terms first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+            int n = 0, done = 0;
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i][t], bv[cur][j][t], acc[i][j], 0, 0, 0);
-                        if constexpr (ISSUE) {
-                            const int n = ((g * 4 + t) * FM + i) * FN + j;
-                            if ((n % DMA_EVERY) == 0 && (n / DMA_EVERY) < NPIECE) {
-                                issue_piece(kt + 1, kp_next, NB{}, n / DMA_EVERY);
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
+                    for (int j = 0; j < FN; ++j, ++n) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
+                        if (conv) {
+                            // spread the slices evenly behind the matrix instructions (the first one waits for nothing)
+                            const int upto = ((n + 1) * NS + NM - 1) / NM;
+#pragma unroll
+                            for (int k = 0; k < NS; ++k)
+                                if (k >= done && k < upto) slice(NB{}, NB{}, k);
+                            done = upto > done ? upto : done;
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     }
+        };
+        using B0 = std::integral_constant<int, 0>;
+        using B1 = std::integral_constant<int, 1>;
+        if (kt0 < kt1) {
+            KPos kp = kpos_of(kt0);
+            dma_b(kp, 0, B0{});
+            load_a(kp, 0, B0{});
+#pragma unroll
+            for (int k = 0; k < NS; ++k) slice(B0{}, B0{}, k);
+            load_a(kp, 1, B1{});
+            __syncthreads();
+            for (int kt = kt0; kt < kt1; ++kt) {
+                const bool more = kt + 1 < kt1;
+                const KPos kn = kpos_next(kp);
+                // stage 0 of the chunk (buffer 0): meanwhile stage 1's weights land in buffer 1 and its rows (register set 1) are split
+                dma_b(kp, 1, B1{});
+                if (more) load_a(kn, 0, B0{});
+                stage(B0{}, true);
+                __syncthreads();
+                // stage 1 (buffer 1): the next chunk's stage 0 is prepared in buffer 0
+                if (more) {
+                    dma_b(kn, 0, B0{});
+                    load_a(kn, 1, B1{});
+                }
+                stage(B1{}, more);
+                __syncthreads();
+                kp = kn;
+            }
         }
-    };
-
-    KPos kp = kpos_of(kt0);
-    if (kt0 < kt1) {  // weight pieces of the first chunk need no row geometry: their latency overlaps the decode
-#pragma unroll
-        for (int pc = IA; pc < NPIECE; ++pc) issue_piece(kt0, kp, B0{}, pc);
-    }
-    __syncthreads();  // row table visible (also drains the weight DMA; it had the whole decode to land)
-#pragma unroll
-    for (int i = 0; i < IA; ++i) {
-        const int r = i * 32 + rsub;
-        arow[i] = xg + (s_xoff[r] + (pseg ^ ((r >> 1) & 7)) * 4);
-        amask[i] = s_mask[r];
-    }
-    stamp(1);  // row decode done
-    if (kt0 < kt1) {
-#pragma unroll
-        for (int pc = 0; pc < IA; ++pc) issue_piece(kt0, kp, B0{}, pc);
-    }
-    __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes stage 0
-    stamp(2);  // first chunk landed
-    int kt = kt0;
-    for (; kt + 2 < kt1; kt += 2) {  // two chunks per trip: stage indices are compile-time constants
-        KPos k1 = kpos_next(kp);
-        chunk(kt, B0{}, k1, std::true_type{});
-        __syncthreads();
-        KPos k2 = kpos_next(k1);
-        chunk(kt + 1, B1{}, k2, std::true_type{});
-        __syncthreads();
-        kp = k2;
-    }
-    if (kt + 1 < kt1) {  // two chunks left
-        KPos k1 = kpos_next(kp);
-        chunk(kt, B0{}, k1, std::true_type{});
-        __syncthreads();
-        chunk(kt + 1, B1{}, k1, std::false_type{});
-        __syncthreads();
-    } else if (kt < kt1) {  // one chunk left
-        chunk(kt, B0{}, kp, std::false_type{});
-        __syncthreads();
     }
 
     stamp(3);  // k loop done
@@ -618,8 +777,40 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
     a.tilesN = (a.Npad + BN - 1) / BN;
     a.dTilesN = make_fastdiv(a.tilesN);
     dim3 grid((unsigned)(a.tilesM * a.tilesN), (unsigned)(a.cls_mode ? 4 : a.d.split_k), (unsigned)a.d.groups);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
+    if (a.d.w_format == EGR_W_BF16X3)
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, s, a);
     return egr_launch_status();
+}
+
+// fp32 weight matrix -> (hi, mid, lo) bf16 planes in MFMA-fragment order (layout: egorear_hip.h, egr_pack_w6_f32).
+// One workgroup per (32-column fragment, 32-deep chunk): thread (row = tid / 8, seg = tid % 8) reads 16 bytes of its weight row
+// (a row's 128 bytes are one coalesced segment) and writes 8 bytes per plane; the two threads of an 8-channel group and the 32
+// rows of a lane half fill 512 contiguous bytes of the image.
+__global__ __launch_bounds__(256) void pack_w6_kernel(const float* __restrict__ w, int npad, int K, int cfp, uint8_t* __restrict__ img) {
+    const int KC = K / 32;
+    const int chunk = blockIdx.x % KC, cf = blockIdx.x / KC, g = blockIdx.y;
+    const int row = threadIdx.x >> 3, seg = threadIdx.x & 7;
+    const int col = cf * 32 + row;
+    unsigned h[2] = {0u, 0u}, m[2] = {0u, 0u}, l[2] = {0u, 0u};
+    if (col < npad) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(w + ((int64_t)g * npad + col) * K + chunk * 32 + seg * 4);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float a = x[2 * q], b = x[2 * q + 1];
+            h[q] = cvt_pk_bf16(a, b);
+            const float ra = a - bf16_lo_f32(h[q]), rb = b - bf16_hi_f32(h[q]);
+            m[q] = cvt_pk_bf16(ra, rb);
+            l[q] = cvt_pk_bf16(ra - bf16_lo_f32(m[q]), rb - bf16_hi_f32(m[q]));
+        }
+    }
+    const int step = seg >> 2, half = (seg >> 1) & 1, lane = row + 32 * half;
+    uint8_t* dst = img + (((int64_t)g * cfp + cf) * KC + chunk) * 6144 + step * 3072 + lane * 16 + (seg & 1) * 8;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<u32x2*>(dst) = u32x2{h[0], h[1]};
+    *reinterpret_cast<u32x2*>(dst + 1024) = u32x2{m[0], m[1]};
+    *reinterpret_cast<u32x2*>(dst + 2048) = u32x2{l[0], l[1]};
 }
 
 enum { CFG_AUTO = -1, CFG_128x128 = 0, CFG_256x64 = 1, CFG_64x64 = 2, CFG_128x32 = 3, CFG_128x64 = 4, CFG_COUNT = 5 };
@@ -629,6 +820,23 @@ int g_force_cfg = CFG_AUTO;
 unsigned long long* g_dbg = nullptr;
 
 }  // namespace
+
+extern "C" int64_t egr_w6_elems(int32_t npad, int32_t k) {
+    if (npad <= 0 || k <= 0 || npad % 32 != 0 || k % 32 != 0) return 0;
+    const int64_t cfp = (npad / 32 + 3) / 4 * 4;
+    return cfp * (k / 32) * 3072;   // 6 KiB per (fragment, chunk)
+}
+
+extern "C" int egr_pack_w6_f32(const float* w, int32_t npad, int32_t k, int32_t groups, void* img, void* stream) {
+    if (!w || !img) return EGR_ENULL;
+    if (npad <= 0 || k <= 0 || npad % 32 != 0 || k % 32 != 0 || groups <= 0 || groups > 65535) return EGR_EINVAL;
+    if (((uintptr_t)w & 15) || ((uintptr_t)img & 15)) return EGR_EINVAL;
+    const int cfp = (npad / 32 + 3) / 4 * 4;
+    const int64_t blocks = (int64_t)cfp * (k / 32);
+    if (blocks > 0x7fffffffLL) return EGR_EINVAL;
+    hipLaunchKernelGGL(pack_w6_kernel, dim3((unsigned)blocks, (unsigned)groups), dim3(256), 0, (hipStream_t)stream, w, npad, k, cfp, (uint8_t*)img);
+    return egr_launch_status();
+}
 
 extern "C" int egr_conv_debug_stamps(unsigned long long* buf) {  // diagnostic: 8 x u64 per workgroup, NULL = off
     g_dbg = buf;
@@ -657,6 +865,8 @@ static int conv_run(const egr_conv_desc* dd, const float* x, const float* w, con
     if (d.groups <= 0) d.groups = 1;
     if (d.groups > 1 && ((d.gx | d.gw | d.gp | d.gy | d.gr) % 4 != 0)) return EGR_EINVAL;  // keep 16-byte alignment per group
     if (d.groups > 65535) return EGR_EINVAL;
+    if (d.w_format != EGR_W_F32 && d.w_format != EGR_W_BF16X3) return EGR_EINVAL;
+    if (d.w_format == EGR_W_BF16X3 && d.groups > 1 && d.gw % 8 != 0) return EGR_EINVAL;
     int64_t M64 = (int64_t)d.n * d.ho * d.wo;
     if (M64 >= (1LL << 31)) return EGR_EINVAL;
     // 32-bit offsets inside the kernel: bound the furthest element each operand can touch
@@ -720,7 +930,13 @@ static int conv_run(const egr_conv_desc* dd, const float* x, const float* w, con
     if (cfg == CFG_AUTO) {
         if (a.Npad == 32) cfg = CFG_128x32;
         else if (a.M <= 4096) cfg = CFG_64x64;
-        else if (a.Npad % 128 == 0) cfg = CFG_128x128;
+        else if (d.w_format == EGR_W_BF16X3) {
+            // split-bf16 launches: a stage is only 6 MFMAs per 32x32 fragment, so the wave tile must be at least 64x32 to keep
+            // the barrier count down (N = 64 / 192: 128x64, measured 123 vs 94 TF on 64x64), and 128x128 needs two resident
+            // workgroups per CU to overlap its barriers (layer4 alone: 256 workgroups ran 91 TF, as 128x64 121 TF)
+            const int64_t blocks128 = (int64_t)((a.M + 127) / 128) * ((a.Npad + 127) / 128) * d.groups;
+            cfg = (a.Npad % 128 == 0 && blocks128 >= 512) ? CFG_128x128 : CFG_128x64;
+        } else if (a.Npad % 128 == 0) cfg = CFG_128x128;
         else cfg = CFG_64x64;  // N = 64 / 192: 128x64 wins the isolated micro-benchmark (+15 %) but not the pipeline (26.2 vs 26.0 ms); 256x64 runs at 1 workgroup/CU
     }
     const int bm = kBM[cfg], bn = kBN[cfg];

@@ -25,6 +25,7 @@ drops the cache (load_state_dict does it automatically).
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional, Sequence
 
 import numpy as np
@@ -42,6 +43,19 @@ _WORKSPACE_FLOATS = 16 << 20  # split-K partial slabs (64 MB)
 class PConv:
     """Packed conv / linear weights of `groups` same-shape modules (groups == 1: plain 2-D tensors)."""
     __slots__ = ("w", "scale", "shift", "cout", "cin", "kh", "kw", "stride", "pad", "groups")
+
+
+# Weight operand of the implicit-GEMM launches: "bf16x3" = hip.pack_w6 image (bf16 matrix cores, fp32-exact split, DESIGN.md §5b),
+# "f32" = the packed fp32 matrix (fp32 matrix cores).  Matrices above W6_MAX_ELEMS are streamed once per step from HBM
+# (mlp_pred.0: 67 M weights) and stay in the 4-byte format.
+W_FORMAT = os.environ.get("EGR_W_FORMAT", "bf16x3")
+W6_MAX_ELEMS = 1 << 24
+
+
+def _w_operand(w: Optional[torch.Tensor]):
+    if w is None or W_FORMAT != "bf16x3" or not w.is_cuda or w.shape[-1] % 32 != 0 or w.shape[-2] * w.shape[-1] > W6_MAX_ELEMS:
+        return w
+    return hip.pack_w6(w)
 
 
 def _npad(cout: int) -> int:
@@ -107,7 +121,7 @@ def pack_convs(convs: Sequence[nn.Conv2d], bns: Optional[Sequence[nn.BatchNorm2d
         else:
             scs.append(None)
             shs.append(_pad_vec(c.bias.detach(), p.cout) if c.bias is not None else None)
-    p.w, p.scale, p.shift = _stack(ws), _stack(scs), _stack(shs)
+    p.w, p.scale, p.shift = _w_operand(_stack(ws)), _stack(scs), _stack(shs)
     return p
 
 
@@ -117,7 +131,7 @@ def pack_convs_cin_slice(convs: Sequence[nn.Conv2d], c0: int, c1: int, with_bias
     k0 = convs[0]
     p.cout, p.cin, p.kh, p.kw = k0.weight.shape[0], c1 - c0, 1, 1
     p.stride, p.pad, p.groups = 1, 0, len(convs)
-    p.w = _stack([_pad_rows(pack_conv_weight(c.weight.detach()[:, c0:c1])) for c in convs])
+    p.w = _w_operand(_stack([_pad_rows(pack_conv_weight(c.weight.detach()[:, c0:c1])) for c in convs]))
     p.scale = None
     p.shift = _stack([_pad_vec(c.bias.detach(), p.cout) for c in convs]) if (with_bias and k0.bias is not None) else None
     return p
@@ -130,7 +144,7 @@ def pack_linears(pairs: Sequence) -> PConv:
     p.cout, p.cin = w0.shape
     p.kh = p.kw = p.stride = 1
     p.pad, p.groups = 0, len(pairs)
-    p.w = _stack([_pad_rows(w.detach().float()) for w, _ in pairs])
+    p.w = _w_operand(_stack([_pad_rows(w.detach().float()) for w, _ in pairs]))
     p.scale = None
     p.shift = _stack([_pad_vec(b.detach(), p.cout) if b is not None else None for _, b in pairs])
     return p
@@ -395,10 +409,10 @@ def pack_layers(layers, pres, poss) -> PLayer:
             head_shift[h].append(_pad_vec(cfold[h * P.dh:(h + 1) * P.dh], P.dh))
         if pos is not None:                            # (1, V, HW, C) -> (V, HW, C) projected by W_v
             pos_proj.append((pos.detach()[0].double() @ Wv.t()).float())
-    P.head_w = [_stack(w) for w in head_w]
+    P.head_w = [_w_operand(_stack(w)) for w in head_w]
     P.head_shift = [_stack(s) for s in head_shift]
     # one query set (the lifting head): the heads themselves become the groups of a single launch
-    P.head_w_all = torch.stack([w[0] for w in head_w]).contiguous() if P.groups == 1 else None
+    P.head_w_all = _w_operand(torch.stack([w[0] for w in head_w]).contiguous()) if P.groups == 1 else None
     P.head_shift_all = torch.stack([s[0] for s in head_shift]).contiguous() if P.groups == 1 else None
     P.pos_proj = torch.stack(pos_proj).contiguous() if pos_proj else None
     cas = [l.cross_attn for l in layers]

@@ -24,7 +24,7 @@ EXPORTS = [
     "egr_avgpool_nhwc_f32", "egr_argmax_rows_f32", "egr_layernorm_f32", "egr_joint_mha_f32", "egr_msda_gather_f32",
     "egr_fisheye_project_f32", "egr_linear_smallk_f32", "egr_jqa_sum_f32", "egr_tokens_to_nhwc_f32", "egr_version",
     "egr_device_arch", "egr_conv_force_config", "egr_preprocess_u8_f32", "egr_pose_metrics_f32", "egr_gt_heatmap_f32", "egr_conv_debug_stamps", "egr_conv2d_wgrad_f32", "egr_conv2d_masked_f32", "egr_up2_relu_head_f32",
-    "egr_msda_fwd_f32", "egr_msda_bwd_f32",
+    "egr_msda_fwd_f32", "egr_msda_bwd_f32", "egr_w6_elems", "egr_pack_w6_f32",
 ]
 
 
@@ -42,7 +42,7 @@ class ConvDesc(C.Structure):
         ("groups", C.c_int32),
         ("gx", C.c_int64), ("gw", C.c_int64), ("gp", C.c_int64), ("gy", C.c_int64), ("gr", C.c_int64),
         ("grs", C.c_int64), ("grm", C.c_int64),
-        ("transposed", C.c_int32),
+        ("transposed", C.c_int32), ("w_format", C.c_int32),
     ]
 
 
@@ -67,6 +67,7 @@ def _load() -> C.CDLL:
     lib.egr_jqa_sum_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.egr_tokens_to_nhwc_f32.argtypes = [vp, vp, i32, i32, i32, vp]
     lib.egr_version.restype = C.c_char_p
+    lib.egr_w6_elems.restype = C.c_int64
     lib.egr_device_arch.argtypes = [C.c_char_p, i32]
     lib.egr_conv_force_config.argtypes = [i32]
     lib.egr_up2_relu_head_f32.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, i64, i64, i32, i64, vp]
@@ -74,12 +75,14 @@ def _load() -> C.CDLL:
     lib.egr_conv2d_wgrad_f32.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, C.c_size_t, i32, vp]
     lib.egr_gt_heatmap_f32.argtypes = [vp, i32, C.c_double, i32, i32, vp, vp, vp]
     lib.egr_pose_metrics_f32.argtypes = [vp, vp, i32, i32, f32, i32, vp, vp, vp]
+    lib.egr_pack_w6_f32.argtypes = [vp, i32, i32, i32, vp, vp]
+    lib.egr_w6_elems.argtypes = [i32, i32]
     lib.egr_msda_fwd_f32.argtypes = [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp, vp]
     lib.egr_msda_bwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.egr_preprocess_u8_f32.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     for name in EXPORTS:
         getattr(lib, name)  # fail at import if a symbol is missing
-        if name != "egr_version":
+        if name not in ("egr_version", "egr_w6_elems"):
             getattr(lib, name).restype = C.c_int
     return lib
 
@@ -168,7 +171,47 @@ class Img:
 
 # --------------------------------------------------------------------------- ops
 
-def conv2d(x: Img, w: torch.Tensor, cout: int, kh: int, kw: int, stride: int, pad: int, *, scale=None, shift=None,
+class W6:
+    """Packed weights in the EGR_W_BF16X3 format (egr_pack_w6_f32): every fp32 weight as hi + mid + lo bf16, in fragment
+    order.  Passed to conv2d in place of the packed fp32 matrix, it selects the bf16-matrix-core launch."""
+    __slots__ = ("img", "npad", "K", "groups", "gstride", "f32", "used")
+
+    def __init__(self, img, npad, K, groups, gstride, f32=None):
+        self.img, self.npad, self.K, self.groups, self.gstride = img, npad, K, groups, gstride
+        self.f32 = f32      # the fp32 matrix it was made from: small launches stay on it (X6_MIN_ROWS / X6_MIN_FLOPS)
+        self.used = False   # set by the first launch that takes the image (the training step only re-splits those)
+
+    @property
+    def shape(self):
+        return (self.groups, self.npad, self.K) if self.groups > 1 else (self.npad, self.K)
+
+
+def pack_w6(w: torch.Tensor) -> W6:
+    """w: packed fp32 weights (npad, K) or (groups, npad, K) as conv2d takes them."""
+    _cont(w, "packed weight")
+    groups = w.shape[0] if w.dim() == 3 else 1
+    npad, K = int(w.shape[-2]), int(w.shape[-1])
+    n = int(lib.egr_w6_elems(npad, K))
+    if n == 0:
+        raise RuntimeError(f"egorear_amd.pack_w6: unsupported weight shape {tuple(w.shape)} (rows and K must be multiples of 32)")
+    img = torch.empty(groups * n, device=w.device, dtype=torch.bfloat16)
+    _launch("egr_pack_w6_f32", lib.egr_pack_w6_f32, _p(w), npad, K, groups, _p(img, torch.bfloat16), _stream())
+    return W6(img, npad, K, groups, n, w)
+
+
+def pack_w6_into(w6: W6) -> None:
+    """Refresh an image from its fp32 matrix (w6.f32) in place: the training step does this after every parameter update."""
+    _launch("egr_pack_w6_f32", lib.egr_pack_w6_f32, _p(w6.f32), w6.npad, w6.K, w6.groups, _p(w6.img, torch.bfloat16), _stream())
+
+
+# Launches below these sizes (all groups together) are bound by launch latency or by streaming the weights once, not by the
+# matrix cores: they keep the 4-byte weight format (measured: 3840 rows x K 4096 and 16384 rows x K 576 slower with the split,
+# 8192 rows x N 512 x K 4608 faster)
+X6_MIN_ROWS = 8192
+X6_MIN_FLOPS = 4e9
+
+
+def conv2d(x: Img, w, cout: int, kh: int, kw: int, stride: int, pad: int, *, scale=None, shift=None,
            act: int = ACT_NONE, res: Optional[Img] = None, res_mode: int = RES_NONE, rowscale=None, rowmask=None,
            out: Optional[Img] = None, out_nchw: Optional[torch.Tensor] = None, ymap: Optional[NMap] = None,
            xmap: Optional[NMap] = None, rmap: Optional[NMap] = None, workspace: Optional[torch.Tensor] = None,
@@ -201,15 +244,25 @@ def conv2d(x: Img, w: torch.Tensor, cout: int, kh: int, kw: int, stride: int, pa
     wshape = (groups, npad, K) if groups > 1 else (npad, K)
     if tuple(w.shape) != wshape:
         raise RuntimeError(f"egorear_amd.conv2d: packed weight shape {tuple(w.shape)} != {wshape}")
-    _cont(w, "packed weight")
+    if isinstance(w, W6) and w.f32 is not None:
+        rows_all = x.n * groups * ho * wo
+        if rows_all < X6_MIN_ROWS or 2.0 * rows_all * cout * K < X6_MIN_FLOPS:
+            w = w.f32
+    x6 = isinstance(w, W6)
+    if x6 and not w.used:
+        if w.f32 is not None:
+            pack_w6_into(w)     # an owner that only re-splits the images in use (the training step) may have left this one stale
+        w.used = True
+    wptr = _p(w.img, torch.bfloat16) if x6 else _p(_cont(w, "packed weight"))
     d = ConvDesc()
+    d.w_format = 1 if x6 else 0
     d.n, d.h, d.w, d.cin, d.cout = x.n, x.h, x.w, x.c, cout
     d.kh, d.kw, d.stride, d.pad, d.ho, d.wo = kh, kw, stride, pad, ho, wo
     d.ldx = x.ld
     d.xmap = xmap if xmap is not None else x.nmap()
     d.act, d.res_mode, d.split_k = act, res_mode, split_k
     d.transposed = 1 if transposed_out_hw is not None else 0
-    d.groups, d.gx, d.gw, d.gp, d.grs, d.grm = groups, (gx or 0), (npad * K if groups > 1 else 0), (npad if groups > 1 else 0), grs, grm
+    d.groups, d.gx, d.gw, d.gp, d.grs, d.grm = groups, (gx or 0), ((w.gstride if x6 else npad * K) if groups > 1 else 0), (npad if groups > 1 else 0), grs, grm
     ret = None
     if out_nchw is not None:
         if ymap is None or (groups > 1 and gy is None):
@@ -258,16 +311,16 @@ def conv2d(x: Img, w: torch.Tensor, cout: int, kh: int, kw: int, stride: int, pa
             raise RuntimeError("egorear_amd.conv2d: mask goes with a plain NHWC data gradient only")
         if (mask.n, mask.h, mask.w, mask.c) != (groups * x.n, ho, wo, cout) or not mask.t.is_contiguous() or ret is None or not ret.t.is_contiguous():
             raise RuntimeError("egorear_amd.conv2d: mask must be dense and shaped like the output")
-        _launch("egr_conv2d_nhwc_f32", lib.egr_conv2d_masked_f32, C.byref(d), _p(x.t), _p(w), _p(res.t) if res is not None else None,
+        _launch("egr_conv2d_nhwc_f32", lib.egr_conv2d_masked_f32, C.byref(d), _p(x.t), wptr, _p(res.t) if res is not None else None,
                 _p(mask.t), yptr, ws_ptr, ws_n, _stream(),
                 flops=2.0 * M * cout * K * groups / (stride * stride if transposed_out_hw is not None else 1),
                 nbytes=4.0 * groups * (2 * M * cout + x.n * x.h * x.w * x.c + cout * K),
-                tag=f"{'T ' if transposed_out_hw is not None else ''}masked G{groups} M{M} N{cout} K{K} k{kh}s{stride} cin{x.c}" if PROFILE is not None else "")
+                tag=f"{'T ' if transposed_out_hw is not None else ''}{'x6 ' if x6 else ''}masked G{groups} M{M} N{cout} K{K} k{kh}s{stride} cin{x.c}" if PROFILE is not None else "")
         return ret
-    _launch("egr_conv2d_nhwc_f32", lib.egr_conv2d_nhwc_f32, C.byref(d), _p(x.t), _p(w), _p(scale), _p(shift),
+    _launch("egr_conv2d_nhwc_f32", lib.egr_conv2d_nhwc_f32, C.byref(d), _p(x.t), wptr, _p(scale), _p(shift),
             _p(res.t) if res is not None else None, _p(rowscale), _p(rowmask, torch.uint8), yptr, ws_ptr, ws_n, _stream(),
             flops=2.0 * M * cout * K * groups / (stride * stride if transposed_out_hw is not None else 1), nbytes=4.0 * groups * (M * cout + x.n * x.h * x.w * x.c + cout * K),
-            tag=f"{'T ' if transposed_out_hw is not None else ''}G{groups} M{M} N{cout} K{K} k{kh}s{stride} cin{x.c}" if PROFILE is not None else "")
+            tag=f"{'T ' if transposed_out_hw is not None else ''}{'x6 ' if x6 else ''}G{groups} M{M} N{cout} K{K} k{kh}s{stride} cin{x.c}" if PROFILE is not None else "")
     return ret
 
 

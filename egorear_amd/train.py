@@ -47,7 +47,15 @@ class TPack:
     """`groups` same-shape conv / linear modules packed for the forward kernel (w, bias) and, when a data gradient is
     needed, for the transposed launch (wt).  cin_pad / cout_pad: channel counts the kernels see (multiples of 32 on the
     K side); names: state_dict keys of the weights / biases, one per group."""
-    __slots__ = ("w", "bias", "wt", "cout", "cin", "cin_pad", "cout_pad", "kh", "kw", "stride", "pad", "groups", "wmeta", "bmeta")
+    __slots__ = ("w", "bias", "wt", "cout", "cin", "cin_pad", "cout_pad", "kh", "kw", "stride", "pad", "groups", "wmeta", "bmeta", "w6", "wt6")
+
+    @property
+    def wop(self):      # operand of the forward launch: the bf16x3 image when one is kept (hip.conv2d falls back to w for few rows)
+        return self.w6 if self.w6 is not None else self.w
+
+    @property
+    def wtop(self):     # operand of the data-gradient launch
+        return self.wt6 if self.wt6 is not None else self.wt
 
 
 class PackCache:
@@ -61,6 +69,7 @@ class PackCache:
         self.packs: Dict[object, TPack] = {}
         self.table = repack.RepackTable(device)
         self.torch_refresh: List = []        # (dst, src parameter): dst.copy_(src.t())
+        self.images: List = []               # hip.W6 operands re-split from their fp32 matrices after every refresh
         self.sources: Dict[int, tuple] = {}  # id(param) -> (param, data_ptr)
         self.ready = False
 
@@ -74,6 +83,9 @@ class PackCache:
         self.table.run()
         for dst, src in self.torch_refresh:
             dst.copy_(src.detach().reshape(dst.shape[1], dst.shape[0]).t())
+        for w6 in self.images:
+            if w6.used:        # images no launch has taken (layers whose launches are too small for the split) are left stale
+                hip.pack_w6_into(w6)
 
 
 def _get_cache(net: nn.Module, device) -> PackCache:
@@ -161,6 +173,15 @@ def make_pack(cache: PackCache, key, wparts, bparts, name_of, kh: int = 1, kw: i
                         cin_pad=p.cin_pad, taps=taps, rows_pad=rows_k, k_off=r0, k_tot=p.cout_pad, total=rows_t * rows_k * taps)
                     r0 += rows
     tbl.run()
+    # bf16x3 images of both operands (engine.W_FORMAT / W6_MAX_ELEMS decide; they are re-split after every update)
+    from .engine import _w_operand
+    p.w6 = p.wt6 = None
+    for attr, src in (("w6", p.w), ("wt6", p.wt)):
+        if src is not None:
+            op = _w_operand(src)
+            if isinstance(op, hip.W6):
+                setattr(p, attr, op)
+                cache.images.append(op)
     cache.packs[key] = p
     return p
 
@@ -283,10 +304,10 @@ class Step:
         kw = dict(transposed_out_hw=(h, w), groups=p.groups, res=Img(prev) if prev is not None else None,
                   res_mode=RES_BEFORE_ACT if prev is not None else RES_NONE, workspace=self.ws, split_k=0)
         if id(x) in self.relu_out:
-            dx = hip.conv2d(Img(dz), p.wt, p.cin_pad, p.kh, p.kw, p.stride, p.pad, mask=Img(x), **kw).t
+            dx = hip.conv2d(Img(dz), p.wtop, p.cin_pad, p.kh, p.kw, p.stride, p.pad, mask=Img(x), **kw).t
             self.G.add_masked(x, dx)
         else:
-            self.G.g[id(x)] = hip.conv2d(Img(dz), p.wt, p.cin_pad, p.kh, p.kw, p.stride, p.pad, **kw).t
+            self.G.g[id(x)] = hip.conv2d(Img(dz), p.wtop, p.cin_pad, p.kh, p.kw, p.stride, p.pad, **kw).t
 
     # ---- conv / linear ------------------------------------------------------------------------------------------
     def pack(self, mods: Sequence[nn.Module], need_dx=True) -> TPack:
@@ -328,7 +349,7 @@ class Step:
         y = T.zeros((n, ho, wo, cw), self.dev) if (out_pad and cw != p.cout) else torch.empty((n, ho, wo, cw), device=self.dev)
         yo = Img(y[..., :p.cout]) if cw != p.cout else Img(y)
         # res_up2: `res` is a half-resolution tensor that the epilogue up-samples itself (the FPN top-down add)
-        hip.conv2d(Img(x), p.w, p.cout, p.kh, p.kw, p.stride, p.pad, shift=p.bias, act=act, res=Img(res) if res is not None else None,
+        hip.conv2d(Img(x), p.wop, p.cout, p.kh, p.kw, p.stride, p.pad, shift=p.bias, act=act, res=Img(res) if res is not None else None,
                    res_mode=(hip.RES_UP2_BEFORE_ACT if res_up2 else RES_BEFORE_ACT) if res is not None else RES_NONE, out=yo,
                    workspace=self.ws, split_k=0, groups=p.groups)
 
@@ -761,7 +782,7 @@ def conv_to_planes(S: Step, x: torch.Tensor, p: TPack, planes: torch.Tensor, B: 
     plane = p.cout * h * w
     per_group = n // p.groups
     vpg = per_group // B                       # views per group
-    hip.conv2d(Img(x), p.w, p.cout, 1, 1, 1, 0, shift=p.bias, out_nchw=planes, ymap=NMap(B, V * plane, plane if vpg > 1 else 0),
+    hip.conv2d(Img(x), p.wop, p.cout, 1, 1, 1, 0, shift=p.bias, out_nchw=planes, ymap=NMap(B, V * plane, plane if vpg > 1 else 0),
                gy=vpg * plane, groups=p.groups, workspace=S.ws, split_k=0)
 
     def bwd():

@@ -81,7 +81,24 @@ typedef struct {
      * its in/out channels swapped ([cin_fwd_pad][cout_fwd/32][kh*kw][32]).  Row m = (n, hi, wi) gathers
      * dy[n, (hi+pad-kh)/stride, (wi+pad-kw)/stride, :] for the taps where the division is exact and in range. */
     int32_t transposed;
+    /* Weight operand format.  EGR_W_F32 (0): w is the packed fp32 matrix described above, multiplied on the fp32 matrix
+     * cores.  EGR_W_BF16X3 (1): w points to the image egr_pack_w6_f32 made of that matrix — every weight as the exact sum
+     * of three bf16 numbers, in MFMA-fragment order — and the launch runs on the bf16 matrix cores: the activations are
+     * split the same way on the fly and the six partial products of order <= 2 are accumulated in fp32 (the dropped
+     * ones are below 2^-25 relative: the result is as close to the exact sum as an fp32 fma chain).
+     * gw is then in bf16 elements (egr_w6_elems per group). */
+    int32_t w_format;
 } egr_conv_desc;
+enum { EGR_W_F32 = 0, EGR_W_BF16X3 = 1 };
+
+/* Split a packed fp32 weight matrix w (groups, npad, k) — npad = round_up(cout, 32), k = kh*kw*cin, k % 32 == 0 — into
+ * the EGR_W_BF16X3 image: per group egr_w6_elems(npad, k) bf16 elements laid out
+ * [round_up(npad/32, 4) column fragments][k/32 chunks][2 k16 steps][3 planes hi, mid, lo][64 lanes][8 bf16],
+ * lane l of a fragment holding w[col = 32*frag + (l & 31)][k = 32*chunk + 16*step + 8*(l >> 5) + j], j = 0..7.
+ * hi = bf16(w), mid = bf16(w - hi), lo = bf16(w - hi - mid), round to nearest even: hi + mid + lo == w exactly
+ * (fragments beyond npad/32 are zero).  img must be 16-byte aligned. */
+int64_t egr_w6_elems(int32_t npad, int32_t k);
+int egr_pack_w6_f32(const float* w, int32_t npad, int32_t k, int32_t groups, void* img, void* stream);
 
 int egr_conv2d_nhwc_f32(const egr_conv_desc* d, const float* x, const float* w,
                         const float* scale /* per co, NULL = 1 */, const float* shift /* per co, NULL = 0 */,

@@ -1,0 +1,204 @@
+"""The split-bf16 launch of egr_conv2d_nhwc_f32 (EGR_W_BF16X3: fp32 operands as exact sums of three bf16, six partial products
+on the bf16 matrix cores, fp32 accumulate) against the fp32-matrix-core launch of the same problem and against an fp64
+reference: every mode the model and the training step use (3x3 / 1x1, strides, every tile configuration, grouped, split-K,
+transposed data gradient incl. the stride-2 parity classes, masked epilogue, residual modes, channel-major output).
+The bar: the split launch is as close to the fp64 result as the fp32 launch is (its error may not exceed 1.5x the fp32
+launch's + 1e-7 of the result's magnitude), and both are within 2e-5."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def pack_w(w):
+    from egorear_amd.engine import pack_conv_weight
+    w2 = pack_conv_weight(w)
+    npad = (w.shape[0] + 31) // 32 * 32
+    out = torch.zeros(npad, w2.shape[1])
+    out[:w.shape[0]] = w2
+    return out
+
+
+def pack_w_dgrad(w):
+    return pack_w(w.transpose(0, 1).contiguous())
+
+
+def both(hip, x, wp, *args, **kw):
+    """The same launch with the fp32 matrix and with its split image."""
+    wp = wp.to(DEV)
+    a = hip.conv2d(x, wp, *args, **kw)
+    if kw.get("out") is not None or kw.get("out_nchw") is not None:
+        raise AssertionError("use fresh outputs here")
+    b = hip.conv2d(x, hip.pack_w6(wp), *args, **kw)
+    return a, b
+
+
+def judge(a, b, ref, what=""):
+    ref = ref.double()
+    scale = max(float(ref.abs().max()), 1e-6)
+    ea = float((a.double().cpu() - ref).abs().max()) / scale
+    eb = float((b.double().cpu() - ref).abs().max()) / scale
+    assert ea <= 2e-5 and eb <= 2e-5, (what, ea, eb)
+    assert eb <= 1.5 * ea + 1e-7, (what, "split launch less accurate than the fp32 launch", ea, eb)
+    return ea, eb
+
+
+def test_pack_w6_is_an_exact_three_way_split(hip=None):
+    from egorear_amd import hip
+    npad, K = 96, 9 * 64
+    w = rnd(2, npad, K, seed=3, scale=0.3)
+    w[0, 5, 7] = 1.0
+    w[1, 0, 0] = 3.0e-30
+    w[1, 1, 1] = -2.5e20
+    w6 = hip.pack_w6(w.to(DEV))
+    assert w6.gstride == 4 * (K // 32) * 3072 and w6.img.numel() == 2 * w6.gstride
+    img = w6.img.float().cpu().view(2, 4, K // 32, 2, 3, 64, 8)    # [g][frag][chunk][step][plane][lane][j]
+    recon = img.double().sum(4)                                     # hi + mid + lo, exact in fp64
+    lanes = torch.arange(64)
+    for g in range(2):
+        for cf in range(4):
+            for step in range(2):
+                cols = cf * 32 + (lanes & 31)
+                for ch in (0, K // 32 - 1, 7):
+                    k0 = ch * 32 + step * 16 + 8 * (lanes >> 5)
+                    kk = k0[:, None] + torch.arange(8)[None]
+                    want = torch.zeros(64, 8, dtype=torch.float64) if cf == 3 else w[g][cols[:, None].expand(64, 8), kk].double()
+                    assert torch.equal(recon[g, cf, ch, step], want), (g, cf, ch, step)
+
+
+CONV_CASES = [
+    # n, h, w, cin, cout, k, stride, act, res_mode, bn, cfg
+    (2, 16, 16, 64, 64, 3, 1, 1, 1, True, -1),
+    (2, 16, 16, 64, 128, 3, 2, 1, 0, True, -1),
+    (2, 16, 16, 64, 128, 1, 2, 0, 0, True, -1),
+    (3, 8, 8, 512, 128, 1, 1, 1, 0, False, -1),
+    (1, 64, 64, 128, 256, 3, 2, 1, 0, False, -1),
+    (5, 64, 64, 32, 128, 3, 1, 1, 2, False, -1),     # 128x128 tiles
+    (5, 64, 64, 64, 64, 3, 1, 1, 0, True, -1),       # N = 64 -> 64x64 tiles
+    (5, 64, 64, 128, 192, 1, 1, 0, 0, False, -1),
+    (2, 32, 32, 128, 15, 1, 1, 0, 0, False, -1),     # 15 channels: 128x32 tiles
+    (37, 1, 1, 256, 48, 1, 1, 2, 0, False, -1),      # linear + GELU, ragged rows
+    (5, 64, 64, 64, 64, 3, 1, 1, 0, True, 1),        # forced 256x64 (two staging units per thread)
+    (5, 64, 64, 64, 64, 3, 1, 1, 0, True, 4),        # forced 128x64
+    (3, 33, 17, 96, 160, 3, 1, 0, 0, False, 0),      # odd sizes, 3 channel chunks, ragged tiles in both directions (128x128)
+    (3, 33, 17, 96, 160, 3, 2, 1, 0, False, 2),      # the same on 64x64 tiles, stride 2
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_forward_modes(case):
+    from egorear_amd import hip
+    n, h, w, cin, cout, k, stride, act, res_mode, bn, cfg = case
+    pad = k // 2
+    x = rnd(n, h, w, cin, seed=1)
+    wt = rnd(cout, cin, k, k, seed=2, scale=1.0 / math.sqrt(cin * k * k))
+    scale = (rnd(cout, seed=3) * 0.4 + 1.0) if bn else None
+    shift = rnd(cout, seed=4)
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    res = rnd(n, ho, wo, cout, seed=5) if res_mode else None
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), wt.double(), None, stride, pad)
+    if scale is not None:
+        ref = ref * scale.double().view(1, -1, 1, 1)
+    ref = ref + shift.double().view(1, -1, 1, 1)
+    if res_mode == 1:
+        ref = ref + res.permute(0, 3, 1, 2).double()
+    ref = F.relu(ref) if act == 1 else (F.gelu(ref) if act == 2 else ref)
+    if res_mode == 2:
+        ref = ref + res.permute(0, 3, 1, 2).double()
+    hip.conv_force_config(cfg)
+    try:
+        a, b = both(hip, hip.Img(x.to(DEV)), pack_w(wt), cout, k, k, stride, pad, scale=scale.to(DEV) if scale is not None else None,
+                    shift=shift.to(DEV), act=act, res=hip.Img(res.to(DEV)) if res is not None else None, res_mode=res_mode)
+    finally:
+        hip.conv_force_config(-1)
+    judge(a.t.permute(0, 3, 1, 2), b.t.permute(0, 3, 1, 2), ref, str(case))
+
+
+def test_grouped_and_split_k():
+    from egorear_amd import hip
+    G, n, h, cin, cout, k = 3, 2, 16, 64, 96, 3
+    x = rnd(G * n, h, h, cin, seed=21)
+    wts = [rnd(cout, cin, k, k, seed=30 + g, scale=1 / 24) for g in range(G)]
+    wp = torch.stack([pack_w(w) for w in wts])
+    a, b = both(hip, hip.Img(x.to(DEV)), wp, cout, k, k, 1, 1, groups=G)
+    ref = torch.cat([F.conv2d(x[g * n:(g + 1) * n].permute(0, 3, 1, 2).double(), wts[g].double(), None, 1, 1) for g in range(G)])
+    judge(a.t.permute(0, 3, 1, 2), b.t.permute(0, 3, 1, 2), ref, "grouped")
+    # skinny linear with long K through split-K (explicit and automatic) with row scale / mask
+    m, K, n_out = 6, 4096, 96
+    xl, wl, bl, rs = rnd(m, K, seed=11), rnd(n_out, K, seed=12, scale=1 / 64), rnd(n_out, seed=13), rnd(m, seed=14)
+    mask = torch.tensor([1, 0, 1, 1, 0, 1], dtype=torch.uint8)
+    ref = (xl.double() @ wl.double().t() + bl.double()[None] * rs.double()[:, None]) * mask.double()[:, None]
+    ws = torch.empty(1 << 22, device=DEV)
+    for split in (1, 0, 7):
+        a, b = both(hip, hip.Img(xl.to(DEV).view(m, 1, 1, K)), wl, n_out, 1, 1, 1, 0, shift=bl.to(DEV), rowscale=rs.to(DEV),
+                    rowmask=mask.to(DEV), workspace=ws, split_k=split)
+        judge(a.t.view(m, n_out), b.t.view(m, n_out), ref, f"split {split}")
+
+
+DGRAD_CASES = [
+    (2, 16, 16, 64, 64, 3, 1), (2, 32, 32, 64, 128, 3, 2), (3, 16, 16, 64, 128, 1, 2), (2, 8, 8, 128, 32, 1, 1),
+    (5, 64, 64, 32, 64, 3, 2), (2, 15, 17, 32, 64, 3, 2), (1, 8, 8, 512, 256, 3, 2),
+]
+
+
+@pytest.mark.parametrize("case", DGRAD_CASES)
+def test_data_gradient_modes(case):
+    from egorear_amd import hip
+    n, h, w, cin, cout, k, s = case
+    pad = k // 2
+    x = rnd(n, cin, h, w, seed=1).double().requires_grad_(True)
+    wt = rnd(cout, cin, k, k, seed=2, scale=1.0 / math.sqrt(cin * k * k))
+    y = F.conv2d(x, wt.double(), None, s, pad)
+    dy = rnd(*y.shape, seed=3)
+    (dx_ref,) = torch.autograd.grad(y, x, dy.double())
+    dy_nhwc = hip.Img(dy.permute(0, 2, 3, 1).contiguous().to(DEV))
+    a, b = both(hip, dy_nhwc, pack_w_dgrad(wt), cin, k, k, s, pad, transposed_out_hw=(h, w))
+    judge(a.t.permute(0, 3, 1, 2), b.t.permute(0, 3, 1, 2), dx_ref, str(case))
+    # masked epilogue with an accumulated gradient (the ReLU backward fused into the launch)
+    if cin % 4 == 0:
+        act_fwd, prev = rnd(n, h, w, cin, seed=5), rnd(n, h, w, cin, seed=6)
+        a, b = both(hip, dy_nhwc, pack_w_dgrad(wt), cin, k, k, s, pad, transposed_out_hw=(h, w), res=hip.Img(prev.to(DEV)),
+                    res_mode=hip.RES_BEFORE_ACT, mask=hip.Img(act_fwd.to(DEV)))
+        ref = (dx_ref.permute(0, 2, 3, 1) + prev.double()) * (act_fwd > 0)
+        judge(a.t, b.t, ref, "masked " + str(case))
+
+
+def test_channel_major_output_and_upsampled_residual():
+    from egorear_amd import hip
+    n, h, w, cin, cout = 4, 16, 16, 64, 32
+    x = rnd(n, h, w, cin, seed=7).to(DEV)
+    wt = rnd(cout, cin, 1, 1, seed=8, scale=0.1)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).cpu().double(), wt.double())
+    plane = cout * h * w
+    outs = []
+    for wop in (pack_w(wt).to(DEV), hip.pack_w6(pack_w(wt).to(DEV))):
+        out = torch.zeros(2, 2, cout, h, w, device=DEV)
+        hip.conv2d(hip.Img(x), wop, cout, 1, 1, 1, 0, out_nchw=out, ymap=hip.NMap(2, 2 * plane, plane))
+        outs.append(out.permute(1, 0, 2, 3, 4).reshape(n, cout, h, w))
+    judge(outs[0], outs[1], ref, "nchw")
+    lo = rnd(n, h // 2, w // 2, cout, seed=9)
+    up = F.interpolate(lo.permute(0, 3, 1, 2).double(), scale_factor=2, mode="bilinear", align_corners=True)
+    a, b = both(hip, hip.Img(x), pack_w(wt), cout, 1, 1, 1, 0, res=hip.Img(lo.to(DEV)), res_mode=hip.RES_UP2_BEFORE_ACT, act=hip.ACT_RELU)
+    judge(a.t.permute(0, 3, 1, 2), b.t.permute(0, 3, 1, 2), F.relu(ref + up), "up2 residual")
+
+
+def test_wide_dynamic_range_and_zero_padding_rows():
+    """Operands spanning many binades (the split is exact at every magnitude) and an input with exact zeros / tiny values."""
+    from egorear_amd import hip
+    n, h, cin, cout = 2, 16, 64, 64
+    g = torch.Generator().manual_seed(5)
+    x = rnd(n, h, h, cin, seed=1) * torch.exp2(torch.randint(-20, 20, (n, h, h, cin), generator=g).float())
+    x[0, :4] = 0.0
+    wt = rnd(cout, cin, 3, 3, seed=2) * torch.exp2(torch.randint(-12, 4, (cout, cin, 3, 3), generator=g).float())
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), wt.double(), None, 1, 1)
+    a, b = both(hip, hip.Img(x.to(DEV)), pack_w(wt), cout, 3, 3, 1, 1)
+    judge(a.t.permute(0, 3, 1, 2), b.t.permute(0, 3, 1, 2), ref, "dynamic range")

@@ -31,6 +31,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--cfgs", default="-1")
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--only", default="")
+ap.add_argument("--x6", action="store_true", help="weights in the bf16x3 split format (bf16 matrix cores)")
 ap.add_argument("--ksweep", action="store_true", help="1x1, N=128, M=524288: K = 32..1024 (fixed per-block cost)")
 a = ap.parse_args()
 cfgs = [int(c) for c in a.cfgs.split(",")]
@@ -47,6 +48,8 @@ for (n, h, w, cin, cout, k, s, rm, label) in SHAPES:
     x = torch.randn(n, h, w, cin, device=dev)
     npad = (cout + 31) // 32 * 32
     wt = torch.randn(npad, k * k * cin, device=dev) * 0.05
+    if a.x6:
+        wt = hip.pack_w6(wt)
     sc, sh = torch.rand(npad, device=dev) + 0.5, torch.randn(npad, device=dev)
     ho, wo = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
     res = torch.randn(n, ho, wo, cout, device=dev) if rm else None
