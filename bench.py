@@ -72,7 +72,7 @@ def _host_cores() -> int:
     return max(1, min(n, int(os.environ.get("EGR_CPU_THREADS", "16"))))
 
 
-def _pmc_traffic(batch: int):
+def _pmc_traffic(batch: int, fmt: str = ""):
     """HBM bytes per launch of the conv kernel from the committed rocprofv3 PMC passes (profiles/*pmc_traffic.json,
     produced by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command, with the
     gfx950 x2 correction on FETCH_SIZE).  Counters cannot be collected from inside the timed run; null if the file
@@ -84,7 +84,12 @@ def _pmc_traffic(batch: int):
     try:
         with open(files[-1]) as f:
             t = json.load(f)
-        return t["hbm_bytes_per_launch"] if t.get("batch") == batch else None
+        if t.get("batch") != batch:
+            return None
+        if fmt and t.get("by_format"):      # per weight format of the implicit-GEMM kernel ("bf16x3" / "f32")
+            e = t["by_format"].get(fmt)
+            return e["hbm_bytes_per_launch"] if e else None
+        return t["hbm_bytes_per_launch"]
     except Exception:
         return None
 
@@ -308,7 +313,7 @@ def main():
                 k["flops"] += flops
                 k["bytes"] += nbytes
             dom = max(kernels, key=lambda n: kernels[n]["ms"])
-            roof = _roofline(dom, kernels[dom], _pmc_traffic(B))
+            roof = _roofline(dom, kernels[dom], _pmc_traffic(B, "bf16x3" if dom.endswith("[bf16x3]") else "f32"))
             roof["all_kernels_ms_per_step"] = round(sum(v["ms"] for v in kernels.values()), 3)
 
     parity_out = None

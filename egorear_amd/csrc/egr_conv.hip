@@ -20,8 +20,11 @@
 //    lane and whole 512-byte rows per wave: scale/shift (BatchNorm or bias), per-row bias scale, residual
 //    before/after the activation, ReLU / exact-erf GELU, row mask; NHWC (any pixel stride / channel offset)
 //    or channel-major planes.
-// f32 MFMA is a k-ordered fp32 fma chain: results are deterministic and fp32-exact in the reference's
-// sense (no reduced-precision path exists on gfx950, and none is wanted: argmax indices must match).
+// f32 MFMA is a k-ordered fp32 fma chain: results are deterministic and fp32-exact in the reference's sense.
+//  * X6 = true (EGR_W_BF16X3): the same GEMM on the bf16 matrix cores without giving up that exactness: every
+//    fp32 operand is the exact sum of three bf16 numbers, the six partial products of order <= 2 are accumulated in fp32
+//    (the dropped ones are below fp32 rounding).  Weights arrive pre-split in fragment order (egr_pack_w6_f32), the
+//    activations are split while they are staged.  Same row table, modes and epilogue as the fp32 main loop.
 #include <type_traits>
 
 #include <cstdlib>

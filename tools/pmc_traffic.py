@@ -10,7 +10,9 @@ def load(d, counter):
     per = collections.defaultdict(float); n = collections.Counter()
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter: continue
-        k = "conv" if "conv_igemm" in r["Kernel_Name"] else "other"
+        nm = r["Kernel_Name"]
+        # conv_igemm_kernel<BM, BN, WM, WN, X6>: the last template argument tells the split-bf16 launches from the fp32 ones
+        k = ("conv_x6" if (", true>" in nm or ", 1>" in nm.replace("(bool)", "")) else "conv") if "conv_igemm" in nm else "other"
         per[k] += float(r["Counter_Value"]); n[(k, r["Dispatch_Id"])] += 1
     launches = collections.Counter(k for (k, _d) in n)
     return per, launches
@@ -18,11 +20,18 @@ def load(d, counter):
 fetch, lf = load(sys.argv[1], "FETCH_SIZE")
 write, lw = load(sys.argv[2], "WRITE_SIZE")
 batch = int(sys.argv[4]) if len(sys.argv) > 4 else 64
-n = lf["conv"]
-out = {"batch": batch, "kernel": "conv_igemm_kernel (egr_conv2d_nhwc_f32)", "launches_counted": n,
-       "fetch_bytes_per_launch_raw_x1024": fetch["conv"] * 1024 / n, "fetch_correction": 2.0,
-       "write_bytes_per_launch": write["conv"] * 1024 / lw["conv"],
-       "hbm_bytes_per_launch": (2.0 * fetch["conv"] * 1024) / n + write["conv"] * 1024 / lw["conv"],
-       "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline"}
+def entry(key, label):
+    n = lf[key]
+    if not n:
+        return None
+    return {"kernel": label, "launches_counted": n, "fetch_bytes_per_launch_raw_x1024": fetch[key] * 1024 / n, "fetch_correction": 2.0,
+            "write_bytes_per_launch": write[key] * 1024 / lw[key],
+            "hbm_bytes_per_launch": (2.0 * fetch[key] * 1024) / n + write[key] * 1024 / lw[key]}
+
+x6 = entry("conv_x6", "conv_igemm_kernel<..., true> (egr_conv2d_nhwc_f32, EGR_W_BF16X3 launches)")
+f32 = entry("conv", "conv_igemm_kernel<..., false> (egr_conv2d_nhwc_f32, fp32-matrix-core launches)")
+main = x6 or f32
+out = {"batch": batch, **main, "by_format": {"bf16x3": x6, "f32": f32},
+       "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-train"}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out))
