@@ -113,8 +113,8 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
 __device__ __forceinline__ float bf16_hi_f32(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
 __device__ __forceinline__ float bf16_lo_f32(unsigned p) { return __uint_as_float(p << 16); }
 
-template <int BM, int BN, int WM, int WN, bool X6 = false>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+template <int BM, int BN, int WM, int WN, bool X6>
+__device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     static_assert(WM * WN == 4, "four waves per workgroup");
     constexpr int NT = 256;
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -476,8 +476,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         constexpr int NS = 9 * NU;          // slices per stage
         constexpr int NM = 6 * FM * FN;     // MFMAs per stage
         // MFMAs of the stage in buffer BUF; when `conv`, the registers of set BUF^1 are split into buffer BUF^1 behind them
-        auto stage = [&](auto buf_tag, bool conv) {
+        auto stage = [&](auto buf_tag, auto conv_tag) {
             constexpr int BUF = decltype(buf_tag)::value;
+            constexpr bool conv = decltype(conv_tag)::value;   // compile time: the slice bookkeeping below must fold to constants
             using NB = std::integral_constant<int, BUF ^ 1>;
             const uint8_t* st = lb + BUF * STB;
             bf16x8 af[FM][3], bf[FN][3];
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int j = 0; j < FN; ++j, ++n) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
-                        if (conv) {
+                        if constexpr (conv) {
                             // spread the slices evenly behind the matrix instructions (the first one waits for nothing)
                             const int upto = ((n + 1) * NS + NM - 1) / NM;
 #pragma unroll
@@ -526,14 +527,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                 // stage 0 of the chunk (buffer 0): meanwhile stage 1's weights land in buffer 1 and its rows (register set 1) are split
                 dma_b(kp, 1, B1{});
                 if (more) load_a(kn, 0, B0{});
-                stage(B0{}, true);
+                stage(B0{}, std::true_type{});
                 __syncthreads();
                 // stage 1 (buffer 1): the next chunk's stage 0 is prepared in buffer 0
                 if (more) {
                     dma_b(kn, 0, B0{});
                     load_a(kn, 1, B1{});
                 }
-                stage(B1{}, more);
+                if (more) stage(B1{}, std::true_type{});
+                else stage(B1{}, std::false_type{});
                 __syncthreads();
                 kp = kn;
             }
@@ -775,15 +777,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a) {
 }
 
 template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+    conv_igemm_body<BM, BN, WM, WN, false>(a);
+}
+
+// split-bf16 launches: two workgroups per CU (their barriers overlap), so at most 256 registers per lane
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_x6_kernel(const ConvArgs a) {
+    conv_igemm_body<BM, BN, WM, WN, true>(a);
+}
+
+template <int BM, int BN, int WM, int WN>
 int launch_cfg(ConvArgs& a, hipStream_t s) {
     a.tilesM = (a.M + BM - 1) / BM;
     a.tilesN = (a.Npad + BN - 1) / BN;
     a.dTilesN = make_fastdiv(a.tilesN);
     dim3 grid((unsigned)(a.tilesM * a.tilesN), (unsigned)(a.cls_mode ? 4 : a.d.split_k), (unsigned)a.d.groups);
     if (a.d.w_format == EGR_W_BF16X3)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((conv_igemm_x6_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
     return egr_launch_status();
 }
 

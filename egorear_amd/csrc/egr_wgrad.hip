@@ -207,6 +207,241 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     }
 }
 
+// ---- the same weight gradient on the bf16 matrix cores, fp32-exact: both operands are activations here, so
+// both are split on the fly into (hi, mid, lo) bf16 planes while they are staged, and the six products of order <= 2 go to
+// v_mfma_f32_32x32x16_bf16.  The reduction runs over pixels, so a lane's operand fragment is 8 PIXELS of one channel: the
+// planes are stored pixel-major ([16 pixels][channels] bf16, 8-byte writes) and read with ds_read_b64_tr_b16, the transposing
+// LDS read (a 16-lane group fetches 4 pixel rows x 16 channels and each lane receives one channel's 4 pixels).  Row stride =
+// channels * 2 + 64 bytes: the four rows of a transposed read fall into four different 64-byte bank windows.
+// A stage is 16 pixels; rows are requested two stages ahead, split one stage ahead behind the MFMAs (as in conv_igemm_kernel<.., true>).
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short wg_s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned wg_u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned wg_cvt_pk(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float wg_hi(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
+__device__ __forceinline__ float wg_lo(unsigned p) { return __uint_as_float(p << 16); }
+
+template <int BCO>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_x6_kernel(const WgradArgs a) {
+    constexpr int PS = 16;                                       // pixels per stage = one k16 step
+    constexpr int TM = BCO / 2, FM = TM / 32, FN = 2;            // waves 2 (co) x 2 (k); wave tile TM x 64
+    constexpr int ROW_DY = 2 * BCO + 64, ROW_A = 2 * BKO + 64;   // bytes per pixel row of a plane
+    constexpr int PL_DY = PS * ROW_DY, PL_A = PS * ROW_A;
+    constexpr int STB = 3 * (PL_DY + PL_A);                      // bytes per stage (30 KiB for BCO = 128)
+    constexpr int SEG_DY = BCO / 4;                              // 16-byte segments per dy row
+    constexpr int ND = PS * SEG_DY / 256, NA = PS * 32 / 256;    // staging units (4 floats of one pixel) per thread
+    constexpr int NUN = ND + NA;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * STB];
+    __shared__ int s_xoff[4][PS];
+    __shared__ int s_yoff[4][PS];
+    __shared__ unsigned s_mask[4][PS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const float* xg = a.x + (int64_t)blockIdx.z * a.gx;
+    const float* dyg = a.dy + (int64_t)blockIdx.z * a.gy;
+    float* wsg = a.ws + (int64_t)blockIdx.z * a.splits * a.cout * a.K;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int tk = blockIdx.x % a.tilesK, tco = blockIdx.x / a.tilesK;
+    const int co0 = tco * BCO, chunk0 = tk * 4;
+    const int split = blockIdx.y;
+    const int m_begin = split * a.rows_per_split;
+    const int m_end = min(a.M, m_begin + a.rows_per_split);
+    const int nstages = (m_end > m_begin) ? (m_end - m_begin + PS - 1) / PS : 0;
+    const int HoWo = a.ho * a.wo;
+
+    // staging roles.  dy unit i: pixel d_pix + (256 / SEG_DY) * i, segment d_seg; A unit i: pixel a_pix + 8 i, chunk a_chunk, segment a_seg
+    const int d_pix = tid / SEG_DY, d_seg = tid % SEG_DY;
+    const bool d_ok = (co0 + d_seg * 4) < a.cout;
+    const int a_pix = tid >> 5, a_chunk = (tid >> 3) & 3, a_seg = tid & 7;
+    const int chunk = chunk0 + a_chunk;
+    const bool chunk_ok = chunk < a.chunks;
+    int a_tap = 0, a_toff = 0;
+    if (chunk_ok) {
+        int cb = chunk / a.taps;
+        a_tap = chunk - cb * a.taps;
+        int kh = a_tap / a.kw, kw = a_tap - kh * a.kw;
+        a_toff = (kh * a.w + kw) * a.ldx + cb * 32 + a_seg * 4;
+    }
+
+    auto decode = [&](int stage) {  // rows of `stage` -> table stage & 3; 16 lanes of wave 0
+        if (tid < PS) {
+            const int r = tid, tb = stage & 3;
+            int m = m_begin + stage * PS + r;
+            int xo = 0, yo = -1;
+            unsigned mk = 0u;
+            if (stage < nstages && m < m_end) {
+                int n, pix, ho, wo;
+                if (a.howo_shift >= 0) { n = m >> a.howo_shift; pix = m & (HoWo - 1); }
+                else { n = m / HoWo; pix = m - n * HoWo; }
+                if (a.wo_shift >= 0) { ho = pix >> a.wo_shift; wo = pix & (a.wo - 1); }
+                else { ho = pix / a.wo; wo = pix - ho * a.wo; }
+                const int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
+                xo = (int)egr_map(a.xmap, n) + (hi0 * a.w + wi0) * a.ldx;
+                yo = (int)egr_map(a.ymap, n) + pix * a.ldy;
+                const int kh_lo = max(0, -hi0), kh_hi = min(a.kh, a.h - hi0);
+                const int kw_lo = max(0, -wi0), kw_hi = min(a.kw, a.w - wi0);
+                const unsigned rowbits = (kw_hi > kw_lo) ? (((1u << (kw_hi - kw_lo)) - 1u) << kw_lo) : 0u;
+                for (int kh = kh_lo; kh < kh_hi; ++kh) mk |= rowbits << (kh * a.kw);
+            }
+            s_xoff[tb][r] = xo;
+            s_yoff[tb][r] = yo;
+            s_mask[tb][r] = mk;
+        }
+    };
+
+    f32x4 xr[2][NUN];
+    auto request = [&](int stage, auto set_tag) {   // global loads of `stage` (its table must be visible) into register set SET
+        constexpr int SET = decltype(set_tag)::value;
+        const int tb = stage & 3;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int yo = s_yoff[tb][d_pix + (256 / SEG_DY) * i];
+            const float* p = (yo >= 0 && d_ok) ? dyg + yo + co0 + d_seg * 4 : egr_wg_zero16;
+            xr[SET][i] = *reinterpret_cast<const f32x4*>(p);
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int r = a_pix + 8 * i;
+            const bool ok = chunk_ok && s_yoff[tb][r] >= 0 && ((s_mask[tb][r] >> a_tap) & 1u);
+            const float* p = ok ? xg + (s_xoff[tb][r] + a_toff) : egr_wg_zero16;
+            xr[SET][ND + i] = *reinterpret_cast<const f32x4*>(p);
+        }
+    };
+    // slice k of the staging work: unit k / 5; step 0/1 = hi parts + residuals of the unit's two pairs, 2/3 = mid + lo, 4 = the writes
+    unsigned sh_[NUN][2], sm_[NUN][2], sl_[NUN][2];
+    float ra_[NUN][2], rb_[NUN][2];
+    auto slice = [&](auto set_tag, auto buf_tag, int k) {
+        constexpr int SET = decltype(set_tag)::value;
+        constexpr int BUF = decltype(buf_tag)::value;
+        const int u = k / 5, q = k % 5;
+        if (q < 2) {
+            const float v0 = xr[SET][u][2 * q], v1 = xr[SET][u][2 * q + 1];
+            sh_[u][q] = wg_cvt_pk(v0, v1);
+            ra_[u][q] = v0 - wg_lo(sh_[u][q]);
+            rb_[u][q] = v1 - wg_hi(sh_[u][q]);
+        } else if (q < 4) {
+            const int t = q - 2;
+            sm_[u][t] = wg_cvt_pk(ra_[u][t], rb_[u][t]);
+            sl_[u][t] = wg_cvt_pk(ra_[u][t] - wg_lo(sm_[u][t]), rb_[u][t] - wg_hi(sm_[u][t]));
+        } else {
+            uint8_t* dst;
+            int pl;
+            if (u < ND) { dst = lds + BUF * STB + (d_pix + (256 / SEG_DY) * u) * ROW_DY + d_seg * 8; pl = PL_DY; }
+            else { dst = lds + BUF * STB + 3 * PL_DY + (a_pix + 8 * (u - ND)) * ROW_A + (a_chunk * 32 + a_seg * 4) * 2; pl = PL_A; }
+            *reinterpret_cast<wg_u32x2*>(dst) = wg_u32x2{sh_[u][0], sh_[u][1]};
+            *reinterpret_cast<wg_u32x2*>(dst + pl) = wg_u32x2{sm_[u][0], sm_[u][1]};
+            *reinterpret_cast<wg_u32x2*>(dst + 2 * pl) = wg_u32x2{sl_[u][0], sl_[u][1]};
+        }
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposed-read address of this lane inside a plane: row (pixel) 8*half + 4*rd + q, 4 channels starting at 16*((lane>>4)&1) + 4*p
+    const int tq = (lane >> 2) & 3, tp = lane & 3, tg = (lane >> 4) & 1;
+    auto frag = [&](const uint8_t* plane, int row_bytes, int c0) {
+        wg_bf16x8 v;
+        const uint8_t* p = plane + (8 * half + tq) * row_bytes + (c0 + 16 * tg + 4 * tp) * 2;
+        const wg_s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_s16x4*)(p));
+        const wg_s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_s16x4*)(p + 4 * row_bytes));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const s16x8 both = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+        __builtin_memcpy(&v, &both, 16);
+        return v;
+    };
+    constexpr int NS = 5 * NUN, NM = 6 * FM * FN;
+    auto stage = [&](auto buf_tag, auto conv_tag) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        constexpr bool conv = decltype(conv_tag)::value;   // compile time: the slice bookkeeping below must fold to constants
+        using NB = std::integral_constant<int, BUF ^ 1>;
+        const uint8_t* st = lds + BUF * STB;
+        wg_bf16x8 af[FM][3], bf[FN][3];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) af[i][pl] = frag(st + pl * PL_DY, ROW_DY, wm * TM + 32 * i);
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bf[j][pl] = frag(st + 3 * PL_DY + pl * PL_A, ROW_A, wn * 64 + 32 * j);
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+        int n = 0, done = 0;
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j, ++n) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
+                    if constexpr (conv) {
+                        const int upto = ((n + 1) * NS + NM - 1) / NM;
+#pragma unroll
+                        for (int k = 0; k < NS; ++k)
+                            if (k >= done && k < upto) slice(NB{}, NB{}, k);
+                        done = upto > done ? upto : done;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+    };
+
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    // stage t lives in buffer t & 1 and register set t & 1; its rows are requested during stage t-2, split during stage t-1.
+    // Hand-over between stages: this wave's LDS traffic done, then the workgroup barrier.  NOT __syncthreads(), which also waits
+    // for vmcnt(0), i.e. for the rows just requested for the stage after next (their latency would be exposed in every stage).
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    decode(0);
+    decode(1);
+    decode(2);
+    lds_barrier();
+    if (nstages > 0) {
+        request(0, B0{});
+#pragma unroll
+        for (int k = 0; k < NS; ++k) slice(B0{}, B0{}, k);
+        request(1, B1{});
+    }
+    lds_barrier();
+    for (int t = 0; t < nstages; t += 2) {
+        // even stage: buffer 0; set 1 (stage t+1) -> buffer 1; set 0 requests stage t+2
+        decode(t + 3);
+        if (t + 2 < nstages) request(t + 2, B0{});
+        if (t + 1 < nstages) stage(B0{}, std::true_type{});
+        else stage(B0{}, std::false_type{});
+        lds_barrier();
+        if (t + 1 >= nstages) break;
+        decode(t + 4);
+        if (t + 3 < nstages) request(t + 3, B1{});
+        if (t + 2 < nstages) stage(B1{}, std::true_type{});
+        else stage(B1{}, std::false_type{});
+        lds_barrier();
+    }
+
+    // partial tile -> slab [split][co][k]; C/D map: col = lane&31 (k column), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (co)
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int kcol = chunk0 * 32 + wn * 64 + 32 * j + l31;
+            if (kcol >= a.K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * TM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (co < a.cout) wsg[((int64_t)split * a.cout + co) * a.K + kcol] = acc[i][j][r];
+            }
+        }
+}
+
 // Sum of the split slabs in a fixed order (deterministic).  A block owns 16 float4 outputs; 16 split lanes walk the slabs
 // with stride 16 (independent loads in flight instead of one dependent chain of `splits` loads), then an LDS tree in
 // lane order.
@@ -336,7 +571,13 @@ extern "C" int egr_conv2d_wgrad_f32(const egr_conv_desc* dd, const float* x, con
     const bool direct = (a.splits == 1 && !accumulate && d.gw == (int64_t)d.cout * a.K);   // the slab IS the result
     if (direct) a.ws = dw;
     dim3 grid((unsigned)tiles, (unsigned)a.splits, (unsigned)G);
-    if (bco == 128) hipLaunchKernelGGL(conv_wgrad_kernel<128>, grid, dim3(256), 0, s, a);
+    // large problems run on the bf16 matrix cores with exact three-way operand splits (same result class as the fp32 kernel);
+    // w_format == EGR_W_BF16X3 requests it, small ones stay on the fp32 kernel (latency-bound)
+    const bool x6 = (d.w_format & EGR_W_BF16X3) && ((d.w_format & EGR_W_FORCE) || (a.M >= 8192 && 2.0 * (double)a.M * d.cout * a.K * G >= 4e9));
+    if (x6) {
+        if (bco == 128) hipLaunchKernelGGL(conv_wgrad_x6_kernel<128>, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(conv_wgrad_x6_kernel<64>, grid, dim3(256), 0, s, a);
+    } else if (bco == 128) hipLaunchKernelGGL(conv_wgrad_kernel<128>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(conv_wgrad_kernel<64>, grid, dim3(256), 0, s, a);
     int rc = egr_launch_status();
     if (rc) return rc;

@@ -324,8 +324,13 @@ def conv2d(x: Img, w, cout: int, kh: int, kw: int, stride: int, pad: int, *, sca
     return ret
 
 
+# weight gradients of large layers on the bf16 matrix cores with exact operand splits (the kernel keeps small ones on fp32 MFMA)
+WGRAD_X6 = os.environ.get("EGR_W_FORMAT", "bf16x3") == "bf16x3"
+
+
 def conv2d_wgrad(x: Img, dy: Img, kh: int, kw: int, stride: int, pad: int, workspace: torch.Tensor, *, want_bias: bool = False,
-                 dw: Optional[torch.Tensor] = None, db: Optional[torch.Tensor] = None, accumulate: bool = False, groups: int = 1):
+                 dw: Optional[torch.Tensor] = None, db: Optional[torch.Tensor] = None, accumulate: bool = False, groups: int = 1,
+                 x6: Optional[bool] = None):
     """Weight (+ bias) gradient of the forward conv x -> y.  x, dy NHWC Imgs (all groups' images back to back when
     groups > 1).  Returns (dw, db): dw ([groups,] cout, kh*kw*cin) in the packed K order of conv2d
     (engine.unpack_conv_weight turns it back into OIHW), db ([groups,] cout)."""
@@ -342,6 +347,7 @@ def conv2d_wgrad(x: Img, dy: Img, kh: int, kw: int, stride: int, pad: int, works
     d.xmap, d.ymap = NMap(ng, x.nstride, 0), NMap(ng, dy.nstride, 0)
     K = kh * kw * cin
     d.groups, d.gx, d.gy, d.gw, d.gp = groups, ng * x.nstride, ng * dy.nstride, cout * K, cout
+    d.w_format = 3 if x6 == "force" else (1 if (WGRAD_X6 if x6 is None else x6) else 0)   # "force": the split kernel at any size
     shape_w, shape_b = ((groups, cout, K), (groups, cout)) if groups > 1 else ((cout, K), (cout,))
     if dw is None:
         dw = torch.empty(shape_w, device=x.t.device, dtype=torch.float32)

@@ -89,7 +89,8 @@ typedef struct {
      * gw is then in bf16 elements (egr_w6_elems per group). */
     int32_t w_format;
 } egr_conv_desc;
-enum { EGR_W_F32 = 0, EGR_W_BF16X3 = 1 };
+enum { EGR_W_F32 = 0, EGR_W_BF16X3 = 1,
+       EGR_W_FORCE = 2 /* egr_conv2d_wgrad_f32 only: with EGR_W_BF16X3, take the split kernel whatever the problem size (tests) */ };
 
 /* Split a packed fp32 weight matrix w (groups, npad, k) — npad = round_up(cout, 32), k = kh*kw*cin, k % 32 == 0 — into
  * the EGR_W_BF16X3 image: per group egr_w6_elems(npad, k) bf16 elements laid out
@@ -117,6 +118,8 @@ int egr_conv2d_masked_f32(const egr_conv_desc* d, const float* x, const float* w
  * db[co] (+)= sum_m dy[m][co] (db may be NULL).  dw is in the packed weight layout of egr_conv2d_nhwc_f32.  The pixels are
  * split over workgroups; partial tiles go through `workspace` and are summed in fixed order (deterministic).
  * Replaces autograd of nn.Conv2d / nn.Linear for config 5 (pl_wrappers/egoposeformer/pose_3d_mvf_ex.py:117-153). */
+/* d->w_format & EGR_W_BF16X3: large problems (>= 8192 pixels and >= 4 GFLOP) run on the bf16 matrix cores with both operands
+ * split exactly into three bf16 on the fly; the result class is the fp32 kernel's. */
 int egr_conv2d_wgrad_f32(const egr_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
                          float* workspace, size_t workspace_floats, int32_t accumulate, void* stream);
 

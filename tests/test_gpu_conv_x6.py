@@ -202,3 +202,40 @@ def test_wide_dynamic_range_and_zero_padding_rows():
     ref = F.conv2d(x.permute(0, 3, 1, 2).double(), wt.double(), None, 1, 1)
     a, b = both(hip, hip.Img(x.to(DEV)), pack_w(wt), cout, 3, 3, 1, 1)
     judge(a.t.permute(0, 3, 1, 2), b.t.permute(0, 3, 1, 2), ref, "dynamic range")
+
+
+WGRAD_CASES = [
+    # n, h, w, cin, cout, k, stride, groups
+    (8, 32, 32, 64, 64, 3, 1, 1),        # 64-wide output tile (BCO = 64), 8192 pixels
+    (8, 32, 32, 64, 128, 3, 2, 2),       # stride 2, grouped
+    (4, 64, 64, 128, 128, 1, 1, 1),      # 1x1
+    (9, 32, 32, 32, 96, 3, 1, 1),        # cout not a multiple of 32, ragged K tile (9 chunks)
+    (2, 64, 64, 256, 256, 3, 1, 1),      # deeper K: several K tiles
+    (3, 61, 45, 64, 128, 3, 1, 1),       # odd sizes: pixel count not a multiple of the stage
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_weight_gradient_split_launch(case):
+    """conv_wgrad_x6_kernel (both operands split on the fly, transposing LDS reads) against the fp32 kernel and fp64 autograd."""
+    from egorear_amd import hip
+    from egorear_amd.engine import unpack_conv_weight
+    n, h, w, cin, cout, k, s, G = case
+    pad = k // 2
+    x = rnd(G * n, cin, h, w, seed=21)
+    ho, wo = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+    dy = rnd(G * n, cout, ho, wo, seed=22)
+    ws = torch.empty(1 << 25, device=DEV)
+    xi, dyi = hip.Img(x.permute(0, 2, 3, 1).contiguous().to(DEV)), hip.Img(dy.permute(0, 2, 3, 1).contiguous().to(DEV))
+    out = {}
+    for fmt in (False, "force"):
+        dw, db = hip.conv2d_wgrad(xi, dyi, k, k, s, pad, ws, want_bias=True, groups=G, x6=fmt)
+        out[bool(fmt)] = (dw.clone(), db.clone())
+    for g in range(G):
+        wt = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+        b = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(x[g * n:(g + 1) * n].double(), wt, b, s, pad)
+        dw_ref, db_ref = torch.autograd.grad(y, (wt, b), dy[g * n:(g + 1) * n].double())
+        dwa = out[False][0][g] if G > 1 else out[False][0]
+        dwb = out[True][0][g] if G > 1 else out[True][0]
+        judge(unpack_conv_weight(dwa, cin, k, k), unpack_conv_weight(dwb, cin, k, k), dw_ref, f"dw {case} g{g}")

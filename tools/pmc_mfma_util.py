@@ -3,14 +3,14 @@
     rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d DIR -- python3 bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline
     python tools/pmc_mfma_util.py DIR out.json
 SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD (64 per v_mfma_f32_32x32x2_f32, 32 per v_mfma_f32_32x32x16_bf16), summed over the chip's
-1024 SIMDs; conv_igemm_bf16x3 = the launches of conv_igemm_kernel<..., true> (split-bf16 operands);
+1024 SIMDs; conv_igemm_bf16x3 = the launches of conv_igemm_x6_kernel (split-bf16 operands);
 GRBM_GUI_ACTIVE is summed over the 8 XCDs (guide: effective clock = GRBM_GUI_ACTIVE / 8 / wall time)."""
 import collections, csv, glob, json, sys
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)[0]
 per = collections.defaultdict(lambda: collections.defaultdict(float)); dur = collections.defaultdict(float); seen = set()
 for r in csv.DictReader(open(f)):
     n = r["Kernel_Name"]
-    x6 = ", true>" in n or ", 1>" in n.replace("(bool)", "")
+    x6 = "conv_igemm_x6" in n
     k = ("conv_igemm_bf16x3" if x6 else "conv_igemm") if "conv_igemm" in n else ("conv_wgrad" if "conv_wgrad" in n else ("stem" if "stem_kernel" in n else "other"))
     per[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if (r["Dispatch_Id"]) not in seen:
