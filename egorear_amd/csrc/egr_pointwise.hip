@@ -378,7 +378,7 @@ extern "C" int egr_tokens_to_nhwc_f32(const float* x, float* y, int32_t b, int32
     return egr_launch_status();
 }
 
-extern "C" const char* egr_version(void) { return "egorear_hip 0.1 (gfx950, fp32 MFMA)"; }
+extern "C" const char* egr_version(void) { return "egorear_hip 0.2 (gfx950, fp32 MFMA + exact bf16x3 split MFMA)"; }
 
 extern "C" int egr_device_arch(char* buf, int32_t buflen) {
     if (!buf || buflen <= 0) return EGR_ENULL;

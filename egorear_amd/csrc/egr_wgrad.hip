@@ -573,7 +573,7 @@ extern "C" int egr_conv2d_wgrad_f32(const egr_conv_desc* dd, const float* x, con
     dim3 grid((unsigned)tiles, (unsigned)a.splits, (unsigned)G);
     // large problems run on the bf16 matrix cores with exact three-way operand splits (same result class as the fp32 kernel);
     // w_format == EGR_W_BF16X3 requests it, small ones stay on the fp32 kernel (latency-bound)
-    const bool x6 = (d.w_format & EGR_W_BF16X3) && ((d.w_format & EGR_W_FORCE) || (a.M >= 8192 && 2.0 * (double)a.M * d.cout * a.K * G >= 4e9));
+    const bool x6 = (d.w_format & EGR_W_BF16X3) && ((d.w_format & EGR_W_FORCE) || (a.M >= 1024 && 2.0 * (double)a.M * d.cout * a.K * G >= 4e9));
     if (x6) {
         if (bco == 128) hipLaunchKernelGGL(conv_wgrad_x6_kernel<128>, grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(conv_wgrad_x6_kernel<64>, grid, dim3(256), 0, s, a);

@@ -118,7 +118,7 @@ int egr_conv2d_masked_f32(const egr_conv_desc* d, const float* x, const float* w
  * db[co] (+)= sum_m dy[m][co] (db may be NULL).  dw is in the packed weight layout of egr_conv2d_nhwc_f32.  The pixels are
  * split over workgroups; partial tiles go through `workspace` and are summed in fixed order (deterministic).
  * Replaces autograd of nn.Conv2d / nn.Linear for config 5 (pl_wrappers/egoposeformer/pose_3d_mvf_ex.py:117-153). */
-/* d->w_format & EGR_W_BF16X3: large problems (>= 8192 pixels and >= 4 GFLOP) run on the bf16 matrix cores with both operands
+/* d->w_format & EGR_W_BF16X3: large problems (>= 1024 pixels and >= 4 GFLOP) run on the bf16 matrix cores with both operands
  * split exactly into three bf16 on the fly; the result class is the fp32 kernel's. */
 int egr_conv2d_wgrad_f32(const egr_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
                          float* workspace, size_t workspace_floats, int32_t accumulate, void* stream);
