@@ -104,7 +104,9 @@ def _roofline(key: str, k: dict, traffic):
     r = {"bound": "mfma", "kernel": key, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
          "traffic": traffic, "launches_per_step": k["launches"], "avg_launch_us": round(1e3 * k["ms"] / k["launches"], 2),
          "flops_per_launch": round(k["flops"] / k["launches"], 1), "algorithmic_bytes_per_launch": round(k["bytes"] / k["launches"], 1),
-         "kernel_ms_per_step": round(k["ms"], 3), "algorithmic_tflops": round(alg, 2)}
+         "kernel_ms_per_step": round(k["ms"], 3), "algorithmic_tflops": round(alg, 2),
+         # the same computation priced against the roof it faced before (and still faces with EGR_W_FORMAT=f32)
+         "algorithmic_frac_of_f32_mfma_peak": round(alg / PEAK_F32_MFMA_TFLOPS, 4)}
     if x6:
         r["matrix_core_path"] = (f"fp32 operands as exact sums of three bf16; {X6_TERMS} bf16 MFMA products per fp32 product, fp32 accumulate; "
                                  f"achieved = {X6_TERMS} x algorithmic rate; the fp32 matrix cores peak at {PEAK_F32_MFMA_TFLOPS} TFLOP/s")

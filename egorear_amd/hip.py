@@ -207,8 +207,8 @@ def pack_w6_into(w6: W6) -> None:
 # Launches below these sizes (all groups together) are bound by launch latency or by streaming the weights once, not by the
 # matrix cores: they keep the 4-byte weight format (measured: 3840 rows x K 4096 and 16384 rows x K 576 slower with the split,
 # 8192 rows x N 512 x K 4608 faster)
-X6_MIN_ROWS = 8192
-X6_MIN_FLOPS = 4e9
+X6_MIN_ROWS = int(os.environ.get("EGR_X6_MIN_ROWS", "8192"))
+X6_MIN_FLOPS = float(os.environ.get("EGR_X6_MIN_FLOPS", "4e9"))
 
 
 def conv2d(x: Img, w, cout: int, kh: int, kw: int, stride: int, pad: int, *, scale=None, shift=None,

@@ -198,6 +198,68 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
             }
 }
 
+// ---- bound: BOTH operands pre-split in fragment order (as if the producer of A had written bf16 planes): LDS-DMA only, no VALU
+// in the loop.  What the on-the-fly split costs, and what a pre-splitting epilogue could gain.
+__global__ __launch_bounds__(256) void gemm_presplit_kernel(const uint8_t* __restrict__ Aimg, const uint8_t* __restrict__ Wimg, float* __restrict__ C, int M, int N, int K) {
+    constexpr int OP = 4 * 3 * UNIT, ST = 2 * OP;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * ST + 22 * 1024];   // padded to two workgroups per CU like the conv kernel
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tilesN = N / BN;
+    const int tm = blockIdx.x / tilesN, tn = blockIdx.x % tilesN;
+    const int ktiles = K / 16;
+    if (K < 0) lds[2 * ST + tid] = 1;
+    const uint8_t* ab = Aimg + (int64_t)tm * ktiles * OP + tid * 16;
+    const uint8_t* wb = Wimg + (int64_t)tn * ktiles * OP + tid * 16;
+    auto dma = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < OP / 4096; ++i) {
+            glds16(ab + (int64_t)kt * OP + i * 4096, lds + buf * ST + i * 4096 + wave * 1024);
+            glds16(wb + (int64_t)kt * OP + i * 4096, lds + buf * ST + OP + i * 4096 + wave * 1024);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    dma(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < ktiles) dma(kt + 1, cur ^ 1);
+        const uint8_t* st = lds + cur * ST;
+        bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                af[i][p] = *reinterpret_cast<const bf16x8*>(st + ((wm * 2 + i) * 3 + p) * UNIT + lane * 16);
+                bf[i][p] = *reinterpret_cast<const bf16x8*>(st + OP + ((wn * 2 + i) * 3 + p) * UNIT + lane * 16);
+            }
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = tm * BM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int col = tn * BN + wn * 64 + j * 32 + (lane & 31);
+                C[(int64_t)row * N + col] = acc[i][j][r];
+            }
+}
+
 // fp32 FMA-chain reference on the device (what an fp32 MFMA / any fp32 kernel delivers), one thread per output
 __global__ void ref_f32_kernel(const float* A, const float* W, float* C, int M, int N, int K) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -254,6 +316,28 @@ int main(int argc, char** argv) {
                             }
         return img;
     };
+    std::vector<uint8_t> imgA;
+    {
+        const int ktiles = K / 16, OP = 4 * 3 * UNIT, tilesM = M / BM;
+        imgA.resize((size_t)tilesM * ktiles * OP);
+        for (int tmi = 0; tmi < tilesM; ++tmi)
+            for (int kt = 0; kt < ktiles; ++kt)
+                for (int f = 0; f < 4; ++f)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 8; ++j) {
+                            const int row = tmi * BM + f * 32 + (l & 31), k = kt * 16 + 8 * (l >> 5) + j;
+                            const float w = hA[(size_t)row * K + k];
+                            const uint16_t h = bf16_rne(w);
+                            const float r1 = w - bf16_to_f(h);
+                            const uint16_t m = bf16_rne(r1);
+                            const float r2 = r1 - bf16_to_f(m);
+                            const uint16_t lo = bf16_rne(r2);
+                            uint8_t* base = imgA.data() + ((size_t)tmi * ktiles + kt) * OP + (f * 3) * UNIT + l * 16 + j * 2;
+                            memcpy(base, &h, 2);
+                            memcpy(base + UNIT, &m, 2);
+                            memcpy(base + 2 * UNIT, &lo, 2);
+                        }
+    }
     std::vector<uint8_t> img1 = make_image(1), img2 = make_image(2);
     float *dA, *dW, *dC, *dR;
     uint8_t *dI1, *dI2;
@@ -263,6 +347,9 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dR, (size_t)M * N * 4));
     CK(hipMalloc(&dI1, img1.size()));
     CK(hipMalloc(&dI2, img2.size()));
+    uint8_t* dIA;
+    CK(hipMalloc(&dIA, imgA.size()));
+    CK(hipMemcpy(dIA, imgA.data(), imgA.size(), hipMemcpyHostToDevice));
     CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dW, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dI1, img1.data(), img1.size(), hipMemcpyHostToDevice));
@@ -304,10 +391,11 @@ int main(int argc, char** argv) {
     err_vs_truth(hR, me, re);
     printf("M %d N %d K %d  blocks %d\n", M, N, K, blocks);
     printf("fp32 fma chain      : max err %.3e  rms err %.3e (relative to rms of the result)\n", me, re);
-    for (int ks : {1, 3, 2})
+    for (int ks : {1, 3, 9})
         for (int terms : {6}) {
             auto launch = [&]() {
-                if (ks == 3) gemm_kernel<6, 1, 22 * 1024><<<blocks, 256>>>(dA, dI1, dC, M, N, K);  // 70 KiB: 2 workgroups per CU
+                if (ks == 9) gemm_presplit_kernel<<<blocks, 256>>>(dIA, dI1, dC, M, N, K);   // label 9 = both operands pre-split
+                else if (ks == 3) gemm_kernel<6, 1, 22 * 1024><<<blocks, 256>>>(dA, dI1, dC, M, N, K);  // 70 KiB: 2 workgroups per CU
                 else if (ks == 1 && terms == 6) gemm_kernel<6, 1><<<blocks, 256>>>(dA, dI1, dC, M, N, K);
                 else if (ks == 1) gemm_kernel<3, 1><<<blocks, 256>>>(dA, dI1, dC, M, N, K);
                 else if (terms == 6) gemm_kernel<6, 2><<<blocks, 256>>>(dA, dI2, dC, M, N, K);
