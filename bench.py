@@ -191,7 +191,9 @@ def train_leg(args, dev, rank: int, world: int, backend: str):
     net = EgoPoseFormerMVFEX(**copy.deepcopy(configs.pose3d_cfg("ego4view_rw")))
     synth.load_synth(net, 42)
     net = net.to(dev)
-    tr = train.Trainer(net, use_graph=(world == 1))   # one process: the whole step replays as one hipGraph after two eager steps
+    # after two eager steps the step replays as one hipGraph (one process) or as one hipGraph per gradient stage with the
+    # all-reduces issued between the replays (several processes)
+    tr = train.Trainer(net, use_graph=True)
     img = synth.synth_images(B, 4, seed=4321 + rank).to(dev)
     ctm = synth.synth_coord_trans_mat(B, seed=77 + rank).to(dev)
     gt_pose = synth.synth_gt_pose(B, seed=99 + rank).to(dev)
@@ -223,7 +225,8 @@ def train_leg(args, dev, rank: int, world: int, backend: str):
            "workload": "ego4view_rw_pose3d fine-tune step (config 5): train-mode BatchNorm, MPJPE x4 + heat-map row-norm x2 losses, "
                        "all 126 M parameters, gradient-norm clip 5.0, AdamW(1e-3, wd 5e-4, two groups)",
            "parallelism": f"dp{world}: frames sharded, stage-bucketed gradient all-reduce overlapped with backward" if world > 1 else "single GPU",
-           "launch": "hipGraph replay" if tr.graph is not None else "eager", "arithmetic": ARITHMETIC,
+           "launch": ("eager" if tr.graph is None else "hipGraph replay" if not isinstance(tr.graph, list)
+                      else f"{len(tr.graph)} hipGraph segments per step, gradient all-reduces between them"), "arithmetic": ARITHMETIC,
            "loss_total": round(float(state["terms"].sum()), 4)}
     if world == 1 and not args.no_cpu_baseline:
         leg["cpu_baseline"] = cpu_train_baseline()

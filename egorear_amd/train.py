@@ -1157,8 +1157,10 @@ class Trainer:
     """The native optimisation step of config 5: forward (training mode) + losses + backward + (all-reduce) + clip + AdamW.
 
     use_graph: after two eager steps the whole step (~2600 kernel launches and copies) is captured into ONE hipGraph on
-    static input buffers and replayed, which takes the host out of the loop (eager: ~40 ms of enqueue work per 56 ms
-    step).  Single-process only; with a process group the step stays eager (the all-reduce is not captured)."""
+    static input buffers and replayed, which takes the host out of the loop (eager: ~45 ms of enqueue work per step, more
+    than the kernels take).  With a process group the step is captured as one graph PER GRADIENT STAGE: the collectives stay
+    ordinary eager calls between the replays (nothing of RCCL is captured), so each stage's all-reduce still starts as soon
+    as its gradients are complete and overlaps with the replay of the stages that follow."""
 
     def __init__(self, net: nn.Module, lr: float = 1e-3, weight_decay: float = 5e-4, clip: float = 5.0, warmup_iters: int = 500,
                  w_mpjpe: float = W_MPJPE, w_heatmap: float = W_HEATMAP, process_group=None, use_graph: bool = False):
@@ -1171,13 +1173,20 @@ class Trainer:
         self._static = None
         self._graph_out = None
         self._graph_step = None     # keeps the captured step's tensors / pinned tables alive
+        self._cuts = None           # multi-process capture: gradient stage handed to the all-reduce after each graph segment
 
-    def _run(self, img, ctm, gt_pose, gt_heatmap, update: bool):
+    def _distributed(self) -> bool:
+        from .dist import world_size
+        return world_size(self.opt.pg) > 1 or self.opt.force_collective
+
+    def _run(self, img, ctm, gt_pose, gt_heatmap, update: bool, hook=None):
         net = self.net
         S = Step(net, img.device)
         S.gviews = self.opt.gviews
-        from .dist import grad_seed_scale, world_size
-        if world_size(self.opt.pg) > 1 or self.opt.force_collective:
+        from .dist import grad_seed_scale
+        if hook is not None:
+            S.stage_hook = hook                    # capture: cuts the recording at every stage boundary
+        elif self._distributed():
             S.stage_hook = self.opt.reduce_stage   # bucketed all-reduce overlapped with the rest of the reverse pass
         with torch.no_grad():
             preds, hms, aux = forward_train(S, net, img, ctm)
@@ -1203,10 +1212,20 @@ class Trainer:
                     if dst is not None:
                         dst.copy_(src, non_blocking=True)
                 self.opt.begin_update()
-                self.graph.replay()
+                if self._cuts is None:
+                    self.graph.replay()
+                else:   # one segment per gradient stage; its all-reduce starts behind it and overlaps with the next segments
+                    for i, g in enumerate(self.graph):
+                        if i == len(self._cuts):        # the update segment: every stage must have arrived
+                            for h in self.opt.pending:
+                                h.wait()
+                            self.opt.pending = []
+                        g.replay()
+                        if i < len(self._cuts):
+                            self.opt.reduce_stage(self._cuts[i])
                 self._invalidate()
                 return self._graph_out
-        if self.use_graph and self.graph is None and self._eager_done >= 2 and world_size(self.opt.pg) == 1 and not self.opt.force_collective:
+        if self.use_graph and self.graph is None and self._eager_done >= 2:
             try:
                 self._capture(img, ctm, gt_pose, gt_heatmap)
             except Exception:      # capture is an optimisation: any refusal leaves the eager path in charge
@@ -1224,10 +1243,40 @@ class Trainer:
         self._static = [None if t is None else t.detach().to(device=dev, dtype=torch.float32).clone().contiguous()
                         for t in (img, ctm, gt_pose, gt_heatmap)]
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="relaxed"):
-            S, outs = self._run(*self._static, update=False)       # recorded, not executed: no update is counted
-        self.graph, self._graph_step, self._graph_out = g, S, (S.loss_terms, outs)
+        if not self._distributed():
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="relaxed"):
+                S, outs = self._run(*self._static, update=False)       # recorded, not executed: no update is counted
+            self.graph, self._graph_step, self._graph_out = g, S, (S.loss_terms, outs)
+            return
+        # multi-process: the recording is cut wherever a gradient stage is complete (the stage hook); segment i ends with
+        # stage cuts[i] flushed into the flat gradient buffer, the last segment is norm + clip + AdamW.  All segments share
+        # one memory pool and are replayed in recording order.
+        pool = torch.cuda.graph_pool_handle()
+        segs, cuts, cur = [], [], {}
+
+        def begin():
+            cur["g"] = torch.cuda.CUDAGraph()
+            cur["ctx"] = torch.cuda.graph(cur["g"], pool=pool, capture_error_mode="relaxed")
+            cur["ctx"].__enter__()
+
+        def end():
+            cur["ctx"].__exit__(None, None, None)
+            segs.append(cur["g"])
+
+        def cut(stage):
+            end()
+            cuts.append(stage)
+            begin()
+
+        begin()
+        try:
+            S, outs = self._run(*self._static, update=False, hook=cut)
+        except BaseException:
+            cur["ctx"].__exit__(None, None, None)
+            raise
+        end()
+        self.graph, self._cuts, self._graph_step, self._graph_out = segs, cuts, S, (S.loss_terms, outs)
 
 
 # --------------------------------------------------------------------------- autograd bridge (drop-in for the wrapper)

@@ -101,20 +101,25 @@ def _rccl_worker(port, out):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         from egorear_amd import train
-        plain, forced = train.Trainer(_build()), train.Trainer(_build())
+        plain, forced, graphed = train.Trainer(_build()), train.Trainer(_build()), train.Trainer(_build(), use_graph=True)
         forced.opt.force_collective = True
+        graphed.opt.force_collective = True      # captured as one hipGraph per gradient stage, collectives eager in between
         losses = []
-        for t in range(3):
-            args = _data(t)
+        for t in range(5):
+            args = _data(t % 3)
             a, _ = plain.step(*args)
             b, _ = forced.step(*args)
+            c, _ = graphed.step(*args)
             torch.cuda.synchronize()
             losses.append((float(a.sum()), float(b.sum())))
-        assert not forced.opt.pending
+            losses.append((float(a.sum()), float(c.sum())))
+        assert not forced.opt.pending and not graphed.opt.pending
+        assert isinstance(graphed.graph, list) and len(graphed.graph) == len(graphed._cuts) + 1 and len(graphed._cuts) >= 2, "segmented capture refused"
         worst = 0.0
-        for (k, p), (_, q) in zip(plain.net.named_parameters(), forced.net.named_parameters()):
-            if "k_proj.bias" not in k:
-                worst = max(worst, float(((p - q).abs() > 2e-4).float().mean()))
+        for other in (forced, graphed):
+            for (k, p), (_, q) in zip(plain.net.named_parameters(), other.net.named_parameters()):
+                if "k_proj.bias" not in k:
+                    worst = max(worst, float(((p - q).abs() > 2e-4).float().mean()))
         out.put((losses, worst, forced.opt.steps, None))
     except Exception as exc:  # noqa: BLE001 - reported to the parent
         out.put((None, None, None, f"{type(exc).__name__}: {exc}"))
@@ -134,7 +139,57 @@ def test_one_rank_rccl_group_runs_the_overlapped_exchange():
     losses, worst, steps, err = out.get(timeout=600)
     p.join(timeout=120)
     assert err is None, err
-    assert p.exitcode == 0 and steps == 3
+    assert p.exitcode == 0 and steps == 5
     for a, b in losses:
         assert abs(a - b) <= 1e-5 * abs(a), losses
     assert worst < 0.02, worst
+
+
+def _graph_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from egorear_amd import train
+        torch.cuda.set_device(0)
+        eager, graphed = train.Trainer(_build()), train.Trainer(_build(), use_graph=True)
+        for t in range(4):
+            args = _data(rank + 2 * t)
+            a, _ = eager.step(*args)
+            b, _ = graphed.step(*args)
+            torch.cuda.synchronize()
+            assert abs(float(a.sum()) - float(b.sum())) <= 1e-5 * abs(float(a.sum())), (t, float(a.sum()), float(b.sum()))
+        assert isinstance(graphed.graph, list) and len(graphed._cuts) >= 2, "segmented capture refused"
+        worst = 0.0
+        for (k, p), (_, q) in zip(eager.net.named_parameters(), graphed.net.named_parameters()):
+            if "k_proj.bias" not in k:
+                worst = max(worst, float(((p - q).abs() > 2e-4).float().mean()))
+        out.put((rank, worst, {k: _sample(p) for k, p in graphed.net.named_parameters()}, None))
+    except Exception as exc:  # noqa: BLE001
+        out.put((rank, None, None, f"{type(exc).__name__}: {exc}"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_segmented_graph_step_tracks_the_eager_one():
+    """Two ranks (gloo, one GPU): the step captured as one hipGraph per gradient stage with the gradient exchange between the
+    replays follows the eager data-parallel trainer, and both ranks end with the same parameters."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_graph_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, worst, par, err = out.get(timeout=900)
+        assert err is None, err
+        got[rank] = (worst, par)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got[0][0] < 0.02 and got[1][0] < 0.02, (got[0][0], got[1][0])
+    for k in got[0][1]:
+        np.testing.assert_array_equal(got[0][1][k], got[1][1][k], err_msg=k)
