@@ -239,3 +239,68 @@ def test_weight_gradient_split_launch(case):
         dwa = out[False][0][g] if G > 1 else out[False][0]
         dwb = out[True][0][g] if G > 1 else out[True][0]
         judge(unpack_conv_weight(dwa, cin, k, k), unpack_conv_weight(dwb, cin, k, k), dw_ref, f"dw {case} g{g}")
+
+
+def test_randomised_shapes_split_vs_fp32_launches():
+    """Seeded sweep over shapes the fixed cases do not hit (ragged tiles in both directions, 5x5 kernels, three groups, every
+    tile configuration, forward and data-gradient mode, stride 2 with odd and even sizes): the split launch (forced on at any
+    size) must agree with the fp32 launch of the same problem to fp32 rounding, and the split weight gradient with the fp32 one."""
+    from egorear_amd import hip
+    g = torch.Generator().manual_seed(1234)
+
+    def pick(options):
+        return options[int(torch.randint(len(options), (1,), generator=g))]
+
+    saved = hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS
+    hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = 0, 0.0
+    ws = torch.empty(1 << 24, device=DEV)
+    try:
+        for it in range(48):
+            G = pick([1, 1, 2, 3])
+            n, h, w = pick([1, 2, 3, 5]), pick([5, 8, 13, 16, 33]), pick([4, 8, 11, 16, 32])
+            cin, cout = pick([32, 64, 96, 160]), pick([8, 15, 32, 48, 64, 100, 128, 200])
+            k, s = pick([1, 3, 3, 5]), pick([1, 1, 2])
+            pad = k // 2
+            cfg = pick([-1, -1, 0, 1, 2, 3, 4])
+            transposed = pick([False, False, True])
+            ho, wo = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+            wts = [rnd(cout, cin, k, k, seed=100 + it * 4 + q, scale=1.0 / math.sqrt(cin * k * k)) for q in range(G)]
+            hip.conv_force_config(cfg)
+            try:
+                if not transposed:
+                    x = rnd(G * n, h, w, cin, seed=it)
+                    wp = torch.stack([pack_w(t) for t in wts]) if G > 1 else pack_w(wts[0])
+                    a, b = both(hip, hip.Img(x.to(DEV)), wp, cout, k, k, s, pad, groups=G, workspace=ws, split_k=pick([1, 0]))
+                    ref = torch.cat([F.conv2d(x[q * n:(q + 1) * n].permute(0, 3, 1, 2).double(), wts[q].double(), None, s, pad) for q in range(G)])
+                    judge(a.t.permute(0, 3, 1, 2), b.t.permute(0, 3, 1, 2), ref, f"fwd it{it} G{G} n{n} {h}x{w} {cin}->{cout} k{k}s{s} cfg{cfg}")
+                else:
+                    if cout % 32:
+                        continue        # the data gradient's K side is the forward cout: padded to 32 by the caller in the model
+                    dy = rnd(G * n, ho, wo, cout, seed=it)
+                    wp = torch.stack([pack_w_dgrad(t) for t in wts]) if G > 1 else pack_w_dgrad(wts[0])
+                    a, b = both(hip, hip.Img(dy.to(DEV)), wp, cin, k, k, s, pad, groups=G, transposed_out_hw=(h, w))
+                    refs = []
+                    for q in range(G):
+                        xr = torch.zeros(n, cin, h, w, dtype=torch.float64, requires_grad=True)
+                        y = F.conv2d(xr, wts[q].double(), None, s, pad)
+                        refs.append(torch.autograd.grad(y, xr, dy[q * n:(q + 1) * n].permute(0, 3, 1, 2).double())[0])
+                    judge(a.t.permute(0, 3, 1, 2), b.t.permute(0, 3, 1, 2), torch.cat(refs), f"dgrad it{it} G{G} n{n} {h}x{w} {cin}->{cout} k{k}s{s} cfg{cfg}")
+            finally:
+                hip.conv_force_config(-1)
+            # weight gradient of the same layer (cout must be a multiple of 4 there)
+            if cout % 4 == 0 and it % 2 == 0:
+                from egorear_amd.engine import unpack_conv_weight
+                x = rnd(G * n, cin, h, w, seed=it + 500)
+                dyw = rnd(G * n, cout, ho, wo, seed=it + 600)
+                xi, dyi = hip.Img(x.permute(0, 2, 3, 1).contiguous().to(DEV)), hip.Img(dyw.permute(0, 2, 3, 1).contiguous().to(DEV))
+                d0, _ = hip.conv2d_wgrad(xi, dyi, k, k, s, pad, ws, groups=G, x6=False)
+                d0 = d0.clone()
+                d1, _ = hip.conv2d_wgrad(xi, dyi, k, k, s, pad, ws, groups=G, x6="force")
+                for q in range(G):
+                    wt = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+                    y = F.conv2d(x[q * n:(q + 1) * n].double(), wt, None, s, pad)
+                    (dw_ref,) = torch.autograd.grad(y, wt, dyw[q * n:(q + 1) * n].double())
+                    judge(unpack_conv_weight(d0[q] if G > 1 else d0, cin, k, k), unpack_conv_weight(d1[q] if G > 1 else d1, cin, k, k), dw_ref,
+                          f"wgrad it{it} G{G} n{n} {h}x{w} {cin}->{cout} k{k}s{s}")
+    finally:
+        hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = saved
