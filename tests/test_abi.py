@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 from conftest import REPO
 
 
@@ -48,3 +50,16 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(root, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, os.path.join(root, f)
+
+
+def test_headers_are_plain_c():
+    """The boundary is a C ABI: both headers must parse as C99 and as C++ on their own (no torch / HIP types in a signature)."""
+    import shutil
+    import subprocess
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    for cc, lang, std in (("gcc", "c", "-std=c99"), ("g++", "c++", "-std=c++17")):
+        if shutil.which(cc) is None:
+            pytest.skip(f"{cc} not available")
+        for h in ("egorear_hip.h", "egorear_train.h"):
+            r = subprocess.run([cc, std, "-fsyntax-only", "-x", lang, "-I" + inc, os.path.join(inc, h)], capture_output=True, text=True)
+            assert r.returncode == 0, (cc, h, r.stderr[-2000:])
