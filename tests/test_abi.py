@@ -38,7 +38,7 @@ def test_training_header_symbols_are_exported():
 def test_struct_layout_matches_header():
     from egorear_amd import hip
     assert ctypes.sizeof(hip.NMap) == 24
-    # 14 leading int32 + 3 nmaps (8-byte aligned) + 5 int32 (+ 4 pad) + 7 int64 group strides + transposed (+ 4 pad)
+    # 14 leading int32 + 3 nmaps (8-byte aligned) + 5 int32 (+ 4 pad) + 7 int64 group strides + transposed + w_format
     assert ctypes.sizeof(hip.ConvDesc) == 56 + 3 * 24 + 24 + 56 + 8
     assert hip.version().startswith("egorear_hip")
 
