@@ -411,6 +411,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
         uint8_t* const lb = reinterpret_cast<uint8_t*>(lds);
         const uint8_t* const wimg = reinterpret_cast<const uint8_t*>(a.w) + (int64_t)grp * d.gw * 2;
         __syncthreads();  // row table visible
+        stamp(1);  // row decode done
         const float* ubase[NU];
         unsigned umask[NU];
         int uwo[NU];
@@ -521,6 +522,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
             for (int k = 0; k < NS; ++k) slice(B0{}, B0{}, k);
             load_a(kp, 1, B1{});
             __syncthreads();
+            stamp(2);  // first stage staged
             for (int kt = kt0; kt < kt1; ++kt) {
                 const bool more = kt + 1 < kt1;
                 const KPos kn = kpos_next(kp);

@@ -9,8 +9,11 @@ from egorear_amd import hip
 SH = [(128, 64, 64, 128, 128, 1, 1, "1x1 K=128 N=128"), (128, 64, 64, 256, 128, 1, 1, "1x1 K=256 N=128"),
       (128, 16, 16, 256, 256, 3, 1, "3x3 layer3"), (128, 64, 64, 128, 128, 3, 1, "3x3 fpn")]
 hip.lib.egr_conv_debug_stamps.argtypes = [ctypes.c_void_p]
+X6 = "--x6" in sys.argv   # weights in the bf16x3 format: the split-bf16 kernel
 for (n, h, w, cin, cout, k, s, label) in SH:
     x = torch.randn(n, h, w, cin, device="cuda"); wt = torch.randn(cout, k * k * cin, device="cuda") * 0.05
+    if X6:
+        wt = hip.pack_w6(wt)
     sh = torch.randn(cout, device="cuda"); out = hip.Img(torch.empty(n, h, w, cout, device="cuda"))
     M = n * h * w; blocks = (M // 128) * (cout // 128)
     buf = torch.zeros(blocks * 8, dtype=torch.int64, device="cuda")
