@@ -198,6 +198,134 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
             }
 }
 
+// ---- variant: v_mfma_f32_16x16x32_bf16 (the guide measures it at a higher held clock than 32x32x16), one K32 chunk per stage.
+// Fragment = 16 rows; lane l holds row l & 15, k = 8 (l >> 4) + j.  Tile 128 x TN, waves 2 x 2 (wave tile 64 x TN/2).
+// TN = 64: 72 KiB of LDS (two workgroups per CU); TN = 128: 96 KiB (one).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int TN>
+__global__ __launch_bounds__(256) void gemm16_kernel(const float* __restrict__ A, const uint8_t* __restrict__ Wimg, float* __restrict__ C, int M, int N, int K) {
+    constexpr int NFA = BM / 16, NFB = TN / 16;
+    constexpr int A_B = NFA * 3 * 1024, B_B = NFB * 3 * 1024, ST = A_B + B_B;
+    constexpr int FM = 4, FN = TN / 32;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * ST];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tilesN = N / TN;
+    const int tm = blockIdx.x / tilesN, tn = blockIdx.x % tilesN;
+    const int ktiles = K / 32;
+    const float* ap0 = A + (int64_t)(tm * BM + (tid >> 2)) * K + (tid & 3) * 8;          // unit 0: row tid/4, k8 group tid%4
+    const float* ap1 = ap0 + (int64_t)64 * K;                                            // unit 1: row + 64
+    const int awo0 = (((tid >> 2) >> 4) * 3) * 1024 + (((tid >> 2) & 15) + 16 * (tid & 3)) * 16;
+    const int awo1 = awo0 + 4 * 3 * 1024;
+    const uint8_t* wb = Wimg + (int64_t)tn * ktiles * B_B + tid * 16;
+    f32x4 x0[2][2], x1[2][2];   // [set][half]
+    auto load_a = [&](int kt, auto set_tag) {
+        constexpr int S = decltype(set_tag)::value;
+        x0[S][0] = *reinterpret_cast<const f32x4*>(ap0 + kt * 32);
+        x0[S][1] = *reinterpret_cast<const f32x4*>(ap0 + kt * 32 + 4);
+        x1[S][0] = *reinterpret_cast<const f32x4*>(ap1 + kt * 32);
+        x1[S][1] = *reinterpret_cast<const f32x4*>(ap1 + kt * 32 + 4);
+    };
+    auto dma_b = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < B_B / 4096; ++i) glds16(wb + (int64_t)kt * B_B + i * 4096, lds + buf * ST + A_B + i * 4096 + wave * 1024);
+    };
+    f32x4v acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    auto stage = [&](auto buf_tag, auto more_tag) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        constexpr int NX = BUF ^ 1;
+        constexpr bool MORE = decltype(more_tag)::value;
+        const uint8_t* st = lds + BUF * ST;
+        uint8_t* nx = lds + NX * ST;
+        bf16x8 af[FM][3], bf[FN][3];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(st + ((wm * FM + i) * 3 + p) * 1024 + lane * 16);
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(st + A_B + ((wn * FN + j) * 3 + p) * 1024 + lane * 16);
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+        constexpr int NM = 6 * FM * FN;
+        u32x4 h0, m0, l0, h1, m1, l1;
+        int n = 0;
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j, ++n) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
+                    if constexpr (MORE) {
+                        if (n == NM / 4) {
+                            split8(x0[NX][0], x0[NX][1], h0, m0, l0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        } else if (n == NM / 4 + 2) {
+                            *reinterpret_cast<u32x4*>(nx + awo0) = h0;
+                            *reinterpret_cast<u32x4*>(nx + awo0 + 1024) = m0;
+                            *reinterpret_cast<u32x4*>(nx + awo0 + 2048) = l0;
+                            __builtin_amdgcn_sched_barrier(0);
+                        } else if (n == NM / 2) {
+                            split8(x1[NX][0], x1[NX][1], h1, m1, l1);
+                            __builtin_amdgcn_sched_barrier(0);
+                        } else if (n == NM / 2 + 2) {
+                            *reinterpret_cast<u32x4*>(nx + awo1) = h1;
+                            *reinterpret_cast<u32x4*>(nx + awo1 + 1024) = m1;
+                            *reinterpret_cast<u32x4*>(nx + awo1 + 2048) = l1;
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+    };
+    load_a(0, S1{});
+    dma_b(0, 0);
+    {
+        u32x4 h, m, l;
+        split8(x0[1][0], x0[1][1], h, m, l);
+        *reinterpret_cast<u32x4*>(lds + awo0) = h; *reinterpret_cast<u32x4*>(lds + awo0 + 1024) = m; *reinterpret_cast<u32x4*>(lds + awo0 + 2048) = l;
+        split8(x1[1][0], x1[1][1], h, m, l);
+        *reinterpret_cast<u32x4*>(lds + awo1) = h; *reinterpret_cast<u32x4*>(lds + awo1 + 1024) = m; *reinterpret_cast<u32x4*>(lds + awo1 + 2048) = l;
+    }
+    if (ktiles > 1) load_a(1, S1{});
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 2 < ktiles; kt += 2) {
+        dma_b(kt + 1, 1);
+        load_a(kt + 2, S0{});
+        stage(S0{}, std::true_type{});
+        __syncthreads();
+        dma_b(kt + 2, 0);
+        if (kt + 3 < ktiles) load_a(kt + 3, S1{});
+        stage(S1{}, std::true_type{});
+        __syncthreads();
+    }
+    if (kt + 1 < ktiles) {
+        dma_b(kt + 1, 1);
+        stage(S0{}, std::true_type{});
+        __syncthreads();
+        stage(S1{}, std::false_type{});
+    } else if (kt < ktiles) {
+        stage(S0{}, std::false_type{});
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = tm * BM + (wm * FM + i) * 16 + (lane >> 4) * 4 + r;
+                const int col = tn * TN + (wn * FN + j) * 16 + (lane & 15);
+                C[(int64_t)row * N + col] = acc[i][j][r];
+            }
+}
+
 // ---- bound: BOTH operands pre-split in fragment order (as if the producer of A had written bf16 planes): LDS-DMA only, no VALU
 // in the loop.  What the on-the-fly split costs, and what a pre-splitting epilogue could gain.
 __global__ __launch_bounds__(256) void gemm_presplit_kernel(const uint8_t* __restrict__ Aimg, const uint8_t* __restrict__ Wimg, float* __restrict__ C, int M, int N, int K) {
@@ -316,6 +444,29 @@ int main(int argc, char** argv) {
                             }
         return img;
     };
+    auto make_image16 = [&](int TN) {
+        const int ktiles = K / 32, NFB = TN / 16, B_B = NFB * 3 * 1024, tiles = N / TN;
+        std::vector<uint8_t> img((size_t)tiles * ktiles * B_B);
+        for (int tn = 0; tn < tiles; ++tn)
+            for (int kt = 0; kt < ktiles; ++kt)
+                for (int f = 0; f < NFB; ++f)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 8; ++j) {
+                            const int col = tn * TN + f * 16 + (l & 15), k = kt * 32 + 8 * (l >> 4) + j;
+                            const float w = hW[(size_t)col * K + k];
+                            const uint16_t h = bf16_rne(w);
+                            const float r1 = w - bf16_to_f(h);
+                            const uint16_t m = bf16_rne(r1);
+                            const float r2 = r1 - bf16_to_f(m);
+                            const uint16_t lo = bf16_rne(r2);
+                            uint8_t* base = img.data() + ((size_t)tn * ktiles + kt) * B_B + (f * 3) * 1024 + l * 16 + j * 2;
+                            memcpy(base, &h, 2);
+                            memcpy(base + 1024, &m, 2);
+                            memcpy(base + 2048, &lo, 2);
+                        }
+        return img;
+    };
+    std::vector<uint8_t> img16a = make_image16(64), img16b = make_image16(128);
     std::vector<uint8_t> imgA;
     {
         const int ktiles = K / 16, OP = 4 * 3 * UNIT, tilesM = M / BM;
@@ -347,7 +498,11 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dR, (size_t)M * N * 4));
     CK(hipMalloc(&dI1, img1.size()));
     CK(hipMalloc(&dI2, img2.size()));
-    uint8_t* dIA;
+    uint8_t *dIA, *dJa, *dJb;
+    CK(hipMalloc(&dJa, img16a.size()));
+    CK(hipMalloc(&dJb, img16b.size()));
+    CK(hipMemcpy(dJa, img16a.data(), img16a.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(dJb, img16b.data(), img16b.size(), hipMemcpyHostToDevice));
     CK(hipMalloc(&dIA, imgA.size()));
     CK(hipMemcpy(dIA, imgA.data(), imgA.size(), hipMemcpyHostToDevice));
     CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
@@ -391,10 +546,12 @@ int main(int argc, char** argv) {
     err_vs_truth(hR, me, re);
     printf("M %d N %d K %d  blocks %d\n", M, N, K, blocks);
     printf("fp32 fma chain      : max err %.3e  rms err %.3e (relative to rms of the result)\n", me, re);
-    for (int ks : {1, 3, 9})
+    for (int ks : {1, 3, 9, 16, 17})
         for (int terms : {6}) {
             auto launch = [&]() {
-                if (ks == 9) gemm_presplit_kernel<<<blocks, 256>>>(dIA, dI1, dC, M, N, K);   // label 9 = both operands pre-split
+                if (ks == 16) gemm16_kernel<64><<<(M / BM) * (N / 64), 256>>>(dA, dJa, dC, M, N, K);          // label 16: 16x16x32, tile 128x64
+                else if (ks == 17) gemm16_kernel<128><<<(M / BM) * (N / 128), 256>>>(dA, dJb, dC, M, N, K);   // label 17: 16x16x32, tile 128x128
+                else if (ks == 9) gemm_presplit_kernel<<<blocks, 256>>>(dIA, dI1, dC, M, N, K);   // label 9 = both operands pre-split
                 else if (ks == 3) gemm_kernel<6, 1, 22 * 1024><<<blocks, 256>>>(dA, dI1, dC, M, N, K);  // 70 KiB: 2 workgroups per CU
                 else if (ks == 1 && terms == 6) gemm_kernel<6, 1><<<blocks, 256>>>(dA, dI1, dC, M, N, K);
                 else if (ks == 1) gemm_kernel<3, 1><<<blocks, 256>>>(dA, dI1, dC, M, N, K);
