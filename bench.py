@@ -108,6 +108,8 @@ def _roofline(key: str, k: dict, traffic):
          # the same computation priced against the roof it faced before (and still faces with EGR_W_FORMAT=f32)
          "algorithmic_frac_of_f32_mfma_peak": round(alg / PEAK_F32_MFMA_TFLOPS, 4)}
     if x6:
+        # measured with tools/proto/mfma_ceiling (profiles/r01_v17_mfma_ceiling_and_ring.txt): register operands only, random data
+        r["bare_mfma_loop_tflops_measured"] = 1700.0
         r["matrix_core_path"] = (f"fp32 operands as exact sums of three bf16; {X6_TERMS} bf16 MFMA products per fp32 product, fp32 accumulate; "
                                  f"achieved = {X6_TERMS} x algorithmic rate; the fp32 matrix cores peak at {PEAK_F32_MFMA_TFLOPS} TFLOP/s")
     return r

@@ -388,6 +388,74 @@ __global__ __launch_bounds__(256) void gemm_presplit_kernel(const uint8_t* __res
             }
 }
 
+// ---- deeper pipeline on the pre-split variant: ring of NB k16 buffers, DMA issued DIST stages ahead, raw barrier that leaves the
+// youngest DIST-1 stages of DMA in flight (s_waitcnt vmcnt((DIST-1)*6)).  Tests whether the one-stage-ahead staging (768 MFMA
+// cycles of cover against ~2000+ cycles of global->LDS latency) is what keeps the matrix pipe at ~55 % in the K loop.
+template <int NB, int DIST>
+__global__ __launch_bounds__(256) void gemm_ring_kernel(const uint8_t* __restrict__ Aimg, const uint8_t* __restrict__ Wimg, float* __restrict__ C, int M, int N, int K) {
+    constexpr int OP = 4 * 3 * UNIT, ST = 2 * OP;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[NB * ST];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tilesN = N / BN;
+    const int tm = blockIdx.x / tilesN, tn = blockIdx.x % tilesN;
+    const int ktiles = K / 16;
+    const uint8_t* ab = Aimg + (int64_t)tm * ktiles * OP + tid * 16;
+    const uint8_t* wb = Wimg + (int64_t)tn * ktiles * OP + tid * 16;
+    auto dma = [&](int kt, int buf) {   // 6 DMA instructions per thread
+#pragma unroll
+        for (int i = 0; i < OP / 4096; ++i) {
+            glds16(ab + (int64_t)kt * OP + i * 4096, lds + buf * ST + i * 4096 + wave * 1024);
+            glds16(wb + (int64_t)kt * OP + i * 4096, lds + buf * ST + OP + i * 4096 + wave * 1024);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int d = 0; d < DIST; ++d)
+        if (d < ktiles) dma(d, d % NB);
+    int cur = 0, nxt = DIST % NB;
+    for (int kt = 0; kt < ktiles; ++kt) {
+        // stage kt must have landed: everything but the youngest (DIST-1) stages' DMA (fewer near the end: then wait for all)
+        if (kt + DIST - 1 < ktiles) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((DIST - 1) * 6) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + DIST < ktiles) dma(kt + DIST, nxt);     // its buffer was read DIST... stages ago (NB > DIST)
+        const uint8_t* st = lds + cur * ST;
+        bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                af[i][p] = *reinterpret_cast<const bf16x8*>(st + ((wm * 2 + i) * 3 + p) * UNIT + lane * 16);
+                bf[i][p] = *reinterpret_cast<const bf16x8*>(st + OP + ((wn * 2 + i) * 3 + p) * UNIT + lane * 16);
+            }
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
+        cur = (cur + 1 == NB) ? 0 : cur + 1;
+        nxt = (nxt + 1 == NB) ? 0 : nxt + 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = tm * BM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int col = tn * BN + wn * 64 + j * 32 + (lane & 31);
+                C[(int64_t)row * N + col] = acc[i][j][r];
+            }
+}
+
 // fp32 FMA-chain reference on the device (what an fp32 MFMA / any fp32 kernel delivers), one thread per output
 __global__ void ref_f32_kernel(const float* A, const float* W, float* C, int M, int N, int K) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -546,10 +614,13 @@ int main(int argc, char** argv) {
     err_vs_truth(hR, me, re);
     printf("M %d N %d K %d  blocks %d\n", M, N, K, blocks);
     printf("fp32 fma chain      : max err %.3e  rms err %.3e (relative to rms of the result)\n", me, re);
-    for (int ks : {1, 3, 9, 16, 17})
+    for (int ks : {3, 9, 32, 43, 63})
         for (int terms : {6}) {
             auto launch = [&]() {
-                if (ks == 16) gemm16_kernel<64><<<(M / BM) * (N / 64), 256>>>(dA, dJa, dC, M, N, K);          // label 16: 16x16x32, tile 128x64
+                if (ks == 32) gemm_ring_kernel<3, 2><<<blocks, 256>>>(dIA, dI1, dC, M, N, K);        // label 32: ring of 3 buffers, DMA 2 stages ahead (72 KiB: 2 per CU)
+                else if (ks == 43) gemm_ring_kernel<4, 3><<<blocks, 256>>>(dIA, dI1, dC, M, N, K);   // label 43: ring of 4, 3 ahead (96 KiB: 1 per CU)
+                else if (ks == 63) gemm_ring_kernel<6, 3><<<blocks, 256>>>(dIA, dI1, dC, M, N, K);   // label 63: ring of 6, 3 ahead (144 KiB: 1 per CU)
+                else if (ks == 16) gemm16_kernel<64><<<(M / BM) * (N / 64), 256>>>(dA, dJa, dC, M, N, K);          // label 16: 16x16x32, tile 128x64
                 else if (ks == 17) gemm16_kernel<128><<<(M / BM) * (N / 128), 256>>>(dA, dJb, dC, M, N, K);   // label 17: 16x16x32, tile 128x128
                 else if (ks == 9) gemm_presplit_kernel<<<blocks, 256>>>(dIA, dI1, dC, M, N, K);   // label 9 = both operands pre-split
                 else if (ks == 3) gemm_kernel<6, 1, 22 * 1024><<<blocks, 256>>>(dA, dI1, dC, M, N, K);  // 70 KiB: 2 workgroups per CU
