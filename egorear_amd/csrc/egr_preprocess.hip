@@ -58,6 +58,62 @@ __global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t* src, uint8
     o[2] = (uint8_t)clip8(s2);
 }
 
+// horizontal pass through LDS: a workgroup owns RH = 4 consecutive source rows (contiguous in memory, 16-byte aligned when the
+// row count per image is a multiple of 4 and a row is a multiple of 4 bytes), stages them with 16-byte loads, computes the
+// 4 x ow outputs from LDS (a thread = one output column of all four rows: its 13 window dwords per row come from LDS, the taps are
+// read once), and writes the 4 x ow x 3 result bytes back as 16-byte stores.  One global read of every source byte instead of ~5
+// overlapping window reads per lane, no byte stores: 269 -> ~70 us for 64 frames of 872 x 872.
+constexpr int RH = 4;
+__global__ __launch_bounds__(256) void resize_h_lds_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ tmp, int64_t rows_total, int w,
+                                                           int ow, const int32_t* __restrict__ bounds, const int32_t* __restrict__ coef, int ksize) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t hl[];
+    const int row_b = w * 3;                          // bytes per source row
+    const int in_b = RH * row_b;                      // multiple of 16 (host-checked)
+    const int out_row_b = ow * 3, out_b = RH * out_row_b;
+    uint32_t* in32 = reinterpret_cast<uint32_t*>(hl);
+    uint8_t* outl = hl + ((in_b + 64 + 15) & ~15);    // + 64: the last window may read up to 13 dwords past its start
+    const int64_t r0 = (int64_t)blockIdx.x * RH;
+    const uint4* g = reinterpret_cast<const uint4*>(src + r0 * row_b);
+    const int nvec = in_b >> 4;
+    for (int i = threadIdx.x; i < nvec; i += 256) reinterpret_cast<uint4*>(hl)[i] = g[i];
+    for (int i = threadIdx.x; i < 16; i += 256) in32[(in_b >> 2) + i] = 0u;   // padding read by the last windows (weights there are 0)
+    __syncthreads();
+    for (int ox = threadIdx.x; ox < ow; ox += 256) {
+        const int xmin = bounds[2 * ox], cnt = bounds[2 * ox + 1];
+        const int32_t* k = coef + (int64_t)ox * ksize;
+        int kk[16];
+#pragma unroll
+        for (int x = 0; x < 16; ++x) kk[x] = (x < cnt && x < ksize) ? k[x < ksize ? x : 0] : 0;
+#pragma unroll
+        for (int r = 0; r < RH; ++r) {
+            const int b0 = r * row_b + xmin * 3;
+            const int a0 = b0 >> 2;
+            const unsigned sh = (unsigned)(b0 & 3);
+            uint32_t raw[13];
+#pragma unroll
+            for (int i = 0; i < 13; ++i) raw[i] = in32[a0 + i];
+            uint32_t al[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) al[i] = __builtin_amdgcn_alignbyte(raw[i + 1], raw[i], sh);
+            int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+#pragma unroll
+            for (int x = 0; x < 16; ++x) {
+                const int bb = 3 * x;
+                s0 += (int)((al[bb >> 2] >> (8 * (bb & 3))) & 0xff) * kk[x];
+                s1 += (int)((al[(bb + 1) >> 2] >> (8 * ((bb + 1) & 3))) & 0xff) * kk[x];
+                s2 += (int)((al[(bb + 2) >> 2] >> (8 * ((bb + 2) & 3))) & 0xff) * kk[x];
+            }
+            uint8_t* o = outl + r * out_row_b + ox * 3;
+            o[0] = (uint8_t)clip8(s0);
+            o[1] = (uint8_t)clip8(s1);
+            o[2] = (uint8_t)clip8(s2);
+        }
+    }
+    __syncthreads();
+    uint4* go = reinterpret_cast<uint4*>(tmp + r0 * out_row_b);
+    for (int i = threadIdx.x; i < (out_b >> 4); i += 256) go[i] = reinterpret_cast<const uint4*>(outl)[i];
+}
+
 // generic horizontal pass (any ksize / size): byte loads
 __global__ __launch_bounds__(256) void resize_h_generic_kernel(const uint8_t* src, uint8_t* tmp, int n, int h, int w, int ow,
                                                                const int32_t* bounds, const int32_t* coef, int ksize) {
@@ -147,7 +203,13 @@ extern "C" int egr_preprocess_u8_f32(const uint8_t* src, int32_t n, int32_t h, i
     hipStream_t s = (hipStream_t)stream;
     int64_t t1 = (int64_t)n * h * ow, t2 = (int64_t)n * oh * (ow / 4);
     if (t1 >= (1LL << 31) * 256 || t2 >= (1LL << 31) * 256) return EGR_EINVAL;
-    if (ksize_h <= 16 && ((int64_t)h * w * 3) % 4 == 0)
+    const int in_b = RH * w * 3, out_b = RH * ow * 3;
+    const size_t lds_b = (size_t)((in_b + 64 + 15) & ~15) + (size_t)out_b;
+    if (ksize_h <= 16 && h % RH == 0 && in_b % 16 == 0 && out_b % 16 == 0 && lds_b <= 64 * 1024 && ((uintptr_t)src & 15) == 0 &&
+        ((uintptr_t)tmp & 15) == 0)
+        hipLaunchKernelGGL(resize_h_lds_kernel, dim3((unsigned)((int64_t)n * h / RH)), dim3(256), lds_b, s, src, tmp, (int64_t)n * h, w, ow,
+                           bounds_h, coef_h, ksize_h);
+    else if (ksize_h <= 16 && ((int64_t)h * w * 3) % 4 == 0)
         hipLaunchKernelGGL(resize_h_kernel, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, s, src, tmp, n, h, w, ow, bounds_h,
                            coef_h, ksize_h);
     else

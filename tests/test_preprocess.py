@@ -93,3 +93,18 @@ def test_hip_preprocess_feeds_the_network():
         o_preds, o_hms, o_aux = E.mvfex_forward(full, E.make_cameras("ego4view_syn", CALIB), img)
     assert torch.equal(net.__dict__["_egr_last_aux"]["heatmap"]["argmax_idx"].cpu().long(), o_aux["heatmap"]["argmax_idx"])
     assert max(float((p.cpu() - q).abs().max()) for p, q in zip(preds, o_preds)) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("in_hw,out_hw", [((872, 872), (256, 256)), ((437, 500), (128, 160)), ((120, 96), (64, 64)), ((64, 1000), (32, 256))])
+def test_hip_preprocess_other_sizes_match_the_oracle(in_hw, out_hw):
+    """Every horizontal-pass kernel (LDS rows: heights that are multiples of 4 with 16-byte row groups; aligned-dword windows;
+    byte loads) against the numpy restatement of Pillow, bit for bit."""
+    from egorear_amd.preprocess import FramePreprocessor
+    g = torch.Generator().manual_seed(in_hw[0] * 1000 + in_hw[1])
+    frames = torch.randint(0, 256, (2, 3, in_hw[0], in_hw[1], 3), generator=g, dtype=torch.uint8)
+    pre = FramePreprocessor(in_hw=in_hw, out_hw=out_hw)
+    x = pre(frames.cuda())
+    ref = O.preprocess_frames(frames.numpy(), out_hw[0], out_hw[1])
+    assert x.shape == (2, 3, 3, out_hw[0], out_hw[1])
+    assert np.array_equal(x.cpu().numpy(), ref)
