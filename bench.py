@@ -21,7 +21,8 @@ Extra objects on the line:
                  path's output on the same frames (arg-max indices equal, largest 3-D joint deviation in cm,
                  MPJPE of both against the seeded synthetic ground truth).
   preprocess, train — the SURVEY.md §8(f) legs (raw 872x872 uint8 -> model input; the config-5 optimisation step),
-                 timed separately, never part of `value`.
+                 timed separately, never part of `value`.  preprocess.from_raw_frames = the whole chain from raw
+                 872x872x4-view uint8 frames in HBM (pre-processing + forward of the same B frames).
 """
 from __future__ import annotations
 
@@ -350,6 +351,26 @@ def main():
         pre_leg = {"frames_per_s": round(nfr / pms * 1e3, 1), "ms_per_batch": round(pms, 3), "batch": nfr,
                    "algorithmic_GBps": round(pbytes / pms / 1e6, 1), "bound": "hbm", "frac_of_8TBps": round(pbytes / pms / 1e6 / PEAK_HBM_GBS, 4),
                    "what": "uint8 (B,4,872,872,3) -> PIL-exact bicubic 256x256 + /255 + ImageNet normalise -> fp32 (B,4,3,256,256)"}
+        # the whole chain from raw 872 x 872 x 4-view uint8 frames resident in HBM (never `value` either: SURVEY.md 8d times the network
+        # on the pre-processed tensor): pre-processing + forward of B frames, eager launches, HIP events
+        try:
+            reps = -(-B // nfr)
+            raw_b = raw.repeat(reps, 1, 1, 1, 1)[:B].contiguous()
+            with torch.no_grad():
+                for _ in range(2):
+                    net(pre(raw_b))
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(5):
+                    net(pre(raw_b))
+                e1.record()
+                torch.cuda.synchronize()
+            rms = e0.elapsed_time(e1) / 5
+            pre_leg["from_raw_frames"] = {"frames_per_s": round(B / rms * 1e3, 1), "ms_per_step": round(rms, 3), "batch": B,
+                                          "what": "raw uint8 (B,4,872,872,3) in HBM -> pre-processing -> full forward (eager launches)"}
+            del raw_b
+        except Exception as exc:  # never at the expense of the main line
+            pre_leg["from_raw_frames"] = {"error": f"{type(exc).__name__}: {exc}"}
     train = None
     if not args.no_train:
         _log("training-step leg")
