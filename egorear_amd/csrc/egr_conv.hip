@@ -806,9 +806,9 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
 // One workgroup per (32-column fragment, 32-deep chunk): thread (row = tid / 8, seg = tid % 8) reads 16 bytes of its weight row
 // (a row's 128 bytes are one coalesced segment) and writes 8 bytes per plane; the two threads of an 8-channel group and the 32
 // rows of a lane half fill 512 contiguous bytes of the image.
-__global__ __launch_bounds__(256) void pack_w6_kernel(const float* __restrict__ w, int npad, int K, int cfp, uint8_t* __restrict__ img) {
+__device__ __forceinline__ void pack_w6_block(const float* __restrict__ w, int npad, int K, int cfp, uint8_t* __restrict__ img, int blk, int g) {
     const int KC = K / 32;
-    const int chunk = blockIdx.x % KC, cf = blockIdx.x / KC, g = blockIdx.y;
+    const int chunk = blk % KC, cf = blk / KC;
     const int row = threadIdx.x >> 3, seg = threadIdx.x & 7;
     const int col = cf * 32 + row;
     unsigned h[2] = {0u, 0u}, m[2] = {0u, 0u}, l[2] = {0u, 0u};
@@ -829,6 +829,26 @@ __global__ __launch_bounds__(256) void pack_w6_kernel(const float* __restrict__ 
     *reinterpret_cast<u32x2*>(dst) = u32x2{h[0], h[1]};
     *reinterpret_cast<u32x2*>(dst + 1024) = u32x2{m[0], m[1]};
     *reinterpret_cast<u32x2*>(dst + 2048) = u32x2{l[0], l[1]};
+}
+
+__global__ __launch_bounds__(256) void pack_w6_kernel(const float* __restrict__ w, int npad, int K, int cfp, uint8_t* __restrict__ img) {
+    pack_w6_block(w, npad, K, cfp, img, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// many matrices in one launch (the training step re-splits ~90 images after every update): a workgroup finds its matrix by
+// binary search in the table's running workgroup count
+__global__ __launch_bounds__(256) void pack_w6_many_kernel(const egr_w6_job* __restrict__ jobs, int count) {
+    int lo = 0, hi = count - 1;
+    const int64_t b = blockIdx.x;
+    while (lo < hi) {   // last job with first_block <= b
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= b) lo = mid; else hi = mid - 1;
+    }
+    const egr_w6_job j = jobs[lo];
+    const int cfp = (j.npad / 32 + 3) / 4 * 4;
+    const int per_group = cfp * (j.k / 32);
+    const int64_t local = b - j.first_block;
+    pack_w6_block(j.w, j.npad, j.k, cfp, reinterpret_cast<uint8_t*>(j.img), (int)(local % per_group), (int)(local / per_group));
 }
 
 enum { CFG_AUTO = -1, CFG_128x128 = 0, CFG_256x64 = 1, CFG_64x64 = 2, CFG_128x32 = 3, CFG_128x64 = 4, CFG_COUNT = 5 };
@@ -853,6 +873,14 @@ extern "C" int egr_pack_w6_f32(const float* w, int32_t npad, int32_t k, int32_t 
     const int64_t blocks = (int64_t)cfp * (k / 32);
     if (blocks > 0x7fffffffLL) return EGR_EINVAL;
     hipLaunchKernelGGL(pack_w6_kernel, dim3((unsigned)blocks, (unsigned)groups), dim3(256), 0, (hipStream_t)stream, w, npad, k, cfp, (uint8_t*)img);
+    return egr_launch_status();
+}
+
+extern "C" int egr_pack_w6_many_f32(const egr_w6_job* jobs, int32_t count, int64_t total_blocks, void* stream) {
+    if (count <= 0 || total_blocks <= 0) return 0;
+    if (!jobs) return EGR_ENULL;
+    if (total_blocks > 0x7fffffffLL) return EGR_EINVAL;
+    hipLaunchKernelGGL(pack_w6_many_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs, count);
     return egr_launch_status();
 }
 

@@ -24,7 +24,7 @@ EXPORTS = [
     "egr_avgpool_nhwc_f32", "egr_argmax_rows_f32", "egr_layernorm_f32", "egr_joint_mha_f32", "egr_msda_gather_f32",
     "egr_fisheye_project_f32", "egr_linear_smallk_f32", "egr_jqa_sum_f32", "egr_tokens_to_nhwc_f32", "egr_version",
     "egr_device_arch", "egr_conv_force_config", "egr_preprocess_u8_f32", "egr_pose_metrics_f32", "egr_gt_heatmap_f32", "egr_conv_debug_stamps", "egr_conv2d_wgrad_f32", "egr_conv2d_masked_f32", "egr_up2_relu_head_f32",
-    "egr_msda_fwd_f32", "egr_msda_bwd_f32", "egr_w6_elems", "egr_pack_w6_f32",
+    "egr_msda_fwd_f32", "egr_msda_bwd_f32", "egr_w6_elems", "egr_pack_w6_f32", "egr_pack_w6_many_f32",
 ]
 
 
@@ -76,6 +76,7 @@ def _load() -> C.CDLL:
     lib.egr_gt_heatmap_f32.argtypes = [vp, i32, C.c_double, i32, i32, vp, vp, vp]
     lib.egr_pose_metrics_f32.argtypes = [vp, vp, i32, i32, f32, i32, vp, vp, vp]
     lib.egr_pack_w6_f32.argtypes = [vp, i32, i32, i32, vp, vp]
+    lib.egr_pack_w6_many_f32.argtypes = [vp, i32, i64, vp]
     lib.egr_w6_elems.argtypes = [i32, i32]
     lib.egr_msda_fwd_f32.argtypes = [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp, vp]
     lib.egr_msda_bwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp, vp, vp, vp]
@@ -202,6 +203,30 @@ def pack_w6(w: torch.Tensor) -> W6:
 def pack_w6_into(w6: W6) -> None:
     """Refresh an image from its fp32 matrix (w6.f32) in place: the training step does this after every parameter update."""
     _launch("egr_pack_w6_f32", lib.egr_pack_w6_f32, _p(w6.f32), w6.npad, w6.K, w6.groups, _p(w6.img, torch.bfloat16), _stream())
+
+
+class W6Job(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("img", C.c_void_p), ("npad", C.c_int32), ("k", C.c_int32), ("groups", C.c_int32), ("reserved", C.c_int32),
+                ("first_block", C.c_int64)]
+
+
+class W6Table:
+    """Device table for egr_pack_w6_many_f32: every image of `images` re-split from its fp32 matrix in ONE launch."""
+
+    def __init__(self, images):
+        self.images = list(images)
+        jobs = (W6Job * max(1, len(self.images)))()
+        first = 0
+        for i, w6 in enumerate(self.images):
+            jobs[i] = W6Job(w6.f32.data_ptr(), w6.img.data_ptr(), w6.npad, w6.K, w6.groups, 0, first)
+            first += w6.groups * ((w6.npad // 32 + 3) // 4 * 4) * (w6.K // 32)
+        self.total = first
+        raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).clone()
+        self.dev = raw.to(self.images[0].img.device) if self.images else None
+
+    def run(self):
+        if self.images:
+            _launch("egr_pack_w6_f32", lib.egr_pack_w6_many_f32, C.c_void_p(self.dev.data_ptr()), len(self.images), self.total, _stream())
 
 
 # Launches below these sizes (all groups together) are bound by launch latency or by streaming the weights once, not by the

@@ -70,6 +70,7 @@ class PackCache:
         self.table = repack.RepackTable(device)
         self.torch_refresh: List = []        # (dst, src parameter): dst.copy_(src.t())
         self.images: List = []               # hip.W6 operands re-split from their fp32 matrices after every refresh
+        self._w6_table, self._w6_key = None, None
         self.sources: Dict[int, tuple] = {}  # id(param) -> (param, data_ptr)
         self.ready = False
 
@@ -83,9 +84,12 @@ class PackCache:
         self.table.run()
         for dst, src in self.torch_refresh:
             dst.copy_(src.detach().reshape(dst.shape[1], dst.shape[0]).t())
-        for w6 in self.images:
-            if w6.used:        # images no launch has taken (layers whose launches are too small for the split) are left stale
-                hip.pack_w6_into(w6)
+        # images no launch has taken (layers whose launches are too small for the split) are left stale; the rest in one launch
+        used = [w6 for w6 in self.images if w6.used]
+        key = tuple(id(w6) for w6 in used)
+        if self._w6_table is None or self._w6_key != key:
+            self._w6_table, self._w6_key = hip.W6Table(used), key
+        self._w6_table.run()
 
 
 def _get_cache(net: nn.Module, device) -> PackCache:

@@ -101,6 +101,16 @@ enum { EGR_W_F32 = 0, EGR_W_BF16X3 = 1,
 int64_t egr_w6_elems(int32_t npad, int32_t k);
 int egr_pack_w6_f32(const float* w, int32_t npad, int32_t k, int32_t groups, void* img, void* stream);
 
+/* The same for many matrices in one launch.  jobs: DEVICE array of `count` records sorted by first_block, record i covering the
+ * workgroups [first_block_i, first_block_i + groups_i * round_up(npad_i/32, 4) * k_i/32); total_blocks = the end of the last one. */
+typedef struct {
+    const float* w;
+    void* img;
+    int32_t npad, k, groups, reserved;
+    int64_t first_block;
+} egr_w6_job;
+int egr_pack_w6_many_f32(const egr_w6_job* jobs, int32_t count, int64_t total_blocks, void* stream);
+
 int egr_conv2d_nhwc_f32(const egr_conv_desc* d, const float* x, const float* w,
                         const float* scale /* per co, NULL = 1 */, const float* shift /* per co, NULL = 0 */,
                         const float* res /* NULL unless res_mode */, const float* rowscale /* per m, NULL = 1 */,

@@ -304,3 +304,15 @@ def test_randomised_shapes_split_vs_fp32_launches():
                           f"wgrad it{it} G{G} n{n} {h}x{w} {cin}->{cout} k{k}s{s}")
     finally:
         hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = saved
+
+
+def test_pack_many_equals_single_launches():
+    from egorear_amd import hip
+    ws = [rnd(64, 9 * 32, seed=1).to(DEV), rnd(3, 160, 128, seed=2).to(DEV), rnd(32, 4096, seed=3).to(DEV), rnd(2, 96, 64, seed=4).to(DEV)]
+    single = [hip.pack_w6(w) for w in ws]
+    many = [hip.pack_w6(w) for w in ws]
+    for w6 in many:
+        w6.img.zero_()
+    hip.W6Table(many).run()
+    for a, b in zip(single, many):
+        assert torch.equal(a.img.view(torch.int16), b.img.view(torch.int16))
