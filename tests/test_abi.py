@@ -40,6 +40,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(hip.NMap) == 24
     # 14 leading int32 + 3 nmaps (8-byte aligned) + 5 int32 (+ 4 pad) + 7 int64 group strides + transposed + w_format
     assert ctypes.sizeof(hip.ConvDesc) == 56 + 3 * 24 + 24 + 56 + 8
+    assert ctypes.sizeof(hip.W6Job) == 40          # egr_w6_job: two pointers, four int32, one int64
     assert hip.version().startswith("egorear_hip")
 
 
