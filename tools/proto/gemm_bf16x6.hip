@@ -326,6 +326,124 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const float* __restrict__ A
             }
 }
 
+// ---- larger wave tile: workgroup 256 x 128, wave tile 128 x 64 (4 x 2 fragments): 18 ds_read_b128 per 48 MFMAs instead of 12 per 24.
+// In a power-limited loop fewer LDS bytes per MFMA should buy clock.  One k16 step per stage, A split on the fly (2 units per thread).
+__global__ __launch_bounds__(256) void gemm_big_kernel(const float* __restrict__ A, const uint8_t* __restrict__ Wimg, float* __restrict__ C, int M, int N, int K) {
+    constexpr int BMB = 256, FM = 4, FN = 2;
+    constexpr int A_B = 8 * 3 * UNIT, B_B = 4 * 3 * UNIT, ST = A_B + B_B;     // 36 KiB per stage
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * ST];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tilesN = N / BN;
+    const int tm = blockIdx.x / tilesN, tn = blockIdx.x % tilesN;
+    const int ktiles = K / 16;
+    const float* ap0 = A + (int64_t)(tm * BMB + (tid >> 1)) * K + (tid & 1) * 8;
+    const float* ap1 = ap0 + (int64_t)128 * K;
+    const int awo0 = (((tid >> 1) >> 5) * 3) * UNIT + (((tid >> 1) & 31) + 32 * (tid & 1)) * 16;
+    const int awo1 = awo0 + 4 * 3 * UNIT;
+    const uint8_t* wb = Wimg + (int64_t)tn * ktiles * B_B + tid * 16;
+    f32x4 x0[2][2], x1[2][2];
+    auto load_a = [&](int kt, auto set_tag) {
+        constexpr int S = decltype(set_tag)::value;
+        x0[S][0] = *reinterpret_cast<const f32x4*>(ap0 + kt * 16);
+        x0[S][1] = *reinterpret_cast<const f32x4*>(ap0 + kt * 16 + 4);
+        x1[S][0] = *reinterpret_cast<const f32x4*>(ap1 + kt * 16);
+        x1[S][1] = *reinterpret_cast<const f32x4*>(ap1 + kt * 16 + 4);
+    };
+    auto dma_b = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < B_B / 4096; ++i) glds16(wb + (int64_t)kt * B_B + i * 4096, lds + buf * ST + A_B + i * 4096 + wave * 1024);
+    };
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    auto stage = [&](auto buf_tag, auto more_tag) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        constexpr int NX = BUF ^ 1;
+        constexpr bool MORE = decltype(more_tag)::value;
+        const uint8_t* st = lds + BUF * ST;
+        uint8_t* nx = lds + NX * ST;
+        bf16x8 af[FM][3], bf[FN][3];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(st + ((wm * FM + i) * 3 + p) * UNIT + lane * 16);
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(st + A_B + ((wn * FN + j) * 3 + p) * UNIT + lane * 16);
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+        constexpr int NM = 6 * FM * FN;
+        u32x4 h0, m0, l0, h1, m1, l1;
+        int n = 0;
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j, ++n) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
+                    if constexpr (MORE) {
+                        if (n == 4) { split8(x0[NX][0], x0[NX][1], h0, m0, l0); __builtin_amdgcn_sched_barrier(0); }
+                        else if (n == 8) {
+                            *reinterpret_cast<u32x4*>(nx + awo0) = h0; *reinterpret_cast<u32x4*>(nx + awo0 + UNIT) = m0; *reinterpret_cast<u32x4*>(nx + awo0 + 2 * UNIT) = l0;
+                            __builtin_amdgcn_sched_barrier(0);
+                        } else if (n == 16) { split8(x1[NX][0], x1[NX][1], h1, m1, l1); __builtin_amdgcn_sched_barrier(0); }
+                        else if (n == 20) {
+                            *reinterpret_cast<u32x4*>(nx + awo1) = h1; *reinterpret_cast<u32x4*>(nx + awo1 + UNIT) = m1; *reinterpret_cast<u32x4*>(nx + awo1 + 2 * UNIT) = l1;
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+    };
+    load_a(0, S1{});
+    dma_b(0, 0);
+    {
+        u32x4 h, m, l;
+        split8(x0[1][0], x0[1][1], h, m, l);
+        *reinterpret_cast<u32x4*>(lds + awo0) = h; *reinterpret_cast<u32x4*>(lds + awo0 + UNIT) = m; *reinterpret_cast<u32x4*>(lds + awo0 + 2 * UNIT) = l;
+        split8(x1[1][0], x1[1][1], h, m, l);
+        *reinterpret_cast<u32x4*>(lds + awo1) = h; *reinterpret_cast<u32x4*>(lds + awo1 + UNIT) = m; *reinterpret_cast<u32x4*>(lds + awo1 + 2 * UNIT) = l;
+    }
+    if (ktiles > 1) load_a(1, S1{});
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 2 < ktiles; kt += 2) {
+        dma_b(kt + 1, 1);
+        load_a(kt + 2, S0{});
+        stage(S0{}, std::true_type{});
+        __syncthreads();
+        dma_b(kt + 2, 0);
+        if (kt + 3 < ktiles) load_a(kt + 3, S1{});
+        stage(S1{}, std::true_type{});
+        __syncthreads();
+    }
+    if (kt + 1 < ktiles) {
+        dma_b(kt + 1, 1);
+        stage(S0{}, std::true_type{});
+        __syncthreads();
+        stage(S1{}, std::false_type{});
+    } else if (kt < ktiles) {
+        stage(S0{}, std::false_type{});
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = tm * BMB + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int col = tn * BN + wn * 64 + j * 32 + (lane & 31);
+                C[(int64_t)row * N + col] = acc[i][j][r];
+            }
+}
+
 // ---- bound: BOTH operands pre-split in fragment order (as if the producer of A had written bf16 planes): LDS-DMA only, no VALU
 // in the loop.  What the on-the-fly split costs, and what a pre-splitting epilogue could gain.
 __global__ __launch_bounds__(256) void gemm_presplit_kernel(const uint8_t* __restrict__ Aimg, const uint8_t* __restrict__ Wimg, float* __restrict__ C, int M, int N, int K) {
@@ -614,10 +732,11 @@ int main(int argc, char** argv) {
     err_vs_truth(hR, me, re);
     printf("M %d N %d K %d  blocks %d\n", M, N, K, blocks);
     printf("fp32 fma chain      : max err %.3e  rms err %.3e (relative to rms of the result)\n", me, re);
-    for (int ks : {3, 9, 32, 43, 63})
+    for (int ks : {3, 32, 77})
         for (int terms : {6}) {
             auto launch = [&]() {
-                if (ks == 32) gemm_ring_kernel<3, 2><<<blocks, 256>>>(dIA, dI1, dC, M, N, K);        // label 32: ring of 3 buffers, DMA 2 stages ahead (72 KiB: 2 per CU)
+                if (ks == 77) gemm_big_kernel<<<(M / 256) * (N / BN), 256>>>(dA, dI1, dC, M, N, K);   // label 77: workgroup 256x128, wave tile 128x64
+                else if (ks == 32) gemm_ring_kernel<3, 2><<<blocks, 256>>>(dIA, dI1, dC, M, N, K);        // label 32: ring of 3 buffers, DMA 2 stages ahead (72 KiB: 2 per CU)
                 else if (ks == 43) gemm_ring_kernel<4, 3><<<blocks, 256>>>(dIA, dI1, dC, M, N, K);   // label 43: ring of 4, 3 ahead (96 KiB: 1 per CU)
                 else if (ks == 63) gemm_ring_kernel<6, 3><<<blocks, 256>>>(dIA, dI1, dC, M, N, K);   // label 63: ring of 6, 3 ahead (144 KiB: 1 per CU)
                 else if (ks == 16) gemm16_kernel<64><<<(M / BM) * (N / 64), 256>>>(dA, dJa, dC, M, N, K);          // label 16: 16x16x32, tile 128x64
