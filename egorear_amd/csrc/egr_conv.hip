@@ -77,6 +77,7 @@ struct ConvArgs {
     FastDiv dHoWo, dWo, dXin, dYin, dRin, dTilesN;  // invariant-divisor division (no integer divide in the kernel)
     int howo_shift, wo_shift;        // >= 0 when ho*wo / wo are powers of two (every layer of the path): shifts, no division
     int x_plain, y_plain, r_plain;   // image map is a plain batch (n_inner >= n): offset = n * stride_inner
+    const float* zero;        // 16 bytes of zeros in device memory (halo taps / padded rows fetch them)
     unsigned long long* dbg;  // diagnostic only: per-block phase stamps (s_memtime), NULL in normal operation
     int vec_ok;   // NHWC output / residual addresses are 16-byte aligned for every (row, channel quad)
     int cls_mode; // stride-2 data gradient split into the four output-parity classes (blockIdx.y): M, dHoWo, dWo, *_shift describe ONE class
@@ -113,6 +114,13 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
 __device__ __forceinline__ float bf16_hi_f32(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
 __device__ __forceinline__ float bf16_lo_f32(unsigned p) { return __uint_as_float(p << 16); }
 
+// a wave-uniform pointer computed with vector instructions (64-bit multiplies have no scalar form), back in scalar registers
+__device__ __forceinline__ void* uniform_ptr(const void* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (void*)(((uint64_t)hi << 32) | lo);
+}
+
 template <int BM, int BN, int WM, int WN, bool X6>
 __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     static_assert(WM * WN == 4, "four waves per workgroup");
@@ -146,7 +154,11 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     float* const yg = a.y + grp * d.gy;
     float* const wsg = a.ws ? a.ws + (int64_t)grp * d.split_k * a.M * a.Npad : nullptr;
     const int tid = threadIdx.x;
+#ifdef EGR_X_UWAVE
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#else
     const int lane = tid & 63, wave = tid >> 6;
+#endif
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, half = lane >> 5;
 
@@ -396,12 +408,193 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
             __syncthreads();
         }
     } else {
+#ifndef EGR_X6_OLD
+        // ---- split-bf16 main loop: fp32 operands as exact sums of three bf16 (hi, mid, lo); the six partial products of order
+        // <= 2 on v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  The dropped ones are ~2^-26 relative, below fp32 rounding.
+        // A stage is ONE k16 step: a chunk (tap x 32 channels) is two stages; stage s multiplies out of LDS buffer s % 2.
+        //   A: a thread owns `unit` = (tile row, 8-channel group).  Its 32 bytes arrive by two buffer loads two stages ahead (a
+        //      halo tap / padded row is an out-of-range offset: the load returns zeros and touches no memory), are split by VALU
+        //      work pinned into the gaps behind the MFMAs one stage ahead, and written in fragment order (ds_write_b128 x 3);
+        //   B: the weights were split once (egr_pack_w6_f32) into fragment order; a wave fetches its 1-KiB pieces into registers
+        //      one stage ahead and writes them to LDS at the top of the next stage.
+        // Everything in the loop is straight-line code with wave-uniform control (exact s_waitcnt vmcnt(N) from the compiler: a
+        // load is only waited for when it is consumed), the stage hand-over is `s_waitcnt lgkmcnt(0); s_barrier` - loads stay in
+        // flight across it - and the last chunk is peeled so that the accumulators never move between registers.
+        constexpr int AU = 2 * BM;                    // staging units per stage
+        constexpr int NU = (AU + NT - 1) / NT;        // per thread
+        constexpr int NFA = BM / 32, NFB = BN / 32;
+        constexpr int A_BYTES = NFA * 3 * 1024;
+        constexpr int STB = P::TILE * 4;              // bytes per stage
+        constexpr int NPB = NFB * 3;                  // weight pieces per stage
+        constexpr int NBJ = (NPB + 3) / 4;            // per wave
+        uint8_t* const lb = reinterpret_cast<uint8_t*>(lds);
+        const int uw = __builtin_amdgcn_readfirstlane(wave);
+        // buffer resources (raw, 2 GiB window): A = the activations of this group shifted back by `abias` bytes so that every
+        // row offset is non-negative; B = the weight image of this group
+        // (a data-gradient launch walks its taps backwards: `tbias` keeps the scalar tap offset non-negative as well)
+        const int abias = (d.kh * d.w + d.kw + 1) * d.ldx * 4;
+        const int tbias = d.transposed ? (((d.kh - 1) / d.stride) * d.w + (d.kw - 1) / d.stride) * d.ldx * 4 : 0;
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+            uniform_ptr(reinterpret_cast<const char*>(xg) - abias - tbias), 0, 0x80000000u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+            uniform_ptr(reinterpret_cast<const uint8_t*>(a.w) + (int64_t)grp * d.gw * 2), 0, 0x80000000u, 0x00020000);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // row table visible
+        stamp(1);  // row decode done
+        int uoff[NU], uinv[NU], uwo[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int u = tid + NT * i, r = (u >> 1) % BM, g = u & 1;
+            const bool live = u < AU;
+            uoff[i] = (live ? s_xoff[r] * 4 : 0) + g * 32 + abias;
+            uinv[i] = live ? (int)~s_mask[r] : -1;     // bit t set: tap t of this row reads zeros
+            uwo[i] = ((r >> 5) * 3) * 1024 + ((r & 31) + 32 * g) * 16;
+        }
+        int bvo[NBJ];
+#pragma unroll
+        for (int j = 0; j < NBJ; ++j) {
+            const int pc = uw + 4 * j;
+            bvo[j] = ((tn * NFB + pc / 3) * a.ktiles * 6 + pc % 3) * 1024 + lane * 16;
+        }
+        const int lds_b = A_BYTES + uw * 1024 + lane * 16;
+        u32x4 xr[2][NU][2], breg[NBJ];
+        auto load_a = [&](KPos kp, int sidx, auto set_tag) {
+            constexpr int SET = decltype(set_tag)::value;
+            const int tap = kp.kh * d.kw + kp.kw;
+            const int toff = ((d.transposed ? -((kp.kh / d.stride) * d.w + (kp.kw / d.stride)) * d.ldx + kp.cb * BK
+                                            : (kp.kh * d.w + kp.kw) * d.ldx + kp.cb * BK) + sidx * 16) * 4 + tbias;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                const int dead = __builtin_amdgcn_sbfe(uinv[i], tap, 1);               // -1 when the tap is outside the image
+                const int vo = (dead & (int)0x80000000) | uoff[i];                      // beyond the window: the load returns zeros
+                xr[SET][i][0] = __builtin_amdgcn_raw_buffer_load_b128(ra, vo, toff, 0);
+                xr[SET][i][1] = __builtin_amdgcn_raw_buffer_load_b128(ra, vo + 16, toff, 0);
+            }
+        };
+        auto load_b = [&](KPos kp, int sidx) {
+            const int soff = ((kp.cb * a.taps + kp.kh * d.kw + kp.kw) * 6 + sidx * 3) * 1024;
+#pragma unroll
+            for (int j = 0; j < NBJ; ++j)
+                if (NPB % 4 == 0 || uw + 4 * j < NPB) breg[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, bvo[j], soff, 0);
+        };
+        auto write_b = [&](auto buf_tag) {
+            constexpr int BUF = decltype(buf_tag)::value;
+#pragma unroll
+            for (int j = 0; j < NBJ; ++j)
+                if (NPB % 4 == 0 || uw + 4 * j < NPB) *reinterpret_cast<u32x4*>(lb + BUF * STB + lds_b + j * 4096) = breg[j];
+        };
+        // one slice of the split of a unit: 0-3 hi halves + first residuals of pair k, 4-7 mid / lo halves, 8 the three writes
+        u32x4 sh_[NU], sm_[NU], sl_[NU];
+        float ra_[NU][4], rb_[NU][4];
+        auto slice = [&](auto set_tag, auto buf_tag, int k) {
+            constexpr int SET = decltype(set_tag)::value;
+            constexpr int BUF = decltype(buf_tag)::value;
+            const int i = k / 9, q = k % 9;
+            if (q < 4) {
+                const float v0 = __uint_as_float(xr[SET][i][q >> 1][(q & 1) * 2]), v1 = __uint_as_float(xr[SET][i][q >> 1][(q & 1) * 2 + 1]);
+                sh_[i][q] = cvt_pk_bf16(v0, v1);
+                ra_[i][q] = v0 - bf16_lo_f32(sh_[i][q]);
+                rb_[i][q] = v1 - bf16_hi_f32(sh_[i][q]);
+            } else if (q < 8) {
+                const int t = q - 4;
+                sm_[i][t] = cvt_pk_bf16(ra_[i][t], rb_[i][t]);
+                sl_[i][t] = cvt_pk_bf16(ra_[i][t] - bf16_lo_f32(sm_[i][t]), rb_[i][t] - bf16_hi_f32(sm_[i][t]));
+            } else if (AU >= NT * (i + 1) || tid + NT * i < AU) {
+                uint8_t* dst = lb + BUF * STB + uwo[i];
+                *reinterpret_cast<u32x4*>(dst) = sh_[i];
+                *reinterpret_cast<u32x4*>(dst + 1024) = sm_[i];
+                *reinterpret_cast<u32x4*>(dst + 2048) = sl_[i];
+            }
+        };
+        constexpr int NS = 9 * NU;          // slices per stage
+        constexpr int NM = 6 * FM * FN;     // MFMAs per stage
+        constexpr int S0 = (NM >= 12) ? NM / 6 : 0;   // MFMAs in front of the first slice (its operands are the youngest loads but two)
+        // One stage.  BUF: the LDS buffer multiplied.  CONV: the registers of set BUF^1 / breg hold the next stage's operands and
+        // go to buffer BUF^1.  LOADS: the operands of the stage after next are requested (A into set BUF, B into breg).
+        auto stage = [&](auto buf_tag, auto conv_tag, auto loads_tag, KPos kl, int sl) {
+            constexpr int BUF = decltype(buf_tag)::value;
+            constexpr bool conv = decltype(conv_tag)::value;
+            constexpr bool loads = decltype(loads_tag)::value;
+            using NB = std::integral_constant<int, BUF ^ 1>;
+            using CB = std::integral_constant<int, BUF>;
+            const uint8_t* st = lb + BUF * STB;
+            bf16x8 af[FM][3], bf[FN][3];
+            // fragments in the order of their first use: (lo, hi) (hi, lo) (mid, mid)
+            constexpr int RA[3] = {2, 0, 1}, RB[3] = {0, 2, 1};
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i) af[i][RA[q]] = *reinterpret_cast<const bf16x8*>(st + ((wm * FM + i) * 3 + RA[q]) * 1024 + lane * 16);
+#pragma unroll
+                for (int j = 0; j < FN; ++j) bf[j][RB[q]] = *reinterpret_cast<const bf16x8*>(st + A_BYTES + ((wn * FN + j) * 3 + RB[q]) * 1024 + lane * 16);
+            }
+            if constexpr (conv) write_b(NB{});
+            if constexpr (loads) {
+                load_b(kl, sl);
+                load_a(kl, sl, CB{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // smallest terms first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+            int n = 0, done = 0;
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j, ++n) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
+                        if constexpr (conv) {
+                            // spread the slices evenly behind the matrix instructions S0 .. NM-1
+                            const int upto = (n + 1 <= S0) ? 0 : ((n + 1 - S0) * NS + (NM - S0) - 1) / (NM - S0);
+#pragma unroll
+                            for (int k = 0; k < NS; ++k)
+                                if (k >= done && k < upto) slice(NB{}, NB{}, k);
+                            done = upto > done ? upto : done;
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        };
+        using B0 = std::integral_constant<int, 0>;
+        using B1 = std::integral_constant<int, 1>;
+        using TT = std::true_type;
+        using FF = std::false_type;
+        if (kt0 < kt1) {
+            KPos kp = kpos_of(kt0);
+            load_b(kp, 0);
+            load_a(kp, 0, B0{});
+            write_b(B0{});
+#pragma unroll
+            for (int k = 0; k < NS; ++k) slice(B0{}, B0{}, k);
+            load_b(kp, 1);
+            load_a(kp, 1, B1{});
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            stamp(2);  // first stage staged
+            for (int kt = kt0; kt + 1 < kt1; ++kt) {
+                const KPos kn = kpos_next(kp);
+                stage(B0{}, TT{}, TT{}, kn, 0);
+                stage(B1{}, TT{}, TT{}, kn, 1);
+                kp = kn;
+            }
+            stage(B0{}, TT{}, FF{}, kp, 0);
+            stage(B1{}, FF{}, FF{}, kp, 0);
+        }
+#else
         // ---- split-bf16 main loop: fp32 operands as exact sums of three bf16 (hi, mid, lo); the six partial products of order
         // <= 2 on v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  The dropped ones are ~2^-26 relative, below fp32 rounding.
         // A stage is ONE k16 step: a chunk (tap x 32 channels) is two stages, stage s of a chunk lives in LDS buffer s.
         //   A: a thread owns `unit` = (tile row, 8-channel group); its 32 bytes are loaded into registers one stage ahead,
         //      split by VALU work pinned into the gaps behind the MFMAs, and written in fragment order (ds_write_b128 x 3);
         //   B: the weights were split once (egr_pack_w6_f32) into the same fragment order: LDS-DMA, 1 KiB per wave-instruction.
+#ifdef EGR_X_PRIO
+        // the two waves that share a SIMD (one per resident workgroup) run the same program: give one of them the matrix pipe
+        if (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 1u) __builtin_amdgcn_s_setprio(EGR_X_PRIO);
+#endif
+#ifdef EGR_X_ZARG
+        const float* const zbuf = a.zero;
+#else
+        const float* const zbuf = egr_zero16;
+#endif
         constexpr int AU = 2 * BM;                    // staging units per stage
         constexpr int NU = (AU + NT - 1) / NT;        // per thread
         constexpr int NFA = BM / 32, NFB = BN / 32;
@@ -432,8 +625,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
                 const bool ok = (umask[i] >> tap) & 1u;
-                const float* p0 = ok ? ubase[i] + toff : egr_zero16;
-                const float* p1 = ok ? ubase[i] + toff + 4 : egr_zero16;
+                const float* p0 = ok ? ubase[i] + toff : zbuf;
+                const float* p1 = ok ? ubase[i] + toff + 4 : zbuf;
                 xr[SET][i][0] = *reinterpret_cast<const f32x4*>(p0);
                 xr[SET][i][1] = *reinterpret_cast<const f32x4*>(p1);
             }
@@ -542,6 +735,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
                 kp = kn;
             }
         }
+#endif
     }
 
     stamp(3);  // k loop done
@@ -924,10 +1118,19 @@ static int conv_run(const egr_conv_desc* dd, const float* x, const float* w, con
     int64_t ypix = d.out_nchw ? (int64_t)d.cout * d.ho * d.wo : (int64_t)d.ho * d.wo * d.ldy;
     if (span(d.ymap, d.n) + ypix >= (1LL << 31)) return EGR_EINVAL;
     if (d.res_mode && span(d.rmap, d.n) + (int64_t)d.ho * d.wo * d.ldr >= (1LL << 31)) return EGR_EINVAL;   // (upper bound for the half-size mode too)
+    // split-bf16 launches address the activations through a 2-GiB buffer window (byte offsets, shifted by the halo bias)
+    if (d.w_format == EGR_W_BF16X3 &&
+        (span(d.xmap, d.n) + (int64_t)d.h * d.w * d.ldx + 2 * (int64_t)(d.kh * d.w + d.kw + 1) * d.ldx) * 4 + 64 >= (1LL << 31))
+        return EGR_EINVAL;
 
     a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.res = res; a.rowscale = rowscale; a.rowmask = rowmask;
     a.y = y; a.ws = workspace;
     a.mask = mask;
+    {
+        static float* zp = nullptr;
+        if (!zp && hipGetSymbolAddress((void**)&zp, HIP_SYMBOL(egr_zero16)) != hipSuccess) return EGR_EINVAL;
+        a.zero = zp;
+    }
     a.dbg = g_dbg;
     a.M = (int)M64;
     a.Npad = (d.cout + 31) / 32 * 32;

@@ -14,7 +14,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libegorear_hip.so")
+LIB_PATH = os.environ.get("EGR_LIB") or os.path.join(_HERE, "csrc", "libegorear_hip.so")   # EGR_LIB: experiment builds (tools/build_variant.py)
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 RES_NONE, RES_BEFORE_ACT, RES_AFTER_ACT, RES_UP2_BEFORE_ACT = 0, 1, 2, 3
@@ -271,7 +271,9 @@ def conv2d(x: Img, w, cout: int, kh: int, kw: int, stride: int, pad: int, *, sca
         raise RuntimeError(f"egorear_amd.conv2d: packed weight shape {tuple(w.shape)} != {wshape}")
     if isinstance(w, W6) and w.f32 is not None:
         rows_all = x.n * groups * ho * wo
-        if rows_all < X6_MIN_ROWS or 2.0 * rows_all * cout * K < X6_MIN_FLOPS:
+        # (the split kernel addresses one group's activations through a 2-GiB buffer window)
+        x_bytes = 4 * ((x.n - 1) * x.nstride + (x.h * x.w + 2 * (kh * x.w + kw + 1)) * x.ld) + 64
+        if rows_all < X6_MIN_ROWS or 2.0 * rows_all * cout * K < X6_MIN_FLOPS or x_bytes >= (1 << 31):
             w = w.f32
     x6 = isinstance(w, W6)
     if x6 and not w.used:
