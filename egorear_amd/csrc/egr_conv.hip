@@ -72,18 +72,28 @@ struct ConvArgs {
     int M, Npad, K;
     int ktiles, ktiles_per_split;
     int tilesM, tilesN;
+    int ntiles;   // tilesM * tilesN: tiles of one group (gridDim.x of a non-persistent launch)
     int cblocks;  // cin / 32
     int taps;     // kh * kw
     FastDiv dHoWo, dWo, dXin, dYin, dRin, dTilesN;  // invariant-divisor division (no integer divide in the kernel)
     int howo_shift, wo_shift;        // >= 0 when ho*wo / wo are powers of two (every layer of the path): shifts, no division
     int x_plain, y_plain, r_plain;   // image map is a plain batch (n_inner >= n): offset = n * stride_inner
-    const float* zero;        // 16 bytes of zeros in device memory (halo taps / padded rows fetch them)
     unsigned long long* dbg;  // diagnostic only: per-block phase stamps (s_memtime), NULL in normal operation
     int vec_ok;   // NHWC output / residual addresses are 16-byte aligned for every (row, channel quad)
     int cls_mode; // stride-2 data gradient split into the four output-parity classes (blockIdx.y): M, dHoWo, dWo, *_shift describe ONE class
 };
 
 constexpr int BK = 32;
+#ifndef X6_OCC_SMALL
+#define X6_OCC_SMALL 4
+#endif
+#ifndef X6_OCC_BIG
+#define X6_OCC_BIG 2
+#endif
+
+// resident workgroup slots a persistent split-bf16 launch is sized for (2 per CU x 256 CUs); 0 = one workgroup per tile
+int g_persist = getenv("EGR_CONV_PERSIST") ? atoi(getenv("EGR_CONV_PERSIST")) : 512;
+int g_persist_ktiles = getenv("EGR_CONV_PERSIST_KTILES") ? atoi(getenv("EGR_CONV_PERSIST_KTILES")) : 4;   // K <= 128: persistent
 
 __device__ __attribute__((aligned(16))) float egr_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -92,14 +102,16 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <int BM, int BN, bool X6 = false>
+template <int BM, int BN, bool X6 = false, bool PERSIST_ = false>
 struct LdsPlan {
     // floats per stage.  fp32 path: BK = 32 deep rows of both operands.  Split-bf16 path: one k16 step of (hi, mid, lo) bf16
     // planes in fragment order, 1 KiB per (32-row fragment, plane)
     static constexpr int TILE = X6 ? (BM / 32 + BN / 32) * 3 * 256 : (BM + BN) * BK;
     static constexpr int CS = BN + 4;                       // epilogue staging row stride
     static constexpr int ROWOFF = (2 * TILE > BM * CS) ? 2 * TILE : BM * CS;  // row offsets (y, res) live past both
-    static constexpr int FLOATS = ROWOFF + 4 * BM;                            // + per-row input offset and tap mask
+    static constexpr bool PERSIST = X6 && PERSIST_;                           // persistent workgroups, see the tile loop of the split kernel
+    static constexpr int TABLES = PERSIST ? 2 : 1;                            // the next tile's table is decoded under the epilogue
+    static constexpr int FLOATS = ROWOFF + 4 * BM * TABLES;                   // + per-row input offset and tap mask
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -121,14 +133,14 @@ __device__ __forceinline__ void* uniform_ptr(const void* p) {
     return (void*)(((uint64_t)hi << 32) | lo);
 }
 
-template <int BM, int BN, int WM, int WN, bool X6>
+template <int BM, int BN, int WM, int WN, bool X6, bool PERSIST = false>
 __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     static_assert(WM * WN == 4, "four waves per workgroup");
     constexpr int NT = 256;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 32, FN = TN / 32;
     constexpr int IA = BM / 32, IB = BN / 32;  // 32 rows per load pass (8 rows per wave-instruction)
-    using P = LdsPlan<BM, BN, X6>;
+    using P = LdsPlan<BM, BN, X6, PERSIST>;
     static_assert(FM >= 1 && FN >= 1, "wave tile must be >= 32x32");
 
     __shared__ __attribute__((aligned(16))) float lds[P::FLOATS];
@@ -154,21 +166,22 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     float* const yg = a.y + grp * d.gy;
     float* const wsg = a.ws ? a.ws + (int64_t)grp * d.split_k * a.M * a.Npad : nullptr;
     const int tid = threadIdx.x;
-#ifdef EGR_X_UWAVE
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#else
     const int lane = tid & 63, wave = tid >> 6;
-#endif
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, half = lane >> 5;
 
     // XCD-aware tile order: blocks b and b+8 share an L2; hand each XCD a contiguous run of tiles,
     // with the N tiles of one M tile adjacent so the activation tile is fetched into one L2 only.
-    int bid = blockIdx.x;
-    const int nb = gridDim.x;
-    if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
-    const int tm = (a.tilesN == 1) ? bid : fdiv(bid, a.dTilesN);
-    const int tn = bid - tm * a.tilesN;
+    // A persistent launch (a.ntiles > gridDim.x, split kernel only) walks tiles blockIdx.x, + gridDim.x, ...: gridDim.x is a
+    // multiple of 8 then, so a workgroup's tiles stay on its XCD's run.
+    const int nb = a.ntiles;
+    auto tile_of = [&](int bid, int& tm_, int& tn_) {
+        if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
+        tm_ = (a.tilesN == 1) ? bid : fdiv(bid, a.dTilesN);
+        tn_ = bid - tm_ * a.tilesN;
+    };
+    int tm, tn;
+    tile_of((int)blockIdx.x, tm, tn);
     // Stride-2 data gradient: output pixel (ho, wo) only sees the taps with kh = (ho+pad) mod 2, kw = (wo+pad) mod 2, so the
     // launch is split into the four output-parity classes (blockIdx.y).  A class enumerates its (ho/2, wo/2) sub-grid
     // and walks only its own taps: no structurally-zero MFMA work (1 + 2 + 2 + 4 of the 9 taps of a 3x3 kernel).
@@ -190,13 +203,15 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     // offsets.  Per chunk a lane then adds the wave-uniform tap offset and tests one mask bit.
     const int rsub = wave * 8 + (lane >> 3);
     const int pseg = lane & 7;
-    int* s_yoff = reinterpret_cast<int*>(lds + P::ROWOFF);
-    int* s_roff = s_yoff + BM;
-    int* s_xoff = s_roff + BM;
-    unsigned* s_mask = reinterpret_cast<unsigned*>(s_xoff + BM);
+    int* const tab0 = reinterpret_cast<int*>(lds + P::ROWOFF);   // table `slot`: [yoff | roff | xoff | mask] x BM
     const unsigned fullmask = (d.kh * d.kw >= 32) ? 0xffffffffu : ((1u << (d.kh * d.kw)) - 1u);
+    auto decode = [&](int tm_, int slot) {
+    int* const s_yoff = tab0 + slot * 4 * BM;
+    int* const s_roff = s_yoff + BM;
+    int* const s_xoff = s_roff + BM;
+    unsigned* const s_mask = reinterpret_cast<unsigned*>(s_xoff + BM);
     for (int r = tid; r < BM; r += NT) {
-        const int m = tm * BM + r;
+        const int m = tm_ * BM + r;
         int xo = 0, yo = -1, ro = 0;
         unsigned mk = 0u;
         if (m < a.M) {
@@ -248,6 +263,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
         s_yoff[r] = yo;
         s_roff[r] = ro;
     }
+    };
+    decode(tm, 0);
+    int* s_yoff = tab0;
+    int* s_roff = s_yoff + BM;
+    int* s_xoff = s_roff + BM;
+    unsigned* s_mask = reinterpret_cast<unsigned*>(s_xoff + BM);
     // wave-uniform position of a chunk in K: (channel chunk cb, tap (kh, kw)); advanced incrementally
     struct KPos { int cb, kh, kw; };
     auto kpos_of = [&](int kt) {
@@ -273,471 +294,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if constexpr (!X6) {
-        const float* wrow[IB];
-#pragma unroll
-        for (int i = 0; i < IB; ++i) {
-            int r = i * 32 + rsub;
-            int co = tn * BN + r;
-            wrow[i] = (co < a.Npad) ? wg + (int64_t)co * a.K + (pseg ^ ((r >> 1) & 7)) * 4 : nullptr;
-        }
-        const float* arow[IA];
-        unsigned amask[IA];
-
-        // one 1-KiB DMA piece (8 rows x 128 B) of a stage: pieces [0, IA) are A rows, [IA, IA+IB) weight rows.
-        // The stage buffer is a compile-time constant so LDS addresses fold into instruction immediates.
-        const uint32_t zlo = (uint32_t)(uint64_t)egr_zero16, zhi = (uint32_t)((uint64_t)egr_zero16 >> 32);
-        auto issue_piece = [&](int kt, KPos kp, auto buf_tag, int piece) {
-            constexpr int BUF = decltype(buf_tag)::value;
-            float* sA = lds + BUF * P::TILE;
-            if (piece < IA) {
-                const int tap = kp.kh * d.kw + kp.kw;
-                // wave-uniform, 32-bit.  Transposed mode: th - kh = stride*(bh - kh/stride) + (th%stride - kh%stride), and the mask
-                // bit is set only where the remainders agree, so the source pixel is (bh - kh/stride, bw - kw/stride).
-                const int toff = d.transposed ? -((kp.kh / d.stride) * d.w + (kp.kw / d.stride)) * d.ldx + kp.cb * BK
-                                              : (kp.kh * d.w + kp.kw) * d.ldx + kp.cb * BK;
-                const uint64_t pa = (uint64_t)(arow[piece] + toff);
-                const bool ok = (amask[piece] >> tap) & 1u;
-                // select between the pixel row and the zero buffer with two 32-bit v_cndmask (no branch, no 64-bit logic)
-                const uint32_t lo = ok ? (uint32_t)pa : zlo, hi = ok ? (uint32_t)(pa >> 32) : zhi;
-                glds16(reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo), sA + (piece * 32 + wave * 8) * BK);
-            } else {
-                const int i = piece - IA;
-                const float* p = wrow[i] ? wrow[i] + (kp.cb * a.taps + kp.kh * d.kw + kp.kw) * BK : egr_zero16;   // chunk index in K
-                glds16(p, sA + BM * BK + (i * 32 + wave * 8) * BK);
-            }
-        };
-
-        // fragment read offsets (floats) inside a stage for the four k-groups of a chunk, computed once:
-        // row * 32 + ((q ^ swz(row)) * 4) with q = 2*g + half
-        int afo[FM][4], bfo[FN][4];
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            const int r = wm * TM + i * 32 + l31;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) afo[i][g] = r * BK + (((2 * g + half) ^ ((r >> 1) & 7)) << 2);
-        }
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int r = wn * TN + j * 32 + l31;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) bfo[j][g] = BM * BK + r * BK + (((2 * g + half) ^ ((r >> 1) & 7)) << 2);
-        }
-
-        constexpr int NPIECE = IA + IB;
-        constexpr int DMA_EVERY = (FM * FN >= 4) ? 2 : 1;  // big tiles: one DMA piece behind every 2nd MFMA (measured +2.5 %)
-        using B0 = std::integral_constant<int, 0>;
-        using B1 = std::integral_constant<int, 1>;
-
-        // multiply one staged chunk; when ISSUE, the next chunk's DMA pieces go out one per MFMA behind the first
-        // matrix instructions (pinned with sched_barrier), so their issue slots hide under the 64-cycle MFMAs
-        auto chunk = [&](int kt, auto buf_tag, KPos kp_next, auto issue_tag) {
-            constexpr int BUF = decltype(buf_tag)::value;
-            constexpr bool ISSUE = decltype(issue_tag)::value;
-            using NB = std::integral_constant<int, BUF ^ 1>;
-            const float* st = lds + BUF * P::TILE;
-            f32x4 av[2][FM], bv[2][FN];
-#pragma unroll
-            for (int i = 0; i < FM; ++i) av[0][i] = *reinterpret_cast<const f32x4*>(&st[afo[i][0]]);
-#pragma unroll
-            for (int j = 0; j < FN; ++j) bv[0][j] = *reinterpret_cast<const f32x4*>(&st[bfo[j][0]]);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int cur = g & 1, nxt = cur ^ 1;
-                if (g < 3) {  // fragments of the next k-group are fetched under this group's MFMAs
-#pragma unroll
-                    for (int i = 0; i < FM; ++i) av[nxt][i] = *reinterpret_cast<const f32x4*>(&st[afo[i][g + 1]]);
-#pragma unroll
-                    for (int j = 0; j < FN; ++j) bv[nxt][j] = *reinterpret_cast<const f32x4*>(&st[bfo[j][g + 1]]);
-                }
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int i = 0; i < FM; ++i)
-#pragma unroll
-                        for (int j = 0; j < FN; ++j) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i][t], bv[cur][j][t], acc[i][j], 0, 0, 0);
-                            if constexpr (ISSUE) {
-                                const int n = ((g * 4 + t) * FM + i) * FN + j;
-                                if ((n % DMA_EVERY) == 0 && (n / DMA_EVERY) < NPIECE) {
-                                    issue_piece(kt + 1, kp_next, NB{}, n / DMA_EVERY);
-                                    __builtin_amdgcn_sched_barrier(0);
-                                }
-                            }
-                        }
-            }
-        };
-
-        KPos kp = kpos_of(kt0);
-        if (kt0 < kt1) {  // weight pieces of the first chunk need no row geometry: their latency overlaps the decode
-#pragma unroll
-            for (int pc = IA; pc < NPIECE; ++pc) issue_piece(kt0, kp, B0{}, pc);
-        }
-        __syncthreads();  // row table visible (also drains the weight DMA; it had the whole decode to land)
-#pragma unroll
-        for (int i = 0; i < IA; ++i) {
-            const int r = i * 32 + rsub;
-            arow[i] = xg + (s_xoff[r] + (pseg ^ ((r >> 1) & 7)) * 4);
-            amask[i] = s_mask[r];
-        }
-        stamp(1);  // row decode done
-        if (kt0 < kt1) {
-#pragma unroll
-            for (int pc = 0; pc < IA; ++pc) issue_piece(kt0, kp, B0{}, pc);
-        }
-        __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes stage 0
-        stamp(2);  // first chunk landed
-        int kt = kt0;
-        for (; kt + 2 < kt1; kt += 2) {  // two chunks per trip: stage indices are compile-time constants
-            KPos k1 = kpos_next(kp);
-            chunk(kt, B0{}, k1, std::true_type{});
-            __syncthreads();
-            KPos k2 = kpos_next(k1);
-            chunk(kt + 1, B1{}, k2, std::true_type{});
-            __syncthreads();
-            kp = k2;
-        }
-        if (kt + 1 < kt1) {  // two chunks left
-            KPos k1 = kpos_next(kp);
-            chunk(kt, B0{}, k1, std::true_type{});
-            __syncthreads();
-            chunk(kt + 1, B1{}, k1, std::false_type{});
-            __syncthreads();
-        } else if (kt < kt1) {  // one chunk left
-            chunk(kt, B0{}, kp, std::false_type{});
-            __syncthreads();
-        }
-    } else {
-#ifndef EGR_X6_OLD
-        // ---- split-bf16 main loop: fp32 operands as exact sums of three bf16 (hi, mid, lo); the six partial products of order
-        // <= 2 on v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  The dropped ones are ~2^-26 relative, below fp32 rounding.
-        // A stage is ONE k16 step: a chunk (tap x 32 channels) is two stages; stage s multiplies out of LDS buffer s % 2.
-        //   A: a thread owns `unit` = (tile row, 8-channel group).  Its 32 bytes arrive by two buffer loads two stages ahead (a
-        //      halo tap / padded row is an out-of-range offset: the load returns zeros and touches no memory), are split by VALU
-        //      work pinned into the gaps behind the MFMAs one stage ahead, and written in fragment order (ds_write_b128 x 3);
-        //   B: the weights were split once (egr_pack_w6_f32) into fragment order; a wave fetches its 1-KiB pieces into registers
-        //      one stage ahead and writes them to LDS at the top of the next stage.
-        // Everything in the loop is straight-line code with wave-uniform control (exact s_waitcnt vmcnt(N) from the compiler: a
-        // load is only waited for when it is consumed), the stage hand-over is `s_waitcnt lgkmcnt(0); s_barrier` - loads stay in
-        // flight across it - and the last chunk is peeled so that the accumulators never move between registers.
-        constexpr int AU = 2 * BM;                    // staging units per stage
-        constexpr int NU = (AU + NT - 1) / NT;        // per thread
-        constexpr int NFA = BM / 32, NFB = BN / 32;
-        constexpr int A_BYTES = NFA * 3 * 1024;
-        constexpr int STB = P::TILE * 4;              // bytes per stage
-        constexpr int NPB = NFB * 3;                  // weight pieces per stage
-        constexpr int NBJ = (NPB + 3) / 4;            // per wave
-        uint8_t* const lb = reinterpret_cast<uint8_t*>(lds);
-        const int uw = __builtin_amdgcn_readfirstlane(wave);
-        // buffer resources (raw, 2 GiB window): A = the activations of this group shifted back by `abias` bytes so that every
-        // row offset is non-negative; B = the weight image of this group
-        // (a data-gradient launch walks its taps backwards: `tbias` keeps the scalar tap offset non-negative as well)
-        const int abias = (d.kh * d.w + d.kw + 1) * d.ldx * 4;
-        const int tbias = d.transposed ? (((d.kh - 1) / d.stride) * d.w + (d.kw - 1) / d.stride) * d.ldx * 4 : 0;
-        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-            uniform_ptr(reinterpret_cast<const char*>(xg) - abias - tbias), 0, 0x80000000u, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-            uniform_ptr(reinterpret_cast<const uint8_t*>(a.w) + (int64_t)grp * d.gw * 2), 0, 0x80000000u, 0x00020000);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // row table visible
-        stamp(1);  // row decode done
-        int uoff[NU], uinv[NU], uwo[NU];
-#pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            const int u = tid + NT * i, r = (u >> 1) % BM, g = u & 1;
-            const bool live = u < AU;
-            uoff[i] = (live ? s_xoff[r] * 4 : 0) + g * 32 + abias;
-            uinv[i] = live ? (int)~s_mask[r] : -1;     // bit t set: tap t of this row reads zeros
-            uwo[i] = ((r >> 5) * 3) * 1024 + ((r & 31) + 32 * g) * 16;
-        }
-        int bvo[NBJ];
-#pragma unroll
-        for (int j = 0; j < NBJ; ++j) {
-            const int pc = uw + 4 * j;
-            bvo[j] = ((tn * NFB + pc / 3) * a.ktiles * 6 + pc % 3) * 1024 + lane * 16;
-        }
-        const int lds_b = A_BYTES + uw * 1024 + lane * 16;
-        u32x4 xr[2][NU][2], breg[NBJ];
-        auto load_a = [&](KPos kp, int sidx, auto set_tag) {
-            constexpr int SET = decltype(set_tag)::value;
-            const int tap = kp.kh * d.kw + kp.kw;
-            const int toff = ((d.transposed ? -((kp.kh / d.stride) * d.w + (kp.kw / d.stride)) * d.ldx + kp.cb * BK
-                                            : (kp.kh * d.w + kp.kw) * d.ldx + kp.cb * BK) + sidx * 16) * 4 + tbias;
-#pragma unroll
-            for (int i = 0; i < NU; ++i) {
-                const int dead = __builtin_amdgcn_sbfe(uinv[i], tap, 1);               // -1 when the tap is outside the image
-                const int vo = (dead & (int)0x80000000) | uoff[i];                      // beyond the window: the load returns zeros
-                xr[SET][i][0] = __builtin_amdgcn_raw_buffer_load_b128(ra, vo, toff, 0);
-                xr[SET][i][1] = __builtin_amdgcn_raw_buffer_load_b128(ra, vo + 16, toff, 0);
-            }
-        };
-        auto load_b = [&](KPos kp, int sidx) {
-            const int soff = ((kp.cb * a.taps + kp.kh * d.kw + kp.kw) * 6 + sidx * 3) * 1024;
-#pragma unroll
-            for (int j = 0; j < NBJ; ++j)
-                if (NPB % 4 == 0 || uw + 4 * j < NPB) breg[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, bvo[j], soff, 0);
-        };
-        auto write_b = [&](auto buf_tag) {
-            constexpr int BUF = decltype(buf_tag)::value;
-#pragma unroll
-            for (int j = 0; j < NBJ; ++j)
-                if (NPB % 4 == 0 || uw + 4 * j < NPB) *reinterpret_cast<u32x4*>(lb + BUF * STB + lds_b + j * 4096) = breg[j];
-        };
-        // one slice of the split of a unit: 0-3 hi halves + first residuals of pair k, 4-7 mid / lo halves, 8 the three writes
-        u32x4 sh_[NU], sm_[NU], sl_[NU];
-        float ra_[NU][4], rb_[NU][4];
-        auto slice = [&](auto set_tag, auto buf_tag, int k) {
-            constexpr int SET = decltype(set_tag)::value;
-            constexpr int BUF = decltype(buf_tag)::value;
-            const int i = k / 9, q = k % 9;
-            if (q < 4) {
-                const float v0 = __uint_as_float(xr[SET][i][q >> 1][(q & 1) * 2]), v1 = __uint_as_float(xr[SET][i][q >> 1][(q & 1) * 2 + 1]);
-                sh_[i][q] = cvt_pk_bf16(v0, v1);
-                ra_[i][q] = v0 - bf16_lo_f32(sh_[i][q]);
-                rb_[i][q] = v1 - bf16_hi_f32(sh_[i][q]);
-            } else if (q < 8) {
-                const int t = q - 4;
-                sm_[i][t] = cvt_pk_bf16(ra_[i][t], rb_[i][t]);
-                sl_[i][t] = cvt_pk_bf16(ra_[i][t] - bf16_lo_f32(sm_[i][t]), rb_[i][t] - bf16_hi_f32(sm_[i][t]));
-            } else if (AU >= NT * (i + 1) || tid + NT * i < AU) {
-                uint8_t* dst = lb + BUF * STB + uwo[i];
-                *reinterpret_cast<u32x4*>(dst) = sh_[i];
-                *reinterpret_cast<u32x4*>(dst + 1024) = sm_[i];
-                *reinterpret_cast<u32x4*>(dst + 2048) = sl_[i];
-            }
-        };
-        constexpr int NS = 9 * NU;          // slices per stage
-        constexpr int NM = 6 * FM * FN;     // MFMAs per stage
-        constexpr int S0 = (NM >= 12) ? NM / 6 : 0;   // MFMAs in front of the first slice (its operands are the youngest loads but two)
-        // One stage.  BUF: the LDS buffer multiplied.  CONV: the registers of set BUF^1 / breg hold the next stage's operands and
-        // go to buffer BUF^1.  LOADS: the operands of the stage after next are requested (A into set BUF, B into breg).
-        auto stage = [&](auto buf_tag, auto conv_tag, auto loads_tag, KPos kl, int sl) {
-            constexpr int BUF = decltype(buf_tag)::value;
-            constexpr bool conv = decltype(conv_tag)::value;
-            constexpr bool loads = decltype(loads_tag)::value;
-            using NB = std::integral_constant<int, BUF ^ 1>;
-            using CB = std::integral_constant<int, BUF>;
-            const uint8_t* st = lb + BUF * STB;
-            bf16x8 af[FM][3], bf[FN][3];
-            // fragments in the order of their first use: (lo, hi) (hi, lo) (mid, mid)
-            constexpr int RA[3] = {2, 0, 1}, RB[3] = {0, 2, 1};
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-#pragma unroll
-                for (int i = 0; i < FM; ++i) af[i][RA[q]] = *reinterpret_cast<const bf16x8*>(st + ((wm * FM + i) * 3 + RA[q]) * 1024 + lane * 16);
-#pragma unroll
-                for (int j = 0; j < FN; ++j) bf[j][RB[q]] = *reinterpret_cast<const bf16x8*>(st + A_BYTES + ((wn * FN + j) * 3 + RB[q]) * 1024 + lane * 16);
-            }
-            if constexpr (conv) write_b(NB{});
-            if constexpr (loads) {
-                load_b(kl, sl);
-                load_a(kl, sl, CB{});
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // smallest terms first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
-            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-            int n = 0, done = 0;
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-#pragma unroll
-                    for (int j = 0; j < FN; ++j, ++n) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
-                        if constexpr (conv) {
-                            // spread the slices evenly behind the matrix instructions S0 .. NM-1
-                            const int upto = (n + 1 <= S0) ? 0 : ((n + 1 - S0) * NS + (NM - S0) - 1) / (NM - S0);
-#pragma unroll
-                            for (int k = 0; k < NS; ++k)
-                                if (k >= done && k < upto) slice(NB{}, NB{}, k);
-                            done = upto > done ? upto : done;
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        };
-        using B0 = std::integral_constant<int, 0>;
-        using B1 = std::integral_constant<int, 1>;
-        using TT = std::true_type;
-        using FF = std::false_type;
-        if (kt0 < kt1) {
-            KPos kp = kpos_of(kt0);
-            load_b(kp, 0);
-            load_a(kp, 0, B0{});
-            write_b(B0{});
-#pragma unroll
-            for (int k = 0; k < NS; ++k) slice(B0{}, B0{}, k);
-            load_b(kp, 1);
-            load_a(kp, 1, B1{});
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            stamp(2);  // first stage staged
-            for (int kt = kt0; kt + 1 < kt1; ++kt) {
-                const KPos kn = kpos_next(kp);
-                stage(B0{}, TT{}, TT{}, kn, 0);
-                stage(B1{}, TT{}, TT{}, kn, 1);
-                kp = kn;
-            }
-            stage(B0{}, TT{}, FF{}, kp, 0);
-            stage(B1{}, FF{}, FF{}, kp, 0);
-        }
-#else
-        // ---- split-bf16 main loop: fp32 operands as exact sums of three bf16 (hi, mid, lo); the six partial products of order
-        // <= 2 on v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  The dropped ones are ~2^-26 relative, below fp32 rounding.
-        // A stage is ONE k16 step: a chunk (tap x 32 channels) is two stages, stage s of a chunk lives in LDS buffer s.
-        //   A: a thread owns `unit` = (tile row, 8-channel group); its 32 bytes are loaded into registers one stage ahead,
-        //      split by VALU work pinned into the gaps behind the MFMAs, and written in fragment order (ds_write_b128 x 3);
-        //   B: the weights were split once (egr_pack_w6_f32) into the same fragment order: LDS-DMA, 1 KiB per wave-instruction.
-#ifdef EGR_X_PRIO
-        // the two waves that share a SIMD (one per resident workgroup) run the same program: give one of them the matrix pipe
-        if (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 1u) __builtin_amdgcn_s_setprio(EGR_X_PRIO);
-#endif
-#ifdef EGR_X_ZARG
-        const float* const zbuf = a.zero;
-#else
-        const float* const zbuf = egr_zero16;
-#endif
-        constexpr int AU = 2 * BM;                    // staging units per stage
-        constexpr int NU = (AU + NT - 1) / NT;        // per thread
-        constexpr int NFA = BM / 32, NFB = BN / 32;
-        constexpr int A_BYTES = NFA * 3 * 1024;
-        constexpr int STB = P::TILE * 4;              // bytes per stage
-        constexpr int NPB = NFB * 3;                  // weight pieces per stage
-        uint8_t* const lb = reinterpret_cast<uint8_t*>(lds);
-        const uint8_t* const wimg = reinterpret_cast<const uint8_t*>(a.w) + (int64_t)grp * d.gw * 2;
-        __syncthreads();  // row table visible
-        stamp(1);  // row decode done
-        const float* ubase[NU];
-        unsigned umask[NU];
-        int uwo[NU];
-#pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            const int u = tid + NT * i, r = (u >> 1) % BM, g = u & 1;
-            const bool live = u < AU;
-            ubase[i] = xg + (live ? s_xoff[r] : 0) + g * 8;
-            umask[i] = live ? s_mask[r] : 0u;
-            uwo[i] = ((r >> 5) * 3) * 1024 + ((r & 31) + 32 * g) * 16;
-        }
-        f32x4 xr[2][NU][2];
-        auto load_a = [&](KPos kp, int sidx, auto set_tag) {
-            constexpr int SET = decltype(set_tag)::value;
-            const int tap = kp.kh * d.kw + kp.kw;
-            const int toff = (d.transposed ? -((kp.kh / d.stride) * d.w + (kp.kw / d.stride)) * d.ldx + kp.cb * BK
-                                           : (kp.kh * d.w + kp.kw) * d.ldx + kp.cb * BK) + sidx * 16;
-#pragma unroll
-            for (int i = 0; i < NU; ++i) {
-                const bool ok = (umask[i] >> tap) & 1u;
-                const float* p0 = ok ? ubase[i] + toff : zbuf;
-                const float* p1 = ok ? ubase[i] + toff + 4 : zbuf;
-                xr[SET][i][0] = *reinterpret_cast<const f32x4*>(p0);
-                xr[SET][i][1] = *reinterpret_cast<const f32x4*>(p1);
-            }
-        };
-        auto dma_b = [&](KPos kp, int sidx, auto buf_tag) {
-            constexpr int BUF = decltype(buf_tag)::value;
-            const int64_t kc = (int64_t)(kp.cb * a.taps + kp.kh * d.kw + kp.kw);
-#pragma unroll
-            for (int j = 0; j < (NPB + 3) / 4; ++j) {
-                const int pc = wave + 4 * j;
-                if (pc < NPB) {
-                    const int cf = tn * NFB + pc / 3, pl = pc % 3;
-                    glds16(reinterpret_cast<const float*>(wimg + (((int64_t)cf * a.ktiles + kc) * 6 + sidx * 3 + pl) * 1024 + lane * 16),
-                           reinterpret_cast<float*>(lb + BUF * STB + A_BYTES + pc * 1024));
-                }
-            }
-        };
-        // one slice of the split of a unit: 0-3 hi halves + first residuals of pair k, 4-7 mid / lo halves, 8 the three writes
-        u32x4 sh_[NU], sm_[NU], sl_[NU];
-        float ra_[NU][4], rb_[NU][4];
-        auto slice = [&](auto set_tag, auto buf_tag, int k) {
-            constexpr int SET = decltype(set_tag)::value;
-            constexpr int BUF = decltype(buf_tag)::value;
-            const int i = k / 9, q = k % 9;
-            if (q < 4) {
-                const float v0 = xr[SET][i][q >> 1][(q & 1) * 2], v1 = xr[SET][i][q >> 1][(q & 1) * 2 + 1];
-                sh_[i][q] = cvt_pk_bf16(v0, v1);
-                ra_[i][q] = v0 - bf16_lo_f32(sh_[i][q]);
-                rb_[i][q] = v1 - bf16_hi_f32(sh_[i][q]);
-            } else if (q < 8) {
-                const int t = q - 4;
-                sm_[i][t] = cvt_pk_bf16(ra_[i][t], rb_[i][t]);
-                sl_[i][t] = cvt_pk_bf16(ra_[i][t] - bf16_lo_f32(sm_[i][t]), rb_[i][t] - bf16_hi_f32(sm_[i][t]));
-            } else if (AU >= NT * (i + 1) || tid + NT * i < AU) {
-                uint8_t* dst = lb + BUF * STB + uwo[i];
-                *reinterpret_cast<u32x4*>(dst) = sh_[i];
-                *reinterpret_cast<u32x4*>(dst + 1024) = sm_[i];
-                *reinterpret_cast<u32x4*>(dst + 2048) = sl_[i];
-            }
-        };
-        constexpr int NS = 9 * NU;          // slices per stage
-        constexpr int NM = 6 * FM * FN;     // MFMAs per stage
-        // MFMAs of the stage in buffer BUF; when `conv`, the registers of set BUF^1 are split into buffer BUF^1 behind them
-        auto stage = [&](auto buf_tag, auto conv_tag) {
-            constexpr int BUF = decltype(buf_tag)::value;
-            constexpr bool conv = decltype(conv_tag)::value;   // compile time: the slice bookkeeping below must fold to constants
-            using NB = std::integral_constant<int, BUF ^ 1>;
-            const uint8_t* st = lb + BUF * STB;
-            bf16x8 af[FM][3], bf[FN][3];
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) af[i][pl] = *reinterpret_cast<const bf16x8*>(st + ((wm * FM + i) * 3 + pl) * 1024 + lane * 16);
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8*>(st + A_BYTES + ((wn * FN + j) * 3 + pl) * 1024 + lane * 16);
-            // smallest terms first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
-            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-            int n = 0, done = 0;
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-#pragma unroll
-                    for (int j = 0; j < FN; ++j, ++n) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
-                        if constexpr (conv) {
-                            // spread the slices evenly behind the matrix instructions (the first one waits for nothing)
-                            const int upto = ((n + 1) * NS + NM - 1) / NM;
-#pragma unroll
-                            for (int k = 0; k < NS; ++k)
-                                if (k >= done && k < upto) slice(NB{}, NB{}, k);
-                            done = upto > done ? upto : done;
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-        };
-        using B0 = std::integral_constant<int, 0>;
-        using B1 = std::integral_constant<int, 1>;
-        if (kt0 < kt1) {
-            KPos kp = kpos_of(kt0);
-            dma_b(kp, 0, B0{});
-            load_a(kp, 0, B0{});
-#pragma unroll
-            for (int k = 0; k < NS; ++k) slice(B0{}, B0{}, k);
-            load_a(kp, 1, B1{});
-            __syncthreads();
-            stamp(2);  // first stage staged
-            for (int kt = kt0; kt < kt1; ++kt) {
-                const bool more = kt + 1 < kt1;
-                const KPos kn = kpos_next(kp);
-                // stage 0 of the chunk (buffer 0): meanwhile stage 1's weights land in buffer 1 and its rows (register set 1) are split
-                dma_b(kp, 1, B1{});
-                if (more) load_a(kn, 0, B0{});
-                stage(B0{}, std::true_type{});
-                __syncthreads();
-                // stage 1 (buffer 1): the next chunk's stage 0 is prepared in buffer 0
-                if (more) {
-                    dma_b(kn, 0, B0{});
-                    load_a(kn, 1, B1{});
-                }
-                if (more) stage(B1{}, std::true_type{});
-                else stage(B1{}, std::false_type{});
-                __syncthreads();
-                kp = kn;
-            }
-        }
-#endif
-    }
-
+    // ---- epilogue of one tile (tm_, tn_) whose row table is (s_yoff, s_roff); `hook` runs on every thread right after the
+    // accumulators are staged
+    auto epilogue = [&](const int tm, const int tn, const int* const s_yoff, const int* const s_roff, auto&& hook) {
     stamp(3);  // k loop done
     // ---- epilogue: accumulators -> LDS [BM][BN+4] -> 16-byte row-contiguous global accesses
     float* sC = lds;
@@ -753,6 +312,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
             }
     __syncthreads();
     stamp(4);  // accumulators staged
+    hook();    // (split kernel, persistent: the next tile's first operands are requested here and fly under the stores)
 
     if (d.split_k > 1) {  // raw partial sums; the epilogue runs in splitk_reduce_kernel
         constexpr int QPR = BN / 4;
@@ -937,6 +497,361 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
                 if (co + e < d.cout) yp[e] = v[e];
     }
     stamp(5);  // stores issued
+    };
+
+    if constexpr (!X6) {
+        const float* wrow[IB];
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+            int r = i * 32 + rsub;
+            int co = tn * BN + r;
+            wrow[i] = (co < a.Npad) ? wg + (int64_t)co * a.K + (pseg ^ ((r >> 1) & 7)) * 4 : nullptr;
+        }
+        const float* arow[IA];
+        unsigned amask[IA];
+
+        // one 1-KiB DMA piece (8 rows x 128 B) of a stage: pieces [0, IA) are A rows, [IA, IA+IB) weight rows.
+        // The stage buffer is a compile-time constant so LDS addresses fold into instruction immediates.
+        const uint32_t zlo = (uint32_t)(uint64_t)egr_zero16, zhi = (uint32_t)((uint64_t)egr_zero16 >> 32);
+        auto issue_piece = [&](int kt, KPos kp, auto buf_tag, int piece) {
+            constexpr int BUF = decltype(buf_tag)::value;
+            float* sA = lds + BUF * P::TILE;
+            if (piece < IA) {
+                const int tap = kp.kh * d.kw + kp.kw;
+                // wave-uniform, 32-bit.  Transposed mode: th - kh = stride*(bh - kh/stride) + (th%stride - kh%stride), and the mask
+                // bit is set only where the remainders agree, so the source pixel is (bh - kh/stride, bw - kw/stride).
+                const int toff = d.transposed ? -((kp.kh / d.stride) * d.w + (kp.kw / d.stride)) * d.ldx + kp.cb * BK
+                                              : (kp.kh * d.w + kp.kw) * d.ldx + kp.cb * BK;
+                const uint64_t pa = (uint64_t)(arow[piece] + toff);
+                const bool ok = (amask[piece] >> tap) & 1u;
+                // select between the pixel row and the zero buffer with two 32-bit v_cndmask (no branch, no 64-bit logic)
+                const uint32_t lo = ok ? (uint32_t)pa : zlo, hi = ok ? (uint32_t)(pa >> 32) : zhi;
+                glds16(reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo), sA + (piece * 32 + wave * 8) * BK);
+            } else {
+                const int i = piece - IA;
+                const float* p = wrow[i] ? wrow[i] + (kp.cb * a.taps + kp.kh * d.kw + kp.kw) * BK : egr_zero16;   // chunk index in K
+                glds16(p, sA + BM * BK + (i * 32 + wave * 8) * BK);
+            }
+        };
+
+        // fragment read offsets (floats) inside a stage for the four k-groups of a chunk, computed once:
+        // row * 32 + ((q ^ swz(row)) * 4) with q = 2*g + half
+        int afo[FM][4], bfo[FN][4];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int r = wm * TM + i * 32 + l31;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) afo[i][g] = r * BK + (((2 * g + half) ^ ((r >> 1) & 7)) << 2);
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int r = wn * TN + j * 32 + l31;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bfo[j][g] = BM * BK + r * BK + (((2 * g + half) ^ ((r >> 1) & 7)) << 2);
+        }
+
+        constexpr int NPIECE = IA + IB;
+        constexpr int DMA_EVERY = (FM * FN >= 4) ? 2 : 1;  // big tiles: one DMA piece behind every 2nd MFMA (measured +2.5 %)
+        using B0 = std::integral_constant<int, 0>;
+        using B1 = std::integral_constant<int, 1>;
+
+        // multiply one staged chunk; when ISSUE, the next chunk's DMA pieces go out one per MFMA behind the first
+        // matrix instructions (pinned with sched_barrier), so their issue slots hide under the 64-cycle MFMAs
+        auto chunk = [&](int kt, auto buf_tag, KPos kp_next, auto issue_tag) {
+            constexpr int BUF = decltype(buf_tag)::value;
+            constexpr bool ISSUE = decltype(issue_tag)::value;
+            using NB = std::integral_constant<int, BUF ^ 1>;
+            const float* st = lds + BUF * P::TILE;
+            f32x4 av[2][FM], bv[2][FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) av[0][i] = *reinterpret_cast<const f32x4*>(&st[afo[i][0]]);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bv[0][j] = *reinterpret_cast<const f32x4*>(&st[bfo[j][0]]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cur = g & 1, nxt = cur ^ 1;
+                if (g < 3) {  // fragments of the next k-group are fetched under this group's MFMAs
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) av[nxt][i] = *reinterpret_cast<const f32x4*>(&st[afo[i][g + 1]]);
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) bv[nxt][j] = *reinterpret_cast<const f32x4*>(&st[bfo[j][g + 1]]);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i][t], bv[cur][j][t], acc[i][j], 0, 0, 0);
+                            if constexpr (ISSUE) {
+                                const int n = ((g * 4 + t) * FM + i) * FN + j;
+                                if ((n % DMA_EVERY) == 0 && (n / DMA_EVERY) < NPIECE) {
+                                    issue_piece(kt + 1, kp_next, NB{}, n / DMA_EVERY);
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                            }
+                        }
+            }
+        };
+
+        KPos kp = kpos_of(kt0);
+        if (kt0 < kt1) {  // weight pieces of the first chunk need no row geometry: their latency overlaps the decode
+#pragma unroll
+            for (int pc = IA; pc < NPIECE; ++pc) issue_piece(kt0, kp, B0{}, pc);
+        }
+        __syncthreads();  // row table visible (also drains the weight DMA; it had the whole decode to land)
+#pragma unroll
+        for (int i = 0; i < IA; ++i) {
+            const int r = i * 32 + rsub;
+            arow[i] = xg + (s_xoff[r] + (pseg ^ ((r >> 1) & 7)) * 4);
+            amask[i] = s_mask[r];
+        }
+        stamp(1);  // row decode done
+        if (kt0 < kt1) {
+#pragma unroll
+            for (int pc = 0; pc < IA; ++pc) issue_piece(kt0, kp, B0{}, pc);
+        }
+        __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes stage 0
+        stamp(2);  // first chunk landed
+        int kt = kt0;
+        for (; kt + 2 < kt1; kt += 2) {  // two chunks per trip: stage indices are compile-time constants
+            KPos k1 = kpos_next(kp);
+            chunk(kt, B0{}, k1, std::true_type{});
+            __syncthreads();
+            KPos k2 = kpos_next(k1);
+            chunk(kt + 1, B1{}, k2, std::true_type{});
+            __syncthreads();
+            kp = k2;
+        }
+        if (kt + 1 < kt1) {  // two chunks left
+            KPos k1 = kpos_next(kp);
+            chunk(kt, B0{}, k1, std::true_type{});
+            __syncthreads();
+            chunk(kt + 1, B1{}, k1, std::false_type{});
+            __syncthreads();
+        } else if (kt < kt1) {  // one chunk left
+            chunk(kt, B0{}, kp, std::false_type{});
+            __syncthreads();
+        }
+        epilogue(tm, tn, s_yoff, s_roff, [] {});
+    } else {
+        // ---- split-bf16 main loop: fp32 operands as exact sums of three bf16 (hi, mid, lo); the six partial products of order
+        // <= 2 on v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  The dropped ones are ~2^-26 relative, below fp32 rounding.
+        // A stage is ONE k16 step: a chunk (tap x 32 channels) is two stages; stage s multiplies out of LDS buffer s % 2.
+        //   A: a thread owns `unit` = (tile row, 8-channel group).  Its 32 bytes arrive by two buffer loads two stages ahead (a
+        //      halo tap / padded row is an out-of-range offset: the load returns zeros and touches no memory), are split by VALU
+        //      work pinned into the gaps behind the MFMAs one stage ahead, and written in fragment order (ds_write_b128 x 3);
+        //   B: the weights were split once (egr_pack_w6_f32) into fragment order; a wave fetches its 1-KiB pieces into registers
+        //      one stage ahead and writes them to LDS at the top of the next stage.
+        // Everything in the loop is straight-line code with wave-uniform control (exact s_waitcnt vmcnt(N) from the compiler: a
+        // load is only waited for when it is consumed), the stage hand-over is `s_waitcnt lgkmcnt(0); s_barrier` - loads stay in
+        // flight across it - and the last chunk is peeled so that the accumulators never move between registers.
+        constexpr int AU = 2 * BM;                    // staging units per stage
+        constexpr int NU = (AU + NT - 1) / NT;        // per thread
+        constexpr int NFA = BM / 32, NFB = BN / 32;
+        constexpr int A_BYTES = NFA * 3 * 1024;
+        constexpr int STB = P::TILE * 4;              // bytes per stage
+        constexpr int NPB = NFB * 3;                  // weight pieces per stage
+        constexpr int NBJ = (NPB + 3) / 4;            // per wave
+        uint8_t* const lb = reinterpret_cast<uint8_t*>(lds);
+        const int uw = __builtin_amdgcn_readfirstlane(wave);
+        // buffer resources (raw, 2 GiB window): A = the activations of this group shifted back by `abias` bytes so that every
+        // row offset is non-negative; B = the weight image of this group
+        // (a data-gradient launch walks its taps backwards: `tbias` keeps the scalar tap offset non-negative as well)
+        const int abias = (d.kh * d.w + d.kw + 1) * d.ldx * 4;
+        const int tbias = d.transposed ? (((d.kh - 1) / d.stride) * d.w + (d.kw - 1) / d.stride) * d.ldx * 4 : 0;
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+            uniform_ptr(reinterpret_cast<const char*>(xg) - abias - tbias), 0, 0x80000000u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+            uniform_ptr(reinterpret_cast<const uint8_t*>(a.w) + (int64_t)grp * d.gw * 2), 0, 0x80000000u, 0x00020000);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // row table visible
+        stamp(1);  // row decode done
+        int uoff[NU], uinv[NU], uwo[NU], bvo[NBJ];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int u = tid + NT * i, r = (u >> 1) % BM, g = u & 1;
+            uwo[i] = ((r >> 5) * 3) * 1024 + ((r & 31) + 32 * g) * 16;
+        }
+        // a tile's staging roles: row offsets / dead-tap masks from table `slot`, weight piece offsets of column tile tn_
+        auto unit_setup = [&](int slot, int tn_) {
+            const int* const t_xoff = tab0 + slot * 4 * BM + 2 * BM;
+            const int* const t_mask = t_xoff + BM;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                const int u = tid + NT * i, r = (u >> 1) % BM, g = u & 1;
+                const bool live = u < AU;
+                uoff[i] = (live ? t_xoff[r] * 4 : 0) + g * 32 + abias;
+                uinv[i] = live ? ~t_mask[r] : -1;     // bit t set: tap t of this row reads zeros
+            }
+#pragma unroll
+            for (int j = 0; j < NBJ; ++j) {
+                const int pc = (uw + 4 * j) % NPB;
+                bvo[j] = ((tn_ * NFB + pc / 3) * a.ktiles * 6 + pc % 3) * 1024 + lane * 16;
+            }
+        };
+        unit_setup(0, tn);
+        // weight piece (uw + 4 j) mod NPB: when the pieces do not divide evenly over the four waves, some are fetched twice (the
+        // same bytes to the same place) - cheaper than a wave-dependent branch, behind which the compiler waits for every load
+        int lds_b[NBJ];
+#pragma unroll
+        for (int j = 0; j < NBJ; ++j) lds_b[j] = A_BYTES + ((uw + 4 * j) % NPB) * 1024 + lane * 16;
+        u32x4 xr[2][NU][2], breg[NBJ];
+        auto load_a = [&](KPos kp, int sidx, auto set_tag) {
+            constexpr int SET = decltype(set_tag)::value;
+            const int tap = kp.kh * d.kw + kp.kw;
+            const int toff = ((d.transposed ? -((kp.kh / d.stride) * d.w + (kp.kw / d.stride)) * d.ldx + kp.cb * BK
+                                            : (kp.kh * d.w + kp.kw) * d.ldx + kp.cb * BK) + sidx * 16) * 4 + tbias;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                const int dead = __builtin_amdgcn_sbfe(uinv[i], tap, 1);               // -1 when the tap is outside the image
+                const int vo = (dead & (int)0x80000000) | uoff[i];                      // beyond the window: the load returns zeros
+                xr[SET][i][0] = __builtin_amdgcn_raw_buffer_load_b128(ra, vo, toff, 0);
+                xr[SET][i][1] = __builtin_amdgcn_raw_buffer_load_b128(ra, vo + 16, toff, 0);
+            }
+        };
+        auto load_b = [&](KPos kp, int sidx) {
+            const int soff = ((kp.cb * a.taps + kp.kh * d.kw + kp.kw) * 6 + sidx * 3) * 1024;
+#pragma unroll
+            for (int j = 0; j < NBJ; ++j) breg[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, bvo[j], soff, 0);
+        };
+        auto write_b = [&](auto buf_tag) {
+            constexpr int BUF = decltype(buf_tag)::value;
+#pragma unroll
+            for (int j = 0; j < NBJ; ++j) *reinterpret_cast<u32x4*>(lb + BUF * STB + lds_b[j]) = breg[j];
+        };
+        // one slice of the split of a unit: 0-3 hi halves + first residuals of pair k, 4-7 mid / lo halves, 8 the three writes
+        u32x4 sh_[NU], sm_[NU], sl_[NU];
+        float ra_[NU][4], rb_[NU][4];
+        auto slice = [&](auto set_tag, auto buf_tag, int k) {
+            constexpr int SET = decltype(set_tag)::value;
+            constexpr int BUF = decltype(buf_tag)::value;
+            const int i = k / 9, q = k % 9;
+            if (q < 4) {
+                const float v0 = __uint_as_float(xr[SET][i][q >> 1][(q & 1) * 2]), v1 = __uint_as_float(xr[SET][i][q >> 1][(q & 1) * 2 + 1]);
+                sh_[i][q] = cvt_pk_bf16(v0, v1);
+                ra_[i][q] = v0 - bf16_lo_f32(sh_[i][q]);
+                rb_[i][q] = v1 - bf16_hi_f32(sh_[i][q]);
+            } else if (q < 8) {
+                const int t = q - 4;
+                sm_[i][t] = cvt_pk_bf16(ra_[i][t], rb_[i][t]);
+                sl_[i][t] = cvt_pk_bf16(ra_[i][t] - bf16_lo_f32(sm_[i][t]), rb_[i][t] - bf16_hi_f32(sm_[i][t]));
+            } else if (AU >= NT * (i + 1) || tid + NT * i < AU) {
+                uint8_t* dst = lb + BUF * STB + uwo[i];
+                *reinterpret_cast<u32x4*>(dst) = sh_[i];
+                *reinterpret_cast<u32x4*>(dst + 1024) = sm_[i];
+                *reinterpret_cast<u32x4*>(dst + 2048) = sl_[i];
+            }
+        };
+        constexpr int NS = 9 * NU;          // slices per stage
+        constexpr int NM = 6 * FM * FN;     // MFMAs per stage
+        constexpr int S0 = (NM >= 12) ? NM / 6 : 0;   // MFMAs in front of the first slice (its operands are the youngest loads but two)
+        // One stage.  BUF: the LDS buffer multiplied.  CONV: the registers of set BUF^1 / breg hold the next stage's operands and
+        // go to buffer BUF^1.  LOADS: the operands of the stage after next are requested (A into set BUF, B into breg).
+        auto stage = [&](auto buf_tag, auto conv_tag, auto loads_tag, KPos kl, int sl) {
+            constexpr int BUF = decltype(buf_tag)::value;
+            constexpr bool conv = decltype(conv_tag)::value;
+            constexpr bool loads = decltype(loads_tag)::value;
+            using NB = std::integral_constant<int, BUF ^ 1>;
+            using CB = std::integral_constant<int, BUF>;
+            const uint8_t* st = lb + BUF * STB;
+            bf16x8 af[FM][3], bf[FN][3];
+            // fragments in the order of their first use: (lo, hi) (hi, lo) (mid, mid)
+            constexpr int RA[3] = {2, 0, 1}, RB[3] = {0, 2, 1};
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i) af[i][RA[q]] = *reinterpret_cast<const bf16x8*>(st + ((wm * FM + i) * 3 + RA[q]) * 1024 + lane * 16);
+#pragma unroll
+                for (int j = 0; j < FN; ++j) bf[j][RB[q]] = *reinterpret_cast<const bf16x8*>(st + A_BYTES + ((wn * FN + j) * 3 + RB[q]) * 1024 + lane * 16);
+            }
+            if constexpr (conv) write_b(NB{});
+            if constexpr (loads) {
+                load_b(kl, sl);
+                load_a(kl, sl, CB{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // smallest terms first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+            int n = 0, done = 0;
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j, ++n) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
+                        if constexpr (conv) {
+                            // spread the slices evenly behind the matrix instructions S0 .. NM-1
+                            const int upto = (n + 1 <= S0) ? 0 : ((n + 1 - S0) * NS + (NM - S0) - 1) / (NM - S0);
+#pragma unroll
+                            for (int k = 0; k < NS; ++k)
+                                if (k >= done && k < upto) slice(NB{}, NB{}, k);
+                            done = upto > done ? upto : done;
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        };
+        using B0 = std::integral_constant<int, 0>;
+        using B1 = std::integral_constant<int, 1>;
+        using TT = std::true_type;
+        using FF = std::false_type;
+        // Tiles of this workgroup: blockIdx.x, + gridDim.x, ...  While tile i is stored, tile i+1 is already under way: its
+        // row table is decoded before the accumulators are staged, and its first operands (weights of stage 0, rows of stages 0
+        // and 1) are requested right after - they arrive under the stores.
+        const KPos kp0 = kpos_of(kt0);
+        const bool work = kt0 < kt1;
+        auto first_loads = [&]() {
+            load_b(kp0, 0);
+            load_a(kp0, 0, B0{});
+            load_a(kp0, 1, B1{});
+        };
+        if (work) first_loads();
+        int slot = 0;
+        for (int vb = blockIdx.x;;) {
+            if (work) {
+                KPos kp = kp0;
+                write_b(B0{});
+#pragma unroll
+                for (int k = 0; k < NS; ++k) slice(B0{}, B0{}, k);
+                load_b(kp, 1);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                stamp(2);  // first stage staged
+                for (int kt = kt0; kt + 1 < kt1; ++kt) {
+                    const KPos kn = kpos_next(kp);
+                    stage(B0{}, TT{}, TT{}, kn, 0);
+                    stage(B1{}, TT{}, TT{}, kn, 1);
+                    kp = kn;
+                }
+                stage(B0{}, TT{}, FF{}, kp, 0);
+                stage(B1{}, FF{}, FF{}, kp, 0);
+            }
+            const int vn = vb + (int)gridDim.x;
+            const bool more = P::PERSIST && vn < a.ntiles;
+            int tmn = 0, tnn = 0;
+            if (more) {
+                tile_of(vn, tmn, tnn);
+                decode(tmn, slot ^ 1);
+            }
+            const int* const t_yoff = tab0 + slot * 4 * BM;
+            epilogue(tm, tn, t_yoff, t_yoff + BM, [&] {
+                if (more) {
+                    unit_setup(slot ^ 1, tnn);
+                    if (work) first_loads();
+                }
+            });
+            if (!more) break;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the staged tile
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            vb = vn; tm = tmn; tn = tnn; slot ^= 1;
+        }
+    }
+
 }
 
 // split-K second pass: sum the partial slabs in fixed order (deterministic) and apply the epilogue.
@@ -977,10 +892,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     conv_igemm_body<BM, BN, WM, WN, false>(a);
 }
 
-// split-bf16 launches: two workgroups per CU (their barriers overlap), so at most 256 registers per lane
+// split-bf16 launches: at least two workgroups per CU (their barriers and fixed phases overlap), so at most 256 registers per
+// lane; the narrower tiles hold fewer accumulators, are not persistent and are bounded for four (128 registers: measured
+// 131 TFLOP/s on the 64-channel 3x3 layers against 122 at three and 112-118 at two workgroups per CU)
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv_igemm_x6_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? X6_OCC_SMALL : X6_OCC_BIG) void conv_igemm_x6_kernel(const ConvArgs a) {
     conv_igemm_body<BM, BN, WM, WN, true>(a);
+}
+
+// persistent variant (short K: a tile is mostly fixed cost and HBM traffic - the next tile's decode and first loads overlap the
+// stores; measured 106 -> 121 TFLOP/s on 1x1 128 -> 128 at 64x64 pixels, -1.5 % on the long-K layers, which keep the plain launch)
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_x6p_kernel(const ConvArgs a) {
+    conv_igemm_body<BM, BN, WM, WN, true, true>(a);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -988,8 +912,24 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
     a.tilesM = (a.M + BM - 1) / BM;
     a.tilesN = (a.Npad + BN - 1) / BN;
     a.dTilesN = make_fastdiv(a.tilesN);
-    dim3 grid((unsigned)(a.tilesM * a.tilesN), (unsigned)(a.cls_mode ? 4 : a.d.split_k), (unsigned)a.d.groups);
-    if (a.d.w_format == EGR_W_BF16X3)
+    a.ntiles = a.tilesM * a.tilesN;
+    const int ny = a.cls_mode ? 4 : a.d.split_k;
+    int gx = a.ntiles;
+    bool persist = false;
+    if (a.d.w_format == EGR_W_BF16X3 && g_persist && BM * BN > 128 * 64 && a.ktiles <= g_persist_ktiles) {
+        // persistent launch: as many workgroups as stay resident (2 per CU, launch bounds), each walking `rounds` tiles; a
+        // multiple of 8 so that a workgroup's tiles keep its XCD (the tile order hands each XCD a contiguous run)
+        const int slots = (g_persist / (ny * a.d.groups)) & ~7;
+        if (slots >= 8 && a.ntiles > slots) {
+            const int rounds = (a.ntiles + slots - 1) / slots;
+            gx = ((a.ntiles + rounds - 1) / rounds + 7) & ~7;
+            persist = true;
+        }
+    }
+    dim3 grid((unsigned)gx, (unsigned)ny, (unsigned)a.d.groups);
+    if (persist) {
+        if constexpr (BM * BN > 128 * 64) hipLaunchKernelGGL((conv_igemm_x6p_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
+    } else if (a.d.w_format == EGR_W_BF16X3)
         hipLaunchKernelGGL((conv_igemm_x6_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);
@@ -1126,11 +1066,6 @@ static int conv_run(const egr_conv_desc* dd, const float* x, const float* w, con
     a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.res = res; a.rowscale = rowscale; a.rowmask = rowmask;
     a.y = y; a.ws = workspace;
     a.mask = mask;
-    {
-        static float* zp = nullptr;
-        if (!zp && hipGetSymbolAddress((void**)&zp, HIP_SYMBOL(egr_zero16)) != hipSuccess) return EGR_EINVAL;
-        a.zero = zp;
-    }
     a.dbg = g_dbg;
     a.M = (int)M64;
     a.Npad = (d.cout + 31) / 32 * 32;
@@ -1184,7 +1119,7 @@ static int conv_run(const egr_conv_desc* dd, const float* x, const float* w, con
             // the barrier count down (N = 64 / 192: 128x64, measured 123 vs 94 TF on 64x64), and 128x128 needs two resident
             // workgroups per CU to overlap its barriers (layer4 alone: 256 workgroups ran 91 TF, as 128x64 121 TF)
             const int64_t blocks128 = (int64_t)((a.M + 127) / 128) * ((a.Npad + 127) / 128) * d.groups;
-            cfg = (a.Npad % 128 == 0 && blocks128 >= 512) ? CFG_128x128 : CFG_128x64;
+            cfg = (a.Npad % 128 == 0 && blocks128 >= 256) ? CFG_128x128 : CFG_128x64;   // (256 workgroups of 128x128: 186 TF, as 128x64: 170)
         } else if (a.Npad % 128 == 0) cfg = CFG_128x128;
         else cfg = CFG_64x64;  // N = 64 / 192: 128x64 wins the isolated micro-benchmark (+15 %) but not the pipeline (26.2 vs 26.0 ms); 256x64 runs at 1 workgroup/CU
     }
