@@ -59,16 +59,19 @@ def pose3d_cfg(camera_model: str = "ego4view_syn") -> dict:
 
 
 def load_model_cfg(yaml_path: str) -> dict:
-    """model_cfg of an unchanged reference YAML (use_imagenet_pretrain is forced off: no network)."""
+    """model_cfg of an unchanged reference YAML, exactly as written there (`use_imagenet_pretrain: True` included: the trunk
+    then loads the ImageNet weights or says loudly that it could not - tree.load_imagenet_resnet18)."""
     import yaml
     with open(yaml_path) as f:
-        cfg = yaml.safe_load(f)["model"]["init_args"]["model_cfg"]
+        return yaml.safe_load(f)["model"]["init_args"]["model_cfg"]
 
-    def _walk(d):
-        for k, v in d.items():
-            if k == "use_imagenet_pretrain":
-                d[k] = False
-            elif isinstance(v, dict):
-                _walk(v)
-    _walk(cfg)
+
+def set_imagenet_pretrain(cfg: dict, value: bool) -> dict:
+    """Set every `use_imagenet_pretrain` of a model_cfg (the presets above say False: benchmarks and tests load seeded weights
+    right after construction; the shipped YAMLs say True)."""
+    for k, v in cfg.items():
+        if k == "use_imagenet_pretrain":
+            cfg[k] = value
+        elif isinstance(v, dict):
+            set_imagenet_pretrain(v, value)
     return cfg

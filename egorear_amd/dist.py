@@ -78,3 +78,73 @@ def allreduce_gradients_(flat: torch.Tensor, group=None, async_op: bool = False,
         return None if async_op else flat
     h = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
     return h if async_op else flat
+
+
+def _via_host(t: torch.Tensor, group) -> bool:
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def broadcast_(t: torch.Tensor, src: int = 0, group=None, force: bool = False) -> torch.Tensor:
+    """In-place broadcast from rank `src` (no-op for one process unless `force`; device tensors staged through the host under gloo)."""
+    if world_size(group) <= 1 and not (force and dist.is_available() and dist.is_initialized()):
+        return t
+    if _via_host(t, group):
+        host = t.detach().cpu()
+        dist.broadcast(host, src=src, group=group)
+        t.copy_(host)
+        return t
+    dist.broadcast(t, src=src, group=group)
+    return t
+
+
+def allreduce_mean_(t: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place mean over the ranks: what Lightning's `self.log(..., sync_dist=True)` does to every logged scalar
+    (pl_wrappers/egoposeformer/pose_3d_mvf_ex.py:208, heatmap.py:140, heatmap_mvf_ex.py:183)."""
+    n = world_size(group)
+    if n <= 1:
+        return t
+    if _via_host(t, group):
+        host = t.detach().cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(host / n)
+        return t
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    t.div_(n)
+    return t
+
+
+class BufferSync:
+    """DDP's `broadcast_buffers=True` for the native trainer: before every forward, rank 0's module buffers (the BatchNorm running
+    statistics and `num_batches_tracked`; the reference runs plain BatchNorm, no SyncBN) replace every other rank's, so the
+    replicas' running statistics do not drift apart.  The buffers are re-homed ONCE into one flat tensor per
+    dtype (their `.data` become views), so a step costs one broadcast per dtype and no gather / scatter copies; state_dict keys,
+    shapes and values are unchanged."""
+
+    def __init__(self, module: torch.nn.Module, group=None):
+        self.group = group
+        self.flat = {}
+        by_dtype = {}
+        for name, b in module.named_buffers():
+            if b is None or b.numel() == 0:
+                continue
+            by_dtype.setdefault(b.dtype, []).append((name, b))
+        self.names = {dt: [n for n, _ in lst] for dt, lst in by_dtype.items()}
+        with torch.no_grad():
+            for dt, lst in by_dtype.items():
+                total = sum(b.numel() for _, b in lst)
+                flat = torch.empty(total, dtype=dt, device=lst[0][1].device)
+                off = 0
+                for _, b in lst:
+                    n = b.numel()
+                    flat[off:off + n].copy_(b.detach().reshape(-1))
+                    b.data = flat[off:off + n].view(b.shape)
+                    off += n
+                self.flat[dt] = flat
+
+    def numel(self) -> int:
+        return sum(f.numel() for f in self.flat.values())
+
+    def broadcast(self, src: int = 0, force: bool = False) -> None:
+        for flat in self.flat.values():
+            broadcast_(flat, src, self.group, force=force)
+

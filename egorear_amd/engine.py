@@ -178,10 +178,16 @@ class State:
         return v
 
 
+# Bumped whenever packed weights are created or dropped: a captured hipGraph holds raw pointers into the packs it was recorded
+# with (runner.GraphedForward), so a replay is only valid while this number has not moved since the capture.
+GENERATION = [0]
+
+
 def _state(mod: nn.Module, device) -> State:
     st = mod.__dict__.get("_egr_state")
     if st is None or st.device != device:
         st = State(device)
+        GENERATION[0] += 1
         mod.__dict__["_egr_state"] = st
         if "_egr_hook" not in mod.__dict__:
             mod.__dict__["_egr_hook"] = mod.register_load_state_dict_post_hook(lambda m, _k: invalidate(m))
@@ -190,7 +196,8 @@ def _state(mod: nn.Module, device) -> State:
 
 def invalidate(mod: nn.Module):
     """Drop packed weights (call after mutating parameters in place; load_state_dict does it itself)."""
-    mod.__dict__.pop("_egr_state", None)
+    if mod.__dict__.pop("_egr_state", None) is not None:
+        GENERATION[0] += 1
 
 
 def _check_input(img: torch.Tensor, mod: nn.Module):

@@ -103,7 +103,22 @@ def _check(rc: int, name: str):
 PROFILE = None
 
 
+# Device of the launch being assembled: set by the first tensor handed to _p(), checked for every further one, consumed by
+# _launch().  The kernel goes to the current stream OF THAT DEVICE (not of torch's current device), and the C entry point is called
+# with that device current - a module on cuda:1 works while torch.cuda.current_device() is 0 (two replicas in one process, a caller
+# that never called set_device).
+_DEV = [None]
+
+
 def _launch(name: str, cfunc, *args, flops: float = 0.0, nbytes: float = 0.0, tag: str = ""):
+    idx, _DEV[0] = _DEV[0], None
+    if idx is not None and idx != torch.cuda.current_device():
+        with torch.cuda.device(idx):
+            return _launch_here(name, cfunc, args, flops, nbytes, tag)
+    return _launch_here(name, cfunc, args, flops, nbytes, tag)
+
+
+def _launch_here(name, cfunc, args, flops, nbytes, tag):
     if PROFILE is None:
         rc = cfunc(*args)
     else:
@@ -119,14 +134,29 @@ def _p(t: Optional[torch.Tensor], dtype=torch.float32):
     if t is None:
         return None
     if not t.is_cuda:
+        _DEV[0] = None
         raise RuntimeError("egorear_amd: tensor is not on a HIP device (no CPU path exists)")
     if t.dtype != dtype:
+        _DEV[0] = None
         raise RuntimeError(f"egorear_amd: expected {dtype}, got {t.dtype}")
+    idx = t.device.index
+    if _DEV[0] is None:
+        _DEV[0] = idx
+    elif _DEV[0] != idx:
+        first, _DEV[0] = _DEV[0], None
+        raise RuntimeError(f"egorear_amd: operands of one launch live on different devices (cuda:{first} and cuda:{idx})")
     return C.c_void_p(t.data_ptr())
 
 
+def _pv(t: Optional[torch.Tensor]):
+    """Raw device pointer of a tensor of any dtype (same device bookkeeping as _p)."""
+    return None if t is None else _p(t, t.dtype)
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Current stream of the device the launch's tensors live on (falls back to torch's current device for tensor-less calls)."""
+    idx = _DEV[0] if _DEV[0] is not None else torch.cuda.current_device()
+    return C.c_void_p(torch.cuda.current_stream(idx).cuda_stream)
 
 
 def _cont(t: torch.Tensor, what: str):
@@ -226,7 +256,7 @@ class W6Table:
 
     def run(self):
         if self.images:
-            _launch("egr_pack_w6_f32", lib.egr_pack_w6_many_f32, C.c_void_p(self.dev.data_ptr()), len(self.images), self.total, _stream())
+            _launch("egr_pack_w6_f32", lib.egr_pack_w6_many_f32, _p(self.dev, torch.uint8), len(self.images), self.total, _stream())
 
 
 # Launches below these sizes (all groups together) are bound by launch latency or by streaming the weights once, not by the

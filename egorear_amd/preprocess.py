@@ -83,7 +83,7 @@ class FramePreprocessor:
         tmp = torch.empty((n, H, ow, 3), device=frames.device, dtype=torch.uint8)
         dst = torch.empty(lead + (3, oh, ow), device=frames.device, dtype=torch.float32)
         u8 = torch.empty(lead + (oh, ow, 3), device=frames.device, dtype=torch.uint8) if return_u8 else None
-        vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        vp = hip._pv
         hip._launch("egr_preprocess_u8_f32", hip.lib.egr_preprocess_u8_f32, vp(frames), n, H, W, oh, ow, vp(self.bh), vp(self.ch),
                     self.kh, vp(self.bv), vp(self.cv), self.kv, C.cast(self._mean, C.c_void_p), C.cast(self._std, C.c_void_p),
                     vp(tmp), vp(dst), vp(u8), hip._stream(),

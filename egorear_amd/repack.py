@@ -8,7 +8,7 @@ from typing import List
 import numpy as np
 import torch
 
-from .hip import _launch, _stream, lib
+from .hip import _launch, _pv, _stream, lib
 
 COPYPAD, FWD, DGRAD, UNPACK = 0, 1, 2, 3
 _BLOCK = 1024
@@ -68,5 +68,4 @@ class RepackTable:
             return
         if self.table is None:
             self.finalize()
-        _launch("egr_repack_f32", lib.egr_repack_f32, C.c_void_p(self.table.data_ptr()), C.c_void_p(self.blocks.data_ptr()), self.n_blocks,
-                _stream())
+        _launch("egr_repack_f32", lib.egr_repack_f32, _pv(self.table), _pv(self.blocks), self.n_blocks, _stream())

@@ -1054,6 +1054,21 @@ def is_no_decay(name: str) -> bool:
     return ("norm" in name) or ("bn" in name) or ("ln" in name) or ("bias" in name)
 
 
+def flat_layout(named):
+    """Layout of the flat parameter / gradient / moment buffers for `named` = [(name, tensor-like with .numel())]: ordered by the
+    stage of the reverse pass that finishes a tensor's gradient (so a stage is ONE contiguous all-reduce bucket that can start
+    while earlier layers are still being differentiated), then [no-decay | decayed]; every slot starts 16-byte aligned.
+    Returns (ordered list, slots [(name, offset, numel, decay)], stage_range {stage: [begin, end)}, total elements)."""
+    order = sorted(named, key=lambda kp: (grad_stage(kp[0]), not is_no_decay(kp[0])))
+    slots, stage_range, off = [], {}, 0
+    for k, p in order:
+        rng = stage_range.setdefault(grad_stage(k), [off, off])
+        slots.append((k, off, p.numel(), not is_no_decay(k)))
+        off += (p.numel() + 3) // 4 * 4
+        rng[1] = off
+    return order, slots, stage_range, off
+
+
 class FusedAdamW:
     """AdamW over ONE flat fp32 buffer that the module's parameters are re-homed into (their .data become views), with
     flat gradient / moment buffers of the same layout: [no-decay parameters | decayed parameters].  A step is a gradient
@@ -1062,8 +1077,10 @@ class FusedAdamW:
     gradient over RCCL instead of one per tensor.
 
     Matches torch.optim.AdamW(lr, betas=(0.9, 0.999), eps=1e-8, weight_decay) + clip_grad_norm_(clip) with the reference's
-    two parameter groups (pose_3d_mvf_ex.py:219-234) and its warm-up hook (:212-217: the rescale happens after the step,
-    so update 1 runs at the full lr and update t >= 2 at lr * min(1, t / warmup_iters))."""
+    two parameter groups (pose_3d_mvf_ex.py:219-234) and its warm-up hook (:212-217).  The hook runs inside Lightning's
+    `optimizer_step`, after `optimizer.step()` and BEFORE Lightning counts the step as completed, so during update t it sees
+    `trainer.global_step == t - 1` and leaves lr * min(1, t / warmup_iters) behind for update t + 1: update 1 runs at the full
+    lr, update t >= 2 at lr * min(1, (t - 1) / warmup_iters) - update 2 at 1 / warmup_iters."""
 
     def __init__(self, net: nn.Module, lr: float = 1e-3, weight_decay: float = 5e-4, clip: float = 5.0, warmup_iters: int = 500,
                  betas=(0.9, 0.999), eps: float = 1e-8, process_group=None):
@@ -1074,18 +1091,7 @@ class FusedAdamW:
         dev = named[0][1].device
         if dev.type != "cuda":
             raise RuntimeError("egorear_amd.train: parameters must live on the HIP device")
-        # flat order: by the stage of the reverse pass that finishes a tensor's gradient (so a stage is one contiguous
-        # all-reduce bucket that can start while earlier layers are still being differentiated), then [no-decay | decayed]
-        order = sorted(named, key=lambda kp: (grad_stage(kp[0]), not is_no_decay(kp[0])))
-        self.slots = []                      # (name, offset, numel, decay)
-        self.stage_range = {}                # stage -> [begin, end) in the flat buffers
-        off = 0
-        for k, p in order:
-            st = grad_stage(k)
-            rng = self.stage_range.setdefault(st, [off, off])
-            self.slots.append((k, off, p.numel(), not is_no_decay(k)))
-            off += (p.numel() + 3) // 4 * 4
-            rng[1] = off
+        order, self.slots, self.stage_range, off = flat_layout(named)
         self.total = off
         self.pending = []                    # async all-reduce handles of this step
         self.flat_p = torch.zeros(off, device=dev, dtype=torch.float32)
@@ -1104,7 +1110,7 @@ class FusedAdamW:
         self.lr_scale_epoch = 1.0            # MultiStepLR(lr_decay_epochs, 0.1) factor, set by the caller per epoch
 
     def lr_at(self, t: int) -> float:
-        return self.lr * self.lr_scale_epoch * (1.0 if t <= 1 else min(1.0, float(t) / float(self.warmup)))
+        return self.lr * self.lr_scale_epoch * (1.0 if t <= 1 else min(1.0, float(t - 1) / float(self.warmup)))
 
     def _runs(self, have):
         runs, cur = [], None
@@ -1178,6 +1184,10 @@ class Trainer:
         self._graph_out = None
         self._graph_step = None     # keeps the captured step's tensors / pinned tables alive
         self._cuts = None           # multi-process capture: gradient stage handed to the all-reduce after each graph segment
+        # DDP side channels: rank 0's BatchNorm buffers are broadcast before every forward
+        # (DDP broadcast_buffers=True), and logged scalars can be averaged over the ranks (Lightning sync_dist=True)
+        from .dist import BufferSync, world_size
+        self.buffers = BufferSync(net, process_group) if world_size(process_group) > 1 else None
 
     def _distributed(self) -> bool:
         from .dist import world_size
@@ -1206,9 +1216,24 @@ class Trainer:
         for m in (self.net, self.net.heatmap_estimator, self.net.pose3d_estimator):
             invalidate(m)
 
+    def sync_buffers(self, force: bool = False):
+        """Rank 0's module buffers to every rank (what DDP does at the start of each forward); a no-op for one process."""
+        if self.buffers is None and force:
+            from .dist import BufferSync
+            self.buffers = BufferSync(self.net, self.opt.pg)
+        if self.buffers is not None:
+            self.buffers.broadcast(0, force=force)
+
+    def mean_over_ranks(self, terms: torch.Tensor) -> torch.Tensor:
+        """A copy of `terms` averaged over the data-parallel ranks: the value `self.log(..., sync_dist=True)` records
+        (pose_3d_mvf_ex.py:208).  `step` itself returns this rank's terms, like the reference's un-synced training log."""
+        from .dist import allreduce_mean_
+        return allreduce_mean_(terms.clone(), self.opt.pg)
+
     def step(self, img, ctm, gt_pose, gt_heatmap):
         """Returns (loss terms (6,) float64 device tensor, outputs).  Parameters are updated in place."""
         from .dist import world_size
+        self.sync_buffers(force=self.opt.force_collective)   # eager, in front of the (possibly replayed) forward
         if self.graph is not None:
             same = all((a is None) == (b is None) and (a is None or a.shape == b.shape) for a, b in zip(self._static, (img, ctm, gt_pose, gt_heatmap)))
             if same:

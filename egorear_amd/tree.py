@@ -83,13 +83,64 @@ class ResNet18Trunk(nn.Module):
             raise NotImplementedError("model type [%s] is invalid" % model_name)
         if out_stride != 4:
             raise NotImplementedError("only out_stride=4 is on the hot path (SURVEY.md §2)")
-        # use_imagenet_pretrain needs a download; weights always arrive through load_state_dict here.
         self.layer_s2 = nn.Sequential(nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True))
         self.layer_s4 = nn.Sequential(nn.MaxPool2d(3, 2, 1), _res_stage(64, 64, 1))
         self.layer_s8 = _res_stage(64, 128, 2)
         self.layer_s16 = _res_stage(128, 256, 2)
         self.layer_s32 = _res_stage(256, 512, 2)
         self.out_stride = out_stride
+        self.use_imagenet_pretrain = bool(use_imagenet_pretrain)
+        if use_imagenet_pretrain:   # resnet.py:31-39: torchvision.models.resnet18(weights='DEFAULT')
+            load_imagenet_resnet18(self)
+
+
+_TV_PREFIX = (("conv1.", "layer_s2.0."), ("bn1.", "layer_s2.1."), ("layer1.", "layer_s4.1."), ("layer2.", "layer_s8."),
+              ("layer3.", "layer_s16."), ("layer4.", "layer_s32."))
+
+
+def torchvision_resnet18_to_trunk(tv_state: dict) -> dict:
+    """torchvision resnet18 `state_dict` keys -> the reference's split of its children (resnet.py:14-21); `fc.*` is dropped
+    (the reference discards avgpool / fc)."""
+    out = {}
+    for k, v in tv_state.items():
+        for src, dst in _TV_PREFIX:
+            if k.startswith(src):
+                out[dst + k[len(src):]] = v
+                break
+    return out
+
+
+def load_imagenet_resnet18(trunk: "ResNet18Trunk") -> str:
+    """`use_imagenet_pretrain: True` (all 12 shipped YAMLs; reference resnet.py:31-39).  Sources, in order: the file named by
+    EGR_RESNET18_WEIGHTS (a torchvision resnet18 state_dict, for boxes without network), torchvision's own `weights='DEFAULT'`
+    (its cache or a download).  If neither is available the trunk keeps its random initialisation and this says so LOUDLY - or
+    raises when EGR_STRICT_PRETRAIN=1 - because a stage-1 fit would otherwise silently start from other weights than the
+    reference's.  Returns the source used ("file", "torchvision" or "none")."""
+    import os
+    import warnings
+    path = os.environ.get("EGR_RESNET18_WEIGHTS")
+    tv_state, source, why = None, "none", ""
+    if path:
+        tv_state, source = torch.load(path, map_location="cpu"), "file"
+        if isinstance(tv_state, dict) and "state_dict" in tv_state:
+            tv_state = tv_state["state_dict"]
+    else:
+        try:
+            import torchvision
+            tv_state, source = torchvision.models.resnet18(weights="DEFAULT").state_dict(), "torchvision"
+        except Exception as exc:   # torchvision missing, or no cached weights and no network
+            why = f"{type(exc).__name__}: {exc}"
+    if tv_state is None:
+        msg = ("egorear_amd: use_imagenet_pretrain=True but the ImageNet ResNet-18 weights are not available here (" + why +
+               "); the trunk keeps its RANDOM initialisation, unlike the reference (models/backbones/resnet.py:31-39).  Point "
+               "EGR_RESNET18_WEIGHTS at a torchvision resnet18 state_dict file, or load a checkpoint afterwards.")
+        if os.environ.get("EGR_STRICT_PRETRAIN") == "1":
+            raise RuntimeError(msg)
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+        return "none"
+    mapped = torchvision_resnet18_to_trunk(tv_state)
+    trunk.load_state_dict(mapped, strict=True)
+    return source
 
 
 class FPNNeck(nn.Module):

@@ -10,7 +10,8 @@ Restates, over the functional oracle in egorear_oracle.py, what the reference's 
                                   'norm' | 'bn' | 'ln' | 'bias' get weight_decay 0
   * gradient clipping             configs/ego4view_rw_pose3d.yaml trainer.gradient_clip_val 5.0, algorithm norm
                                   (Lightning -> torch.nn.utils.clip_grad_norm_)
-  * warm-up                       pose_3d_mvf_ex.py:212-217: lr is rescaled AFTER optimizer.step, so step 0 runs at the full lr
+  * warm-up                       pose_3d_mvf_ex.py:212-217: lr is rescaled AFTER optimizer.step with the pre-increment
+                                  trainer.global_step: update 1 at the full lr, update t >= 2 at lr * min(1, (t - 1) / 500)
 
 The Lightning wrapper itself cannot be imported here (no pytorch_lightning); oracle/make_golden_train.py pins this file
 against the real reference *network* + the real MpjpeLoss run under autograd.
@@ -144,8 +145,8 @@ def optimizer_step(params: Dict[str, torch.Tensor], grads: Dict[str, Optional[to
 
 class OracleTrainer:
     """Several optimisation steps of config 5 exactly as Lightning would run the reference: persistent torch.optim.AdamW
-    (two parameter groups), clip_grad_norm_, the warm-up hook of pose_3d_mvf_ex.py:212-217 (applied AFTER each step: update
-    t + 1 runs at lr * min(1, (t + 1) / warmup_iters)), and BatchNorm buffers carried from step to step."""
+    (two parameter groups), clip_grad_norm_, the warm-up hook of pose_3d_mvf_ex.py:212-217 (applied AFTER each step with the
+    pre-increment global_step: update t + 1 runs at lr * min(1, t / warmup_iters)), and BatchNorm buffers carried from step to step."""
 
     def __init__(self, sd: Dict[str, torch.Tensor], param_names, cams, lr: float = LR, weight_decay: float = WEIGHT_DECAY,
                  clip: float = CLIP_NORM, warmup_iters: int = WARMUP_ITERS):
@@ -166,9 +167,12 @@ class OracleTrainer:
             p.grad = grads[k]
         total_norm = float(torch.nn.utils.clip_grad_norm_(list(self.params.values()), self.clip))
         self.opt.step()
-        self.global_step += 1
-        if self.global_step < self.warmup:                    # optimizer_step hook, after optimizer.step()
+        # optimizer_step hook (pose_3d_mvf_ex.py:212-217): runs after optimizer.step() but BEFORE Lightning marks the step
+        # completed (optim_progress.optimizer.step.increment_completed() follows the hook), so it sees the pre-increment
+        # trainer.global_step: after update t the lr is lr * min(1, t / warmup), and update 2 runs at 1 / warmup
+        if self.global_step < self.warmup:
             scale = min(1.0, float(self.global_step + 1) / float(self.warmup))
             for pg in self.opt.param_groups:
                 pg["lr"] = scale * self.lr
+        self.global_step += 1
         return losses, total_norm

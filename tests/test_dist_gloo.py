@@ -105,3 +105,105 @@ def test_two_rank_gradient_average_is_one_sum_allreduce():
         assert p.exitcode == 0
     assert torch.allclose(got, ref, rtol=1e-12, atol=1e-14)
     assert grad_seed_scale() == 1.0 and allreduce_gradients_(got) is got   # single process: no-ops
+
+
+# --------------------------------------------------------------------------- training side channels
+
+def _full_net_on_meta():
+    import copy
+    from egorear_amd import configs
+    from egorear_amd.estimator import EgoPoseFormerMVFEX
+    with torch.device("meta"):
+        return EgoPoseFormerMVFEX(**copy.deepcopy(configs.pose3d_cfg("ego4view_rw")))
+
+
+def test_gradient_stage_buckets_cover_the_flat_buffer_exactly_once():
+    """The flat gradient buffer is exchanged as one all-reduce per stage of the reverse pass: the stage ranges must tile
+    [0, total) without gap or overlap, every parameter must sit in exactly one of them, 16-byte aligned, no-decay before decay."""
+    from egorear_amd.train import N_GRAD_STAGES, flat_layout, grad_stage, is_no_decay
+    net = _full_net_on_meta()
+    named = list(net.named_parameters())
+    order, slots, stage_range, total = flat_layout(named)
+    assert sorted(stage_range) == list(range(N_GRAD_STAGES))
+    spans = [tuple(stage_range[s]) for s in sorted(stage_range)]
+    assert spans[0][0] == 0 and spans[-1][1] == total
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))          # contiguous, disjoint
+    assert sum(e - b for b, e in spans) == total
+    seen = set()
+    end = 0
+    for (k, off, n, decay), (k2, p) in zip(slots, order):
+        assert k == k2 and n == p.numel() and off % 4 == 0 and off >= end
+        b, e = stage_range[grad_stage(k)]
+        assert b <= off and off + n <= e                                   # inside its own stage's bucket
+        assert decay == (not is_no_decay(k))
+        seen.add(k)
+        end = off + n
+    assert seen == {k for k, _ in named} and len(slots) == len(named)
+    assert total >= sum(p.numel() for _, p in named) and total - sum(p.numel() for _, p in named) < 4 * len(named)
+    # bucket sizes in the order they are sent (DESIGN.md 9): the lifting head's 268 MB mlp_pred.0 goes first
+    mb = [4 * (e - b) / 1e6 for b, e in spans]
+    assert mb[0] > 250 and sum(mb) > 500
+
+
+def _side_channel_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import copy
+        from egorear_amd import configs
+        from egorear_amd.dist import BufferSync, allreduce_mean_
+        from egorear_amd.estimator import EgoPoseFormerHeatmap
+        from egorear_amd.train import flat_layout
+        torch.manual_seed(100 + rank)                                      # ranks start from DIFFERENT buffers and gradients
+        net = EgoPoseFormerHeatmap(**copy.deepcopy(configs.heatmap_cfg()))
+        for b in net.buffers():
+            if b.dtype.is_floating_point:
+                b.uniform_(0.5, 1.5)
+            else:
+                b.fill_(rank + 1)
+        keys = list(net.state_dict().keys())
+        sync = BufferSync(net)
+        assert list(net.state_dict().keys()) == keys                       # re-homing keeps the state_dict contract
+        mine = {k: v.clone().numpy() for k, v in net.named_buffers()}       # numpy: tensors do not survive the queue
+        sync.broadcast(0)
+        after = {k: v.clone().numpy() for k, v in net.named_buffers()}
+        # the stage buckets of the real layout, exchanged one all-reduce per stage
+        named = list(net.named_parameters())
+        _, slots, stage_range, total = flat_layout(named)
+        flat = torch.full((total,), float(rank + 1), dtype=torch.float64)
+        for s in sorted(stage_range):
+            b, e = stage_range[s]
+            allreduce_gradients_(flat[b:e])
+        terms = torch.tensor([1.0 + rank, 10.0 * (rank + 1)], dtype=torch.float64)
+        mean = allreduce_mean_(terms.clone())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (mine, after, float(flat.min()), float(flat.max()), mean.tolist(), sync.numel()))
+        if rank == 0:
+            out.put(gathered)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_buffer_broadcast_stage_allreduce_and_metric_mean():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_side_channel_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    g0, g1 = out.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    mine0, after0, lo0, hi0, mean0, n0 = g0
+    mine1, after1, lo1, hi1, mean1, n1 = g1
+    import numpy as np
+    assert any(not np.array_equal(mine0[k], mine1[k]) for k in mine0)      # they did differ before
+    for k in mine0:                                                        # DDP broadcast_buffers: rank 0 wins everywhere
+        assert np.array_equal(after0[k], mine0[k]) and np.array_equal(after1[k], mine0[k]), k
+    assert n0 == n1 == sum(v.size for v in mine0.values())
+    assert lo0 == hi0 == lo1 == hi1 == 3.0                                 # every element summed exactly once (1 + 2)
+    assert mean0 == mean1 == [1.5, 15.0]                                   # sync_dist=True: mean over ranks

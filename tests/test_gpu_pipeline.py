@@ -245,3 +245,38 @@ def test_graphed_forward_replays_identically(nets):
         p, h = g(img)
         assert all(torch.equal(a, b) for a, b in zip(p, ref_p)) and all(torch.equal(a, b) for a, b in zip(h, ref_h))
     assert len(g._graphs) == 1          # same shape -> one capture, replayed
+
+
+def test_graphed_forward_recaptures_after_weights_change():
+    """A captured hipGraph points into the packed weights of its capture: new weights (load_state_dict drops the packs) must
+    lead to a new capture, never to a replay over freed / stale buffers."""
+    from egorear_amd import configs, synth
+    from egorear_amd.estimator import EgoPoseFormerHeatmap
+    from egorear_amd.runner import GraphedForward
+    net = _build(EgoPoseFormerHeatmap, configs.heatmap_cfg())
+    img = synth.synth_images(2, 2, seed=33).to(DEV)
+    g = GraphedForward(net)
+    first = g(img).clone()
+    sd = {k: (v * 1.25 if v.dtype.is_floating_point and "running_var" not in k else v) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    with torch.no_grad():
+        eager = net(img)
+    replayed = g(img)
+    assert torch.equal(replayed, eager)
+    assert not torch.equal(replayed, first)
+    again = g(img)                       # and the new capture is replayed from then on
+    assert torch.equal(again, eager) and len(g._graphs) == 1
+
+
+def test_launch_goes_to_the_tensors_device_not_torchs_current_one():
+    """hip.py derives the device (and its current stream) from the operands; with one GPU this can only pin the bookkeeping:
+    the launch works from inside another stream context and leaves no device state behind."""
+    from egorear_amd import hip
+    x = torch.randn(4, 8, 8, 32, device=DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        y = hip.maxpool(hip.Img(x), 3, 2, 1).t
+    side.synchronize()
+    ref = torch.nn.functional.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    assert torch.equal(y, ref) and hip._DEV[0] is None

@@ -50,7 +50,13 @@ def _worker(rank, world, port, out):
         torch.cuda.synchronize()
         res = {k: (float(v.double().norm()), _sample(v)) for k, v in tr.opt.gviews.items()}
         par = {k: _sample(p) for k, p in net.named_parameters()}
-        out.put((rank, res, par, tr.opt.grad_norm()))
+        # DDP side channels: the ranks saw different frames, so their BatchNorm running statistics differ after the step; the
+        # broadcast in front of the next forward makes rank 0's the common ones, and logged terms can be averaged over ranks
+        bn_before = float(sum(b.double().sum() for k, b in net.named_buffers() if k.endswith("running_mean")))
+        tr.sync_buffers()
+        bn_after = float(sum(b.double().sum() for k, b in net.named_buffers() if k.endswith("running_mean")))
+        mean_terms = tr.mean_over_ranks(torch.tensor([float(rank), 2.0], dtype=torch.float64, device=DEV)).tolist()
+        out.put((rank, res, par, tr.opt.grad_norm(), bn_before, bn_after, mean_terms))
     finally:
         dist.destroy_process_group()
 
@@ -68,11 +74,14 @@ def test_two_ranks_average_gradients_and_stay_in_sync():
         p.start()
     got = dict()
     for _ in range(2):
-        rank, res, par, gn = out.get(timeout=600)
-        got[rank] = (res, par, gn)
+        rank, res, par, gn, bn_before, bn_after, mean_terms = out.get(timeout=600)
+        got[rank] = (res, par, gn, bn_before, bn_after, mean_terms)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    assert got[0][3] != got[1][3]                                  # per-rank batch statistics (no SyncBN), ...
+    assert got[0][4] == got[1][4] == got[0][3]                     # ... rank 0's buffers everywhere after the broadcast
+    assert got[0][5] == got[1][5] == [0.5, 2.0]                    # sync_dist-style mean over the ranks
     # both ranks hold the same reduced gradient and made the same update
     assert abs(got[0][2] - got[1][2]) <= 1e-6 * got[0][2]
     for k in got[0][1]:

@@ -250,7 +250,7 @@ def test_stage2_mvfex_training_dropin(golden_dir):
 
 def test_three_native_steps_track_the_reference_optimiser():
     """Three consecutive native steps (operand refresh, BatchNorm buffers, AdamW moments, the warm-up rule: update 1 at the
-    full lr, update t >= 2 at lr * t / 500) against the oracle driving torch.optim.AdamW the way Lightning drives it."""
+    full lr, update t >= 2 at lr * (t - 1) / 500) against the oracle driving torch.optim.AdamW the way Lightning drives it."""
     from egorear_amd import configs, synth, train
     from egorear_amd.estimator import EgoPoseFormerMVFEX
     from oracle import egorear_oracle as O
@@ -271,7 +271,10 @@ def test_three_native_steps_track_the_reference_optimiser():
         total, o_total = float(terms.sum()), sum(o_losses.values())
         assert abs(total - o_total) <= 5e-4 * o_total, (t, total, o_total)          # later steps see the earlier updates
         assert abs(tr.opt.grad_norm() - o_norm) <= 2e-3 * o_norm, (t, tr.opt.grad_norm(), o_norm)
-    assert abs(tr.opt.lr_at(2) - 1e-3 * 2 / 500) < 1e-12 and tr.opt.lr_at(1) == 1e-3
+    # update 1 at the full lr, update 2 at 1/500 of it (the hook sees Lightning's pre-increment global_step), full lr from 501 on
+    assert tr.opt.lr_at(1) == 1e-3 and abs(tr.opt.lr_at(2) - 1e-3 / 500) < 1e-12 and abs(tr.opt.lr_at(3) - 2e-3 / 500) < 1e-12
+    assert abs(tr.opt.lr_at(500) - 1e-3 * 499 / 500) < 1e-12 and tr.opt.lr_at(501) == 1e-3 and tr.opt.lr_at(9000) == 1e-3
+    assert abs(ref.opt.param_groups[0]["lr"] - tr.opt.lr_at(4)) < 1e-12           # the oracle's hook after 3 updates = the lr of update 4
     # Adam's first update moves every element by ~lr * sign(g): where g is rounding noise (exactly-zero gradients such as
     # k_proj.bias, weights that only ever see zero inputs) the sign is arbitrary, so compare the bulk, not the maximum
     fr = []

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Launch census of ONE eager forward under rocprofv3 --kernel-trace (run me under rocprofv3; I print nothing useful myself):
+    rocprofv3 --kernel-trace --output-format csv -d gpurun_out/census -- python3 tools/launch_census.py [--batch 64]
+    python tools/launch_census.py --report gpurun_out/census"""
+import argparse, collections, copy, csv, glob, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=64); ap.add_argument("--report", default=""); ap.add_argument("--reps", type=int, default=3)
+a = ap.parse_args()
+if a.report:
+    f = sorted(glob.glob(a.report + "/**/*kernel_trace.csv", recursive=True))[-1]
+    rows = list(csv.DictReader(open(f)))
+    # the forwards are bracketed by marker launches of egr_argmax... no: by count - the script runs warm-up + reps identical forwards;
+    # take the last third of the trace
+    names = [r["Kernel_Name"] for r in rows]
+    per = len(names)
+    # find period: the trace ends with `reps` identical forwards
+    for n in range(20, len(names) // 2):
+        if names[-n:] == names[-2 * n:-n]:
+            per = n; break
+    last = rows[-per:]
+    cnt = collections.Counter(); dur = collections.Counter()
+    for r in last:
+        k = r["Kernel_Name"].replace("void (anonymous namespace)::", "").split("(")[0][:70]
+        cnt[k] += 1; dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    print(f"launches per forward: {per}; kernel time {sum(dur.values()) / 1e3:.3f} ms; span {(int(last[-1]['End_Timestamp']) - int(last[0]['Start_Timestamp'])) / 1e6:.3f} ms")
+    for k, c in sorted(cnt.items(), key=lambda kv: -dur[kv[0]]):
+        print(f"{c:4d}  {dur[k]:9.1f} us  {k}")
+    sys.exit(0)
+import torch
+from egorear_amd import configs, synth
+from egorear_amd.estimator import EgoPoseFormerMVFEX
+net = EgoPoseFormerMVFEX(**copy.deepcopy(configs.pose3d_cfg())).eval(); synth.load_synth(net, 42); net = net.cuda()
+img = synth.synth_images(a.batch, 4, seed=1234).cuda()
+with torch.no_grad():
+    for _ in range(2 + a.reps):
+        net(img); torch.cuda.synchronize()
