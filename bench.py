@@ -20,6 +20,12 @@ Extra objects on the line:
   parity_vs_cpu_oracle — the metric's "MPJPE vs ref" half: the oracle's warm-up forward of that sample checks the HIP
                  path's output on the same frames (arg-max indices equal, largest 3-D joint deviation in cm,
                  MPJPE of both against the seeded synthetic ground truth).
+  ranks        — world size, backend, and one record per rank (device index, PCI address / UUID, host, own frames/s): an N > 1 line
+                 can be checked for one distinct GPU per rank (the run refuses to start otherwise unless EGR_ALLOW_SHARED_GPU=1).
+  configs      — the other single-GPU configurations BASELINE.json lists, timed separately at N = 1 (never part of `value`):
+                 config 2 (two stereo heat-map estimators, batch 32), config 3 (HeatmapMVFEX, batch 32), each with its own
+                 parity object against the CPU oracle on a small sample, and the CPU leg of config 1 (batch 1, two views).
+  roofline_hbm — the HBM-bound kernels of the forward: algorithmic bytes / measured time against 8 TB/s.
   preprocess, train — the SURVEY.md §8(f) legs (raw 872x872 uint8 -> model input; the config-5 optimisation step),
                  timed separately, never part of `value`.  preprocess.from_raw_frames = the whole chain from raw
                  872x872x4-view uint8 frames in HBM (pre-processing + forward of the same B frames).
@@ -59,6 +65,7 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-iters", type=int, default=12)
     ap.add_argument("--no-train", action="store_true", help="skip the training-step leg (config 5)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the config 1-3 legs")
     ap.add_argument("--train-batch", type=int, default=32, help="frames per GPU per optimisation step (config 5: 256 / 8)")
     ap.add_argument("--train-steps", type=int, default=10)
     return ap.parse_args()
@@ -181,6 +188,111 @@ def cpu_train_baseline(batch: int = 4, iters: int = 4):
             "sample": f"{iters} optimisation steps of batch {batch} (train-mode forward, autograd backward, clip, torch AdamW; torch-CPU fp32, {cores} threads), {dt:.1f} s"}
 
 
+HBM_KERNELS = ("egr_maxpool_nhwc_f32", "egr_upsample2x_nhwc_f32", "egr_argmax_rows_f32", "egr_msda_gather_f32", "egr_avgpool_nhwc_f32",
+               "egr_layernorm_f32", "egr_up2_relu_head_f32", "egr_stem_conv7x7_f32")
+
+
+def roofline_hbm(kernels: dict, pre_leg) -> list:
+    """bytes / time of the memory-bound kernels of one forward against the 8 TB/s HBM peak (algorithmic bytes: inputs read once +
+    outputs written once; the gather kernel's figure counts every sampled corner, most of which L2 serves)."""
+    out = []
+    for name in HBM_KERNELS:
+        k = kernels.get(name)
+        if k and k["bytes"] > 0 and k["ms"] > 0:
+            gbs = k["bytes"] / k["ms"] / 1e6
+            e = {"kernel": name, "launches_per_step": k["launches"], "ms_per_step": round(k["ms"], 3), "algorithmic_GBps": round(gbs, 1),
+                 "peak": PEAK_HBM_GBS, "frac": round(gbs / PEAK_HBM_GBS, 4)}
+            if name == "egr_msda_gather_f32":
+                e["note"] = "sampled-corner bytes: a 64x64x128 feature map (2 MB per view) is re-read 60-64 times per frame from L2, so this is an L2 gather rate, not HBM traffic"
+            if name in ("egr_stem_conv7x7_f32", "egr_up2_relu_head_f32"):
+                e["note"] = "matrix-core kernel with a memory-bound output side; its MFMA rate is in kernel_ms / DESIGN.md"
+            out.append(e)
+    if pre_leg:
+        out.append({"kernel": "egr_preprocess_u8_f32", "ms_per_step": pre_leg["ms_per_batch"], "algorithmic_GBps": pre_leg["algorithmic_GBps"],
+                    "peak": PEAK_HBM_GBS, "frac": pre_leg["frac_of_8TBps"]})
+    return out
+
+
+def _gpu_time_ms(fn, warmup: int, iters: int) -> float:
+    import torch
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def config_legs(args, dev, with_cpu: bool):
+    """BASELINE.json configs 2 and 3 on this GPU (batch 32, eager launches, HIP events) and the CPU leg of config 1.  Never part
+    of `value`.  Each GPU leg carries its own parity object: the CPU oracle on a small sample of the same seeded frames."""
+    import torch
+    from egorear_amd import configs, synth
+    from egorear_amd.estimator import EgoPoseFormerHeatmapMVFEX
+    from oracle import egorear_oracle as O
+    B, PB = 32, 2
+    net = EgoPoseFormerHeatmapMVFEX(**copy.deepcopy(configs.heatmap_mvfex_cfg("ego4view_syn"))).eval()
+    synth.load_synth(net, 42)
+    cpu_sd = {k: v.clone() for k, v in net.state_dict().items()} if with_cpu else None
+    net = net.to(dev)
+    img = synth.synth_images(B, 4, seed=1234).to(dev)
+    front, back = net.heatmap_estimator_stereo_front, net.heatmap_estimator_stereo_back
+    img_f, img_b = img[:, 0:2].contiguous(), img[:, 2:4].contiguous()
+    legs = {}
+    with torch.no_grad():
+        ms2 = _gpu_time_ms(lambda: (front(img_f), back(img_b)), 3, 10)
+        ms3 = _gpu_time_ms(lambda: net(img), 3, 10)
+        legs["config2_heatmap_4view"] = {
+            "workload": "ego4view_syn_heatmap_stereo_front + stereo_back: two EgoPoseFormerHeatmap estimators (ResNet18 + FPN + 1x1 head), views 0-1 / 2-3, eval/no_grad",
+            "value": round(B / ms2 * 1e3, 1), "unit": "frames/s", "ms_per_step": round(ms2, 3), "batch": B, "launch": "eager",
+            "algorithmic_gflop_per_frame": 27.27, "path_tflops": round(B / ms2 * 27.27, 2)}
+        legs["config3_heatmap_mvfex"] = {
+            "workload": "ego4view_syn_heatmap_mvfex-n1_jqa: EgoPoseFormerHeatmapMVFEX (2 encoders, init heads, 4 MVFEx/JQA refiners), eval/no_grad",
+            "value": round(B / ms3 * 1e3, 1), "unit": "frames/s", "ms_per_step": round(ms3, 3), "batch": B, "launch": "eager",
+            "algorithmic_gflop_per_frame": 61.11, "path_tflops": round(B / ms3 * 61.11, 2)}
+        if with_cpu:
+            cores = _host_cores()
+            torch.set_num_threads(cores)
+            sample = synth.synth_images(PB, 4, seed=1234)
+            g_f, g_b = front(sample[:, 0:2].contiguous().to(dev)).cpu(), back(sample[:, 2:4].contiguous().to(dev)).cpu()
+            g_hms, _ = net(sample.to(dev))
+            o_f = O.heatmap_forward(cpu_sd, "heatmap_estimator_stereo_front", sample[:, 0:2])
+            o_b = O.heatmap_forward(cpu_sd, "heatmap_estimator_stereo_back", sample[:, 2:4])
+            o_hms, _, _ = O.heatmap_mvfex_forward(cpu_sd, "", sample)
+
+            def am(t):
+                return t.flatten(-2).argmax(-1)
+            legs["config2_heatmap_4view"]["parity_vs_cpu_oracle"] = {
+                "frames": PB, "argmax_equal": bool((am(g_f) == am(o_f)).all() and (am(g_b) == am(o_b)).all()),
+                "argmax_compared": int(am(o_f).numel() + am(o_b).numel()),
+                "max_heatmap_err": float(max((g_f - o_f).abs().max(), (g_b - o_b).abs().max()))}
+            legs["config3_heatmap_mvfex"]["parity_vs_cpu_oracle"] = {
+                "frames": PB, "argmax_equal": bool(all((am(a.cpu()) == am(b)).all() for a, b in zip(g_hms, o_hms))),
+                "argmax_compared": int(sum(am(b).numel() for b in o_hms)),
+                "max_heatmap_err": float(max((a.cpu() - b).abs().max() for a, b in zip(g_hms, o_hms)))}
+            # config 1: the reference's own CPU-runnable case - one stereo estimator, batch 1, two views
+            one = sample[:1, 0:2]
+            O.heatmap_forward(cpu_sd, "heatmap_estimator_stereo_front", one)
+            n_it = 20
+            t0 = time.perf_counter()
+            for _ in range(n_it):
+                O.heatmap_forward(cpu_sd, "heatmap_estimator_stereo_front", one)
+            dt = time.perf_counter() - t0
+            ms1 = _gpu_time_ms(lambda: front(img_f[:1]), 3, 20)
+            legs["config1_heatmap_stereo_front_b1"] = {
+                "workload": "ego4view_syn_heatmap_stereo_front, batch 1, 2 views (13.63 GFLOP per two-view frame)",
+                "cpu_baseline": {"value": round(n_it / dt, 2), "unit": "two-view frames/s", "cores": cores, "kind": "port",
+                                 "sample": f"{n_it} forwards of batch 1 (torch-CPU fp32, {cores} threads), {dt:.2f} s"},
+                "gpu": {"value": round(1e3 / ms1, 1), "unit": "two-view frames/s", "ms_per_step": round(ms1, 3), "launch": "eager"}}
+    del net
+    torch.cuda.empty_cache()
+    return legs
+
+
 def train_leg(args, dev, rank: int, world: int, backend: str):
     """SURVEY.md §8(f) rank 2 / BASELINE.json config 5, timed separately (never part of `value`): one optimisation step =
     training-mode forward + wrapper losses + backward + gradient all-reduce (RCCL, world > 1) + clip + AdamW, all on the
@@ -254,7 +366,9 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    dev_index = local_rank % max(1, torch.cuda.device_count())  # one GPU per rank; ranks only share a device in rehearsals
+    from egorear_amd.dist import check_distinct_devices, claim_device, device_record, gather_rank_records
+    allow_shared = os.environ.get("EGR_ALLOW_SHARED_GPU") == "1"
+    dev_index = claim_device(local_rank, allow_shared)           # one distinct GPU per rank, or the run refuses to start
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     backend = os.environ.get("EGR_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; "gloo" only for rehearsals on one GPU
@@ -301,7 +415,15 @@ def main():
             run = step
 
         from egorear_amd.dist import timed_steps
-        elapsed = timed_steps(run, args.steps, args.warmup, torch.cuda.synchronize, dev if backend == "nccl" else None)
+        own = {}
+        elapsed = timed_steps(run, args.steps, args.warmup, torch.cuda.synchronize, dev if backend == "nccl" else None, detail=own)
+        import socket
+        rec = {"rank": rank, "local_rank": local_rank, "host": socket.gethostname(), **device_record(dev_index),
+               "frames_per_s": round(B * args.steps / own["own_s"], 2)}
+        records = gather_rank_records(rec)                       # collective: every rank takes part
+        ranks_obj = {"world_size": dist.get_world_size() if world > 1 else 1,
+                     "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else "none (single process)",
+                     "distinct_devices": check_distinct_devices(records, allow_shared), "per_rank": records}
 
         # ---- roofline leg: per-launch HIP-event timing of one instrumented (eager) step
         roof = None
@@ -371,6 +493,13 @@ def main():
             del raw_b
         except Exception as exc:  # never at the expense of the main line
             pre_leg["from_raw_frames"] = {"error": f"{type(exc).__name__}: {exc}"}
+    cfg_legs = None
+    if rank == 0 and world == 1 and not args.no_configs:
+        _log("config 2 / 3 legs (+ config 1 on the CPU)")
+        try:
+            cfg_legs = config_legs(args, dev, with_cpu=not args.no_cpu_baseline)
+        except Exception as exc:  # never at the expense of the main line
+            cfg_legs = {"error": f"{type(exc).__name__}: {exc}"}
     train = None
     if not args.no_train:
         _log("training-step leg")
@@ -398,6 +527,9 @@ def main():
             "path_tflops_per_gpu": round(fps / world * GFLOP_PER_FRAME / 1e3, 2),
             "path_frac_of_f32_mfma_peak": round(fps / world * GFLOP_PER_FRAME / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),  # > 1 is possible: most contractions run on the bf16 matrix cores
             "roofline": roof,
+            "roofline_hbm": roofline_hbm(kernels, pre_leg),
+            "ranks": ranks_obj,
+            "configs": cfg_legs,
             "preprocess": pre_leg,
             "train": train,
         }

@@ -27,9 +27,10 @@ def shard_range(n_frames: int, rank: int, world: int) -> Tuple[int, int]:
     return begin, begin + base + (1 if rank < rem else 0)
 
 
-def timed_steps(run: Callable[[], object], steps: int, warmup: int, sync: Callable[[], None], device=None) -> float:
+def timed_steps(run: Callable[[], object], steps: int, warmup: int, sync: Callable[[], None], device=None, detail=None) -> float:
     """W untimed + exactly K timed calls of `run`, bracketed by barrier + device sync on both sides;
-    returns the MAX elapsed seconds over ranks (works without an initialised process group too)."""
+    returns the MAX elapsed seconds over ranks (works without an initialised process group too).  `detail` (a dict) receives
+    "own_s": this rank's own time for its K steps, taken before the closing barrier."""
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     for _ in range(warmup):
         run()
@@ -41,6 +42,8 @@ def timed_steps(run: Callable[[], object], steps: int, warmup: int, sync: Callab
     for _ in range(steps):
         run()
     sync()
+    if detail is not None:
+        detail["own_s"] = time.perf_counter() - t0
     if multi:
         dist.barrier()
     sync()
@@ -147,4 +150,52 @@ class BufferSync:
     def broadcast(self, src: int = 0, force: bool = False) -> None:
         for flat in self.flat.values():
             broadcast_(flat, src, self.group, force=force)
+
+
+def device_record(dev_index: int) -> dict:
+    """What identifies the GPU behind a rank in a bench line: torch's index plus the PCI address / UUID the driver reports."""
+    p = torch.cuda.get_device_properties(dev_index)
+    rec = {"device_index": dev_index, "name": p.name}
+    for key in ("pci_domain_id", "pci_bus_id", "pci_device_id"):
+        if hasattr(p, key):
+            rec[key] = int(getattr(p, key))
+    if hasattr(p, "uuid"):
+        rec["uuid"] = str(p.uuid)
+    return rec
+
+
+def claim_device(local_rank: int, allow_shared: bool = False) -> int:
+    """One distinct GPU per local rank: LOCAL_RANK must name an existing device.  A launcher that starts more ranks than the node
+    has GPUs would otherwise make ranks share a device silently and still report an N-GPU figure; only rehearsals on a one-GPU
+    box may do that, explicitly (`allow_shared`, bench.py: EGR_ALLOW_SHARED_GPU=1)."""
+    n = torch.cuda.device_count()
+    if n <= 0:
+        raise RuntimeError("egorear_amd: no HIP device visible")
+    if local_rank >= n:
+        if not allow_shared:
+            raise RuntimeError(f"egorear_amd: LOCAL_RANK {local_rank} but only {n} GPU(s) visible: ranks would share a device "
+                               "(set EGR_ALLOW_SHARED_GPU=1 for a rehearsal on fewer GPUs)")
+        return local_rank % n
+    return local_rank
+
+
+def gather_rank_records(record: dict, group=None) -> list:
+    """Every rank's record on every rank (a list indexed by rank); one process: [record]."""
+    if world_size(group) <= 1:
+        return [record]
+    out = [None] * world_size(group)
+    dist.all_gather_object(out, record, group=group)
+    return out
+
+
+def check_distinct_devices(records: list, allow_shared: bool = False) -> bool:
+    """True when no two ranks of this node report the same GPU (by PCI address when known, else by index); raises otherwise
+    unless `allow_shared`."""
+    def ident(r):
+        return (r.get("host"), r.get("pci_domain_id"), r.get("pci_bus_id"), r.get("pci_device_id")) if "pci_bus_id" in r else (r.get("host"), r["device_index"])
+    ids = [ident(r) for r in records]
+    distinct = len(set(ids)) == len(ids)
+    if not distinct and not allow_shared:
+        raise RuntimeError(f"egorear_amd: ranks share a GPU: {ids} (EGR_ALLOW_SHARED_GPU=1 allows it for rehearsals)")
+    return distinct
 

@@ -444,7 +444,8 @@ def maxpool(x: Img, k: int, stride: int, pad: int) -> Img:
     ho = (x.h + 2 * pad - k) // stride + 1
     wo = (x.w + 2 * pad - k) // stride + 1
     y = torch.empty((x.n, ho, wo, x.c), device=x.t.device, dtype=torch.float32)
-    _launch("egr_maxpool_nhwc_f32", lib.egr_maxpool_nhwc_f32, _p(x.t), _p(y), x.n, x.h, x.w, x.c, k, stride, pad, _stream())
+    _launch("egr_maxpool_nhwc_f32", lib.egr_maxpool_nhwc_f32, _p(x.t), _p(y), x.n, x.h, x.w, x.c, k, stride, pad, _stream(),
+            nbytes=4.0 * x.n * x.c * (x.h * x.w + ho * wo))
     return Img(y)
 
 
@@ -482,7 +483,8 @@ def avgpool(x: Img) -> torch.Tensor:
     if not x.t.is_contiguous():
         raise RuntimeError("egorear_amd.avgpool: contiguous input expected")
     y = torch.empty((x.n, x.c), device=x.t.device, dtype=torch.float32)
-    _launch("egr_avgpool_nhwc_f32", lib.egr_avgpool_nhwc_f32, _p(x.t), _p(y), x.n, x.h * x.w, x.c, _stream())
+    _launch("egr_avgpool_nhwc_f32", lib.egr_avgpool_nhwc_f32, _p(x.t), _p(y), x.n, x.h * x.w, x.c, _stream(),
+            nbytes=4.0 * x.n * x.c * (x.h * x.w + 1))
     return y
 
 
@@ -497,7 +499,7 @@ def argmax_rows(hm: torch.Tensor, thr: float):
     valid = torch.empty((rows,), device=dev, dtype=torch.uint8)
     index = torch.empty((rows,), device=dev, dtype=torch.int32)
     _launch("egr_argmax_rows_f32", lib.egr_argmax_rows_f32, _p(hm), rows, H, W, float(thr), _p(anchors), _p(maxvals), _p(valid, torch.uint8),
-                                   _p(index, torch.int32), _stream())
+                                   _p(index, torch.int32), _stream(), nbytes=4.0 * hm.numel() + 17.0 * rows)
     return anchors, maxvals, valid, index
 
 
@@ -511,7 +513,7 @@ def layernorm(x: torch.Tensor, gamma, beta, res: Optional[torch.Tensor] = None, 
         raise RuntimeError("egorear_amd.layernorm: gamma/beta/groups mismatch")
     y = torch.empty_like(x)
     _launch("egr_layernorm_f32", lib.egr_layernorm_f32, _p(x), _p(res), _p(gamma), _p(beta), _p(y), rows, c, eps,
-            rows // groups if groups > 1 else 0, _stream())
+            rows // groups if groups > 1 else 0, _stream(), nbytes=4.0 * rows * c * (3 if res is not None else 2))
     return y
 
 
@@ -548,7 +550,10 @@ def msda_gather(feat: torch.Tensor, pos: Optional[torch.Tensor], offs_logits: to
     sigma = torch.empty((groups, heads, rows), device=dev, dtype=torch.float32)
     rowmask = torch.empty((rows,), device=dev, dtype=torch.uint8)
     _launch("egr_msda_gather_f32", lib.egr_msda_gather_f32, _p(feat), cf, _p(pos), dh, _p(offs_logits), _p(anchors), _p(valid, torch.uint8), b, views,
-                                   joints, heads, hgt, wid, _p(g), _p(e), _p(sigma), _p(rowmask, torch.uint8), groups, _stream())
+                                   joints, heads, hgt, wid, _p(g), _p(e), _p(sigma), _p(rowmask, torch.uint8), groups, _stream(),
+            # algorithmic bytes: 16 points x 4 bilinear corners x (cf + dh) floats per (query set, row, head) gathered (served
+            # mostly by L2), the offsets / logits read, g / e / sigma written
+            nbytes=4.0 * groups * rows * heads * (64.0 * (cf + (dh if pos is not None else 0)) + 48 + cf + (dh if pos is not None else 0) + 1))
     return g, e, sigma, rowmask
 
 

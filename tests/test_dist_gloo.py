@@ -207,3 +207,23 @@ def test_two_rank_buffer_broadcast_stage_allreduce_and_metric_mean():
     assert n0 == n1 == sum(v.size for v in mine0.values())
     assert lo0 == hi0 == lo1 == hi1 == 3.0                                 # every element summed exactly once (1 + 2)
     assert mean0 == mean1 == [1.5, 15.0]                                   # sync_dist=True: mean over ranks
+
+
+def test_one_distinct_gpu_per_rank_or_refuse(monkeypatch):
+    """bench.py's N > 1 line must be verifiable: LOCAL_RANK beyond the visible GPUs is refused (it would make ranks share a device
+    silently), duplicates in the gathered per-rank records are refused, and both have an explicit rehearsal override."""
+    import pytest
+    from egorear_amd import dist as D
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    assert [D.claim_device(r) for r in range(4)] == [0, 1, 2, 3]
+    with pytest.raises(RuntimeError, match="share a device"):
+        D.claim_device(4)
+    assert D.claim_device(5, allow_shared=True) == 1
+    recs = [{"host": "n0", "device_index": i, "pci_domain_id": 0, "pci_bus_id": 0x10 + i, "pci_device_id": 0} for i in range(4)]
+    assert D.check_distinct_devices(recs) is True
+    dup = recs[:3] + [dict(recs[0], rank=3)]
+    with pytest.raises(RuntimeError, match="share a GPU"):
+        D.check_distinct_devices(dup)
+    assert D.check_distinct_devices(dup, allow_shared=True) is False
+    assert D.check_distinct_devices([{"host": "n0", "device_index": 0}, {"host": "n0", "device_index": 1}]) is True
+    assert D.gather_rank_records({"rank": 0}) == [{"rank": 0}]            # single process: no collective
