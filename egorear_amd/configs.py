@@ -35,7 +35,8 @@ def heatmap_mvfex_cfg(camera_model: str = "ego4view_syn") -> dict:
     """configs/ego4view_*_heatmap_mvfex-n1_jqa.yaml: model_cfg (inference-relevant keys)."""
     return {"num_views": 4, "image_size": [256, 256], "num_heatmap": 15, "feat_down_stride": 4,
             "heatmap_threshold": 0.5, "camera_model": camera_model, "encoder_cfg": copy.deepcopy(_ENCODER),
-            "mvf_cfg": _mvf_cfg()}
+            "mvf_cfg": _mvf_cfg(),
+            "num_joints": 16, "anchor_2d_update": True}   # in the YAMLs, swallowed by the constructor's **kwargs (SURVEY.md 5)
 
 
 def pose3d_cfg(camera_model: str = "ego4view_syn") -> dict:

@@ -200,6 +200,17 @@ def invalidate(mod: nn.Module):
         GENERATION[0] += 1
 
 
+def as_rgb(img: torch.Tensor) -> torch.Tensor:
+    """(B, V, H, W) grayscale frames -> (B, V, 3, H, W) with the plane repeated, as the reference's trunk does
+    (models/backbones/resnet.py:44-46); 5-D input is returned unchanged."""
+    if img.dim() == 4:
+        B, V, H, W = img.shape
+        return img.unsqueeze(2).expand(B, V, 3, H, W).contiguous()
+    if img.dim() != 5:
+        raise RuntimeError(f"egorear_amd: expected a (B, V, 3, H, W) or (B, V, H, W) image batch, got {tuple(img.shape)}")
+    return img
+
+
 def _check_input(img: torch.Tensor, mod: nn.Module):
     if not img.is_cuda:
         raise RuntimeError("egorear_amd: input is on %s; the hot path runs on a HIP device only (no CPU fallback)" % img.device)
@@ -364,6 +375,7 @@ def _heatmap_core(mod, img):
 
 def heatmap_backbone_api(mod, img):
     _check_input(img, mod)
+    img = as_rgb(img)
     B, V = img.shape[:2]
     _, feat, pyr = _heatmap_core(mod, img)
     return _vb_view(feat, V, B), [_vb_view(p.t, V, B) for p in pyr]
@@ -372,6 +384,7 @@ def heatmap_backbone_api(mod, img):
 def heatmap_forward_api(mod, img, return_feat=False):
     """EgoPoseFormerHeatmap.forward (egoposeformer_heatmap.py:29-44)."""
     _check_input(img, mod)
+    img = as_rgb(img)
     B, V = img.shape[:2]
     st, feat, pyr = _heatmap_core(mod, img)
     H4, W4 = feat.shape[1:3]
@@ -577,6 +590,7 @@ def _mvfex(mod, img: torch.Tensor, heatmap_for_anchor=None):
 def heatmap_mvfex_forward_api(mod, img, heatmap_for_anchor=None):
     """EgoPoseFormerHeatmapMVFEX.forward -> ([hm_init, hm_refined], [feat_init, feat_refined])."""
     _check_input(img, mod)
+    img = as_rgb(img)
     B, V = img.shape[:2]
     hm_init, hm_ref, feat_all, feat_ref, aux = _mvfex(mod, img, heatmap_for_anchor)
     mod.__dict__["_egr_last_aux"] = aux
@@ -675,6 +689,7 @@ def pose3d_forward_api(p3, feat_init, feat_final, ctm=None):
 def mvfex_forward_api(mod, img, ctm=None):
     """EgoPoseFormerMVFEX.forward (egoposeformer_mvf_ex.py:50-59) -> (list_pred_pose3d, list_pred_heatmap)."""
     _check_input(img, mod)
+    img = as_rgb(img)
     B, V = img.shape[:2]
     he = mod.heatmap_estimator
     hm_init, hm_ref, feat_all, feat_ref, aux_h = _mvfex(he, img)

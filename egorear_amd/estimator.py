@@ -7,8 +7,13 @@ attributes read by the wrappers and `state_dict` keys as the reference
 C-ABI library (egorear_amd.hip).  There is no PyTorch/CPU fallback: a missing
 library or a non-GPU tensor raises.
 
-Scope of this round: inference (`torch.no_grad()` / eval).  Training forward+backward
-through the HIP kernels is a SURVEY.md §8(f) "next" row and raises NotImplementedError.
+Modes.  eval(): inference under `torch.no_grad()` (engine.py).  train(): `EgoPoseFormerHeatmap`, `EgoPoseFormerHeatmapMVFEX`
+and `EgoPoseFormerMVFEX` run the training-mode forward on the HIP kernels and return outputs attached to ONE autograd node
+whose backward is the hand-written reverse pass (train.py) - the three stages of the reference's schedule train through their
+unchanged Lightning wrappers.  What is refused, loudly: a module in eval() mode with autograd enabled (the reference would
+differentiate through eval-mode BatchNorm there; no shipped flow does), and the two sub-entry points no shipped wrapper calls
+under autograd: `EgoPoseFormerPose3D.forward` on its own and `EgoPoseFormerHeatmap.forward_backbone` (the parent modules
+train; these two are inference-only, torch.no_grad()).
 """
 from __future__ import annotations
 
@@ -36,8 +41,9 @@ def _no_dynamo(fn):
 def _require_inference(module: nn.Module):
     if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
         raise NotImplementedError(
-            "egorear_amd: only the inference hot path is built (run under torch.no_grad()); "
-            "HIP backward for training is a SURVEY.md §8(f) next row")
+            "egorear_amd: this entry point is inference-only - call it under torch.no_grad() (eval mode), or put the parent "
+            "estimator in train() mode: EgoPoseFormerHeatmap / EgoPoseFormerHeatmapMVFEX / EgoPoseFormerMVFEX train through "
+            "their own forward (egorear_amd.train)")
 
 
 class EgoPoseFormerHeatmap(nn.Module):

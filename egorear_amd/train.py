@@ -1358,6 +1358,8 @@ def mvfex_training_forward(net, img, ctm=None):
     """EgoPoseFormerMVFEX.forward in training mode -> (list_pred_pose3d, list_pred_heatmap) like the reference."""
     from .engine import _check_input, invalidate
     _check_input(img, net)
+    from .engine import as_rgb
+    img = as_rgb(img)                      # (B, V, H, W) grayscale frames: resnet.py:44-46
     for m in (net, net.heatmap_estimator, net.pose3d_estimator):
         invalidate(m)                      # parameters are about to change: drop the inference packs
     params = [p for p in net.parameters()]
@@ -1467,6 +1469,8 @@ class _HeatmapMVFEXTrainFn(torch.autograd.Function):
 def _training_entry(net, img, fn, eager):
     from .engine import _check_input, invalidate
     _check_input(img, net)
+    from .engine import as_rgb
+    img = as_rgb(img)                      # (B, V, H, W) grayscale frames: resnet.py:44-46
     invalidate(net)
     params = [p for p in net.parameters()]
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
