@@ -401,7 +401,12 @@ def heatmap_forward_api(mod, img, return_feat=False):
 
 class PLayer:
     __slots__ = ("offs_logits", "head_w", "head_shift", "head_w_all", "head_shift_all", "pos_proj", "out_proj", "fuse", "ln_cross", "qkv", "mha_out",
-                 "ln_spatial", "ffn0", "ffn1", "ln_ffn", "heads", "dh", "C", "groups")
+                 "ln_spatial", "ffn0", "ffn1", "ln_ffn", "heads", "dh", "C", "groups", "fused", "ol_plain")
+
+
+# One launch per transformer layer behind the sampling (egr_joint_layer_f32) instead of ~14 small ones; EGR_FUSED_LAYER=0 keeps
+# the per-op launches (the training forward always uses those: it needs the intermediates).
+FUSED_LAYER = os.environ.get("EGR_FUSED_LAYER", "1") != "0"
 
 
 def pack_layers(layers, pres, poss) -> PLayer:
@@ -451,7 +456,47 @@ def pack_layers(layers, pres, poss) -> PLayer:
         return (torch.cat([getattr(l, name).weight.detach().float() for l in layers]).contiguous(),
                 torch.cat([getattr(l, name).bias.detach().float() for l in layers]).contiguous())
     P.ln_cross, P.ln_spatial, P.ln_ffn = ln("norm_cross"), ln("norm_spatial"), ln("norm_ffn")
+    # ---- the same parameters as plain (groups, out, in) stacks for the fused layer kernel
+    def stk(ts):
+        return torch.stack([t.detach().float() for t in ts]).contiguous()
+    wf, cf_ = [], []
+    for layer, (pre_w, pre_b), _ in zip(layers, pres, poss):
+        ca = layer.cross_attn
+        Wv, bv = ca.value_proj.weight.detach().double(), ca.value_proj.bias.detach().double()
+        Wp, bp = pre_w.detach().double().reshape(pre_w.shape[0], -1), pre_b.detach().double()
+        wf.append((Wv @ Wp).float())
+        cf_.append((Wv @ bp + bv).float())
+    sas_ = [l.spatial_attn for l in layers]
+    P.fused = {
+        "w_fold": stk(wf), "c_fold": stk(cf_),
+        "w_out": stk([c.output_proj.weight for c in cas]), "b_out": stk([c.output_proj.bias for c in cas]),
+        "w_fuse": stk([l.fuse_mlp.weight for l in layers]), "b_fuse": stk([l.fuse_mlp.bias for l in layers]),
+        "ln1_g": P.ln_cross[0], "ln1_b": P.ln_cross[1],
+        "w_qkv": stk([torch.cat([s_.q_proj.weight, s_.k_proj.weight, s_.v_proj.weight], 0) for s_ in sas_]),
+        "b_qkv": stk([torch.cat([s_.q_proj.bias, s_.k_proj.bias, s_.v_proj.bias], 0) for s_ in sas_]),
+        "w_mo": stk([s_.out_proj.weight for s_ in sas_]), "b_mo": stk([s_.out_proj.bias for s_ in sas_]),
+        "ln2_g": P.ln_spatial[0], "ln2_b": P.ln_spatial[1],
+        "w_f0": stk([l.ffn.layers[0][0].weight for l in layers]), "b_f0": stk([l.ffn.layers[0][0].bias for l in layers]),
+        "w_f1": stk([l.ffn.layers[1].weight for l in layers]), "b_f1": stk([l.ffn.layers[1].bias for l in layers]),
+        "ln3_g": P.ln_ffn[0], "ln3_b": P.ln_ffn[1],
+    }
+    P.ol_plain = {"w": stk([torch.cat([c.sampling_offsets.weight, c.attention_weights.weight], 0) for c in cas]),
+                  "b": stk([torch.cat([c.sampling_offsets.bias, c.attention_weights.bias], 0) for c in cas])}
     return P
+
+
+def run_layer_fused(st: State, P: PLayer, x: torch.Tensor, memory: torch.Tensor, anchors: torch.Tensor, valid: torch.Tensor,
+                    B: int, V: int, J: int, hgt: int, wid: int, ol: Optional[torch.Tensor] = None, next_P: Optional[PLayer] = None,
+                    post=None, reg=None, want_xn: bool = False):
+    """run_layer as TWO launches: the sampling (egr_msda_gather_f32) and everything behind it (egr_joint_layer_f32), optionally
+    with the next layer's offsets / logits, post_norm and the regression head as tails.  `ol`: this layer's offsets / logits if a
+    previous fused layer already produced them.  Returns (x, ol_next | None, xn | None, pred | None)."""
+    G, C, heads, dh = P.groups, P.C, P.heads, P.dh
+    if ol is None:
+        ol = linear(st, x, P.offs_logits)
+    g, e, sigma, rowmask = hip.msda_gather(memory, P.pos_proj, ol, anchors, valid, B, V, J, heads, dh, hgt, wid, groups=G)
+    return hip.joint_layer(x, g, e, sigma, rowmask, P.fused, B, J, V, C, G, ol=next_P.ol_plain if next_P is not None else None,
+                           post=post, reg=reg, want_xn=want_xn)
 
 
 def run_layer(st: State, P: PLayer, x: torch.Tensor, memory: torch.Tensor, anchors: torch.Tensor, valid: torch.Tensor,
@@ -534,9 +579,13 @@ def _run_refiners(st: State, rs, B: int, V: int, hm_init: torch.Tensor, feat_all
     # --- own-view feature projection: group g reads feat_all[g*B:(g+1)*B]
     ff = run_stack(st, [r.frame_feat_proj_layers for r in rs], Img(feat_all))  # (G*B, 32, 32, 128)
     # --- transformer layer over the 4-view memory (sampled un-projected, see pack_layers)
-    x = run_layer(st, P.layer, x, feat_all.view(V, B, hw, feat_all.shape[-1]), anchors, valid, B, V, J, hgt, wid)
     # --- head: LN -> (B, J, 16, 16) image with joints as channels -> 1x1 15->64, up x2, 1x1 64->128 (+ frame_feat)
-    xn = hip.layernorm(x, P.post_norm[0], P.post_norm[1], groups=G)
+    if FUSED_LAYER:
+        _, _, xn, _ = run_layer_fused(st, P.layer, x, feat_all.view(V, B, hw, feat_all.shape[-1]), anchors, valid, B, V, J, hgt, wid,
+                                      post={"g": P.post_norm[0], "b": P.post_norm[1]}, want_xn=True)
+    else:
+        x = run_layer(st, P.layer, x, feat_all.view(V, B, hw, feat_all.shape[-1]), anchors, valid, B, V, J, hgt, wid)
+        xn = hip.layernorm(x, P.post_norm[0], P.post_norm[1], groups=G)
     side = int(math.isqrt(C))
     tok = hip.tokens_to_nhwc(xn, G * B, J, C)                                # (G*B, 256, J)
     h0 = hip.linear_smallk(tok, J, 1, P.head0_w, P.head0_b, G * B * C, P.head0_w.shape[1], J, ACT_RELU, groups=G)
@@ -600,7 +649,7 @@ def heatmap_mvfex_forward_api(mod, img, heatmap_for_anchor=None):
 # --------------------------------------------------------------------------- EgoPoseFormerPose3D (a20-a24)
 
 class PPose:
-    __slots__ = ("mlp0", "mlp1", "mlp2", "qg0_w", "qg0_b", "qg2", "qg4", "layers", "post", "reg0", "reg2", "cams")
+    __slots__ = ("mlp0", "mlp1", "mlp2", "qg0_w", "qg0_b", "qg2", "qg4", "layers", "post", "reg0", "reg2", "cams", "reg_plain")
 
 
 def _pack_pose3d(p3) -> PPose:
@@ -624,6 +673,7 @@ def _pack_pose3d(p3) -> PPose:
     P.post = [(f32(n.weight), f32(n.bias)) for n in p3.post_norm]
     P.reg0 = [pack_linear_mods([r[0]]) for r in p3.reg_mlp]
     P.reg2 = [pack_linear_mods([r[2]]) for r in p3.reg_mlp]
+    P.reg_plain = [(f32(r[0].weight), f32(r[0].bias), f32(r[2].weight), f32(r[2].bias)) for r in p3.reg_mlp]
     rec = np.stack([c.packed() for c in p3.cameras()])
     P.cams = torch.from_numpy(rec).to(w0.device)
     return P
@@ -658,11 +708,19 @@ def _pose3d(p3, st: State, feat_init: torch.Tensor, feat_final: torch.Tensor, B:
     memory = src.view(V, B, hgt * wid, src.shape[-1])
     preds = [mlp_pred]
     a3 = anchors_3d.view(B * J, 3)
+    ol = None
     for i, L in enumerate(P.layers):
-        x = run_layer(st, L, x, memory, anchors_2d, valid, B, V, J, hgt, wid)
-        xn = hip.layernorm(x, P.post[i][0], P.post[i][1])
-        r = linear(st, xn, P.reg0[i], ACT_GELU)
-        pred = linear(st, r, P.reg2[i], res=_rows(a3), res_mode=RES_AFTER_ACT)   # offset + init_anchors_3d
+        if FUSED_LAYER:
+            nxt = P.layers[i + 1] if i + 1 < len(P.layers) else None
+            x, ol, _, pred = run_layer_fused(st, L, x, memory, anchors_2d, valid, B, V, J, hgt, wid, ol=ol, next_P=nxt,
+                                             post={"g": P.post[i][0], "b": P.post[i][1]},
+                                             reg={"w0": P.reg_plain[i][0], "b0": P.reg_plain[i][1], "w2": P.reg_plain[i][2],
+                                                  "b2": P.reg_plain[i][3], "anchors": a3})
+        else:
+            x = run_layer(st, L, x, memory, anchors_2d, valid, B, V, J, hgt, wid)
+            xn = hip.layernorm(x, P.post[i][0], P.post[i][1])
+            r = linear(st, xn, P.reg0[i], ACT_GELU)
+            pred = linear(st, r, P.reg2[i], res=_rows(a3), res_mode=RES_AFTER_ACT)   # offset + init_anchors_3d
         preds.append(pred.view(B, J, 3))
     aux = {"anchors_2d": anchors_2d, "anchors_valid": valid, "anchors_3d_after": anchors_3d}
     return preds, aux

@@ -24,7 +24,7 @@ EXPORTS = [
     "egr_avgpool_nhwc_f32", "egr_argmax_rows_f32", "egr_layernorm_f32", "egr_joint_mha_f32", "egr_msda_gather_f32",
     "egr_fisheye_project_f32", "egr_linear_smallk_f32", "egr_jqa_sum_f32", "egr_tokens_to_nhwc_f32", "egr_version",
     "egr_device_arch", "egr_conv_force_config", "egr_preprocess_u8_f32", "egr_pose_metrics_f32", "egr_gt_heatmap_f32", "egr_conv_debug_stamps", "egr_conv2d_wgrad_f32", "egr_conv2d_masked_f32", "egr_up2_relu_head_f32",
-    "egr_msda_fwd_f32", "egr_msda_bwd_f32", "egr_w6_elems", "egr_pack_w6_f32", "egr_pack_w6_many_f32",
+    "egr_msda_fwd_f32", "egr_msda_bwd_f32", "egr_w6_elems", "egr_pack_w6_f32", "egr_pack_w6_many_f32", "egr_joint_layer_f32",
 ]
 
 
@@ -44,6 +44,19 @@ class ConvDesc(C.Structure):
         ("grs", C.c_int64), ("grm", C.c_int64),
         ("transposed", C.c_int32), ("w_format", C.c_int32),
     ]
+
+
+class LayerDesc(C.Structure):
+    """egr_layer_desc of include/egorear_hip.h (field for field)."""
+    _P = C.c_void_p
+    _fields_ = ([(n, C.c_int32) for n in ("B", "J", "V", "C", "heads", "cf", "groups", "ffn_dim")] +
+                [("eps", C.c_float), ("mha_scale", C.c_float)] +
+                [(n, C.c_void_p) for n in ("x", "g", "e", "sigma", "rowmask",
+                                           "w_fold", "c_fold", "w_out", "b_out", "w_fuse", "b_fuse", "ln1_g", "ln1_b",
+                                           "w_qkv", "b_qkv", "w_mo", "b_mo", "ln2_g", "ln2_b", "w_f0", "b_f0", "w_f1", "b_f1", "ln3_g", "ln3_b",
+                                           "x_out", "w_ol", "b_ol", "ol_out")] +
+                [("ol_n", C.c_int32), ("reserved", C.c_int32)] +
+                [(n, C.c_void_p) for n in ("lnp_g", "lnp_b", "xn_out", "w_r0", "b_r0", "w_r2", "b_r2", "anchors3d", "pred_out")])
 
 
 def _load() -> C.CDLL:
@@ -80,6 +93,7 @@ def _load() -> C.CDLL:
     lib.egr_w6_elems.argtypes = [i32, i32]
     lib.egr_msda_fwd_f32.argtypes = [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp, vp]
     lib.egr_msda_bwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp, vp, vp, vp]
+    lib.egr_joint_layer_f32.argtypes = [C.POINTER(LayerDesc), vp]
     lib.egr_preprocess_u8_f32.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     for name in EXPORTS:
         getattr(lib, name)  # fail at import if a symbol is missing
@@ -605,3 +619,61 @@ def tokens_to_nhwc(x: torch.Tensor, b: int, j: int, hw: int) -> torch.Tensor:
     y = torch.empty((b, hw, j), device=x.device, dtype=torch.float32)
     _launch("egr_tokens_to_nhwc_f32", lib.egr_tokens_to_nhwc_f32, _p(x), _p(y), b, j, hw, _stream())
     return y
+
+
+def joint_layer(x: torch.Tensor, g: torch.Tensor, e: Optional[torch.Tensor], sigma: torch.Tensor, rowmask: torch.Tensor, W: dict,
+                B: int, J: int, V: int, Cdim: int, groups: int, *, ol: Optional[dict] = None, post: Optional[dict] = None,
+                reg: Optional[dict] = None, want_xn: bool = False):
+    """One transformer layer behind egr_msda_gather_f32 as one launch (egr_joint_layer_f32).  W: the layer's plain weight stacks
+    (engine.pack_layer_fused).  ol = {"w", "b"}: also the next layer's offsets / logits; post = {"g", "b"}: also post_norm
+    (want_xn: return it); reg = {"w0", "b0", "w2", "b2", "anchors"}: also the 3-D regression head.
+    Returns (x_out, ol_out | None, xn | None, pred | None)."""
+    rows = groups * B * J
+    if x.shape != (rows, Cdim) or not x.is_contiguous():
+        raise RuntimeError("egorear_amd.joint_layer: x must be (groups*B*J, C) contiguous")
+    if g.numel() != groups * B * J * V * 4 * 128 or sigma.numel() != groups * 4 * B * J * V or rowmask.numel() != B * J * V:
+        raise RuntimeError("egorear_amd.joint_layer: sampled operands do not match (B, J, V)")
+    if e is not None and e.numel() != groups * B * J * V * Cdim:
+        raise RuntimeError("egorear_amd.joint_layer: e does not match")
+    need = {"w_fold": groups * Cdim * 128, "c_fold": groups * Cdim, "w_out": groups * Cdim * Cdim, "b_out": groups * Cdim,
+            "w_fuse": groups * Cdim * V * Cdim, "b_fuse": groups * Cdim, "ln1_g": groups * Cdim, "ln1_b": groups * Cdim,
+            "w_qkv": groups * 3 * Cdim * Cdim, "b_qkv": groups * 3 * Cdim, "w_mo": groups * Cdim * Cdim, "b_mo": groups * Cdim,
+            "ln2_g": groups * Cdim, "ln2_b": groups * Cdim, "w_f0": groups * 512 * Cdim, "b_f0": groups * 512,
+            "w_f1": groups * Cdim * 512, "b_f1": groups * Cdim, "ln3_g": groups * Cdim, "ln3_b": groups * Cdim}
+    d = LayerDesc()
+    d.B, d.J, d.V, d.C, d.heads, d.cf, d.groups, d.ffn_dim = B, J, V, Cdim, 4, 128, groups, 512
+    d.eps, d.mha_scale = 1e-5, float((Cdim // 4) ** -0.5)
+    d.x, d.g, d.e, d.sigma, d.rowmask = _p(x), _p(_cont(g, "g")), _p(e), _p(_cont(sigma, "sigma")), _p(rowmask, torch.uint8)
+    for k, n in need.items():
+        t = W[k]
+        if t.numel() != n or not t.is_contiguous():
+            raise RuntimeError(f"egorear_amd.joint_layer: weight {k} has {t.numel()} elements, expected {n}")
+        setattr(d, k, _p(t))
+    x_out = torch.empty_like(x)
+    d.x_out = _p(x_out)
+    ol_out = xn = pred = None
+    if ol is not None:
+        n = ol["w"].shape[-2]
+        if ol["w"].numel() != groups * n * Cdim or ol["b"].numel() != groups * n or n % 16:
+            raise RuntimeError("egorear_amd.joint_layer: offsets / logits weights do not match")
+        ol_out = torch.empty((rows, n), device=x.device, dtype=torch.float32)
+        d.w_ol, d.b_ol, d.ol_out, d.ol_n = _p(_cont(ol["w"], "w_ol")), _p(ol["b"]), _p(ol_out), n
+    if post is not None:
+        if post["g"].numel() != groups * Cdim or post["b"].numel() != groups * Cdim:
+            raise RuntimeError("egorear_amd.joint_layer: post_norm parameters do not match")
+        d.lnp_g, d.lnp_b = _p(post["g"]), _p(post["b"])
+        if want_xn:
+            xn = torch.empty_like(x)
+            d.xn_out = _p(xn)
+    if reg is not None:
+        if post is None:
+            raise RuntimeError("egorear_amd.joint_layer: the regression head sits behind post_norm")
+        if reg["w0"].numel() != groups * Cdim * Cdim or reg["w2"].numel() != groups * 3 * Cdim or reg["anchors"].numel() != rows * 3:
+            raise RuntimeError("egorear_amd.joint_layer: regression head operands do not match")
+        pred = torch.empty((rows, 3), device=x.device, dtype=torch.float32)
+        d.w_r0, d.b_r0, d.w_r2, d.b_r2 = _p(_cont(reg["w0"], "w_r0")), _p(reg["b0"]), _p(_cont(reg["w2"], "w_r2")), _p(reg["b2"])
+        d.anchors3d, d.pred_out = _p(_cont(reg["anchors"], "anchors")), _p(pred)
+    flops = 2.0 * groups * B * (J * V * (Cdim * 128 + Cdim * Cdim) + J * (V * Cdim * Cdim + 3 * Cdim * Cdim + Cdim * Cdim + 2 * 512 * Cdim))
+    _launch("egr_joint_layer_f32", lib.egr_joint_layer_f32, C.byref(d), _stream(), flops=flops)
+    return x_out, ol_out, xn, pred
+

@@ -211,6 +211,42 @@ int egr_msda_gather_f32(const float* feat /* (views, b, hgt*wid, cf) */, int32_t
                         int32_t groups /* query sets sharing feat/anchors/valid: pos, offs_logits, g, e, sigma are [groups][...] */,
                         void* stream);
 
+/*
+ * One joint-query transformer layer behind its deformable sampling, as ONE launch (egr_layer.hip).  Replaces, per layer of
+ * MultiViewTransformerLayer (egoposeformer_heatmap_mvf_ex.py:874-935) / EgoPoseFormerTransformerLayer
+ * (egoposeformer_mvf_ex.py:546-588): MSDeformAttn's value / output projections on the sampled rows
+ * (models/utils/deform_attn.py:122-168, sample-then-project form) with masked_fill(~valid), the concatenation over views +
+ * fuse_mlp + residual + norm_cross, SpatialMHA (q/k/v/out projections and the softmax core, models/utils/transformer.py:36-93)
+ * + residual + norm_spatial, FFN (transformer.py:8-33, exact-erf GELU) + residual + norm_ffn.  Optional tails: the NEXT layer's
+ * sampling_offsets / attention_weights Linear on the new tokens, post_norm (heatmap_mvf_ex.py:707 / mvf_ex.py:411), and the
+ * 3-D regression head reg_mlp + init anchors (mvf_ex.py:255-262, 412-418).
+ * Operands: every weight is a plain row-major (groups, out, in) fp32 stack in the reference's Linear layout, biases / affine
+ * parameters (groups, out).  g / e / sigma / rowmask are egr_msda_gather_f32's outputs; x the layer input (groups*b*joints, c).
+ *   w_fold (groups, c, cf) = value_proj.weight . W_pre   (W_pre: the 1x1 conv in front of the attention), rows in head order
+ *   c_fold (groups, c)     = value_proj.weight . b_pre + value_proj.bias       (scaled by sigma per row: zero padding)
+ * Limits: views = 4, heads = 4, cf = 128, ffn_dim = 512, c in {128, 256}, joints <= 16; 16-byte aligned weights.
+ */
+typedef struct egr_layer_desc {
+    int32_t B, J, V, C, heads, cf, groups, ffn_dim;
+    float eps, mha_scale;                              /* LayerNorm eps (1e-5); softmax scale = (c / heads)^-1/2 */
+    const float *x, *g, *e /* or NULL */, *sigma;
+    const uint8_t* rowmask;
+    const float *w_fold, *c_fold, *w_out, *b_out, *w_fuse, *b_fuse, *ln1_g, *ln1_b;
+    const float *w_qkv, *b_qkv, *w_mo, *b_mo, *ln2_g, *ln2_b, *w_f0, *b_f0, *w_f1, *b_f1, *ln3_g, *ln3_b;
+    float* x_out;                                      /* (groups*b*joints, c) */
+    /* tail: next layer's offsets / logits (NULL = off): ol_out (groups*b*joints, ol_n), ol_n % 16 == 0 */
+    const float *w_ol, *b_ol;
+    float* ol_out;
+    int32_t ol_n, reserved;
+    /* tail: post_norm (lnp_g NULL = off) -> xn_out (or NULL); with it the regression head: w_r0 (groups, c, c), w_r2 (groups, 3, c),
+     * pred_out (groups*b*joints, 3) = reg(xn) + anchors3d */
+    const float *lnp_g, *lnp_b;
+    float* xn_out;
+    const float *w_r0, *b_r0, *w_r2, *b_r2, *anchors3d;
+    float* pred_out;
+} egr_layer_desc;
+int egr_joint_layer_f32(const egr_layer_desc* d, void* stream);
+
 /* utils/camera_models.py:53-104 + egoposeformer_mvf_ex.py:340-348,400-406: project the (b, joints, 3) proposals
  * into the four fisheye cameras.  cams: 4 records [npoly, cx, cy, W, H, poly[12]] (fp32).  syn mode
  * (ctm == NULL) reproduces the reference's in-place offset chain: `pts` is updated in place to the

@@ -327,3 +327,30 @@ def test_grayscale_input_is_repeated_to_three_channels(nets):
     assert a.shape == (2, 2, 15, 64, 64) and torch.equal(a, b)
     with torch.no_grad(), pytest.raises(RuntimeError, match="image batch"):
         net(gray[0])
+
+
+def test_fused_transformer_layer_matches_the_per_op_launches(nets):
+    """egr_joint_layer_f32 (one launch per layer behind the sampling, with the next layer's offsets / post_norm / regression head
+    as tails) against the per-op launches it replaces: same arithmetic up to the order of the fp32 sums."""
+    from egorear_amd import engine, synth
+    for cam in ("syn", "rw"):
+        net = nets(cam)
+        img = synth.synth_images(3, 4, seed=41).to(DEV)
+        ctm = synth.synth_coord_trans_mat(3).to(DEV) if cam == "rw" else None
+        saved = engine.FUSED_LAYER
+        try:
+            with torch.no_grad():
+                engine.FUSED_LAYER = True
+                p1, h1 = net(img, ctm)
+                aux1 = net.__dict__["_egr_last_aux"]["heatmap"]["argmax_idx"].clone()
+                engine.FUSED_LAYER = False
+                p0, h0 = net(img, ctm)
+                aux0 = net.__dict__["_egr_last_aux"]["heatmap"]["argmax_idx"]
+        finally:
+            engine.FUSED_LAYER = saved
+        assert torch.equal(aux0, aux1)
+        assert torch.equal(h0[0], h1[0])                                   # the initial heat maps do not involve the layer
+        assert float((h0[1] - h1[1]).abs().max()) < 2e-5
+        assert torch.equal(h0[1].flatten(-2).argmax(-1), h1[1].flatten(-2).argmax(-1))
+        for a, b in zip(p0, p1):
+            assert float((a - b).abs().max()) < 2e-4                       # cm
