@@ -33,29 +33,42 @@ constexpr int PAD = 4;   // LDS row padding (floats)
 
 __device__ __forceinline__ float gelu_erf(float t) { return 0.5f * t * (1.0f + erff(t * 0.70710678118654752440f)); }
 
-// acc[rb] (+)= A[rb*16 .. +16][0..K) . W[nb*16 .. +16][0..K)^T for NSEG (A, W) segment pairs: A segment s starts at A + s*a_seg
-// (row stride lda), W segment s at W + s*w_seg (row stride ldw).  K % 128 == 0.
-template <int RB, int NSEG>
-__device__ __forceinline__ void mfma_block(f32x4_t (&acc)[RB], const float* __restrict__ A, int lda, int a_seg, const float* __restrict__ W, int ldw,
-                                           int w_seg, int K, int nb, int lane) {
+// Column blocks nb = nb0, nb0 + nstep, ... < nb1 of  out[rb*16 .. +16][nb*16 .. +16] = A . W^T, as ONE software pipeline over
+// the flattened (column block, 128-deep chunk) sequence: the weights of step s+1 are requested before the MFMAs of step s, also
+// across column blocks, so a weight fetch is exposed once per call, not once per block.  NSEG (A, W) segment pairs of depth K
+// each: A segment s starts at A + s*a_seg (row stride lda), W segment s at W + s*w_seg (row stride ldw); K % 128 == 0.
+// epi(nb, acc) consumes a finished block.
+template <int RB, int NSEG, typename Epi>
+__device__ __forceinline__ void gemm_cols(const float* __restrict__ A, int lda, int a_seg, const float* __restrict__ W, int ldw, int w_seg, int K,
+                                          int nb0, int nstep, int nb1, int lane, Epi&& epi) {
     const int i = lane & 15, q = lane >> 4;
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const float* wrow = W + (int64_t)(nb * 16 + i) * ldw + 4 * q;
-    const float* arow = A + i * lda + 4 * q;
     constexpr int CH = 8;      // 16-deep k blocks per chunk (128 k)
-    const int chunks = NSEG * (K / (16 * CH));
-    const int cps = K / (16 * CH);   // chunks per segment
-    auto wptr = [&](int c) { return wrow + (c / cps) * w_seg + (c % cps) * (16 * CH); };
-    auto aptr = [&](int c) { return arow + (c / cps) * a_seg + (c % cps) * (16 * CH); };
+    const int cps = K / (16 * CH);          // chunks per segment
+    const int cpb = NSEG * cps;             // chunks per column block
+    const int nblk = (nb1 - nb0 + nstep - 1) / nstep;
+    if (nblk <= 0) return;
+    const int steps = nblk * cpb;
+    const float* const arow = A + i * lda + 4 * q;
+    const float* const wbase = W + (int64_t)i * ldw + 4 * q;
     f32x4_t b0[CH], b1[CH];
-    auto load = [&](f32x4_t (&b)[CH], int c) {
-        const float* p = wptr(c);
+    f32x4_t acc[RB];
+    // step -> (block ordinal, chunk in block), advanced incrementally
+    int l_blk = 0, l_c = 0;                 // position of the next LOAD
+    auto load = [&](f32x4_t (&b)[CH]) {
+        const int seg = l_c / cps, cc = l_c - seg * cps;
+        const float* p = wbase + (int64_t)((nb0 + l_blk * nstep) * 16) * ldw + seg * w_seg + cc * (16 * CH);
 #pragma unroll
         for (int u = 0; u < CH; ++u) b[u] = *reinterpret_cast<const f32x4_t*>(p + 16 * u);
+        if (++l_c == cpb) { l_c = 0; ++l_blk; }
     };
-    auto compute = [&](const f32x4_t (&b)[CH], int c) {
-        const float* p = aptr(c);
+    int c_blk = 0, c_c = 0;                 // position of the next COMPUTE
+    auto compute = [&](const f32x4_t (&b)[CH]) {
+        if (c_c == 0) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+        const int seg = c_c / cps, cc = c_c - seg * cps;
+        const float* p = arow + seg * a_seg + cc * (16 * CH);
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
 #pragma unroll
@@ -65,23 +78,28 @@ __device__ __forceinline__ void mfma_block(f32x4_t (&acc)[RB], const float* __re
                 for (int t = 0; t < 4; ++t) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t], b[u][t], acc[rb], 0, 0, 0);
             }
         }
+        if (++c_c == cpb) {
+            epi(nb0 + c_blk * nstep, acc);
+            c_c = 0;
+            ++c_blk;
+        }
     };
-    load(b0, 0);
-    for (int c = 0; c < chunks; c += 2) {
-        if (c + 1 < chunks) load(b1, c + 1);
-        compute(b0, c);
-        if (c + 2 < chunks) load(b0, c + 2);
-        if (c + 1 < chunks) compute(b1, c + 1);
+    load(b0);
+    for (int s = 0; s < steps; s += 2) {
+        if (s + 1 < steps) load(b1);
+        compute(b0);
+        if (s + 2 < steps) load(b0);
+        if (s + 1 < steps) compute(b1);
     }
 }
 
-// rows [r0, r0 + 4) of a 16-row tile: y = LayerNorm(t [+ res]) * gamma + beta, lane -> channels i*64 + lane (layernorm_kernel)
-template <int VPL>
+// rows of a 16-row tile owned by this wave: y = LayerNorm(t [+ res]) * gamma + beta, lane -> channels i*64 + lane (layernorm_kernel)
+template <int VPL, int NW>
 __device__ __forceinline__ void ln_rows(const float* t, int ldt, const float* res, int ldr, const float* gamma, const float* beta, float eps,
                                         float* y, int ldy, int wave, int lane) {
     constexpr int c = VPL * 64;
-    for (int rr = 0; rr < 4; ++rr) {
-        const int row = wave * 4 + rr;
+    for (int rr = 0; rr < 16 / NW; ++rr) {
+        const int row = wave * (16 / NW) + rr;
         float v[VPL];
         float s = 0.f;
 #pragma unroll
@@ -108,20 +126,33 @@ __device__ __forceinline__ void ln_rows(const float* t, int ldt, const float* re
     }
 }
 
+constexpr int NW = 8;            // waves per workgroup (two per SIMD: one's weight fetches hide under the other's MFMAs)
+constexpr int NTH = NW * 64;
+
 template <int C>
-__global__ __launch_bounds__(256) void joint_layer_kernel(const LayerArgs a) {
+struct LayerLds {
+    static constexpr int HEADS = 4, DH = C / HEADS, CF = 128, FF = 512;
+    static constexpr int LC = C + PAD, LG = CF + PAD, LQ = 3 * C + PAD, LF = FF + PAD;
+    static constexpr int T = 16 * LC;                         // one 16-row tile of C-wide activations
+    static constexpr int PW = (NW * 16 < C) ? NW * 16 : C;    // output columns of one value-projection pass
+    static constexpr int HPP = PW / DH;                       // heads staged per pass
+    static constexpr int BUFA = 2 * T;                        // a_half (32 rows) | later tile0 / tile1
+    static constexpr int M1 = 64 * LC, M2 = 16 * LQ, M3 = 16 * LF;
+    static constexpr int BUFO = (M1 > M2 ? (M1 > M3 ? M1 : M3) : (M2 > M3 ? M2 : M3));
+    static constexpr int BUFG = (HPP * 32 * LG > T ? HPP * 32 * LG : T);
+    static constexpr size_t BYTES = sizeof(float) * (size_t)(BUFA + BUFO + BUFG);
+};
+
+template <int C>
+__global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
     const egr_layer_desc& d = a.d;
-    constexpr int HEADS = 4, DH = C / HEADS, CF = 128, FF = 512, VPL = C / 64;
-    constexpr int LC = C + PAD, LG = CF + PAD, LQ = 3 * C + PAD, LF = FF + PAD;
-    constexpr int T = 16 * LC;                         // one 16-row tile of C-wide activations
-    constexpr int HPP = 64 / DH;                       // heads staged per 64-column pass of the value projection
-    constexpr int BUFA = 2 * T;                        // a_half (32 rows) | later tile0 / tile1
-    constexpr int BUFO = (64 * LC > 16 * LQ ? (64 * LC > 16 * LF ? 64 * LC : 16 * LF) : (16 * LQ > 16 * LF ? 16 * LQ : 16 * LF));
-    constexpr int BUFG = (HPP * 32 * LG > T ? HPP * 32 * LG : T);
+    using L = LayerLds<C>;
+    constexpr int HEADS = L::HEADS, DH = L::DH, CF = L::CF, FF = L::FF, VPL = C / 64;
+    constexpr int LC = L::LC, LG = L::LG, LQ = L::LQ, LF = L::LF, T = L::T, PW = L::PW, HPP = L::HPP;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const bufA = lds;
-    float* const bufO = bufA + BUFA;
-    float* const bufG = bufO + BUFO;
+    float* const bufO = bufA + L::BUFA;
+    float* const bufG = bufO + L::BUFO;
     float* const tile0 = bufA;
     float* const tile1 = bufA + T;
 
@@ -164,11 +195,24 @@ __global__ __launch_bounds__(256) void joint_layer_kernel(const LayerArgs a) {
     const float* const w_f1 = d.w_f1 + (int64_t)grp * C * FF;
     const float* const b_f1 = d.b_f1 + grp * C;
 
+    // plain "Linear on a 16-row tile": out[16][ldo] = act(A . W^T + bias)
+    auto linear16 = [&](const float* A, int lda, const float* W, int K, const float* bias, int N, float* out, int ldo, bool gelu) {
+        gemm_cols<1, 1>(A, lda, 0, W, K, 0, K, wave, NW, N / 16, lane, [&](int nb, const f32x4_t (&acc)[1]) {
+            const int col = nb * 16 + i16;
+            const float bb = bias[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[0][r] + bb;
+                out[(4 * q4 + r) * ldo + col] = gelu ? gelu_erf(v) : v;
+            }
+        });
+    };
+
     // ---- value projection of the sampled rows (sample-then-project) + output_proj, in two 32-row halves
     for (int hf = 0; hf < 2; ++hf) {
-        for (int ps = 0; ps < C / 64; ++ps) {          // 64 output columns per pass: one 16-column block per wave
+        for (int ps = 0; ps < C / PW; ++ps) {          // PW output columns per pass: one 16-column block per wave
             // stage the sampled features of the heads behind these columns: bufG[hp][32][LG]
-            for (int idx = tid; idx < HPP * 32 * (CF / 4); idx += 256) {
+            for (int idx = tid; idx < HPP * 32 * (CF / 4); idx += NTH) {
                 const int cq = idx % (CF / 4), r = (idx / (CF / 4)) % 32, hp = idx / (32 * (CF / 4));
                 const int rl = hf * 32 + r, h = ps * HPP + hp;
                 f32x4_t v = {0.f, 0.f, 0.f, 0.f};
@@ -176,32 +220,30 @@ __global__ __launch_bounds__(256) void joint_layer_kernel(const LayerArgs a) {
                 *reinterpret_cast<f32x4_t*>(bufG + (hp * 32 + r) * LG + cq * 4) = v;
             }
             __syncthreads();
-            {
-                const int n0 = ps * 64 + wave * 16;    // this wave's output columns [n0, n0 + 16)
+            if (wave * 16 < PW) {
+                const int n0 = ps * PW + wave * 16;    // this wave's output columns [n0, n0 + 16)
                 const int h = n0 / DH, hp = h - ps * HPP;
-                f32x4_t acc[2];
-                mfma_block<2, 1>(acc, bufG + hp * 32 * LG, LG, 0, w_fold, CF, 0, CF, n0 / 16, lane);
-                const int col = n0 + i16;
-                const float cf_ = c_fold[col];
+                gemm_cols<2, 1>(bufG + hp * 32 * LG, LG, 0, w_fold, CF, 0, CF, n0 / 16, 1, n0 / 16 + 1, lane, [&](int nb, const f32x4_t (&acc)[2]) {
+                    const int col = nb * 16 + i16;
+                    const float cf_ = c_fold[col];
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
+                    for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int rl32 = rb * 16 + 4 * q4 + r, rl = hf * 32 + rl32;
-                        float v = 0.f;
-                        if (rl < nrow) {
-                            v = acc[rb][r] * 1.0f + cf_ * sg[(int64_t)h * rows_all + row0 + rl];
-                            if (eq) v += eq[(int64_t)(row0 + rl) * C + col];
+                        for (int r = 0; r < 4; ++r) {
+                            const int rl32 = rb * 16 + 4 * q4 + r, rl = hf * 32 + rl32;
+                            float v = 0.f;
+                            if (rl < nrow) {
+                                v = acc[rb][r] + cf_ * sg[(int64_t)h * rows_all + row0 + rl];
+                                if (eq) v += eq[(int64_t)(row0 + rl) * C + col];
+                            }
+                            bufA[rl32 * LC + col] = v;
                         }
-                        bufA[rl32 * LC + col] = v;
-                    }
+                });
             }
             __syncthreads();
         }
         // output_proj on the 32 rows of this half; masked_fill(~valid) AFTER it (the bias is zeroed too)
-        for (int nb = wave; nb < C / 16; nb += 4) {
-            f32x4_t acc[2];
-            mfma_block<2, 1>(acc, bufA, LC, 0, w_out, C, 0, C, nb, lane);
+        gemm_cols<2, 1>(bufA, LC, 0, w_out, C, 0, C, wave, NW, C / 16, lane, [&](int nb, const f32x4_t (&acc)[2]) {
             const int col = nb * 16 + i16;
             const float bo = b_out[col];
 #pragma unroll
@@ -212,44 +254,32 @@ __global__ __launch_bounds__(256) void joint_layer_kernel(const LayerArgs a) {
                     const bool keep = rl < nrow && d.rowmask[row0 + rl] != 0;
                     bufO[rl * LC + col] = keep ? acc[rb][r] + bo : 0.f;
                 }
-        }
+        });
         __syncthreads();
     }
     // ---- cat over views -> fuse_mlp: token j = rows 4j .. 4j+3 of bufO side by side (V segments of K = C)
-    for (int nb = wave; nb < C / 16; nb += 4) {
-        f32x4_t acc[1];
-        mfma_block<1, 4>(acc, bufO, V * LC, LC, w_fuse, V * C, C, C, nb, lane);
+    gemm_cols<1, 4>(bufO, V * LC, LC, w_fuse, V * C, C, C, wave, NW, C / 16, lane, [&](int nb, const f32x4_t (&acc)[1]) {
         const int col = nb * 16 + i16;
         const float bb = b_fuse[col];
 #pragma unroll
         for (int r = 0; r < 4; ++r) tile0[(4 * q4 + r) * LC + col] = acc[0][r] + bb;
+    });
+    // ---- + residual (the layer input, from global memory) -> norm_cross
+    // residual rows of tokens >= J do not exist: point them at token 0 (their results are never stored)
+    for (int idx = tid; idx < 16 * C; idx += NTH) {
+        const int r = idx / C, ch = idx - r * C;
+        bufG[r * LC + ch] = d.x[(xrow0 + (r < J ? r : 0)) * C + ch];
     }
     __syncthreads();
-    // ---- + residual (the layer input, from global memory) -> norm_cross
-    {
-        // residual rows of tokens >= J do not exist: point them at token 0 (their results are never stored)
-        for (int idx = tid; idx < 16 * C; idx += 256) {
-            const int r = idx / C, ch = idx - r * C;
-            bufG[r * LC + ch] = d.x[(xrow0 + (r < J ? r : 0)) * C + ch];
-        }
-        __syncthreads();
-        ln_rows<VPL>(tile0, LC, bufG, LC, d.ln1_g + grp * C, d.ln1_b + grp * C, d.eps, tile1, LC, wave, lane);
-    }
+    ln_rows<VPL, NW>(tile0, LC, bufG, LC, d.ln1_g + grp * C, d.ln1_b + grp * C, d.eps, tile1, LC, wave, lane);
     __syncthreads();
     // ---- q/k/v projections -> bufO [16][3C]
-    for (int nb = wave; nb < 3 * C / 16; nb += 4) {
-        f32x4_t acc[1];
-        mfma_block<1, 1>(acc, tile1, LC, 0, w_qkv, C, 0, C, nb, lane);
-        const int col = nb * 16 + i16;
-        const float bb = b_qkv[col];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bufO[(4 * q4 + r) * LQ + col] = acc[0][r] + bb;
-    }
+    linear16(tile1, LC, w_qkv, C, b_qkv, 3 * C, bufO, LQ, false);
     __syncthreads();
-    // ---- joint-to-joint attention, one wave per head (joint_mha_kernel's arithmetic) -> tile0
-    {
+    // ---- joint-to-joint attention (joint_mha_kernel's arithmetic): scores by waves 0-3 (one per head), PV by all waves -> tile0
+    if (wave < HEADS) {
         const int h = wave;
-        float* const sp = bufG + wave * 256;          // this head's 16 x 16 probabilities
+        float* const sp = bufG + h * 256;             // this head's 16 x 16 probabilities
         const float scale = d.mha_scale;
         const int i = lane >> 2, gq_ = lane & 3;
         float s[4];
@@ -275,8 +305,12 @@ __global__ __launch_bounds__(256) void joint_layer_kernel(const LayerArgs a) {
         sum += __shfl_xor(sum, 2, 64);
 #pragma unroll
         for (int t = 0; t < 4; ++t) sp[i * 16 + gq_ + 4 * t] = (i < J) ? s[t] / sum : 0.f;
-        __syncthreads();
-        for (int idx = lane; idx < 16 * DH; idx += 64) {
+    }
+    __syncthreads();
+    {
+        const int h = wave & (HEADS - 1), part = wave / HEADS;      // NW / HEADS waves share a head's 16 x DH outputs
+        const float* const sp = bufG + h * 256;
+        for (int idx = part * 64 + lane; idx < 16 * DH; idx += 64 * (NW / HEADS)) {
             const int t = idx / DH, dd = idx - t * DH;
             float o = 0.f;
             for (int jj = 0; jj < J; ++jj) o = fmaf(sp[t * 16 + jj], bufO[jj * LQ + 2 * C + h * DH + dd], o);
@@ -285,40 +319,19 @@ __global__ __launch_bounds__(256) void joint_layer_kernel(const LayerArgs a) {
     }
     __syncthreads();
     // ---- out_proj -> bufG, + residual (tile1) -> norm_spatial -> tile0
-    for (int nb = wave; nb < C / 16; nb += 4) {
-        f32x4_t acc[1];
-        mfma_block<1, 1>(acc, tile0, LC, 0, w_mo, C, 0, C, nb, lane);
-        const int col = nb * 16 + i16;
-        const float bb = b_mo[col];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bufG[(4 * q4 + r) * LC + col] = acc[0][r] + bb;
-    }
+    linear16(tile0, LC, w_mo, C, b_mo, C, bufG, LC, false);
     __syncthreads();
-    ln_rows<VPL>(bufG, LC, tile1, LC, d.ln2_g + grp * C, d.ln2_b + grp * C, d.eps, tile0, LC, wave, lane);
+    ln_rows<VPL, NW>(bufG, LC, tile1, LC, d.ln2_g + grp * C, d.ln2_b + grp * C, d.eps, tile0, LC, wave, lane);
     __syncthreads();
     // ---- FFN: Linear + GELU -> bufO [16][512]; Linear -> bufG; + residual (tile0) -> norm_ffn -> tile1
-    for (int nb = wave; nb < FF / 16; nb += 4) {
-        f32x4_t acc[1];
-        mfma_block<1, 1>(acc, tile0, LC, 0, w_f0, C, 0, C, nb, lane);
-        const int col = nb * 16 + i16;
-        const float bb = b_f0[col];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bufO[(4 * q4 + r) * LF + col] = gelu_erf(acc[0][r] + bb);
-    }
+    linear16(tile0, LC, w_f0, C, b_f0, FF, bufO, LF, true);
     __syncthreads();
-    for (int nb = wave; nb < C / 16; nb += 4) {
-        f32x4_t acc[1];
-        mfma_block<1, 1>(acc, bufO, LF, 0, w_f1, FF, 0, FF, nb, lane);
-        const int col = nb * 16 + i16;
-        const float bb = b_f1[col];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bufG[(4 * q4 + r) * LC + col] = acc[0][r] + bb;
-    }
+    linear16(bufO, LF, w_f1, FF, b_f1, C, bufG, LC, false);
     __syncthreads();
-    ln_rows<VPL>(bufG, LC, tile0, LC, d.ln3_g + grp * C, d.ln3_b + grp * C, d.eps, tile1, LC, wave, lane);
+    ln_rows<VPL, NW>(bufG, LC, tile0, LC, d.ln3_g + grp * C, d.ln3_b + grp * C, d.eps, tile1, LC, wave, lane);
     __syncthreads();
     // ---- the layer's output tokens
-    for (int idx = tid; idx < J * C; idx += 256) {
+    for (int idx = tid; idx < J * C; idx += NTH) {
         const int r = idx / C, ch = idx - r * C;
         d.x_out[(xrow0 + r) * C + ch] = tile1[r * LC + ch];
     }
@@ -326,38 +339,28 @@ __global__ __launch_bounds__(256) void joint_layer_kernel(const LayerArgs a) {
     if (d.w_ol) {
         const float* const w_ol = d.w_ol + (int64_t)grp * d.ol_n * C;
         const float* const b_ol = d.b_ol + grp * d.ol_n;
-        for (int nb = wave; nb < d.ol_n / 16; nb += 4) {
-            f32x4_t acc[1];
-            mfma_block<1, 1>(acc, tile1, LC, 0, w_ol, C, 0, C, nb, lane);
+        const int oln = d.ol_n;
+        gemm_cols<1, 1>(tile1, LC, 0, w_ol, C, 0, C, wave, NW, oln / 16, lane, [&](int nb, const f32x4_t (&acc)[1]) {
             const int col = nb * 16 + i16;
             const float bb = b_ol[col];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 4 * q4 + r;
-                if (row < J) d.ol_out[(xrow0 + row) * d.ol_n + col] = acc[0][r] + bb;
+                if (row < J) d.ol_out[(xrow0 + row) * oln + col] = acc[0][r] + bb;
             }
-        }
+        });
     }
     // ---- tail: post_norm [+ regression MLP + anchor]
     if (d.lnp_g) {
-        ln_rows<VPL>(tile1, LC, nullptr, 0, d.lnp_g + grp * C, d.lnp_b + grp * C, d.eps, tile0, LC, wave, lane);
+        ln_rows<VPL, NW>(tile1, LC, nullptr, 0, d.lnp_g + grp * C, d.lnp_b + grp * C, d.eps, tile0, LC, wave, lane);
         __syncthreads();
         if (d.xn_out)
-            for (int idx = tid; idx < J * C; idx += 256) {
+            for (int idx = tid; idx < J * C; idx += NTH) {
                 const int r = idx / C, ch = idx - r * C;
                 d.xn_out[(xrow0 + r) * C + ch] = tile0[r * LC + ch];
             }
         if (d.w_r0) {
-            const float* const w_r0 = d.w_r0 + (int64_t)grp * C * C;
-            const float* const b_r0 = d.b_r0 + grp * C;
-            for (int nb = wave; nb < C / 16; nb += 4) {
-                f32x4_t acc[1];
-                mfma_block<1, 1>(acc, tile0, LC, 0, w_r0, C, 0, C, nb, lane);
-                const int col = nb * 16 + i16;
-                const float bb = b_r0[col];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) bufG[(4 * q4 + r) * LC + col] = gelu_erf(acc[0][r] + bb);
-            }
+            linear16(tile0, LC, d.w_r0 + (int64_t)grp * C * C, C, d.b_r0 + grp * C, C, bufG, LC, true);
             __syncthreads();
             // reg_mlp[2]: C -> 3, + init_anchors_3d; one thread per (token, coordinate), sequential k like the GEMM's chain
             if (tid < J * 3) {
@@ -370,15 +373,6 @@ __global__ __launch_bounds__(256) void joint_layer_kernel(const LayerArgs a) {
             }
         }
     }
-}
-
-template <int C>
-constexpr size_t layer_lds_bytes() {
-    constexpr int LC = C + PAD, LG = 128 + PAD, LQ = 3 * C + PAD, LF = 512 + PAD, T = 16 * LC, HPP = 64 / (C / 4);
-    constexpr int BUFA = 2 * T;
-    constexpr int BUFO = (64 * LC > 16 * LQ ? (64 * LC > 16 * LF ? 64 * LC : 16 * LF) : (16 * LQ > 16 * LF ? 16 * LQ : 16 * LF));
-    constexpr int BUFG = (HPP * 32 * LG > T ? HPP * 32 * LG : T);
-    return sizeof(float) * (size_t)(BUFA + BUFO + BUFG);
 }
 
 }  // namespace
@@ -402,7 +396,7 @@ extern "C" int egr_joint_layer_f32(const egr_layer_desc* dd, void* stream) {
     if (al & 15) return EGR_EINVAL;   // 16-byte weight / feature loads
     LayerArgs a;
     a.d = d;
-    const dim3 grid((unsigned)(d.B * d.groups)), block(256);
+    const dim3 grid((unsigned)(d.B * d.groups)), block(NTH);
     hipStream_t s = (hipStream_t)stream;
     // more than 64 KiB of dynamic LDS must be allowed per kernel and per device (a host-side attribute, not a stream operation)
     static bool allowed[2][64] = {};
@@ -411,19 +405,19 @@ extern "C" int egr_joint_layer_f32(const egr_layer_desc* dd, void* stream) {
     if (d.C == 256) {
         if (!allowed[0][dev]) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(joint_layer_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)layer_lds_bytes<256>()) != hipSuccess)
+                                    (int)LayerLds<256>::BYTES) != hipSuccess)
                 return EGR_EINVAL;
             allowed[0][dev] = true;
         }
-        hipLaunchKernelGGL(joint_layer_kernel<256>, grid, block, layer_lds_bytes<256>(), s, a);
+        hipLaunchKernelGGL(joint_layer_kernel<256>, grid, block, LayerLds<256>::BYTES, s, a);
     } else {
         if (!allowed[1][dev]) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(joint_layer_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)layer_lds_bytes<128>()) != hipSuccess)
+                                    (int)LayerLds<128>::BYTES) != hipSuccess)
                 return EGR_EINVAL;
             allowed[1][dev] = true;
         }
-        hipLaunchKernelGGL(joint_layer_kernel<128>, grid, block, layer_lds_bytes<128>(), s, a);
+        hipLaunchKernelGGL(joint_layer_kernel<128>, grid, block, LayerLds<128>::BYTES, s, a);
     }
     return egr_launch_status();
 }
