@@ -105,7 +105,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
                 const int kh_lo = max(0, -hi0), kh_hi = min(a.kh, a.h - hi0);
                 const int kw_lo = max(0, -wi0), kw_hi = min(a.kw, a.w - wi0);
                 const unsigned rowbits = (kw_hi > kw_lo) ? (((1u << (kw_hi - kw_lo)) - 1u) << kw_lo) : 0u;
-                for (int kh = kh_lo; kh < kh_hi; ++kh) mk |= rowbits << (kh * a.kw);
+                if (a.kh <= 3) {   // branch-free for the 1x1 / 3x3 layers of the path (this runs on wave 0 inside every stage)
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh) mk |= (kh >= kh_lo && kh < kh_hi) ? (rowbits << (kh * a.kw)) : 0u;
+                } else {
+                    for (int kh = kh_lo; kh < kh_hi; ++kh) mk |= rowbits << (kh * a.kw);
+                }
             }
             s_xoff[tb][r] = xo;
             s_yoff[tb][r] = yo;
@@ -287,7 +292,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x6_kernel(const WgradArgs a
                 const int kh_lo = max(0, -hi0), kh_hi = min(a.kh, a.h - hi0);
                 const int kw_lo = max(0, -wi0), kw_hi = min(a.kw, a.w - wi0);
                 const unsigned rowbits = (kw_hi > kw_lo) ? (((1u << (kw_hi - kw_lo)) - 1u) << kw_lo) : 0u;
-                for (int kh = kh_lo; kh < kh_hi; ++kh) mk |= rowbits << (kh * a.kw);
+                if (a.kh <= 3) {   // branch-free for the 1x1 / 3x3 layers of the path (this runs on wave 0 inside every stage)
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh) mk |= (kh >= kh_lo && kh < kh_hi) ? (rowbits << (kh * a.kw)) : 0u;
+                } else {
+                    for (int kh = kh_lo; kh < kh_hi; ++kh) mk |= rowbits << (kh * a.kw);
+                }
             }
             s_xoff[tb][r] = xo;
             s_yoff[tb][r] = yo;
@@ -412,7 +422,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x6_kernel(const WgradArgs a
         request(1, B1{});
     }
     lds_barrier();
-    for (int t = 0; t < nstages; t += 2) {
+    int t = 0;
+    // full pairs of stages as branch-free straight-line code (every stage of the pair splits its successor and requests the
+    // one after): with the end-of-range tests inside, the two variants of each stage met in a phi and the compiler moved the
+    // 64 accumulator registers twice per pair
+    for (; t + 3 < nstages; t += 2) {
+        decode(t + 3);
+        request(t + 2, B0{});
+        stage(B0{}, std::true_type{});
+        lds_barrier();
+        decode(t + 4);
+        request(t + 3, B1{});
+        stage(B1{}, std::true_type{});
+        lds_barrier();
+    }
+    for (; t < nstages; t += 2) {   // the last one to three stages
         // even stage: buffer 0; set 1 (stage t+1) -> buffer 1; set 0 requests stage t+2
         decode(t + 3);
         if (t + 2 < nstages) request(t + 2, B0{});

@@ -38,7 +38,17 @@ def both(hip, x, wp, *args, **kw):
     a = hip.conv2d(x, wp, *args, **kw)
     if kw.get("out") is not None or kw.get("out_nchw") is not None:
         raise AssertionError("use fresh outputs here")
-    b = hip.conv2d(x, hip.pack_w6(wp), *args, **kw)
+    # the shipped size rule would send these small problems back to the fp32 kernel: force the split launch
+    saved = hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS
+    hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = 0, 0.0
+    try:
+        prof, hip.PROFILE = hip.PROFILE, []
+        b = hip.conv2d(x, hip.pack_w6(wp), *args, **kw)
+        tags = [t for name, *_, t in hip.PROFILE if name == "egr_conv2d_nhwc_f32"]
+        assert tags and ("x6 " in tags[-1]), "the second launch must be the split-bf16 one"
+    finally:
+        hip.PROFILE = prof
+        hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = saved
     return a, b
 
 
