@@ -469,10 +469,13 @@ def main():
             e1.record()
             torch.cuda.synchronize()
         pms = e0.elapsed_time(e1) / 10
-        pbytes = nfr * 4 * (872 * 872 * 3 + 2 * 872 * 256 * 3 + 256 * 256 * 12)
+        # algorithmic bytes: the frame read once + the fp32 tensor written once (the fused kernel keeps Pillow's uint8 intermediate
+        # in LDS; the two-pass fallback adds its write + read)
+        pbytes = nfr * 4 * (872 * 872 * 3 + (0 if pre.fused else 2 * 872 * 256 * 3) + 256 * 256 * 12)
         pre_leg = {"frames_per_s": round(nfr / pms * 1e3, 1), "ms_per_batch": round(pms, 3), "batch": nfr,
                    "algorithmic_GBps": round(pbytes / pms / 1e6, 1), "bound": "hbm", "frac_of_8TBps": round(pbytes / pms / 1e6 / PEAK_HBM_GBS, 4),
-                   "what": "uint8 (B,4,872,872,3) -> PIL-exact bicubic 256x256 + /255 + ImageNet normalise -> fp32 (B,4,3,256,256)"}
+                   "what": "uint8 (B,4,872,872,3) -> PIL-exact bicubic 256x256 + /255 + ImageNet normalise -> fp32 (B,4,3,256,256)",
+                   "launches": 1 if pre.fused else 2}
         # the whole chain from raw 872 x 872 x 4-view uint8 frames resident in HBM (never `value` either: SURVEY.md 8d times the network
         # on the pre-processed tensor): pre-processing + forward of B frames, eager launches, HIP events
         try:

@@ -190,7 +190,180 @@ __global__ __launch_bounds__(256) void resize_v_norm_kernel(const uint8_t* tmp, 
     *reinterpret_cast<f32x4*>(o + 2 * plane) = r2;
 }
 
+// ------------------------------------------------------------------ both passes in one kernel
+// A workgroup (512 threads) owns OB = 32 output rows of one image.  Their vertical windows cover a band of ~3.4 * 32 + 12 source
+// rows; the band's horizontally resized uint8 rows (Pillow's intermediate image) live in LDS only: the source rows are staged
+// eight at a time (two 16-byte-aligned 4-row blocks, 16-byte loads), every thread computes one output column of four of them
+// (resize_h_lds_kernel's arithmetic), and the vertical pass + ToTensor + Normalize (resize_v_norm_kernel's arithmetic) reads the
+// band back from LDS.  The 0.67 MB intermediate per image never reaches HBM; neighbouring bands recompute ~12 shared rows (+11 %).
+constexpr int FOB = 32, FTH = 512, FRB = 8;
+__global__ __launch_bounds__(FTH) void resize_fused_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, uint8_t* __restrict__ u8out, int h,
+                                                           int w, int oh, int ow, const int32_t* __restrict__ bounds_h,
+                                                           const int32_t* __restrict__ coef_h, int ksize_h, const int32_t* __restrict__ bounds_v,
+                                                           const int32_t* __restrict__ coef_v, int ksize_v, int band_rows, float m0, float m1, float m2,
+                                                           float d0, float d1, float d2) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t fl[];
+    const int row_b = w * 3, out_row_b = ow * 3;
+    const int in_b = FRB * row_b;                              // one staged block (multiple of 16: host-checked)
+    uint32_t* const in32 = reinterpret_cast<uint32_t*>(fl);
+    uint8_t* const mid = fl + ((in_b + 64 + 15) & ~15);        // [band_rows][ow * 3] uint8
+    const int bands = (oh + FOB - 1) / FOB;
+    const int img = blockIdx.x / bands, band = blockIdx.x - img * bands;
+    const int oy0 = band * FOB, oy1 = min(oh, oy0 + FOB);
+    const int r_begin = bounds_v[2 * oy0];
+    const int r_end = bounds_v[2 * (oy1 - 1)] + bounds_v[2 * (oy1 - 1) + 1];   // windows are monotone in oy
+    const uint8_t* const simg = src + (int64_t)img * h * row_b;
+    const int tid = threadIdx.x;
+
+    // ---- horizontal pass into LDS, FRB source rows per round
+    const int ox = tid % ow, rq = tid / ow;                    // (ow = 256: two row quads per round)
+    int kk[16];
+    int xmin = 0;
+    if (tid < 2 * ow) {
+        xmin = bounds_h[2 * ox];
+        const int cnt = bounds_h[2 * ox + 1];
+        const int32_t* k = coef_h + (int64_t)ox * ksize_h;
+#pragma unroll
+        for (int x = 0; x < 16; ++x) kk[x] = (x < cnt && x < ksize_h) ? k[x < ksize_h ? x : 0] : 0;
+    }
+    // the next block's 16-byte pieces are requested into registers before the current block is resampled (their latency hides
+    // under ~500 VALU operations per thread) and parked in LDS afterwards
+    constexpr int NV = 4;                                      // pieces per thread: (8 * 872 * 3 / 16 + 4) / 512 <= 4 (host-checked)
+    const int slots = (in_b >> 4) + 4;
+    uint4 pv[NV];
+    auto fetch = [&](int rb) {
+        const uint4* g = reinterpret_cast<const uint4*>(simg + (int64_t)rb * row_b);
+        const int nvec = (min(FRB, h - rb) * row_b) >> 4;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int i = tid + FTH * u;
+            pv[u] = (i < nvec) ? g[i] : uint4{0u, 0u, 0u, 0u};
+        }
+    };
+    fetch(r_begin & ~3);
+    for (int rb = r_begin & ~3; rb < r_end; rb += FRB) {
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int i = tid + FTH * u;
+            if (i < slots) reinterpret_cast<uint4*>(fl)[i] = pv[u];
+        }
+        __syncthreads();
+        if (rb + FRB < r_end) fetch(rb + FRB);
+        if (tid < 2 * ow) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int r = rq * 4 + r4, sr = rb + r;
+                if (sr < r_begin || sr >= r_end) continue;
+                const int b0 = r * row_b + xmin * 3;
+                const int a0 = b0 >> 2;
+                const unsigned sh = (unsigned)(b0 & 3);
+                uint32_t raw[13];
+#pragma unroll
+                for (int i = 0; i < 13; ++i) raw[i] = in32[a0 + i];
+                uint32_t al[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) al[i] = __builtin_amdgcn_alignbyte(raw[i + 1], raw[i], sh);
+                int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+#pragma unroll
+                for (int x = 0; x < 16; ++x) {
+                    const int bb = 3 * x;
+                    s0 += (int)((al[bb >> 2] >> (8 * (bb & 3))) & 0xff) * kk[x];
+                    s1 += (int)((al[(bb + 1) >> 2] >> (8 * ((bb + 1) & 3))) & 0xff) * kk[x];
+                    s2 += (int)((al[(bb + 2) >> 2] >> (8 * ((bb + 2) & 3))) & 0xff) * kk[x];
+                }
+                uint8_t* o = mid + (sr - r_begin) * out_row_b + ox * 3;
+                o[0] = (uint8_t)clip8(s0);
+                o[1] = (uint8_t)clip8(s1);
+                o[2] = (uint8_t)clip8(s2);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- vertical pass + ToTensor + Normalize out of LDS: one item = (output row, 4 consecutive columns)
+    const int owq = ow >> 2;
+    const int64_t plane = (int64_t)oh * ow;
+    for (int item = tid; item < (oy1 - oy0) * owq; item += FTH) {
+        const int oxq = item % owq, oy = oy0 + item / owq;
+        const int ymin = bounds_v[2 * oy], cnt = bounds_v[2 * oy + 1];
+        const int32_t* k = coef_v + (int64_t)oy * ksize_v;
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(mid + (ymin - r_begin) * out_row_b + oxq * 12);
+        const int rowdw = out_row_b >> 2;
+        int acc[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) acc[i] = 1 << (PRECISION_BITS - 1);
+        for (int y = 0; y < cnt; ++y) {
+            const int kv = k[y];
+            const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+            p += rowdw;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i] += (int)((w0 >> (8 * i)) & 0xff) * kv;
+                acc[4 + i] += (int)((w1 >> (8 * i)) & 0xff) * kv;
+                acc[8 + i] += (int)((w2 >> (8 * i)) & 0xff) * kv;
+            }
+        }
+        int c8[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) c8[i] = clip8(acc[i]);
+        if (u8out) {
+            uint8_t* u = u8out + (((int64_t)img * oh + oy) * ow + oxq * 4) * 3;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) u[i] = (uint8_t)c8[i];
+        }
+        float* o = dst + (int64_t)img * 3 * plane + (int64_t)oy * ow + oxq * 4;
+        f32x4 r0, r1, r2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r0[i] = ((float)c8[3 * i + 0] / 255.0f - m0) / d0;
+            r1[i] = ((float)c8[3 * i + 1] / 255.0f - m1) / d1;
+            r2[i] = ((float)c8[3 * i + 2] / 255.0f - m2) / d2;
+        }
+        *reinterpret_cast<f32x4*>(o) = r0;
+        *reinterpret_cast<f32x4*>(o + plane) = r1;
+        *reinterpret_cast<f32x4*>(o + 2 * plane) = r2;
+    }
+}
+
 }  // namespace
+
+// largest source band (rows) any 32-row output band of the vertical pass touches; the tables are host arrays here
+extern "C" int egr_preprocess_band_rows(const int32_t* bounds_v_host, int32_t oh) {
+    if (!bounds_v_host || oh <= 0) return 0;
+    int best = 0;
+    for (int oy0 = 0; oy0 < oh; oy0 += FOB) {
+        const int oy1 = (oy0 + FOB < oh ? oy0 + FOB : oh) - 1;
+        const int span = bounds_v_host[2 * oy1] + bounds_v_host[2 * oy1 + 1] - bounds_v_host[2 * oy0];
+        if (span > best) best = span;
+    }
+    return best;
+}
+
+// One launch for both passes (the uint8 intermediate stays in LDS).  band_rows: egr_preprocess_band_rows of the vertical table.
+// Falls back (returns EGR_EINVAL, nothing launched) when the shape does not meet the kernel's alignment / LDS limits: the
+// caller then uses egr_preprocess_u8_f32.
+extern "C" int egr_preprocess_fused_u8_f32(const uint8_t* src, int32_t n, int32_t h, int32_t w, int32_t oh, int32_t ow, const int32_t* bounds_h,
+                                           const int32_t* coef_h, int32_t ksize_h, const int32_t* bounds_v, const int32_t* coef_v, int32_t ksize_v,
+                                           int32_t band_rows, const float* mean, const float* stdv, float* dst, uint8_t* u8out, void* stream) {
+    if (!src || !bounds_h || !coef_h || !bounds_v || !coef_v || !mean || !stdv || !dst) return EGR_ENULL;
+    if (n <= 0 || h <= 0 || w <= 0 || oh <= 0 || ow <= 0 || ksize_h <= 0 || ksize_v <= 0 || band_rows <= 0) return EGR_EINVAL;
+    const int in_b = FRB * w * 3;
+    const size_t lds_b = (size_t)((in_b + 64 + 15) & ~15) + (size_t)band_rows * ow * 3;
+    if (ow != FTH / 2 || ksize_h > 16 || ksize_v > MAXK || h % 4 != 0 || (in_b >> 4) + 4 > 4 * FTH || (4 * w * 3) % 16 != 0 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15) ||
+        ((int64_t)h * w * 3) % 16 != 0 || lds_b > 150 * 1024)
+        return EGR_EINVAL;
+    static bool allowed[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return EGR_EINVAL;
+    if (!allowed[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(resize_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+            return EGR_EINVAL;
+        allowed[dev] = true;
+    }
+    const int bands = (oh + FOB - 1) / FOB;
+    hipLaunchKernelGGL(resize_fused_kernel, dim3((unsigned)(n * bands)), dim3(FTH), lds_b, (hipStream_t)stream, src, dst, u8out, h, w, oh, ow, bounds_h,
+                       coef_h, ksize_h, bounds_v, coef_v, ksize_v, band_rows, mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2]);
+    return egr_launch_status();
+}
 
 extern "C" int egr_preprocess_u8_f32(const uint8_t* src, int32_t n, int32_t h, int32_t w, int32_t oh, int32_t ow,
                                      const int32_t* bounds_h, const int32_t* coef_h, int32_t ksize_h,

@@ -25,6 +25,7 @@ EXPORTS = [
     "egr_fisheye_project_f32", "egr_linear_smallk_f32", "egr_jqa_sum_f32", "egr_tokens_to_nhwc_f32", "egr_version",
     "egr_device_arch", "egr_conv_force_config", "egr_preprocess_u8_f32", "egr_pose_metrics_f32", "egr_gt_heatmap_f32", "egr_conv_debug_stamps", "egr_conv2d_wgrad_f32", "egr_conv2d_masked_f32", "egr_up2_relu_head_f32",
     "egr_msda_fwd_f32", "egr_msda_bwd_f32", "egr_w6_elems", "egr_pack_w6_f32", "egr_pack_w6_many_f32", "egr_joint_layer_f32",
+    "egr_preprocess_fused_u8_f32", "egr_preprocess_band_rows",
 ]
 
 
@@ -94,6 +95,8 @@ def _load() -> C.CDLL:
     lib.egr_msda_fwd_f32.argtypes = [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp, vp]
     lib.egr_msda_bwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.egr_joint_layer_f32.argtypes = [C.POINTER(LayerDesc), vp]
+    lib.egr_preprocess_fused_u8_f32.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]
+    lib.egr_preprocess_band_rows.argtypes = [vp, i32]
     lib.egr_preprocess_u8_f32.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     for name in EXPORTS:
         getattr(lib, name)  # fail at import if a symbol is missing

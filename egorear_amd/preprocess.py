@@ -4,7 +4,9 @@ Replaces the reference's CPU loader transform (datasets/ego4view_syn/ego4view_sy
 `Image.resize([256, 256], Image.BICUBIC)` (Pillow's antialiased fixed-point resampling) + `ToTensor` +
 `Normalize(ImageNet mean/std)`.  The resampling tables are computed here on the host, in float64 and in the
 exact order Pillow's precompute_coeffs / normalize_coeffs_8bpc use, so the GPU result equals Pillow's uint8 image
-bit for bit; the kernels (egr_preprocess_u8_f32) are two HBM-bound passes.
+bit for bit.  Two passes through HBM by default (egr_preprocess_u8_f32); a one-launch form that keeps the uint8 intermediate of
+Pillow's two passes in LDS exists too (egr_preprocess_fused_u8_f32, EGR_PREPROCESS_FUSED=1: identical bytes, measured slower -
+the arithmetic, not the memory traffic, is what bounds this step; see FramePreprocessor.__init__).
 """
 from __future__ import annotations
 
@@ -69,6 +71,17 @@ class FramePreprocessor:
         self.bh, self.ch, self.bv, self.cv = up(bh), up(ch), up(bv), up(cv)
         self._mean = (C.c_float * 3)(*MEAN)
         self._std = (C.c_float * 3)(*STD)
+        # source rows the largest 32-output-row band of the vertical pass touches (sizes the fused kernel's LDS band)
+        bvh = np.ascontiguousarray(bv, dtype=np.int32)
+        self.band_rows = int(hip.lib.egr_preprocess_band_rows(bvh.ctypes.data_as(C.c_void_p), out_hw[0]))
+        # Measured on MI355X (64 views of 872 x 872): two passes 108 us, fused 125 us.  Pillow's exact 22-bit fixed-point
+        # resampling costs ~125 integer VALU operations per horizontally resized pixel, so both forms are VALU-bound (2.1 G
+        # lane-operations per 64 views ~ 66 us of pure issue time on the whole chip), not HBM-bound; the fused kernel saves the
+        # intermediate's HBM round trip but recomputes 11 % of the rows (band overlap) and runs at one workgroup per CU (its
+        # 94 KB LDS band).  The two-pass form stays the default; EGR_PREPROCESS_FUSED=1 selects the one-launch form (it falls
+        # back to two passes by itself when it refuses a shape).
+        import os
+        self.fused = os.environ.get("EGR_PREPROCESS_FUSED", "0") == "1"
 
     def __call__(self, frames: torch.Tensor, return_u8: bool = False):
         if not frames.is_cuda or frames.dtype != torch.uint8:
@@ -80,10 +93,20 @@ class FramePreprocessor:
         n = int(np.prod(lead)) if lead else 1
         H, W = self.in_hw
         oh, ow = self.out_hw
-        tmp = torch.empty((n, H, ow, 3), device=frames.device, dtype=torch.uint8)
         dst = torch.empty(lead + (3, oh, ow), device=frames.device, dtype=torch.float32)
         u8 = torch.empty(lead + (oh, ow, 3), device=frames.device, dtype=torch.uint8) if return_u8 else None
         vp = hip._pv
+        if self.fused:
+            try:
+                hip._launch("egr_preprocess_u8_f32", hip.lib.egr_preprocess_fused_u8_f32, vp(frames), n, H, W, oh, ow, vp(self.bh), vp(self.ch),
+                            self.kh, vp(self.bv), vp(self.cv), self.kv, self.band_rows, C.cast(self._mean, C.c_void_p),
+                            C.cast(self._std, C.c_void_p), vp(dst), vp(u8), hip._stream(), nbytes=float(n) * (H * W * 3 + oh * ow * 12))
+                return (dst, u8) if return_u8 else dst
+            except RuntimeError as exc:
+                if "EGR_EINVAL" not in str(exc):
+                    raise
+                self.fused = False      # this shape is outside the fused kernel's limits: two passes from now on
+        tmp = torch.empty((n, H, ow, 3), device=frames.device, dtype=torch.uint8)
         hip._launch("egr_preprocess_u8_f32", hip.lib.egr_preprocess_u8_f32, vp(frames), n, H, W, oh, ow, vp(self.bh), vp(self.ch),
                     self.kh, vp(self.bv), vp(self.cv), self.kv, C.cast(self._mean, C.c_void_p), C.cast(self._std, C.c_void_p),
                     vp(tmp), vp(dst), vp(u8), hip._stream(),

@@ -280,6 +280,16 @@ int egr_preprocess_u8_f32(const uint8_t* src, int32_t n, int32_t h, int32_t w, i
                           const int32_t* bounds_v, const int32_t* coef_v, int32_t ksize_v,
                           const float* mean, const float* stdv, uint8_t* tmp, float* dst, uint8_t* u8out, void* stream);
 
+/* The same conversion as ONE launch: the horizontally resized uint8 rows of a 32-output-row band stay in LDS (no intermediate in
+ * HBM, no `tmp`).  band_rows = egr_preprocess_band_rows(host copy of bounds_v, oh).  Returns EGR_EINVAL without launching when the
+ * shape does not meet the kernel's limits (ow == 256, ksize_h <= 16, h % 4 == 0, 16-byte aligned rows-of-four, band in LDS): the
+ * caller then falls back to egr_preprocess_u8_f32.  Bit-identical results. */
+int egr_preprocess_band_rows(const int32_t* bounds_v_host, int32_t oh);
+int egr_preprocess_fused_u8_f32(const uint8_t* src, int32_t n, int32_t h, int32_t w, int32_t oh, int32_t ow,
+                                const int32_t* bounds_h, const int32_t* coef_h, int32_t ksize_h,
+                                const int32_t* bounds_v, const int32_t* coef_v, int32_t ksize_v, int32_t band_rows,
+                                const float* mean, const float* stdv, float* dst, uint8_t* u8out, void* stream);
+
 /* Pose evaluation metrics per sample, replaces evaluate_pose of
  * pl_wrappers/egoposeformer/pose_3d_mvf_ex.py:317-333 (utils/loss.py:9-48, models/utils/pose_metric.py:104-167):
  * pred, gt (b, joints, 3) fp32 in cm -> out (b, 4) = [MPJPE mm, PA-MPJPE mm (similarity-aligned), PCK@pck_thr_mm %,

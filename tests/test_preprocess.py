@@ -108,3 +108,25 @@ def test_hip_preprocess_other_sizes_match_the_oracle(in_hw, out_hw):
     ref = O.preprocess_frames(frames.numpy(), out_hw[0], out_hw[1])
     assert x.shape == (2, 3, 3, out_hw[0], out_hw[1])
     assert np.array_equal(x.cpu().numpy(), ref)
+
+
+@pytest.mark.gpu
+def test_fused_and_two_pass_preprocessing_are_the_same_bytes():
+    """egr_preprocess_fused_u8_f32 (Pillow's uint8 intermediate kept in LDS, one launch) against the two-pass kernels: identical
+    fp32 output and identical uint8 image; shapes outside the fused kernel's limits fall back by themselves."""
+    from egorear_amd.preprocess import FramePreprocessor
+    frames = synth.synth_raw_frames(3, 4, seed=5).cuda()
+    fused, two = FramePreprocessor(), FramePreprocessor()
+    fused.fused, two.fused = True, False
+    a, a8 = fused(frames, return_u8=True)
+    b, b8 = two(frames, return_u8=True)
+    assert fused.fused is True and fused.band_rows > 100          # 872 -> 256: the fused kernel took it (a ~121-row band in LDS)
+    assert torch.equal(a, b) and torch.equal(a8, b8)
+    small = FramePreprocessor(in_hw=(437, 500), out_hw=(128, 160))
+    small.fused = True
+    g = torch.Generator().manual_seed(3)
+    f2 = torch.randint(0, 256, (1, 2, 437, 500, 3), generator=g, dtype=torch.uint8)
+    x = small(f2.cuda())
+    assert small.fused is False                                    # refused (EGR_EINVAL) -> two passes, same reference result
+    assert np.array_equal(x.cpu().numpy(), O.preprocess_frames(f2.numpy(), 128, 160))
+
