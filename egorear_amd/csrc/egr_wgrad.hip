@@ -231,6 +231,13 @@ __device__ __forceinline__ unsigned wg_cvt_pk(float lo, float hi) {
 __device__ __forceinline__ float wg_hi(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
 __device__ __forceinline__ float wg_lo(unsigned p) { return __uint_as_float(p << 16); }
 
+// a wave-uniform pointer computed with vector instructions (64-bit multiplies have no scalar form), back in scalar registers
+__device__ __forceinline__ void* wg_uniform_ptr(const void* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (void*)(((uint64_t)hi << 32) | lo);
+}
+
 template <int BCO>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_x6_kernel(const WgradArgs a) {
     constexpr int PS = 16;                                       // pixels per stage = one k16 step
@@ -305,6 +312,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x6_kernel(const WgradArgs a
         }
     };
 
+    // Both operands come through 2-GiB buffer windows: a row that does not exist (beyond M, beyond cout, a tap outside the image)
+    // is an out-of-range offset - the load returns zeros and touches no memory; no pointer selects, no zero buffer.  The activation
+    // window starts `abias` bytes before the group's base so that halo rows have non-negative offsets.
+    const int abias = (a.pad * a.w + a.pad + 1) * a.ldx * 4;
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(wg_uniform_ptr(dyg), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rxa = __builtin_amdgcn_make_buffer_rsrc(wg_uniform_ptr(reinterpret_cast<const char*>(xg) - abias), 0, 0x80000000u,
+                                                                         0x00020000);
+    const int d_col = (co0 + d_seg * 4) * 4;          // byte offset of this thread's dy channels
+    const int a_col = a_toff * 4 + abias;              // byte offset of this thread's tap / channel chunk
     f32x4 xr[2][NUN];
     auto request = [&](int stage, auto set_tag) {   // global loads of `stage` (its table must be visible) into register set SET
         constexpr int SET = decltype(set_tag)::value;
@@ -312,15 +328,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x6_kernel(const WgradArgs a
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
             const int yo = s_yoff[tb][d_pix + (256 / SEG_DY) * i];
-            const float* p = (yo >= 0 && d_ok) ? dyg + yo + co0 + d_seg * 4 : egr_wg_zero16;
-            xr[SET][i] = *reinterpret_cast<const f32x4*>(p);
+            const int vo = (yo >= 0 && d_ok) ? yo * 4 + d_col : (int)0x80000000;
+            xr[SET][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, vo, 0, 0));
         }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int r = a_pix + 8 * i;
             const bool ok = chunk_ok && s_yoff[tb][r] >= 0 && ((s_mask[tb][r] >> a_tap) & 1u);
-            const float* p = ok ? xg + (s_xoff[tb][r] + a_toff) : egr_wg_zero16;
-            xr[SET][ND + i] = *reinterpret_cast<const f32x4*>(p);
+            const int vo = ok ? s_xoff[tb][r] * 4 + a_col : (int)0x80000000;
+            xr[SET][ND + i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxa, vo, 0, 0));
         }
     };
     // slice k of the staging work: unit k / 5; step 0/1 = hi parts + residuals of the unit's two pairs, 2/3 = mid + lo, 4 = the writes
@@ -597,7 +613,15 @@ extern "C" int egr_conv2d_wgrad_f32(const egr_conv_desc* dd, const float* x, con
     dim3 grid((unsigned)tiles, (unsigned)a.splits, (unsigned)G);
     // large problems run on the bf16 matrix cores with exact three-way operand splits (same result class as the fp32 kernel);
     // w_format == EGR_W_BF16X3 requests it, small ones stay on the fp32 kernel (latency-bound)
-    const bool x6 = (d.w_format & EGR_W_BF16X3) && ((d.w_format & EGR_W_FORCE) || (a.M >= 1024 && 2.0 * (double)a.M * d.cout * a.K * G >= 4e9));
+    // (its operands are addressed through 2-GiB buffer windows: larger tensors stay on the fp32 kernel)
+    auto span = [](const egr_nmap& m, int n) {
+        const int o = (n - 1) / m.n_inner, i = (n - 1 < m.n_inner ? n - 1 : m.n_inner - 1);
+        return (int64_t)i * m.stride_inner + (int64_t)o * m.stride_outer;
+    };
+    const bool fits = (span(d.xmap, d.n) + (int64_t)(d.h * d.w + 2 * (d.pad * d.w + d.pad + 1)) * d.ldx) * 4 + 64 < (1LL << 31) &&
+                      (span(d.ymap, d.n) + (int64_t)d.ho * d.wo * d.ldy) * 4 + 64 < (1LL << 31);
+    const bool x6 = fits && (d.w_format & EGR_W_BF16X3) &&
+                    ((d.w_format & EGR_W_FORCE) || (a.M >= 1024 && 2.0 * (double)a.M * d.cout * a.K * G >= 4e9));
     if (x6) {
         if (bco == 128) hipLaunchKernelGGL(conv_wgrad_x6_kernel<128>, grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(conv_wgrad_x6_kernel<64>, grid, dim3(256), 0, s, a);
