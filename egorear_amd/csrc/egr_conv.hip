@@ -146,13 +146,14 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     __shared__ __attribute__((aligned(16))) float lds[P::FLOATS];
 
     const egr_conv_desc& d = a.d;
+    int stamp_tile = blockIdx.x;   // persistent launches: the tile being worked on (stamps are per tile)
     auto stamp = [&](int slot) {
         if (a.dbg && threadIdx.x == 0)
-            a.dbg[((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * 8 + slot] = __builtin_amdgcn_s_memtime();
+            a.dbg[((int64_t)blockIdx.z * a.ntiles + stamp_tile) * 8 + slot] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
     if (a.dbg && threadIdx.x == 0)  // physical placement, for co-residency analysis (tools/conv_stamps.py)
-        a.dbg[((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * 8 + 6] =
+        a.dbg[((int64_t)blockIdx.z * a.ntiles + blockIdx.x) * 8 + 6] =
             ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u) << 16) |
             (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu);
     const int grp = blockIdx.z;  // grouped launch: same shape, own operands
@@ -849,6 +850,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
             vb = vn; tm = tmn; tn = tnn; slot ^= 1;
+            stamp_tile = vb;
+            stamp(0);  // (persistent: the tile's turn begins; its rows were requested during the previous tile's stores)
         }
     }
 
@@ -1020,6 +1023,14 @@ extern "C" int egr_pack_w6_many_f32(const egr_w6_job* jobs, int32_t count, int64
 
 extern "C" int egr_conv_debug_stamps(unsigned long long* buf) {  // diagnostic: 8 x u64 per workgroup, NULL = off
     g_dbg = buf;
+    return 0;
+}
+
+// diagnostic / test knob: resident workgroup slots a persistent split-bf16 launch is sized for (0 = never persistent) and the
+// largest K (in 32-deep chunks) that takes the persistent kernel.  Negative values leave a setting unchanged.  Defaults: 512, 4.
+extern "C" int egr_conv_set_persist(int slots, int max_ktiles) {
+    if (slots >= 0) g_persist = slots;
+    if (max_ktiles >= 0) g_persist_ktiles = max_ktiles;
     return 0;
 }
 

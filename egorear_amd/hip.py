@@ -25,7 +25,7 @@ EXPORTS = [
     "egr_fisheye_project_f32", "egr_linear_smallk_f32", "egr_jqa_sum_f32", "egr_tokens_to_nhwc_f32", "egr_version",
     "egr_device_arch", "egr_conv_force_config", "egr_preprocess_u8_f32", "egr_pose_metrics_f32", "egr_gt_heatmap_f32", "egr_conv_debug_stamps", "egr_conv2d_wgrad_f32", "egr_conv2d_masked_f32", "egr_up2_relu_head_f32",
     "egr_msda_fwd_f32", "egr_msda_bwd_f32", "egr_w6_elems", "egr_pack_w6_f32", "egr_pack_w6_many_f32", "egr_joint_layer_f32",
-    "egr_preprocess_fused_u8_f32", "egr_preprocess_band_rows",
+    "egr_preprocess_fused_u8_f32", "egr_preprocess_band_rows", "egr_conv_set_persist",
 ]
 
 
@@ -84,6 +84,7 @@ def _load() -> C.CDLL:
     lib.egr_w6_elems.restype = C.c_int64
     lib.egr_device_arch.argtypes = [C.c_char_p, i32]
     lib.egr_conv_force_config.argtypes = [i32]
+    lib.egr_conv_set_persist.argtypes = [i32, i32]
     lib.egr_up2_relu_head_f32.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, i64, i64, i32, i64, vp]
     lib.egr_conv2d_masked_f32.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.egr_conv2d_wgrad_f32.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, C.c_size_t, i32, vp]
@@ -188,6 +189,10 @@ def version() -> str:
 
 def conv_force_config(cfg: int):
     _check(lib.egr_conv_force_config(cfg), "egr_conv_force_config")
+
+
+def conv_set_persist(slots: int = -1, max_ktiles: int = -1):
+    _check(lib.egr_conv_set_persist(slots, max_ktiles), "egr_conv_set_persist")
 
 
 def device_arch() -> str:

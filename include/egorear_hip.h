@@ -136,6 +136,11 @@ int egr_conv2d_wgrad_f32(const egr_conv_desc* d, const float* x, const float* dy
 /* Tuning knob for measurements: force the tile configuration of egr_conv2d_nhwc_f32
  * (-1 auto, 0 128x128, 1 256x64, 2 64x64, 3 128x32, 4 128x64).  Process-wide; results do not depend on it. */
 int egr_conv_force_config(int cfg);
+/* Tuning / test knob of the persistent split-bf16 launches (short-K layers: a workgroup walks several tiles and requests the next
+ * tile's operands under the current tile's stores): `slots` = resident workgroups a launch is sized for (0: never persistent;
+ * default 512 = 2 per CU), `max_ktiles` = largest K in 32-deep chunks that takes them (default 4).  Negative: unchanged.
+ * Process-wide; results do not depend on it. */
+int egr_conv_set_persist(int slots, int max_ktiles);
 
 /* Tail of a heat-map head in one pass: Upsample(x2, bilinear, align_corners=True) + ReLU, then the final 1x1 conv
  * (cin <= 128 -> cout <= 16, with bias) written as channel-major planes: lo (n, h, w, cin) NHWC, all groups' images back to back;

@@ -382,3 +382,32 @@ def test_split_launch_on_subnormal_and_tiny_operands_stays_within_the_documented
     x[..., ::2] *= 2.0 ** -115
     a, b, ref = _corner_case(hip, x)
     judge(a, b, ref, "tiny next to normal")
+
+
+# --------------------------------------------------------------------------- persistent launches (short-K layers)
+
+@pytest.mark.parametrize("cin,cout,k,res_mode", [(128, 128, 1, 0), (128, 128, 1, 1), (64, 128, 1, 0), (128, 256, 1, 2), (64, 256, 1, 0),
+                                                 (32, 128, 3, 0), (256, 128, 1, 1)])
+def test_persistent_split_launches_match_fp64(cin, cout, k, res_mode):
+    """The persistent variant of the split kernel (a workgroup walks several tiles; the next tile's row table is decoded and its
+    first operands requested under the current tile's stores): forced onto small problems with 8 workgroup slots, so that every
+    workgroup walks many tiles incl. a ragged last round."""
+    from egorear_amd import hip
+    n, h, w = 3, 20, 44                              # M = 2640 rows: 21 tiles of 128 (the last one ragged), 2 column tiles for cout 256
+    x = rnd(n, h, w, cin, seed=cin + cout)
+    wt = rnd(cout, cin, k, k, seed=7, scale=0.2)
+    sc, sh = torch.rand(cout) + 0.5, rnd(cout, seed=9)
+    res = rnd(n, h, w, cout, seed=10) if res_mode else None
+    hip.conv_set_persist(8, 16)
+    try:
+        a, b = both(hip, hip.Img(x.to(DEV)), pack_w(wt), cout, k, k, 1, k // 2, scale=sc.to(DEV), shift=sh.to(DEV), act=1,
+                    res=hip.Img(res.to(DEV)) if res_mode else None, res_mode=res_mode, split_k=1)
+    finally:
+        hip.conv_set_persist(512, 4)
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), wt.double(), padding=k // 2).permute(0, 2, 3, 1) * sc.double() + sh.double()
+    if res_mode == 1:
+        ref = ref + res.double()
+    ref = ref.clamp_min(0)
+    if res_mode == 2:
+        ref = ref + res.double()
+    judge(a.t, b.t, ref, f"persistent cin{cin} cout{cout} k{k} res{res_mode}")
