@@ -102,6 +102,26 @@ def _pmc_traffic(batch: int, fmt: str = ""):
         return None
 
 
+def _pmc_traffic_train(batch: int, key: str):
+    """HBM bytes per launch of a training-step kernel from the committed PMC passes (profiles/*pmc_traffic_train.json, produced by
+    tools/pmc_traffic_train.py from separate FETCH_SIZE / WRITE_SIZE runs of tools/train_bench.py); null if absent / other batch."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*pmc_traffic_train.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            t = json.load(f)
+        if t.get("batch") != batch:
+            return None
+        name = {"egr_conv2d_nhwc_f32[bf16x3]": "conv_igemm_bf16x3", "egr_conv2d_nhwc_f32": "conv_igemm_f32",
+                "egr_conv2d_wgrad_f32": "conv_wgrad_bf16x3"}.get(key)
+        e = t["kernels"].get(name) if name else None
+        return e["hbm_bytes_per_launch"] if e else None
+    except Exception:
+        return None
+
+
 def _roofline(key: str, k: dict, traffic):
     """Roofline object of one profiled kernel.  Split-bf16 launches execute X6_TERMS bf16 MFMA products per algorithmic fp32
     product: `achieved` is the executed bf16 matrix-core rate against the bf16 dense peak; the algorithmic (fp32-equivalent)
@@ -350,7 +370,7 @@ def train_leg(args, dev, rank: int, world: int, backend: str):
         dom = max(kernels, key=lambda n: kernels[n]["ms"])
         k = kernels[dom]
         if k["flops"] > 0:
-            leg["roofline"] = _roofline(dom, k, None)
+            leg["roofline"] = _roofline(dom, k, _pmc_traffic_train(B, dom))
     return leg
 
 
