@@ -1141,7 +1141,8 @@ static int conv_run(const egr_conv_desc* dd, const float* x, const float* w, con
     if (a.cls_mode) d.split_k = 1;
     if (d.split_k <= 0) {
         d.split_k = 1;
-        if (blocks < 128 && a.ktiles >= 32 && workspace) {
+        // (also: a few hundred blocks each walking a very long K alone - heatmap_proj.0: 240 blocks x 128 chunks, latency-bound)
+        if ((blocks < 128 ? a.ktiles >= 32 : (blocks < 512 && a.ktiles >= 64 && d.w_format == EGR_W_F32)) && workspace) {
             // skinny GEMM streaming a long weight matrix (mlp_pred.0: 268 MB): a block's two-stage pipeline moves ~8 GB/s,
             // so the HBM rate is set by how many blocks stream at once -> aim at 4 per CU
             static const int target = getenv("EGR_SPLITK_TARGET") ? atoi(getenv("EGR_SPLITK_TARGET")) : 1024;   // tuning knob
