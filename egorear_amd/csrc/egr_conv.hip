@@ -745,7 +745,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
         };
         constexpr int NS = 9 * NU;          // slices per stage
         constexpr int NM = 6 * FM * FN;     // MFMAs per stage
-        constexpr int S0 = (NM >= 12) ? NM / 6 : 0;   // MFMAs in front of the first slice (its operands are the youngest loads but two)
+        // MFMAs in front of the first slice (its operands are the youngest loads but two).  Measured neutral-to-worse: starting the
+        // slices behind MFMA 2 or 8, finishing them 2 / 4 / 8 MFMAs before the barrier.
+        constexpr int S0 = (NM >= 12) ? NM / 6 : 0;
         // One stage.  BUF: the LDS buffer multiplied.  CONV: the registers of set BUF^1 / breg hold the next stage's operands and
         // go to buffer BUF^1.  LOADS: the operands of the stage after next are requested (A into set BUF, B into breg).
         auto stage = [&](auto buf_tag, auto conv_tag, auto loads_tag, KPos kl, int sl) {
@@ -758,13 +760,18 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
             bf16x8 af[FM][3], bf[FN][3];
             // fragments in the order of their first use: (lo, hi) (hi, lo) (mid, mid)
             constexpr int RA[3] = {2, 0, 1}, RB[3] = {0, 2, 1};
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            auto read_q = [&](int q) {
 #pragma unroll
                 for (int i = 0; i < FM; ++i) af[i][RA[q]] = *reinterpret_cast<const bf16x8*>(st + ((wm * FM + i) * 3 + RA[q]) * 1024 + lane * 16);
 #pragma unroll
                 for (int j = 0; j < FN; ++j) bf[j][RB[q]] = *reinterpret_cast<const bf16x8*>(st + A_BYTES + ((wn * FN + j) * 3 + RB[q]) * 1024 + lane * 16);
-            }
+            };
+            // (lo, hi) and (hi, lo) operands first, pinned in this order; the (mid, mid) ones follow behind the first product's
+            // MFMAs (+1-4 %: the first MFMA of a stage waits for 4 reads instead of 9 - the compiler had shuffled them)
+            read_q(0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_q(1);
+            __builtin_amdgcn_sched_barrier(0);
             if constexpr (conv) write_b(NB{});
             if constexpr (loads) {
                 load_b(kl, sl);
@@ -781,6 +788,11 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
 #pragma unroll
                     for (int j = 0; j < FN; ++j, ++n) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
+                        if (n == FM * FN - 1) {   // the (mid, mid) fragments are first needed by the third product
+                            __builtin_amdgcn_sched_barrier(0);
+                            read_q(2);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                         if constexpr (conv) {
                             // spread the slices evenly behind the matrix instructions S0 .. NM-1
                             const int upto = (n + 1 <= S0) ? 0 : ((n + 1 - S0) * NS + (NM - S0) - 1) / (NM - S0);
