@@ -111,7 +111,8 @@ struct LdsPlan {
     static constexpr int ROWOFF = (2 * TILE > BM * CS) ? 2 * TILE : BM * CS;  // row offsets (y, res) live past both
     static constexpr bool PERSIST = X6 && PERSIST_;                           // persistent workgroups, see the tile loop of the split kernel
     static constexpr int TABLES = PERSIST ? 2 : 1;                            // the next tile's table is decoded under the epilogue
-    static constexpr int FLOATS = ROWOFF + 4 * BM * TABLES;                   // + per-row input offset and tap mask
+    static constexpr int TCOLS = 6;                                           // y / res offset, x offset, tap mask, two bilinear weights (EGR_RES_UP2_BEFORE_ACT)
+    static constexpr int FLOATS = ROWOFF + TCOLS * BM * TABLES;
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -204,10 +205,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     // offsets.  Per chunk a lane then adds the wave-uniform tap offset and tests one mask bit.
     const int rsub = wave * 8 + (lane >> 3);
     const int pseg = lane & 7;
-    int* const tab0 = reinterpret_cast<int*>(lds + P::ROWOFF);   // table `slot`: [yoff | roff | xoff | mask] x BM
+    int* const tab0 = reinterpret_cast<int*>(lds + P::ROWOFF);   // table `slot`: [yoff | roff | xoff | mask | lx | ly] x BM
     const unsigned fullmask = (d.kh * d.kw >= 32) ? 0xffffffffu : ((1u << (d.kh * d.kw)) - 1u);
     auto decode = [&](int tm_, int slot) {
-    int* const s_yoff = tab0 + slot * 4 * BM;
+    int* const s_yoff = tab0 + slot * P::TCOLS * BM;
     int* const s_roff = s_yoff + BM;
     int* const s_xoff = s_roff + BM;
     unsigned* const s_mask = reinterpret_cast<unsigned*>(s_xoff + BM);
@@ -258,6 +259,23 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
             mk &= fullmask;
             yo = (a.y_plain ? n * (int)d.ymap.stride_inner : (int)fmap(d.ymap, a.dYin, n)) + (d.out_nchw ? pix : pix * d.ldy);
             if (d.res_mode == EGR_RES_BEFORE_ACT || d.res_mode == EGR_RES_AFTER_ACT) ro = (a.r_plain ? n * (int)d.rmap.stride_inner : (int)fmap(d.rmap, a.dRin, n)) + pix * d.ldr;
+            if (d.res_mode == EGR_RES_UP2_BEFORE_ACT) {
+                // residual = bilinear x2 upsampling (align_corners=True, ATen arithmetic as in upsample2x_kernel) of a HALF-resolution
+                // tensor: offset of the upper-left neighbour, the two weights; sign bit set = the right / lower neighbour is the
+                // same pixel (last column / row)
+                const int hl = d.ho >> 1, wl = d.wo >> 1;
+                const float shh = (d.ho > 1) ? (float)(hl - 1) / (float)(d.ho - 1) : 0.f;
+                const float sww = (d.wo > 1) ? (float)(wl - 1) / (float)(d.wo - 1) : 0.f;
+                const float fy = shh * (float)ho, fx = sww * (float)wo;
+                const int y0 = (int)fy, x0 = (int)fx;
+                const float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f);
+                ro = (a.r_plain ? n * (int)d.rmap.stride_inner : (int)fmap(d.rmap, a.dRin, n)) + (y0 * wl + x0) * d.ldr;
+                s_yoff[4 * BM + r] = (int)(__float_as_uint(lx1) | (x0 + 1 > wl - 1 ? 0x80000000u : 0u));
+                s_yoff[5 * BM + r] = (int)(__float_as_uint(ly1) | (y0 + 1 > hl - 1 ? 0x80000000u : 0u));
+            }
+        } else if (d.res_mode == EGR_RES_UP2_BEFORE_ACT) {
+            s_yoff[4 * BM + r] = 0;
+            s_yoff[5 * BM + r] = 0;
         }
         s_xoff[r] = xo;
         s_mask[r] = mk;
@@ -364,32 +382,25 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
         }
 
     if (d.res_mode == EGR_RES_UP2_BEFORE_ACT) {
-        // residual = bilinear x2 upsampling (align_corners=True, ATen arithmetic as in upsample2x_kernel) of a HALF-resolution
-        // tensor, evaluated here instead of being materialised by a separate pass (the FPN top-down path): 4 gathers per output
-        const int hl = d.ho >> 1, wl = d.wo >> 1;
-        const float shh = (d.ho > 1) ? (float)(hl - 1) / (float)(d.ho - 1) : 0.f;
-        const float sww = (d.wo > 1) ? (float)(wl - 1) / (float)(d.wo - 1) : 0.f;
-#pragma unroll 4
+        // the residual is interpolated here instead of being materialised by a separate pass (the FPN top-down path): 4 gathers
+        // per output, parameters from the row table.  Straight-line code - the gathers of padded rows read offset 0, only the
+        // store is predicated (a branch around the loads would make every row wait for its own gathers)
+        const int wl = d.wo >> 1;
+        const int dxo = d.ldr, dyo = wl * d.ldr;
+        const float* const rb = resg + co;
+#pragma unroll 8
         for (int it = 0; it < BM / RPI; ++it) {
             const int row = row0 + it * RPI;
             const int yo = s_yoff[row];
-            if (yo < 0) continue;
-            const int m = tm * BM + row;
-            int n, pix, oy, ox;
-            if (a.howo_shift >= 0) { n = m >> a.howo_shift; pix = m & (HoWo - 1); }
-            else { n = fdiv(m, a.dHoWo); pix = m - n * HoWo; }
-            if (a.wo_shift >= 0) { oy = pix >> a.wo_shift; ox = pix & (d.wo - 1); }
-            else { oy = fdiv(pix, a.dWo); ox = pix - oy * d.wo; }
-            const float fy = shh * (float)oy, fx = sww * (float)ox;
-            const int y0 = (int)fy, x0 = (int)fx;
-            const int y1 = min(y0 + 1, hl - 1), x1 = min(x0 + 1, wl - 1);
-            const float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f);
-            const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-            const float* rb = resg + (a.r_plain ? (int64_t)n * d.rmap.stride_inner : (int64_t)fmap(d.rmap, a.dRin, n)) + co;
-            const f32x4 v00 = *reinterpret_cast<const f32x4*>(rb + (int64_t)(y0 * wl + x0) * d.ldr);
-            const f32x4 v01 = *reinterpret_cast<const f32x4*>(rb + (int64_t)(y0 * wl + x1) * d.ldr);
-            const f32x4 v10 = *reinterpret_cast<const f32x4*>(rb + (int64_t)(y1 * wl + x0) * d.ldr);
-            const f32x4 v11 = *reinterpret_cast<const f32x4*>(rb + (int64_t)(y1 * wl + x1) * d.ldr);
+            const int ro = s_roff[row];
+            const unsigned bx = (unsigned)s_yoff[4 * BM + row], by = (unsigned)s_yoff[5 * BM + row];
+            const float lx1 = __uint_as_float(bx & 0x7fffffffu), ly1 = __uint_as_float(by & 0x7fffffffu);
+            const float lx0 = 1.f - lx1, ly0 = 1.f - ly1;
+            const int ox = (bx >> 31) ? 0 : dxo, oy = (by >> 31) ? 0 : dyo;
+            const f32x4 v00 = *reinterpret_cast<const f32x4*>(rb + ro);
+            const f32x4 v01 = *reinterpret_cast<const f32x4*>(rb + ro + ox);
+            const f32x4 v10 = *reinterpret_cast<const f32x4*>(rb + ro + oy);
+            const f32x4 v11 = *reinterpret_cast<const f32x4*>(rb + ro + oy + ox);
             f32x4 v = *reinterpret_cast<const f32x4*>(&sC[row * P::CS + cq * 4]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -397,7 +408,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
                 t += ly0 * (lx0 * v00[e] + lx1 * v01[e]) + ly1 * (lx0 * v10[e] + lx1 * v11[e]);
                 v[e] = (d.act == EGR_ACT_RELU) ? (t > 0.f ? t : 0.f) : t;
             }
-            *reinterpret_cast<f32x4*>(yg + (int64_t)yo + co) = v;
+            if (yo >= 0) *reinterpret_cast<f32x4*>(yg + (int64_t)yo + co) = v;
         }
         return;
     }
@@ -675,7 +686,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
         }
         // a tile's staging roles: row offsets / dead-tap masks from table `slot`, weight piece offsets of column tile tn_
         auto unit_setup = [&](int slot, int tn_) {
-            const int* const t_xoff = tab0 + slot * 4 * BM + 2 * BM;
+            const int* const t_xoff = tab0 + slot * P::TCOLS * BM + 2 * BM;
             const int* const t_mask = t_xoff + BM;
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
@@ -846,7 +857,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
                 tile_of(vn, tmn, tnn);
                 decode(tmn, slot ^ 1);
             }
-            const int* const t_yoff = tab0 + slot * 4 * BM;
+            const int* const t_yoff = tab0 + slot * P::TCOLS * BM;
             epilogue(tm, tn, t_yoff, t_yoff + BM, [&] {
                 if (more) {
                     unit_setup(slot ^ 1, tnn);

@@ -22,6 +22,8 @@ SHAPES = [
     (64, 64, 64, 128, 256, 1, 1, 0, "1x1 128->256 @64 (refiner proj .0)"),
     (128, 64, 64, 128, 128, 1, 1, 0, "1x1 128->128 @64"),
     (128, 64, 64, 64, 128, 1, 1, 0, "1x1 64->128 @64 (lateral0)"),
+    (128, 64, 64, 128, 128, 1, 1, 3, "fuse 1x1 128->128 @64 (+up2 res)"),
+    (128, 32, 32, 128, 128, 1, 1, 3, "fuse 1x1 128->128 @32 (+up2 res)"),
     (256, 64, 64, 128, 64, 1, 1, 0, "1x1 128->64 @64 (conv_frame_feat.0)"),
     (64, 64, 64, 128, 15, 1, 1, 0, "1x1 128->15 @64"),
     (3840, 1, 1, 128, 64, 1, 1, 0, "head value proj M3840"),
@@ -52,7 +54,7 @@ for (n, h, w, cin, cout, k, s, rm, label) in SHAPES:
         wt = hip.pack_w6(wt)
     sc, sh = torch.rand(npad, device=dev) + 0.5, torch.randn(npad, device=dev)
     ho, wo = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
-    res = torch.randn(n, ho, wo, cout, device=dev) if rm else None
+    res = (torch.randn(n, ho // 2, wo // 2, cout, device=dev) if rm == 3 else torch.randn(n, ho, wo, cout, device=dev)) if rm else None
     out = hip.Img(torch.empty(n, ho, wo, cout, device=dev))
     flops = 2.0 * n * ho * wo * cout * k * k * cin
     cells = []

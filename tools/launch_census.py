@@ -20,11 +20,15 @@ if a.report:
     last = rows[-per:]
     cnt = collections.Counter(); dur = collections.Counter()
     for r in last:
-        k = r["Kernel_Name"].replace("void (anonymous namespace)::", "").split("(")[0][:70]
+        k = r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0][:70] or r["Kernel_Name"][:70]
         cnt[k] += 1; dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     print(f"launches per forward: {per}; kernel time {sum(dur.values()) / 1e3:.3f} ms; span {(int(last[-1]['End_Timestamp']) - int(last[0]['Start_Timestamp'])) / 1e6:.3f} ms")
     for k, c in sorted(cnt.items(), key=lambda kv: -dur[kv[0]]):
         print(f"{c:4d}  {dur[k]:9.1f} us  {k}")
+    if os.environ.get("CENSUS_SEQ"):
+        for i, r in enumerate(last):
+            k = r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0][:60] or r["Kernel_Name"][:60]
+            print(f"  {i:3d} {(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:8.1f} us  grid {r.get('Grid_Size_X', '?'):>8}  {k}")
     sys.exit(0)
 import torch
 from egorear_amd import configs, synth
