@@ -7,6 +7,7 @@
 // with the A operand gathered straight out of the staged patch (the (ci,kh,kw) -> LDS offset of every
 // step is a compile-time constant; the two lane halves take the even / odd k of the step).
 #include "egr_common.h"
+#include "egr_stem_pool.h"
 
 namespace {
 
@@ -41,6 +42,8 @@ constexpr int PLOADS = (3 * PH * PW + 255) / 256;         // patch elements per 
 // Persistent workgroups: the 64 x 147 filter bank is staged once per workgroup, which then walks tiles with stride
 // gridDim.x.  The next tile's input patch is fetched into registers before the MFMA loop of the current tile and
 // parked in the other LDS buffer afterwards, so its global-load latency hides under 296 MFMAs.
+// POOL: MaxPool2d(3, 2, 1) in the epilogue (egr_stem_pool.h) - the (n, h/2, w/2, 64) tensor is never written.
+template <bool POOL>
 __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
     __shared__ float s_patch[2][PATCH];
     __shared__ __attribute__((aligned(16))) float s_w[KPAD * 64];
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
     const bool raw = a.scale == nullptr;   // training mode: the bare convolution (BatchNorm on batch statistics follows)
     const float* scale = raw ? nullptr : a.scale + grp * 64;
     const float* shift = raw ? nullptr : a.shift + grp * 64;
-    float* y = a.y + (int64_t)grp * a.n * a.ho * a.wo * 64;
+    float* y = a.y + (int64_t)grp * a.n * (POOL ? (a.ho >> 1) * (a.wo >> 1) : a.ho * a.wo) * 64;
 
     // per-thread patch slots: element i = tid + 256*u -> (ci, py, px) and its LDS offset (tile independent)
     int p_lds[PLOADS], p_ci[PLOADS], p_py[PLOADS], p_px[PLOADS];
@@ -134,6 +137,14 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
         const int t = tile - n * tpi;
         const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
         const int oy0 = ty * TH, ox0 = tx * TW;
+        if constexpr (POOL) {
+            StemPool<TH / 2> pool;
+            pool.reduce(acc, sc, sh, half);
+            __syncthreads();                         // every wave is done with the patch: its buffer is the exchange area now
+            pool.publish(s_patch[buf], wave, l31, half);
+            __syncthreads();
+            pool.finish(s_patch[buf], wave, l31, half, y, n, oy0, ox0, a.ho >> 1, a.wo >> 1);
+        } else
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int oy = oy0 + 2 * wave + i;
@@ -318,7 +329,28 @@ extern "C" int egr_stem_conv7x7_f32(const float* x, egr_nmap xmap, int32_t n, in
     int64_t blocks = 512 / groups;
     if (blocks < 1) blocks = 1;
     if (blocks > tiles) blocks = tiles;
-    hipLaunchKernelGGL(stem_kernel, dim3((unsigned)blocks, (unsigned)groups), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(stem_kernel<false>, dim3((unsigned)blocks, (unsigned)groups), dim3(256), 0, (hipStream_t)stream, a);
+    return egr_launch_status();
+}
+
+extern "C" int egr_stem_conv7x7_pool_f32(const float* x, egr_nmap xmap, int32_t n, int32_t h, int32_t w, const float* wpack,
+                                         const float* scale, const float* shift, float* y, int32_t groups, int64_t gx,
+                                         void* stream) {
+    if (!x || !wpack || !y || !scale || !shift) return EGR_ENULL;
+    if (groups <= 0 || groups > 65535) return EGR_EINVAL;
+    if (n <= 0 || h <= 0 || w <= 0 || h % (2 * TH) != 0 || w % (2 * TW) != 0 || xmap.n_inner <= 0) return EGR_EINVAL;
+    StemArgs a;
+    a.x = x; a.xmap = xmap; a.n = n; a.h = h; a.w = w; a.ho = h / 2; a.wo = w / 2;
+    a.wpack = wpack; a.scale = scale; a.shift = shift; a.y = y;
+    a.tiles_x = a.wo / TW; a.tiles_y = a.ho / TH;
+    a.gx = gx;
+    const int64_t tiles = (int64_t)n * a.tiles_x * a.tiles_y;
+    if (tiles >= (1LL << 31)) return EGR_EINVAL;
+    stem_pool_init<TH / 2>(y, (int64_t)groups * n, a.ho / 2, a.wo / 2, (hipStream_t)stream);
+    int64_t blocks = 512 / groups;
+    if (blocks < 1) blocks = 1;
+    if (blocks > tiles) blocks = tiles;
+    hipLaunchKernelGGL(stem_kernel<true>, dim3((unsigned)blocks, (unsigned)groups), dim3(256), 0, (hipStream_t)stream, a);
     return egr_launch_status();
 }
 

@@ -1,0 +1,131 @@
+// MaxPool2d(3, 2, 1) (models/backbones/resnet.py:17) evaluated in the epilogue of the stem kernels (egr_stem.hip, egr_stem_x6.hip).
+//
+// Geometry shared by both kernels: a tile is 2*NW conv rows x 32 conv columns, wave w owns the conv rows (2w, 2w+1) as two
+// 32x32 MFMA accumulators per channel half (fragment j holds the channels 2*(lane&31) + j; accumulator register r of lane l is
+// conv column (r&3) + 8*(r>>2) + 4*(l>>5)).  Pooled row p of the tile takes the conv rows 2p-1, 2p, 2p+1: the last two are wave
+// p's own, the first is the second row of wave p-1 and comes through LDS.  Pooled column c takes the conv columns 2c-1, 2c, 2c+1:
+// a lane holds whole (2c, 2c+1) pairs, the odd column to their left is in the same lane or in lane ^ 32.  What is missing at
+// the tile's upper / left edge belongs to a neighbouring tile: those pooled pixels - tile row 0, tile column 0, and this tile's
+// own contributions to the next tiles' - are combined with integer atomic max on the float bits (exact, order-independent,
+// valid because everything is >= 0 behind the ReLU) on locations that stem_pool_init_kernel zeroed; the rest are plain stores.
+#pragma once
+#include "egr_common.h"
+
+template <int NW>
+struct StemPool {
+    f32x2 P0[8];   // pooled row w,   pooled columns pc(q), from the conv rows 2w, 2w+1
+    f32x2 P1[8];   // pooled row w+1, the same columns, from the conv row 2w+1 alone
+    f32x2 e0, e1;  // lanes >= 32: conv column 31 -> pooled column 16 (the next tile's column 0) of the rows w / w+1
+
+    static __device__ __forceinline__ int pc(int q, int half) { return (q & 1) + 4 * (q >> 1) + 2 * half; }
+
+    // BatchNorm (scale, shift) + ReLU + the in-register part of the pooling
+    __device__ __forceinline__ void reduce(const f32x16 (&acc)[2][2], const float (&sc)[2], const float (&sh)[2], int half) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float vm[16], v1[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float t0 = acc[0][j][r] * sc[j] + sh[j], t1 = acc[1][j][r] * sc[j] + sh[j];
+                t0 = t0 > 0.f ? t0 : 0.f;
+                t1 = t1 > 0.f ? t1 : 0.f;
+                v1[r] = t1;
+                vm[r] = fmaxf(t0, t1);
+            }
+            float om[4], o1[4];     // the partner half's columns 3, 7, 11, 15 (+ 4 * its half)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { om[g] = __shfl_xor(vm[4 * g + 3], 32); o1[g] = __shfl_xor(v1[4 * g + 3], 32); }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int g = q >> 1;
+                float x0 = fmaxf(vm[2 * q], vm[2 * q + 1]), x1 = fmaxf(v1[2 * q], v1[2 * q + 1]);
+                if (q & 1) { x0 = fmaxf(x0, vm[2 * q - 1]); x1 = fmaxf(x1, v1[2 * q - 1]); }
+                else {
+                    // left neighbour column: half 1 -> the partner's column 4g+3; half 0 -> the partner's 4(g-1)+3 (+4); none for column 0
+                    const float lm = half ? om[g] : (g > 0 ? om[g - 1] : 0.f), l1 = half ? o1[g] : (g > 0 ? o1[g - 1] : 0.f);
+                    x0 = fmaxf(x0, lm); x1 = fmaxf(x1, l1);
+                }
+                P0[q][j] = x0; P1[q][j] = x1;
+            }
+            e0[j] = vm[15]; e1[j] = v1[15];
+        }
+    }
+
+    static constexpr int XFLOATS = (NW - 1) * 16 * 64;   // exchange area: [NW-1][16 pooled columns][64 channels]
+
+    // waves 0 .. NW-2 hand their second conv row to the wave below (call between two barriers)
+    __device__ __forceinline__ void publish(float* s_x, int wave, int l31, int half) const {
+        if (wave < NW - 1) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) *reinterpret_cast<f32x2*>(&s_x[(wave * 16 + pc(q, half)) * 64 + 2 * l31]) = P1[q];
+        }
+    }
+
+    static __device__ __forceinline__ void amax2(float* p, f32x2 v) {
+        atomicMax(reinterpret_cast<int*>(p), __float_as_int(v[0]));
+        atomicMax(reinterpret_cast<int*>(p) + 1, __float_as_int(v[1]));
+    }
+
+    // y: the group's pooled output (n, pho, pwo, 64); (oy0, ox0): the tile's first conv row / column
+    __device__ __forceinline__ void finish(const float* s_x, int wave, int l31, int half, float* y, int n, int oy0, int ox0, int pho, int pwo) {
+        if (wave > 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x2 u = *reinterpret_cast<const f32x2*>(&s_x[((wave - 1) * 16 + pc(q, half)) * 64 + 2 * l31]);
+                P0[q][0] = fmaxf(P0[q][0], u[0]); P0[q][1] = fmaxf(P0[q][1], u[1]);
+            }
+        }
+        const int gp = (oy0 >> 1) + wave, gc0 = ox0 >> 1;
+        float* const yrow = y + (((int64_t)n * pho + gp) * pwo + gc0) * 64 + 2 * l31;
+        const bool arow = wave == 0 && oy0 > 0;          // the tile above contributes to this pooled row
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float* const p = yrow + pc(q, half) * 64;
+            if (arow || (q == 0 && half == 0 && ox0 > 0)) amax2(p, P0[q]);
+            else *reinterpret_cast<f32x2*>(p) = P0[q];
+        }
+        if (half && gc0 + 16 < pwo) {
+            amax2(yrow + 16 * 64, e0);
+            if (gp + 1 < pho) amax2(yrow + (int64_t)pwo * 64 + 16 * 64, e1);
+        }
+        if (wave == NW - 1 && gp + 1 < pho) {            // this tile's last conv row belongs to the next tile's first pooled row
+#pragma unroll
+            for (int q = 0; q < 8; ++q) amax2(yrow + (int64_t)pwo * 64 + pc(q, half) * 64, P1[q]);
+        }
+    }
+};
+
+// zero the pooled pixels that are combined with atomic max: pooled rows p % NW == 0 (p > 0) [region A], pooled columns
+// c % 16 == 0 (c > 0) [region B].  One thread per 4 channels; only those pixels are enumerated.
+template <int NW>
+__global__ __launch_bounds__(256) void stem_pool_init_kernel(float* y, int images, int pho, int pwo) {
+    const int rows = pho / NW - ((pho % NW) ? 0 : 1), cols = pwo / 16 - ((pwo % 16) ? 0 : 1);   // seams inside the image
+    const int64_t na = (int64_t)images * rows * pwo * 16, nb = (int64_t)images * pho * cols * 16;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int n, p, c;
+    if (i < na) {
+        const int q = (int)(i & 15);
+        int64_t t = i >> 4;
+        c = (int)(t % pwo); t /= pwo;
+        p = ((int)(t % rows) + 1) * NW; n = (int)(t / rows);
+        i = q;
+    } else if (i < na + nb) {
+        i -= na;
+        const int q = (int)(i & 15);
+        int64_t t = i >> 4;
+        c = ((int)(t % cols) + 1) * 16; t /= cols;
+        p = (int)(t % pho); n = (int)(t / pho);
+        i = q;
+    } else return;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(y + (((int64_t)n * pho + p) * pwo + c) * 64 + i * 4) = z;
+}
+
+// launch helper: `images` = all groups' images (the groups' outputs are contiguous)
+template <int NW>
+static inline void stem_pool_init(float* y, int64_t images, int pho, int pwo, hipStream_t s) {
+    const int rows = pho / NW - ((pho % NW) ? 0 : 1), cols = pwo / 16 - ((pwo % 16) ? 0 : 1);
+    const int64_t total = images * ((int64_t)rows * pwo + (int64_t)pho * cols) * 16;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(stem_pool_init_kernel<NW>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, y, (int)images, pho, pwo);
+}

@@ -1,0 +1,309 @@
+// ResNet stem on the bf16 matrix cores: conv 7x7 / stride 2 / pad 3, 3 -> 64 channels (+ BatchNorm(eval) + ReLU [+ MaxPool2d(3,2,1)]),
+// fp32 in / fp32 out, every fp32 operand as an exact sum of three bf16 (hi, mid, lo) and the six products of order <= 2 kept
+// (the scheme of egr_conv.hip's split kernel: as exact as an fp32 FMA chain, 2.5x the fp32 MFMA rate).
+//
+// GEMM view: M = output pixels, N = 64 channels, K = (ci, kh) pairs x 8 columns - kw is padded from 7 to 8 so that a lane's 8
+// consecutive k of one v_mfma_f32_32x32x16_bf16 step are 8 consecutive input pixels of one patch row (one (ci, kh) pair per lane
+// half): K = 21 pairs x 8 = 168 -> 11 steps of 16 (the 22nd pair and every 8th column carry zero weights).
+//   A: the input patch of the tile sits in LDS as fp32 (staged once per tile, next tile's patch prefetched into registers under the
+//      MFMA loop); a lane reads its 8 floats (4 x ds_read_b64) and splits them in registers (~45 VALU per fragment and step).
+//   B: the 64 x 176 filter bank, split once by egr_pack_stem_w6_f32 into fragment order, stays in LDS for the workgroup's life
+//      (66 KiB): 6 x ds_read_b128 per step and wave.
+// No barrier inside a tile's K loop (nothing in LDS changes); two per tile.  One persistent workgroup of 8 waves per CU
+// (tile = 16 x 32 output pixels, wave w owns the rows 2w, 2w+1 as 2 x 2 accumulators of 32 x 32).
+// Replaces layer_s2 (+ layer_s4[0]) of models/backbones/resnet.py:16-17,49.
+#include "egr_common.h"
+#include "egr_stem_pool.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NW = 8, NT = NW * 64;
+constexpr int TH = 2 * NW, TW = 32;      // output tile
+constexpr int PH = 2 * TH + 5;           // 37 input rows
+constexpr int PW = 2 * TW + 5;           // 69 input columns (+ 1: the padded 8th tap of the last pixel reads column 69)
+constexpr int PWS = 72;                  // patch row stride (even: 8-byte aligned ds_read_b64)
+constexpr int PATCH = 3 * PH * PWS;      // floats per staged patch
+constexpr int PLOADS = (PATCH + NT - 1) / NT;   // every float of the buffer is (re)written per tile, the pad columns with zeros
+#ifndef STEM_KS
+#define STEM_KS 11
+#endif
+constexpr int KS = STEM_KS;              // k16 steps
+constexpr int WBYTES = KS * 2 * 3 * 1024;
+
+static_assert(StemPool<NW>::XFLOATS <= PATCH, "the pooling exchange area lives in a dead patch buffer");
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float bf16_hi_f32(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
+__device__ __forceinline__ float bf16_lo_f32(unsigned p) { return __uint_as_float(p << 16); }
+
+struct StemX6Args {
+    const float* x;
+    egr_nmap xmap;
+    int n, h, w, ho, wo;
+    const uint8_t* w6;    // [groups][WBYTES]
+    const float* scale;
+    const float* shift;
+    float* y;
+    int tiles_x, tiles_y;
+    int64_t gx;
+};
+
+// LDS offset (floats) of the patch row of (ci, kh) pair p; the zero-weight 22nd pair reads the 21st
+__device__ __forceinline__ constexpr int pair_off(int p) {
+    const int pp = p > 20 ? 20 : p;
+    return (pp / 7) * PH * PWS + (pp % 7) * PWS;
+}
+
+template <bool POOL>
+__global__ __launch_bounds__(NT, 1) void stem_x6_kernel(const StemX6Args a) {
+    __shared__ __attribute__((aligned(16))) float s_patch[2][PATCH];
+    __shared__ __attribute__((aligned(16))) uint8_t s_w[WBYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int grp = blockIdx.y;
+    const int tpi = a.tiles_x * a.tiles_y;
+    const int total = a.n * tpi;
+    const float* xg = a.x + grp * a.gx;
+    const bool raw = a.scale == nullptr;   // training mode: the bare convolution
+    float* y = a.y + (int64_t)grp * a.n * (POOL ? (a.ho >> 1) * (a.wo >> 1) : a.ho * a.wo) * 64;
+
+    // per-thread patch slots: LDS float i = tid + NT*u -> (ci, py, px); columns >= PW are padding (read by the zero-weight 8th tap,
+    // overwritten by the pooling exchange area: rewritten with zeros for every tile so that 0 * x stays 0)
+    int p_lds[PLOADS], p_ci[PLOADS], p_py[PLOADS], p_px[PLOADS];
+#pragma unroll
+    for (int u = 0; u < PLOADS; ++u) {
+        const int i = tid + NT * u;
+        const int ci = i / (PH * PWS);
+        const int r = i - ci * PH * PWS;
+        p_ci[u] = ci; p_py[u] = r / PWS; p_px[u] = r - p_py[u] * PWS;
+        p_lds[u] = (i < PATCH) ? i : -1;
+    }
+    auto fetch = [&](int tile, float (&v)[PLOADS]) {
+        const int n = tile / tpi;
+        const int t = tile - n * tpi;
+        const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+        const int iy0 = 2 * ty * TH - 3, ix0 = 2 * tx * TW - 3;
+        const float* img = xg + egr_map(a.xmap, n);
+#pragma unroll
+        for (int u = 0; u < PLOADS; ++u) {
+            const int iy = iy0 + p_py[u], ix = ix0 + p_px[u];
+            const bool ok = p_lds[u] >= 0 && p_px[u] < PW && iy >= 0 && iy < a.h && ix >= 0 && ix < a.w;
+            v[u] = ok ? img[((int64_t)p_ci[u] * a.h + iy) * a.w + ix] : 0.f;
+        }
+    };
+    auto park = [&](int buf, const float (&v)[PLOADS]) {
+#pragma unroll
+        for (int u = 0; u < PLOADS; ++u)
+            if (p_lds[u] >= 0) s_patch[buf][p_lds[u]] = v[u];
+    };
+
+    {   // the split filter bank, once
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.w6 + (int64_t)grp * WBYTES);
+        for (int i = tid; i < WBYTES / 16; i += NT) reinterpret_cast<u32x4*>(s_w)[i] = src[i];
+    }
+    float pv[PLOADS];
+    int tile = blockIdx.x;
+    if (tile < total) {
+        fetch(tile, pv);
+        park(0, pv);
+    }
+    __syncthreads();
+
+    // wave w owns the tile rows 2w and 2w+1, lane -> column
+    const int abase0 = (2 * (2 * wave)) * PWS + 2 * l31;
+    const int abase1 = (2 * (2 * wave + 1)) * PWS + 2 * l31;
+    float sc[2], sh[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        sc[j] = raw ? 1.f : a.scale[grp * 64 + 2 * l31 + j];
+        sh[j] = raw ? 0.f : a.shift[grp * 64 + 2 * l31 + j];
+    }
+
+    int buf = 0;
+    for (; tile < total; tile += gridDim.x, buf ^= 1) {
+        const int next = tile + gridDim.x;
+        if (next < total) fetch(next, pv);        // in flight during the MFMA loop below
+        const float* sp = s_patch[buf];
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        // Software pipeline over the 11 steps: while step s multiplies, the raw floats and the weight fragments of step s+1 are read
+        // from LDS and the floats are split, one pair of values (11 VALU) behind every third MFMA.
+        f32x2 raw_a[2][4];
+        u32x4 sa[2][2][3];        // [parity][row][plane]: split A of the current / next step
+        bf16x8 bfr[2][2][3];      // [parity][channel half][plane]
+        auto read_a = [&](int s) {
+            const int ao = half ? pair_off(2 * s + 1) : pair_off(2 * s);
+            const float* q0 = sp + abase0 + ao;
+            const float* q1 = sp + abase1 + ao;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                raw_a[0][e] = *reinterpret_cast<const f32x2*>(q0 + 2 * e);
+                raw_a[1][e] = *reinterpret_cast<const f32x2*>(q1 + 2 * e);
+            }
+        };
+        auto read_b = [&](int s, int par) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    bfr[par][j][pl] = *reinterpret_cast<const bf16x8*>(s_w + ((s * 2 + j) * 3 + pl) * 1024 + lane * 16);
+        };
+        auto split_pair = [&](int par, int i, int e) {
+            const float v0 = raw_a[i][e][0], v1 = raw_a[i][e][1];
+            const unsigned h = cvt_pk_bf16(v0, v1);
+            const float r0 = v0 - bf16_lo_f32(h), r1 = v1 - bf16_hi_f32(h);
+            const unsigned m = cvt_pk_bf16(r0, r1);
+            sa[par][i][0][e] = h;
+            sa[par][i][1][e] = m;
+            sa[par][i][2][e] = cvt_pk_bf16(r0 - bf16_lo_f32(m), r1 - bf16_hi_f32(m));
+        };
+        read_a(0);
+        read_b(0, 0);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) split_pair(0, c >> 2, c & 3);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int par = s & 1;
+            if (s + 1 < KS) {
+                read_a(s + 1);
+                read_b(s + 1, par ^ 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // smallest terms first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+            int nm = 0;
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j, ++nm) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, sa[par][i][PA[t]]), bfr[par][j][PB[t]],
+                                                                            acc[i][j], 0, 0, 0);
+                        if (s + 1 < KS && nm % 3 == 2) {
+                            const int c = nm / 3;             // 0..7
+                            split_pair(par ^ 1, c >> 2, c & 3);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+        }
+
+        const int n = tile / tpi;
+        const int t = tile - n * tpi;
+        const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+#ifdef STEM_SKIP_EPI
+        if (acc[0][0][0] + acc[0][1][1] + acc[1][0][2] + acc[1][1][3] == 12345.f) y[tid] = 1.f;
+        if (next < total) park(buf ^ 1, pv);
+        __syncthreads();
+        continue;
+#endif
+        if constexpr (POOL) {
+            StemPool<NW> pool;
+            pool.reduce(acc, sc, sh, half);
+            __syncthreads();                             // A: every wave has left the K loop - the current patch buffer is dead,
+            pool.publish(s_patch[buf], wave, l31, half); //    and so is the exchange area of the previous tile in the other one
+            if (next < total) park(buf ^ 1, pv);
+            __syncthreads();                             // B: exchange rows and the next patch are visible
+            pool.finish(s_patch[buf], wave, l31, half, y, n, oy0, ox0, a.ho >> 1, a.wo >> 1);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int oy = oy0 + 2 * wave + i;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    f32x2 v;
+                    v[0] = acc[i][0][r] * sc[0] + sh[0];
+                    v[1] = acc[i][1][r] * sc[1] + sh[1];
+                    if (!raw) {
+                        v[0] = v[0] > 0.f ? v[0] : 0.f;
+                        v[1] = v[1] > 0.f ? v[1] : 0.f;
+                    }
+                    *reinterpret_cast<f32x2*>(&y[(((int64_t)n * a.ho + oy) * a.wo + ox) * 64 + 2 * l31]) = v;
+                }
+            }
+            if (next < total) park(buf ^ 1, pv);
+            __syncthreads();                           // next patch visible; everybody is done reading the current one
+        }
+    }
+}
+
+// w: [groups][64][148] fp32 (the layout egr_stem_conv7x7_f32 takes: rows = (ci, kh, kw), last column 0) -> the split bank
+// [groups][step s][fragment j][plane hi/mid/lo][lane][8 bf16]: lane l, element e is channel 2*(l&31) + j, pair p = 2s + (l>>5),
+// tap kw = e (zero for e == 7 and p == 21).  One thread per (group, s, j, lane).
+__global__ __launch_bounds__(64) void pack_stem_w6_kernel(const float* __restrict__ w, uint8_t* __restrict__ img) {
+    const int lane = threadIdx.x, j = blockIdx.x & 1, s = blockIdx.x >> 1, grp = blockIdx.y;
+    const int co = 2 * (lane & 31) + j, p = 2 * s + (lane >> 5);
+    const float* wr = w + ((int64_t)grp * 64 + co) * 148;
+    u32x4 h, m, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float v[2];
+#pragma unroll
+        for (int z = 0; z < 2; ++z) {
+            const int kw = 2 * e + z;
+            v[z] = (p <= 20 && kw < 7) ? wr[p * 7 + kw] : 0.f;     // (ci, kh) = (p / 7, p % 7): k = ci*49 + kh*7 + kw = p*7 + kw
+        }
+        h[e] = cvt_pk_bf16(v[0], v[1]);
+        const float r0 = v[0] - bf16_lo_f32(h[e]), r1 = v[1] - bf16_hi_f32(h[e]);
+        m[e] = cvt_pk_bf16(r0, r1);
+        l[e] = cvt_pk_bf16(r0 - bf16_lo_f32(m[e]), r1 - bf16_hi_f32(m[e]));
+    }
+    uint8_t* dst = img + (int64_t)grp * WBYTES + ((s * 2 + j) * 3) * 1024 + lane * 16;
+    *reinterpret_cast<u32x4*>(dst) = h;
+    *reinterpret_cast<u32x4*>(dst + 1024) = m;
+    *reinterpret_cast<u32x4*>(dst + 2048) = l;
+}
+
+}  // namespace
+
+extern "C" int64_t egr_stem_w6_bytes(void) { return WBYTES; }
+
+extern "C" int egr_pack_stem_w6_f32(const float* w, int32_t groups, void* img, void* stream) {
+    if (!w || !img) return EGR_ENULL;
+    if (groups <= 0 || groups > 65535 || ((uintptr_t)img & 15)) return EGR_EINVAL;
+    hipLaunchKernelGGL(pack_stem_w6_kernel, dim3(KS * 2, (unsigned)groups), dim3(64), 0, (hipStream_t)stream, w, (uint8_t*)img);
+    return egr_launch_status();
+}
+
+extern "C" int egr_stem_conv7x7_x6_f32(const float* x, egr_nmap xmap, int32_t n, int32_t h, int32_t w, const void* w6,
+                                       const float* scale, const float* shift, float* y, int32_t pool, int32_t groups, int64_t gx,
+                                       void* stream) {
+    if (!x || !w6 || !y || ((scale == nullptr) != (shift == nullptr))) return EGR_ENULL;   // scale == shift == NULL: raw conv
+    if (pool && !scale) return EGR_EINVAL;                                                   // the fused max relies on the ReLU
+    if (groups <= 0 || groups > 65535 || ((uintptr_t)w6 & 15)) return EGR_EINVAL;
+    if (n <= 0 || h <= 0 || w <= 0 || h % (2 * TH) != 0 || w % (2 * TW) != 0 || xmap.n_inner <= 0) return EGR_EINVAL;
+    StemX6Args a;
+    a.x = x; a.xmap = xmap; a.n = n; a.h = h; a.w = w; a.ho = h / 2; a.wo = w / 2;
+    a.w6 = (const uint8_t*)w6; a.scale = scale; a.shift = shift; a.y = y;
+    a.tiles_x = a.wo / TW; a.tiles_y = a.ho / TH;
+    a.gx = gx;
+    const int64_t tiles = (int64_t)n * a.tiles_x * a.tiles_y;
+    if (tiles >= (1LL << 31)) return EGR_EINVAL;
+    // persistent: one workgroup of 8 waves per CU (130 KiB of LDS), shared by the groups
+    int64_t blocks = 256 / groups;
+    if (blocks < 1) blocks = 1;
+    if (blocks > tiles) blocks = tiles;
+    hipStream_t s = (hipStream_t)stream;
+    if (pool) {
+        stem_pool_init<NW>(y, (int64_t)groups * n, a.ho / 2, a.wo / 2, s);
+        hipLaunchKernelGGL(stem_x6_kernel<true>, dim3((unsigned)blocks, (unsigned)groups), dim3(NT), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(stem_x6_kernel<false>, dim3((unsigned)blocks, (unsigned)groups), dim3(NT), 0, s, a);
+    }
+    return egr_launch_status();
+}

@@ -318,6 +318,13 @@ def _basic_block(st: State, blks, x: Img, out: Optional[Img] = None) -> Img:
     return conv(st, y, p2, ACT_RELU, res=identity, res_mode=RES_BEFORE_ACT, out=out)
 
 
+# Stem conv + BatchNorm + ReLU + MaxPool2d(3, 2, 1) in one pass (egr_stem_conv7x7_pool_f32, bit-identical to the two kernels);
+# EGR_STEM_POOL=0 keeps the two launches.
+STEM_POOL = os.environ.get("EGR_STEM_POOL", "1") != "0"
+# The stem on the bf16 matrix cores (egr_stem_conv7x7_x6_f32: split-bf16 operands like the other convolutions); EGR_STEM_X6=0: fp32 MFMA.
+STEM_X6 = os.environ.get("EGR_STEM_X6", "1") != "0"
+
+
 def run_backbone(st: State, encs, img: torch.Tensor, view0: int, nviews: int, feat_out: Img, s32_out: Optional[Img] = None):
     """ResNet-18 trunk + FPN (resnet.py:43-74,121-137) of len(encs) encoders in grouped launches: encoder g processes
     views [view0 + g*nviews, view0 + (g+1)*nviews).  Writes the stride-4 features into `feat_out`
@@ -326,8 +333,15 @@ def run_backbone(st: State, encs, img: torch.Tensor, view0: int, nviews: int, fe
     trunks, necks = [e.backbone for e in encs], [e.neck for e in encs]
     t0, n0 = trunks[0], necks[0]
     wp, sc, sh = st.get(t0.layer_s2, lambda: _pack_stems(trunks))
-    x = hip.stem(img, view0, nviews, wp, sc, sh, groups=G)
-    x = hip.maxpool(x, 3, 2, 1)
+    if STEM_X6:
+        w6 = st.get((id(t0.layer_s2), "w6"), lambda: hip.pack_stem_w6(wp))
+        x = hip.stem_x6(img, view0, nviews, w6, sc, sh, groups=G, pool=STEM_POOL)   # layer_s2 (+ the max-pool of layer_s4 in the same pass)
+    elif STEM_POOL:
+        x = hip.stem_pool(img, view0, nviews, wp, sc, sh, groups=G)
+    else:
+        x = hip.stem(img, view0, nviews, wp, sc, sh, groups=G)
+    if not STEM_POOL:
+        x = hip.maxpool(x, 3, 2, 1)
     pyramid = []
     stages = [(t.layer_s4[1], t.layer_s8, t.layer_s16, t.layer_s32) for t in trunks]
     for si in range(4):

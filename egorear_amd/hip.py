@@ -25,7 +25,8 @@ EXPORTS = [
     "egr_fisheye_project_f32", "egr_linear_smallk_f32", "egr_jqa_sum_f32", "egr_tokens_to_nhwc_f32", "egr_version",
     "egr_device_arch", "egr_conv_force_config", "egr_preprocess_u8_f32", "egr_pose_metrics_f32", "egr_gt_heatmap_f32", "egr_conv_debug_stamps", "egr_conv2d_wgrad_f32", "egr_conv2d_masked_f32", "egr_up2_relu_head_f32",
     "egr_msda_fwd_f32", "egr_msda_bwd_f32", "egr_w6_elems", "egr_pack_w6_f32", "egr_pack_w6_many_f32", "egr_joint_layer_f32",
-    "egr_preprocess_fused_u8_f32", "egr_preprocess_band_rows", "egr_conv_set_persist",
+    "egr_preprocess_fused_u8_f32", "egr_preprocess_band_rows", "egr_conv_set_persist", "egr_stem_conv7x7_pool_f32",
+    "egr_stem_w6_bytes", "egr_pack_stem_w6_f32", "egr_stem_conv7x7_x6_f32",
 ]
 
 
@@ -69,6 +70,11 @@ def _load() -> C.CDLL:
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     lib.egr_conv2d_nhwc_f32.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.egr_stem_conv7x7_f32.argtypes = [vp, NMap, i32, i32, i32, vp, vp, vp, vp, i32, i64, vp]
+    lib.egr_stem_conv7x7_pool_f32.argtypes = [vp, NMap, i32, i32, i32, vp, vp, vp, vp, i32, i64, vp]
+    lib.egr_stem_w6_bytes.restype = C.c_int64
+    lib.egr_stem_w6_bytes.argtypes = []
+    lib.egr_pack_stem_w6_f32.argtypes = [vp, i32, vp, vp]
+    lib.egr_stem_conv7x7_x6_f32.argtypes = [vp, NMap, i32, i32, i32, vp, vp, vp, vp, i32, i32, i64, vp]
     lib.egr_maxpool_nhwc_f32.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.egr_upsample2x_nhwc_f32.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.egr_avgpool_nhwc_f32.argtypes = [vp, vp, i32, i32, i32, vp]
@@ -101,7 +107,7 @@ def _load() -> C.CDLL:
     lib.egr_preprocess_u8_f32.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     for name in EXPORTS:
         getattr(lib, name)  # fail at import if a symbol is missing
-        if name not in ("egr_version", "egr_w6_elems"):
+        if name not in ("egr_version", "egr_w6_elems", "egr_stem_w6_bytes"):
             getattr(lib, name).restype = C.c_int
     return lib
 
@@ -457,6 +463,60 @@ def stem(img: torch.Tensor, view0: int, nviews: int, wpack, scale, shift, groups
     _launch("egr_stem_conv7x7_f32", lib.egr_stem_conv7x7_f32, _p(base), xmap, n, H, W, _p(_cont(wpack, "stem weight")), _p(scale),
             _p(shift), _p(y), groups, nviews * 3 * H * W, _stream(),
             flops=2.0 * groups * n * (H // 2) * (W // 2) * 64 * 147, nbytes=4.0 * groups * n * (3 * H * W + (H // 2) * (W // 2) * 64))
+    return Img(y)
+
+
+def stem_pool(img: torch.Tensor, view0: int, nviews: int, wpack, scale, shift, groups: int = 1) -> Img:
+    """stem() + maxpool(3, 2, 1) in one pass (eval mode): output NHWC (groups*nviews*B, H/4, W/4, 64)."""
+    B, V, Cc, H, W = img.shape
+    if Cc != 3:
+        raise RuntimeError("egorear_amd.stem_pool: 3-channel input expected")
+    _cont(img, "input image batch")
+    if scale is None or shift is None:
+        raise RuntimeError("egorear_amd.stem_pool: eval-mode BatchNorm scale / shift required")
+    if view0 + groups * nviews > V or wpack.numel() != groups * 64 * 148 or scale.numel() != groups * 64 or shift.numel() != groups * 64:
+        raise RuntimeError("egorear_amd.stem_pool: views / weights mismatch")
+    n = nviews * B
+    y = torch.empty((groups * n, H // 4, W // 4, 64), device=img.device, dtype=torch.float32)
+    base = img.reshape(-1)[view0 * 3 * H * W:]
+    xmap = NMap(B, V * 3 * H * W, 3 * H * W)
+    _launch("egr_stem_conv7x7_pool_f32", lib.egr_stem_conv7x7_pool_f32, _p(base), xmap, n, H, W, _p(_cont(wpack, "stem weight")),
+            _p(scale), _p(shift), _p(y), groups, nviews * 3 * H * W, _stream(),
+            flops=2.0 * groups * n * (H // 2) * (W // 2) * 64 * 147, nbytes=4.0 * groups * n * (3 * H * W + (H // 4) * (W // 4) * 64))
+    return Img(y)
+
+
+def pack_stem_w6(wpack: torch.Tensor) -> torch.Tensor:
+    """(groups, 64, 148) fp32 stem filters -> the split-bf16 bank of stem_x6 ((groups, egr_stem_w6_bytes()) uint8)."""
+    if wpack.dim() != 3 or wpack.shape[1:] != (64, 148) or wpack.dtype != torch.float32:
+        raise RuntimeError("egorear_amd.pack_stem_w6: (groups, 64, 148) fp32 expected")
+    img = torch.empty((wpack.shape[0], int(lib.egr_stem_w6_bytes())), device=wpack.device, dtype=torch.uint8)
+    _launch("egr_pack_stem_w6_f32", lib.egr_pack_stem_w6_f32, _p(_cont(wpack, "stem weight")), wpack.shape[0], _p(img, torch.uint8), _stream())
+    return img
+
+
+def stem_x6(img: torch.Tensor, view0: int, nviews: int, w6: torch.Tensor, scale, shift, groups: int = 1, pool: bool = False) -> Img:
+    """stem() on the bf16 matrix cores (w6 from pack_stem_w6); pool=True: + maxpool(3, 2, 1) in the same pass (eval mode),
+    output (groups*nviews*B, H/4, W/4, 64)."""
+    B, V, Cc, H, W = img.shape
+    if Cc != 3:
+        raise RuntimeError("egorear_amd.stem_x6: 3-channel input expected")
+    _cont(img, "input image batch")
+    raw = scale is None and shift is None
+    if pool and raw:
+        raise RuntimeError("egorear_amd.stem_x6: the fused max-pool needs the eval-mode BatchNorm scale / shift")
+    if (view0 + groups * nviews > V or w6.dtype != torch.uint8 or w6.numel() != groups * int(lib.egr_stem_w6_bytes())
+            or (not raw and (scale.numel() != groups * 64 or shift.numel() != groups * 64))):
+        raise RuntimeError("egorear_amd.stem_x6: views / weights mismatch")
+    n = nviews * B
+    d = 4 if pool else 2
+    y = torch.empty((groups * n, H // d, W // d, 64), device=img.device, dtype=torch.float32)
+    base = img.reshape(-1)[view0 * 3 * H * W:]
+    xmap = NMap(B, V * 3 * H * W, 3 * H * W)
+    _launch("egr_stem_conv7x7_x6_f32", lib.egr_stem_conv7x7_x6_f32, _p(base), xmap, n, H, W, _p(_cont(w6, "stem weight"), torch.uint8), _p(scale),
+            _p(shift), _p(y), 1 if pool else 0, groups, nviews * 3 * H * W, _stream(),
+            flops=2.0 * groups * n * (H // 2) * (W // 2) * 64 * 147, nbytes=4.0 * groups * n * (3 * H * W + (H // d) * (W // d) * 64),
+            tag="x6 pool" if pool else "x6")
     return Img(y)
 
 

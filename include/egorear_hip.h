@@ -165,6 +165,25 @@ int egr_stem_conv7x7_f32(const float* x, egr_nmap xmap, int32_t n, int32_t h, in
                          int32_t groups /* group g: x + g*gx, wpack + g*64*148, scale/shift + g*64, y + g*n*(h/2)*(w/2)*64 */,
                          int64_t gx, void* stream);
 
+/* The same stem followed by MaxPool2d(3, 2, 1) (resnet.py:16-17: layer_s2 + layer_s4[0]) in one pass: y is (n, h/4, w/4, 64) NHWC,
+ * the stride-2 tensor is never written.  Eval mode only (scale / shift required: the fused max relies on the ReLU's >= 0).
+ * Bit-identical to egr_stem_conv7x7_f32 + egr_maxpool_nhwc_f32.  Two launches (a zero-fill of the pooled pixels shared
+ * between tiles, then the convolution); groups as above with y + g*n*(h/4)*(w/4)*64. */
+int egr_stem_conv7x7_pool_f32(const float* x, egr_nmap xmap, int32_t n, int32_t h, int32_t w,
+                              const float* wpack, const float* scale, const float* shift, float* y,
+                              int32_t groups, int64_t gx, void* stream);
+
+/* The stem on the bf16 matrix cores (fp32 in / fp32 out; every operand as hi + mid + lo bf16, six products: the arithmetic of
+ * EGR_W_BF16X3 launches of egr_conv2d_nhwc_f32).  w6: the filter bank split once by egr_pack_stem_w6_f32 from the [groups][64][148]
+ * fp32 layout above (egr_stem_w6_bytes() bytes per group, 16-byte aligned).  pool != 0: MaxPool2d(3, 2, 1) in the same pass,
+ * y = (n, h/4, w/4, 64) (eval mode only; bit-identical to pool == 0 followed by egr_maxpool_nhwc_f32); pool == 0: y = (n, h/2, w/2, 64),
+ * scale == shift == NULL for the bare convolution.  h, w multiples of 64.  Replaces resnet.py:16-17,49. */
+int64_t egr_stem_w6_bytes(void);
+int egr_pack_stem_w6_f32(const float* w, int32_t groups, void* w6, void* stream);
+int egr_stem_conv7x7_x6_f32(const float* x, egr_nmap xmap, int32_t n, int32_t h, int32_t w,
+                            const void* w6, const float* scale, const float* shift, float* y,
+                            int32_t pool, int32_t groups, int64_t gx, void* stream);
+
 /* MaxPool2d(k, stride, pad) on NHWC (resnet.py:17 maxpool 3/2/1; egoposeformer_mvf_ex.py:234 MaxPool2d(2)). c % 4 == 0. */
 int egr_maxpool_nhwc_f32(const float* x, float* y, int32_t n, int32_t h, int32_t w, int32_t c,
                          int32_t k, int32_t stride, int32_t pad, void* stream);

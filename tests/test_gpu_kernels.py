@@ -194,6 +194,58 @@ def test_stem_matches_torch(hip):
     close(y.t.permute(0, 3, 1, 2), ref)
 
 
+@pytest.mark.parametrize("B,H,W,G", [(2, 64, 128, 1), (1, 256, 256, 2), (3, 128, 64, 1)])
+def test_stem_pool_is_stem_then_maxpool_bit_for_bit(hip, B, H, W, G):
+    """egr_stem_conv7x7_pool_f32 (resnet.py:16-17 in one pass; tile seams through atomic max) == the two kernels, exactly;
+    the output buffer starts dirty (the kernel zeroes what it combines atomically)."""
+    V = 2 * G
+    img = rnd(B, V, 3, H, W, seed=25).to(DEV)
+    wp = torch.zeros(G, 64, 148)
+    wp[:, :, :147] = rnd(G, 64, 147, seed=26, scale=0.1)
+    scale, shift = (rnd(G, 64, seed=27) * 0.3 + 1.0).to(DEV), rnd(G, 64, seed=28).to(DEV)
+    wp = wp.to(DEV)
+    two = hip.maxpool(hip.stem(img, 0, 2, wp, scale, shift, groups=G), 3, 2, 1).t
+    torch.empty_like(two).fill_(1e30)        # likely the block stem_pool's output gets
+    one = hip.stem_pool(img, 0, 2, wp, scale, shift, groups=G).t
+    assert one.shape == two.shape == (G * 2 * B, H // 4, W // 4, 64)
+    assert torch.equal(one, two)
+    again = hip.stem_pool(img, 0, 2, wp, scale, shift, groups=G).t
+    assert torch.equal(again, one)
+    with pytest.raises(RuntimeError):
+        hip.stem_pool(img, 0, 2, wp, None, None, groups=G)
+
+
+@pytest.mark.parametrize("B,H,W,G", [(2, 64, 128, 1), (1, 256, 256, 2), (3, 128, 64, 1)])
+def test_stem_x6_matches_torch_and_pools_bit_for_bit(hip, B, H, W, G):
+    """egr_stem_conv7x7_x6_f32 (split-bf16 operands): eval mode and raw mode vs fp64 at fp32-conv accuracy; pool=1 ==
+    pool=0 + maxpool exactly."""
+    V = 2 * G
+    img = rnd(B, V, 3, H, W, seed=35)
+    wt = rnd(G, 64, 3, 7, 7, seed=36, scale=0.1)
+    wp = torch.zeros(G, 64, 148)
+    wp[:, :, :147] = wt.reshape(G, 64, 147)
+    scale, shift = rnd(G, 64, seed=37) * 0.3 + 1.0, rnd(G, 64, seed=38)
+    w6 = hip.pack_stem_w6(wp.to(DEV))
+    assert w6.shape == (G, 11 * 2 * 3 * 1024) and w6.dtype == torch.uint8
+    y = hip.stem_x6(img.to(DEV), 0, 2, w6, scale.to(DEV), shift.to(DEV), groups=G)
+    yraw = hip.stem_x6(img.to(DEV), 0, 2, w6, None, None, groups=G)
+    for g in range(G):
+        xin = img[:, 2 * g:2 * g + 2].permute(1, 0, 2, 3, 4).reshape(2 * B, 3, H, W).double()
+        ref = F.conv2d(xin, wt[g].double(), None, 2, 3)
+        close(yraw.t[g * 2 * B:(g + 1) * 2 * B].permute(0, 3, 1, 2), ref)
+        close(y.t[g * 2 * B:(g + 1) * 2 * B].permute(0, 3, 1, 2), F.relu(ref * scale[g].double().view(1, -1, 1, 1) + shift[g].double().view(1, -1, 1, 1)))
+    # same accuracy class as the fp32-MFMA stem
+    y32 = hip.stem(img.to(DEV), 0, 2, wp.to(DEV), scale.to(DEV), shift.to(DEV), groups=G)
+    assert float((y.t - y32.t).abs().max()) <= 2e-6 * float(y32.t.abs().max())
+    two = hip.maxpool(y, 3, 2, 1).t
+    torch.empty_like(two).fill_(1e30)
+    one = hip.stem_x6(img.to(DEV), 0, 2, w6, scale.to(DEV), shift.to(DEV), groups=G, pool=True).t
+    assert one.shape == (G * 2 * B, H // 4, W // 4, 64) and torch.equal(one, two)
+    assert torch.equal(hip.stem_x6(img.to(DEV), 0, 2, w6, scale.to(DEV), shift.to(DEV), groups=G, pool=True).t, one)
+    with pytest.raises(RuntimeError):
+        hip.stem_x6(img.to(DEV), 0, 2, w6, None, None, groups=G, pool=True)
+
+
 def test_pool_and_upsample_match_torch(hip):
     x = rnd(3, 16, 16, 64, seed=31)
     xc = x.permute(0, 3, 1, 2)
