@@ -28,7 +28,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import hip
+from . import engine, hip
 from . import hip_train as T
 from . import repack
 from .engine import _npad, _pad_rows, _pad_vec, _rows
@@ -614,7 +614,9 @@ def backbone_train(S: Step, encs, img: torch.Tensor, view0: int, nviews: int):
             S.cache.watch(w)
         tbl.run()
         S.cache.packs[key] = wp
-    x = hip.stem(img, view0, nviews, wp, None, None, groups=G).t
+    # (split-bf16 launch like the other convolutions; the bank is re-split from the refreshed fp32 pack every step: one tiny launch)
+    x = hip.stem_x6(img, view0, nviews, hip.pack_stem_w6(wp), None, None, groups=G).t if engine.STEM_X6 else \
+        hip.stem(img, view0, nviews, wp, None, None, groups=G).t
     wnames = [S.name(w) for w in w7]
 
     def bwd_stem(x=x):

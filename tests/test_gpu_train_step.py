@@ -107,9 +107,17 @@ def test_optimizer_step_matches_reference_adamw(golden_dir):
             continue
         ok = np.abs(g["grad_samples"][i]) > 1e-6 * max(float(g["grad_norm"][i]), 1e-12)   # first Adam step ~ lr*sign(g): skip g ~ 0
         ref_d = g["param_delta_samples"][i]
-        # |update| < 0.9 lr means |g| is down at Adam's eps (1e-8): those elements amplify rounding noise of the gradient
-        tol = np.where(np.abs(ref_d) >= 0.9e-3, 2e-5, 1e-4)
-        if (np.abs(d - ref_d)[ok] > tol[ok]).any():
+        # the first step is lr * g / (|g| + eps): where |g| is down near Adam's eps (1e-8) it turns rounding noise of that gradient
+        # element into a visible part of lr.  An element that misses the update tolerance is therefore also judged in gradient
+        # space, with the tolerance of test_gradients_match_reference_autograd (0.4 % of the tensor's RMS gradient + 0.2 % of
+        # its largest sample), and counts only if it misses both
+        big = np.abs(ref_d) >= 0.9e-3
+        err = np.abs(d - ref_d)
+        u, ur = np.clip(d / 1e-3, -0.999, 0.999), np.clip(ref_d / 1e-3, -0.999, 0.999)
+        g_err = 1e-8 * np.abs(u / (1 - np.abs(u)) - ur / (1 - np.abs(ur)))
+        g_tol = 4e-3 * max(float(g["grad_norm"][i]), 1e-3) / np.sqrt(max(after[k].numel(), 1)) + 2e-3 * np.abs(g["grad_samples"][i]).max()
+        wrong = (err > np.where(big, 2e-5, 1e-4)) & (g_err > g_tol)      # (saturated updates: g_err is blunt there, err decides)
+        if wrong[ok].any():
             bad.append((k, d[ok], ref_d[ok]))
     assert not bad, f"{len(bad)} parameters moved differently, e.g. {bad[0]}"
     # the module still works as the drop-in inference module after the update (packed weights are rebuilt)
