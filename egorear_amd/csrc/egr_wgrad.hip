@@ -482,6 +482,187 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x6_kernel(const WgradArgs a
         }
 }
 
+// ---- 3x3 / stride 1 / pad 1 on the bf16 matrix cores with the taps SHARED.  In conv_wgrad_x6_kernel every (tap, pixel) row of
+// the im2col matrix is fetched and split on its own: each input pixel is split nine times, and with only 64 output channels to
+// amortise that over, the kernel is VALU-bound (96 TFLOP/s on layer1 against 150-170 on the wide layers).  Here a stage is 16
+// consecutive output pixels of ONE image row; the three input rows around them (18 pixels each, zeros outside the image) are split
+// once into pixel-major bf16 planes, and the nine taps are nine row-shifted windows of those planes - a shift by whole rows of
+// the transposing LDS read, free.  (WS = 8: images 8 pixels wide - a stage is two image rows, four input rows of 10 pixels.)  A workgroup owns CO_T output channels x CB_T 32-channel input chunks x all 9 taps =
+// 36 accumulator fragments of 32 x 32 (9 per wave: one dy fragment against the 9 taps of one input chunk), i.e. 3.6 split
+// instructions per MFMA instead of 11.  Rows are requested at the start of a stage and split behind its second third.
+template <int CO_T, int CB_T, int WS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad3_x6_kernel(const WgradArgs a) {
+    constexpr int PS = 16;                                       // output pixels per stage: PS / WS image rows of WS pixels
+    constexpr int XP = WS + 2, XR = PS / WS + 2;                 // input pixels per row / input rows, with the halo
+    static_assert(WS == 16 || WS == 8, "16 pixels of one row, or two rows of an 8-pixel-wide image");
+    constexpr int CX = CB_T * 32;                                // input channels of the tile
+    constexpr int ROW_DY = 2 * CO_T + 64, ROW_X = 2 * CX + 32;   // bytes per pixel row of a plane (padding: see frag())
+    constexpr int PL_DY = PS * ROW_DY, PL_X = XR * XP * ROW_X;
+    constexpr int STB = 3 * (PL_DY + PL_X);                      // bytes per stage
+    constexpr int SEG_DY = CO_T / 4, SEG_X = CX / 4;
+    constexpr int UD = PS * SEG_DY, UX = XR * XP * SEG_X;         // staging units (4 floats of one pixel)
+    constexpr int ND = UD / 256, NX = (UX + 255) / 256, NUN = ND + NX;
+    static_assert(UD % 256 == 0 && (CO_T / 32) * CB_T == 4, "tile shape");
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * STB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mfrag = wave / CB_T, cbl = wave % CB_T;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int tilesCB = a.cin / CX;
+    const int tcb = blockIdx.x % tilesCB, tco = blockIdx.x / tilesCB;
+    const int co0 = tco * CO_T, cb0 = tcb * CB_T;
+    const int split = blockIdx.y;
+    const int m_begin = split * a.rows_per_split;
+    const int m_end = min(a.M, m_begin + a.rows_per_split);
+    const int nstages = (m_end > m_begin) ? (m_end - m_begin) / PS : 0;      // M and rows_per_split are multiples of 16
+    const int HoWo = a.ho * a.wo;
+    const float* xg = a.x + (int64_t)blockIdx.z * a.gx;
+    const float* dyg = a.dy + (int64_t)blockIdx.z * a.gy;
+    float* wsg = a.ws + (int64_t)blockIdx.z * a.splits * a.cout * a.K;
+
+    // staging roles (stage independent): element offset relative to the stage's first output pixel, LDS destination
+    int d_off[ND], d_lds[ND], x_off[NX], x_lds[NX], x_row[NX], x_px[NX];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        const int u = tid + 256 * i, dp = u / SEG_DY, ds = u % SEG_DY;
+        d_off[i] = (dp * a.ldy + co0 + ds * 4) * 4;
+        d_lds[i] = dp * ROW_DY + ds * 8;
+    }
+    const int abias = (a.w + 1) * a.ldx * 4;       // the activation window starts one row + one pixel early: halo offsets stay >= 0
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int u = tid + 256 * i, xs = u % SEG_X, xp = (u / SEG_X) % XP, xr_ = u / (SEG_X * XP);
+        x_row[i] = (u < UX) ? xr_ - 1 : -100000;       // never inside the image
+        x_px[i] = xp - 1;
+        x_off[i] = (((xr_ - 1) * a.w + (xp - 1)) * a.ldx + cb0 * 32 + xs * 4) * 4 + abias;
+        x_lds[i] = (xr_ * XP + xp) * ROW_X + xs * 8;
+    }
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(wg_uniform_ptr(dyg), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rxa = __builtin_amdgcn_make_buffer_rsrc(wg_uniform_ptr(reinterpret_cast<const char*>(xg) - abias), 0, 0x80000000u,
+                                                                         0x00020000);
+    f32x4 xr[NUN];
+    auto request = [&](int stage) {     // everything about the stage itself is wave-uniform
+        const int m0 = m_begin + stage * PS;
+        int n, pix, y, x0;
+        if (a.howo_shift >= 0) { n = m0 >> a.howo_shift; pix = m0 & (HoWo - 1); }
+        else { n = m0 / HoWo; pix = m0 - n * HoWo; }
+        if (a.wo_shift >= 0) { y = pix >> a.wo_shift; x0 = pix & (a.wo - 1); }
+        else { y = pix / a.wo; x0 = pix - y * a.wo; }
+        const int so_y = __builtin_amdgcn_readfirstlane(((int)egr_map(a.ymap, n) + pix * a.ldy) * 4);
+        const int so_x = __builtin_amdgcn_readfirstlane(((int)egr_map(a.xmap, n) + (y * a.w + x0) * a.ldx) * 4);
+#pragma unroll
+        for (int i = 0; i < ND; ++i) xr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, d_off[i], so_y, 0));
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const bool ok = (unsigned)(y + x_row[i]) < (unsigned)a.h && (unsigned)(x0 + x_px[i]) < (unsigned)a.w;
+            xr[ND + i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxa, ok ? x_off[i] : (int)0x80000000, so_x, 0));
+        }
+    };
+    // slice k of the staging work: unit k / 5; step 0/1 = hi parts + residuals of the unit's two pairs, 2/3 = mid + lo, 4 = the writes
+    unsigned sh_[NUN][2], sm_[NUN][2], sl_[NUN][2];
+    float ra_[NUN][2], rb_[NUN][2];
+    auto slice = [&](int base, int k) {
+        const int u = k / 5, q = k % 5;
+        if (q < 2) {
+            const float v0 = xr[u][2 * q], v1 = xr[u][2 * q + 1];
+            sh_[u][q] = wg_cvt_pk(v0, v1);
+            ra_[u][q] = v0 - wg_lo(sh_[u][q]);
+            rb_[u][q] = v1 - wg_hi(sh_[u][q]);
+        } else if (q < 4) {
+            const int t = q - 2;
+            sm_[u][t] = wg_cvt_pk(ra_[u][t], rb_[u][t]);
+            sl_[u][t] = wg_cvt_pk(ra_[u][t] - wg_lo(sm_[u][t]), rb_[u][t] - wg_hi(sm_[u][t]));
+        } else if (u < ND || NX * 256 == UX || tid + 256 * (u - ND) < UX) {
+            uint8_t* dst;
+            int pl;
+            if (u < ND) { dst = lds + base + d_lds[u]; pl = PL_DY; }
+            else { dst = lds + base + 3 * PL_DY + x_lds[u - ND]; pl = PL_X; }
+            *reinterpret_cast<wg_u32x2*>(dst) = wg_u32x2{sh_[u][0], sh_[u][1]};
+            *reinterpret_cast<wg_u32x2*>(dst + pl) = wg_u32x2{sm_[u][0], sm_[u][1]};
+            *reinterpret_cast<wg_u32x2*>(dst + 2 * pl) = wg_u32x2{sl_[u][0], sl_[u][1]};
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // transposed-read address of this lane inside a plane: row (pixel) 8*half + 4*rd + q, 4 channels starting at 16*((lane>>4)&1) + 4*p.
+    // Row strides of 2*channels + 64 / + 32 bytes put the four 32-byte rows of one 16-lane read into four different bank ranges.
+    const int tq = (lane >> 2) & 3, tp = lane & 3, tg = (lane >> 4) & 1;
+    auto frag = [&](const uint8_t* plane, int row_bytes, int c0, int hrows) {   // hrows: LDS rows between pixel 0 and pixel 8 of the stage
+        wg_bf16x8 v;
+        const uint8_t* p = plane + (hrows * half + tq) * row_bytes + (c0 + 16 * tg + 4 * tp) * 2;
+        const wg_s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_s16x4*)(p));
+        const wg_s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_s16x4*)(p + 4 * row_bytes));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const s16x8 both = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+        __builtin_memcpy(&v, &both, 16);
+        return v;
+    };
+    constexpr int HB = (WS == 16) ? 8 : XP;      // pixel 8 of the stage: 8 rows further in the same image row, or the start of the next one
+    constexpr int NS = 5 * NUN, NM = 54, S0 = 18;
+    static_assert(NS <= NM - S0, "one slice per MFMA");
+    auto stage = [&](int cur, int nxt, auto conv_tag) {
+        constexpr bool conv = decltype(conv_tag)::value;
+        const uint8_t* st = lds + cur;
+        wg_bf16x8 af[3], bf[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) af[pl] = frag(st + pl * PL_DY, ROW_DY, mfrag * 32, 8);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bf[0][pl] = frag(st + 3 * PL_DY + pl * PL_X, ROW_X, cbl * 32, HB);
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+        int n = 0, done = 0;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 1 < 9) {
+                const int kh = (tap + 1) / 3, kw = (tap + 1) % 3;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bf[(tap + 1) & 1][pl] = frag(st + 3 * PL_DY + pl * PL_X + (kh * XP + kw) * ROW_X, ROW_X, cbl * 32, HB);
+            }
+#pragma unroll
+            for (int t = 0; t < 6; ++t, ++n) {
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t]], bf[tap & 1][PB[t]], acc[tap], 0, 0, 0);
+                if constexpr (conv) {
+                    // (n, hence upto and done, are compile-time values once the tap / product loops are unrolled; NS <= NM - S0:
+                    // at most one slice per MFMA - no inner loop over the slices, which the unroller gives up on at this size)
+                    const int upto = (n + 1 <= S0) ? 0 : ((n + 1 - S0) * NS + (NM - S0) - 1) / (NM - S0);
+                    if (done < upto) { slice(nxt, done); ++done; }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    };
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    if (nstages > 0) {
+        request(0);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) slice(0, k);
+    }
+    lds_barrier();
+    int cur = 0;
+    for (int t = 0; t + 1 < nstages; ++t) {
+        request(t + 1);
+        stage(cur, STB - cur, std::true_type{});
+        lds_barrier();
+        cur = STB - cur;
+    }
+    if (nstages > 0) stage(cur, 0, std::false_type{});
+
+    // partial tile -> slab [split][co][k], k = (chunk, tap, ci % 32); C/D map: col = lane&31 (k column), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (co)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int kcol = ((cb0 + cbl) * 9 + tap) * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + mfrag * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            wsg[((int64_t)split * a.cout + co) * a.K + kcol] = acc[tap][r];
+        }
+    }
+}
+
 // Sum of the split slabs in a fixed order (deterministic).  A block owns 16 float4 outputs; 16 split lanes walk the slabs
 // with stride 16 (independent loads in flight instead of one dependent chain of `splits` loads), then an LDS tree in
 // lane order.
@@ -557,7 +738,13 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial,
     }
 }
 
+int g_last_kernel = 0;
+
 }  // namespace
+
+// diagnostic (tests): which kernel the last egr_conv2d_wgrad_f32 call launched - 0 fp32 MFMA, 1 split-bf16 generic,
+// 2 split-bf16 3x3 tap-sharing 64 x 2 chunks, 3 the same 128 x 1 chunk
+extern "C" int egr_wgrad_last_kernel(void) { return g_last_kernel; }
 
 extern "C" int egr_conv2d_wgrad_f32(const egr_conv_desc* dd, const float* x, const float* dy, float* dw, float* db,
                                     float* workspace, size_t workspace_floats, int32_t accumulate, void* stream) {
@@ -584,20 +771,41 @@ extern "C" int egr_conv2d_wgrad_f32(const egr_conv_desc* dd, const float* x, con
     { auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return ((1 << l) == v) ? l : -1; };
       a.howo_shift = lg(d.ho * d.wo); a.wo_shift = lg(d.wo); }
     a.groups = G; a.gx = d.gx; a.gy = d.gy; a.gw = d.gw; a.gb = d.gp; a.db = db;
+    // large problems run on the bf16 matrix cores with exact three-way operand splits (same result class as the fp32 kernel);
+    // w_format == EGR_W_BF16X3 requests it, small ones stay on the fp32 kernel (latency-bound)
+    // (its operands are addressed through 2-GiB buffer windows: larger tensors stay on the fp32 kernel)
+    auto span = [](const egr_nmap& m, int n) {
+        const int o = (n - 1) / m.n_inner, i = (n - 1 < m.n_inner ? n - 1 : m.n_inner - 1);
+        return (int64_t)i * m.stride_inner + (int64_t)o * m.stride_outer;
+    };
+    const bool fits = (span(d.xmap, d.n) + (int64_t)(d.h * d.w + 2 * (d.pad * d.w + d.pad + 1)) * d.ldx) * 4 + 64 < (1LL << 31) &&
+                      (span(d.ymap, d.n) + (int64_t)d.ho * d.wo * d.ldy) * 4 + 64 < (1LL << 31);
+    const bool x6 = fits && (d.w_format & EGR_W_BF16X3) &&
+                    ((d.w_format & EGR_W_FORCE) || (a.M >= 1024 && 2.0 * (double)a.M * d.cout * a.K * G >= 4e9));
     const int bco = (d.cout > 64) ? 128 : 64;
     a.tilesCO = (d.cout + bco - 1) / bco;
     a.tilesK = (a.chunks + 3) / 4;
-    const int tiles = a.tilesCO * a.tilesK;
+    int tiles = a.tilesCO * a.tilesK;
+    // 3x3 / stride 1 / pad 1 split launches: the tap-sharing kernel (a stage = 16 pixels of one image row)
+    static const int g_wg3 = getenv("EGR_WGRAD3") ? atoi(getenv("EGR_WGRAD3")) : 1;   // diagnostic: 0 = the generic kernel everywhere
+    int wg3 = 0;          // 1: 64 channels x 2 chunks, 2: 128 channels x 1 chunk
+    const bool narrow = d.wo == 8 && d.ho % 2 == 0;     // 8-pixel-wide images: a stage is two rows
+    if (g_wg3 && d.kh == 3 && d.kw == 3 && d.stride == 1 && d.pad == 1 && d.ho == d.h && d.wo == d.w && (d.wo % 16 == 0 || narrow) && x6) {
+        if (d.cout % 128 == 0) wg3 = 2;
+        else if (d.cout % 64 == 0 && d.cin % 64 == 0) wg3 = 1;
+    }
+    if (wg3) tiles = (wg3 == 2) ? (d.cout / 128) * (d.cin / 32) : (d.cout / 64) * (d.cin / 64);
+    const int stage_rows = wg3 ? 16 : RS;
     // Two workgroups fit a CU (64 KiB LDS each): 512 run at once, and equal-sized blocks finish in whole rounds.  Pick the
     // split count that minimises rounds x (rows per block + a fixed per-block cost of ~4 stages: prologue, slab write).
-    const int max_splits = (a.M + 4 * RS - 1) / (4 * RS);  // at least 4 stages per split
+    const int max_splits = (a.M + 4 * stage_rows - 1) / (4 * stage_rows);  // at least 4 stages per split
     int splits = 1;
     {
         double best = 1e30;
         const int64_t tg = (int64_t)tiles * G;
         for (int sp = 1; sp <= max_splits && sp <= 512; ++sp) {
             const int64_t rounds = (tg * sp + 511) / 512;
-            const double cost = (double)rounds * ((double)((a.M + sp - 1) / sp) + 4.0 * RS);
+            const double cost = (double)rounds * ((double)((a.M + sp - 1) / sp) + 4.0 * stage_rows);
             if (cost < best * 0.97) { best = cost; splits = sp; }   // prefer fewer splits unless clearly better
             if (tg * sp > 4096) break;
         }
@@ -611,18 +819,13 @@ extern "C" int egr_conv2d_wgrad_f32(const egr_conv_desc* dd, const float* x, con
     const bool direct = (a.splits == 1 && !accumulate && d.gw == (int64_t)d.cout * a.K);   // the slab IS the result
     if (direct) a.ws = dw;
     dim3 grid((unsigned)tiles, (unsigned)a.splits, (unsigned)G);
-    // large problems run on the bf16 matrix cores with exact three-way operand splits (same result class as the fp32 kernel);
-    // w_format == EGR_W_BF16X3 requests it, small ones stay on the fp32 kernel (latency-bound)
-    // (its operands are addressed through 2-GiB buffer windows: larger tensors stay on the fp32 kernel)
-    auto span = [](const egr_nmap& m, int n) {
-        const int o = (n - 1) / m.n_inner, i = (n - 1 < m.n_inner ? n - 1 : m.n_inner - 1);
-        return (int64_t)i * m.stride_inner + (int64_t)o * m.stride_outer;
-    };
-    const bool fits = (span(d.xmap, d.n) + (int64_t)(d.h * d.w + 2 * (d.pad * d.w + d.pad + 1)) * d.ldx) * 4 + 64 < (1LL << 31) &&
-                      (span(d.ymap, d.n) + (int64_t)d.ho * d.wo * d.ldy) * 4 + 64 < (1LL << 31);
-    const bool x6 = fits && (d.w_format & EGR_W_BF16X3) &&
-                    ((d.w_format & EGR_W_FORCE) || (a.M >= 1024 && 2.0 * (double)a.M * d.cout * a.K * G >= 4e9));
-    if (x6) {
+    g_last_kernel = x6 ? (wg3 ? 1 + wg3 : 1) : 0;
+    if (x6 && wg3) {
+        if (wg3 == 2 && narrow) hipLaunchKernelGGL((conv_wgrad3_x6_kernel<128, 1, 8>), grid, dim3(256), 0, s, a);
+        else if (wg3 == 2) hipLaunchKernelGGL((conv_wgrad3_x6_kernel<128, 1, 16>), grid, dim3(256), 0, s, a);
+        else if (narrow) hipLaunchKernelGGL((conv_wgrad3_x6_kernel<64, 2, 8>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_wgrad3_x6_kernel<64, 2, 16>), grid, dim3(256), 0, s, a);
+    } else if (x6) {
         if (bco == 128) hipLaunchKernelGGL(conv_wgrad_x6_kernel<128>, grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(conv_wgrad_x6_kernel<64>, grid, dim3(256), 0, s, a);
     } else if (bco == 128) hipLaunchKernelGGL(conv_wgrad_kernel<128>, grid, dim3(256), 0, s, a);

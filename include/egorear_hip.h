@@ -132,6 +132,9 @@ int egr_conv2d_masked_f32(const egr_conv_desc* d, const float* x, const float* w
  * split exactly into three bf16 on the fly; the result class is the fp32 kernel's. */
 int egr_conv2d_wgrad_f32(const egr_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
                          float* workspace, size_t workspace_floats, int32_t accumulate, void* stream);
+/* diagnostic (tests): the kernel the last egr_conv2d_wgrad_f32 call launched - 0 fp32 MFMA, 1 split-bf16 generic,
+ * 2 / 3 split-bf16 3x3 stride-1 tap-sharing (64 channels x 2 input chunks / 128 x 1). */
+int egr_wgrad_last_kernel(void);
 
 /* Tuning knob for measurements: force the tile configuration of egr_conv2d_nhwc_f32
  * (-1 auto, 0 128x128, 1 256x64, 2 64x64, 3 128x32, 4 128x64).  Process-wide; results do not depend on it. */

@@ -222,7 +222,15 @@ WGRAD_CASES = [
     (9, 32, 32, 32, 96, 3, 1, 1),        # cout not a multiple of 32, ragged K tile (9 chunks)
     (2, 64, 64, 256, 256, 3, 1, 1),      # deeper K: several K tiles
     (3, 61, 45, 64, 128, 3, 1, 1),       # odd sizes: pixel count not a multiple of the stage
+    (4, 48, 48, 64, 64, 3, 1, 2),        # tap-sharing kernel, 64 x 2 chunks: width not a power of two, grouped
+    (2, 16, 32, 128, 128, 3, 1, 3),      # tap-sharing kernel, 128 x 1 chunk: h != w, three groups
+    (3, 16, 16, 128, 64, 3, 1, 1),       # 64 output channels, two input-chunk tiles
+    (1, 16, 16, 64, 256, 3, 1, 1),       # two output-channel tiles x two input chunks, one image
+    (6, 8, 8, 256, 128, 3, 1, 1),        # 8-pixel-wide images: a stage is two rows (layer4's geometry)
+    (5, 8, 8, 64, 64, 3, 1, 2),
 ]
+# kernel egr_wgrad_last_kernel() must report for the forced split launch of each case (1 generic, 2 / 3 tap-sharing)
+WGRAD_KERNEL = [2, 1, 1, 1, 3, 1, 2, 3, 2, 3, 3, 2]
 
 
 @pytest.mark.parametrize("case", WGRAD_CASES)
@@ -241,6 +249,7 @@ def test_weight_gradient_split_launch(case):
     for fmt in (False, "force"):
         dw, db = hip.conv2d_wgrad(xi, dyi, k, k, s, pad, ws, want_bias=True, groups=G, x6=fmt)
         out[bool(fmt)] = (dw.clone(), db.clone())
+        assert hip.lib.egr_wgrad_last_kernel() == (WGRAD_KERNEL[WGRAD_CASES.index(case)] if fmt else 0)
     for g in range(G):
         wt = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
         b = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
