@@ -205,12 +205,21 @@ __global__ __launch_bounds__(256) void tokens_to_nhwc_kernel(const float* x, flo
 // v_mfma_f32_16x16x4_f32 with N = 16 output channels: lane l supplies a[pixel l%16][channel 4s + l/16], computed on the
 // fly (four source reads, the upsample kernel's interpolation arithmetic, ReLU), and b from registers (the filter,
 // 32 floats per lane, loaded once); D[pixel][co] leaves as one 16-byte store of 4 consecutive pixels per lane.
-constexpr int HT_H = 8, HT_W = 32, HT_SRC_H = 6, HT_SRC_W = 18, HT_MAXCO = 16, HT_MAXCIN = 128;
+#ifndef HT_ROWS
+#define HT_ROWS 8     // (4-row tiles, four workgroups per CU instead of two: 141 us per launch against 119)
+#endif
+constexpr int HT_H = HT_ROWS, HT_W = 32, HT_SRC_H = HT_ROWS / 2 + 2, HT_SRC_W = 18, HT_MAXCO = 16, HT_MAXCIN = 128;
+constexpr int HT_RPW = HT_H / 4, HT_NG = 2 * HT_RPW;       // output rows / 16-pixel groups per wave
 typedef float f32x4_mfma __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void up2_relu_head_kernel(const float* lo, int h, int w, int cin, const float* wgt, const float* bias,
+// CIN > 0: the channel count at compile time (the path's heads: 128) - the 32-step K loop is straight-line code the compiler
+// can software-pipeline (with a run-time trip count it stayed a rolled loop of read -> wait -> interpolate -> MFMA: 160 us
+// per launch).  CIN == 0: any multiple of 4 up to HT_MAXCIN.
+template <int CIN>
+__global__ __launch_bounds__(256) void up2_relu_head_kernel(const float* lo, int h, int w, int cin_rt, const float* wgt, const float* bias,
                                                             int cout, float* planes, egr_nmap map, int npg, int64_t gy) {
     extern __shared__ __attribute__((aligned(16))) float s_src[];   // [HT_SRC_H * HT_SRC_W][cin + 4]
+    const int cin = CIN > 0 ? CIN : cin_rt;
     const int ld = cin + 4;
     const int ho = 2 * h, wo = 2 * w;
     const int tiles_x = wo / HT_W, tiles_y = ho / HT_H;
@@ -225,11 +234,27 @@ __global__ __launch_bounds__(256) void up2_relu_head_kernel(const float* lo, int
     const int sy0 = (int)(sh * (float)oy0), sx0 = (int)(sw * (float)ox0);   // first source row / column of the tile
     const int c4n = cin >> 2;
     const float* src = lo + (int64_t)img * h * w * cin;
-    for (int i = threadIdx.x; i < HT_SRC_H * HT_SRC_W * c4n; i += 256) {
-        const int cq = i % c4n, p = i / c4n;
+    // all of a thread's source loads in flight at once, then the LDS writes (a load -> store loop waited for every load in turn:
+    // 14 memory latencies per workgroup, most of the kernel's time)
+    constexpr int NLD = (HT_SRC_H * HT_SRC_W * (HT_MAXCIN / 4) + 255) / 256;
+    f32x4 stg[NLD];
+    const int nsrc = HT_SRC_H * HT_SRC_W * c4n;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+        const int i = threadIdx.x + 256 * u;
+        const int ii = i < nsrc ? i : 0;
+        const int cq = ii % c4n, p = ii / c4n;
         const int py = p / HT_SRC_W, px = p - py * HT_SRC_W;
         const int iy = min(sy0 + py, h - 1), ix = min(sx0 + px, w - 1);
-        *reinterpret_cast<f32x4*>(&s_src[p * ld + cq * 4]) = *reinterpret_cast<const f32x4*>(src + ((int64_t)iy * w + ix) * cin + cq * 4);
+        stg[u] = *reinterpret_cast<const f32x4*>(src + ((int64_t)iy * w + ix) * cin + cq * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+        const int i = threadIdx.x + 256 * u;
+        if (i < nsrc) {
+            const int cq = i % c4n, p = i / c4n;
+            *reinterpret_cast<f32x4*>(&s_src[p * ld + cq * 4]) = stg[u];
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pj = lane & 15, kq = lane >> 4;                   // MFMA roles: A row / B column pj, k index kq
@@ -244,32 +269,68 @@ __global__ __launch_bounds__(256) void up2_relu_head_kernel(const float* lo, int
     const float* bg = bias ? bias + grp * cout : nullptr;
     const float bco = (bg && pj < cout) ? bg[pj] : 0.f;        // D column = co = pj
     float* outg = planes + grp * gy + egr_map(map, img - grp * npg);
-#pragma unroll 1
-    for (int mg = 0; mg < 4; ++mg) {                            // wave: rows 2*wave, 2*wave+1; 2 groups of 16 columns per row
-        const int oy = oy0 + 2 * wave + (mg >> 1);
-        const int oxg = ox0 + (mg & 1) * 16;
-        const int ox = oxg + pj;                                // this lane's A-row pixel
+    // wave: HT_RPW rows, 2 groups of 16 columns per row = independent accumulator chains advanced together
+    const float* q00[HT_NG]; const float* q01[HT_NG]; const float* q10[HT_NG]; const float* q11[HT_NG];
+    float wy0[HT_NG], wy1[HT_NG], wx0[HT_NG], wx1[HT_NG];
+#pragma unroll
+    for (int mg = 0; mg < HT_NG; ++mg) {
+        const int oy = oy0 + HT_RPW * wave + (mg >> 1);
+        const int ox = ox0 + (mg & 1) * 16 + pj;                // this lane's A-row pixel
         // ATen's align_corners=True source index / weights, as in upsample2x_kernel
         const float fy = sh * (float)oy, fx = sw * (float)ox;
         const int y0 = (int)fy, x0 = (int)fx;
         const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
-        const float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f);
-        const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-        const float* p00 = s_src + ((y0 - sy0) * HT_SRC_W + (x0 - sx0)) * ld + kq;
-        const float* p01 = s_src + ((y0 - sy0) * HT_SRC_W + (x1 - sx0)) * ld + kq;
-        const float* p10 = s_src + ((y1 - sy0) * HT_SRC_W + (x0 - sx0)) * ld + kq;
-        const float* p11 = s_src + ((y1 - sy0) * HT_SRC_W + (x1 - sx0)) * ld + kq;
-        f32x4_mfma acc = {0.f, 0.f, 0.f, 0.f};
+        wy1[mg] = fminf(fmaxf(fy - (float)y0, 0.f), 1.f); wx1[mg] = fminf(fmaxf(fx - (float)x0, 0.f), 1.f);
+        wy0[mg] = 1.f - wy1[mg]; wx0[mg] = 1.f - wx1[mg];
+        q00[mg] = s_src + ((y0 - sy0) * HT_SRC_W + (x0 - sx0)) * ld + kq;
+        q01[mg] = s_src + ((y0 - sy0) * HT_SRC_W + (x1 - sx0)) * ld + kq;
+        q10[mg] = s_src + ((y1 - sy0) * HT_SRC_W + (x0 - sx0)) * ld + kq;
+        q11[mg] = s_src + ((y1 - sy0) * HT_SRC_W + (x1 - sx0)) * ld + kq;
+    }
+    f32x4_mfma acc[HT_NG];
 #pragma unroll
-        for (int s_ = 0; s_ < HT_MAXCIN / 4; ++s_) {
-            if (s_ < ksteps) {
-                const float u = ly0 * (lx0 * p00[4 * s_] + lx1 * p01[4 * s_]) + ly1 * (lx0 * p10[4 * s_] + lx1 * p11[4 * s_]);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(u < 0.f ? 0.f : u, bw[s_], acc, 0, 0, 0);
+    for (int mg = 0; mg < HT_NG; ++mg) acc[mg] = f32x4_mfma{0.f, 0.f, 0.f, 0.f};
+    // the four source values of every chain, two K steps at a time, one pair of steps ahead of their use (pinned: left to
+    // itself the scheduler consumed each LDS read right behind its issue and the wave sat through the LDS latency 32 times).
+    // Vectors over the step pair: a ds_read2_b32 delivers both steps' values in adjacent registers, and the interpolation is
+    // 6 packed instructions (+ 2 max) per chain and step pair instead of 11 scalar ones per step.
+    f32x2 sv[2][HT_NG][4];
+    auto fetch = [&](int s2, int par) {
+#pragma unroll
+        for (int mg = 0; mg < HT_NG; ++mg)
+#pragma unroll
+            for (int z = 0; z < 2; ++z) {
+                sv[par][mg][0][z] = q00[mg][4 * (2 * s2 + z)];
+                sv[par][mg][1][z] = q01[mg][4 * (2 * s2 + z)];
+                sv[par][mg][2][z] = q10[mg][4 * (2 * s2 + z)];
+                sv[par][mg][3][z] = q11[mg][4 * (2 * s2 + z)];
             }
+    };
+    const int kpairs = ksteps >> 1;          // (cin % 8 == 0 is checked by the host)
+    fetch(0, 0);
+#pragma unroll
+    for (int s2 = 0; s2 < HT_MAXCIN / 8; ++s2) {
+        if (s2 < kpairs) {
+            if (s2 + 1 < kpairs) fetch(s2 + 1, (s2 + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mg = 0; mg < HT_NG; ++mg) {
+                const f32x2* v = sv[s2 & 1][mg];
+                const f32x2 u = wy0[mg] * (wx0[mg] * v[0] + wx1[mg] * v[1]) + wy1[mg] * (wx0[mg] * v[2] + wx1[mg] * v[3]);
+                // ReLU as one v_max (NaN -> 0, like the `t > 0 ? t : 0` of the conv epilogues)
+                acc[mg] = __builtin_amdgcn_mfma_f32_16x16x4f32(fmaxf(u[0], 0.f), bw[2 * s2], acc[mg], 0, 0, 0);
+                acc[mg] = __builtin_amdgcn_mfma_f32_16x16x4f32(fmaxf(u[1], 0.f), bw[2 * s2 + 1], acc[mg], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // D[row = 4*kq + r][col = pj]: rows are the pixels oxg + 4*kq + r (contiguous in a plane), col the output channel
-        if (pj < cout) {
-            f32x4 v = {acc[0] + bco, acc[1] + bco, acc[2] + bco, acc[3] + bco};
+    }
+    // D[row = 4*kq + r][col = pj]: rows are the pixels oxg + 4*kq + r (contiguous in a plane), col the output channel
+    if (pj < cout) {
+#pragma unroll
+        for (int mg = 0; mg < HT_NG; ++mg) {
+            const int oy = oy0 + HT_RPW * wave + (mg >> 1);
+            const int oxg = ox0 + (mg & 1) * 16;
+            f32x4 v = {acc[mg][0] + bco, acc[mg][1] + bco, acc[mg][2] + bco, acc[mg][3] + bco};
             *reinterpret_cast<f32x4*>(outg + (int64_t)pj * ho * wo + (int64_t)oy * wo + oxg + 4 * kq) = v;
         }
     }
@@ -305,7 +366,7 @@ extern "C" int egr_up2_relu_head_f32(const float* lo, int32_t n, int32_t h, int3
                                      int32_t cout, float* planes, int32_t n_inner, int64_t stride_inner, int64_t stride_outer,
                                      int32_t groups, int64_t gy, void* stream) {
     if (!lo || !wgt || !planes) return EGR_ENULL;
-    if (n <= 0 || groups <= 0 || n % groups != 0 || h <= 0 || w <= 0 || cin <= 0 || cin % 4 != 0 || cin > HT_MAXCIN || cout <= 0 ||
+    if (n <= 0 || groups <= 0 || n % groups != 0 || h <= 0 || w <= 0 || cin <= 0 || cin % 8 != 0 || cin > HT_MAXCIN || cout <= 0 ||
         cout > HT_MAXCO || (2 * h) % HT_H != 0 || (2 * w) % HT_W != 0 || n_inner <= 0 || ((uintptr_t)planes & 15) ||
         ((stride_inner | stride_outer | gy) % 4 != 0))
         return EGR_EINVAL;
@@ -313,8 +374,12 @@ extern "C" int egr_up2_relu_head_f32(const float* lo, int32_t n, int32_t h, int3
     const size_t lds = (size_t)(HT_SRC_H * HT_SRC_W * (cin + 4)) * sizeof(float);
     const int64_t blocks = (int64_t)n * ((2 * h) / HT_H) * ((2 * w) / HT_W);
     if (blocks >= (1LL << 31) || lds > 64 * 1024) return EGR_EINVAL;
-    hipLaunchKernelGGL(up2_relu_head_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, lo, h, w, cin, wgt, bias, cout,
-                       planes, map, n / groups, gy);
+    if (cin == 128)
+        hipLaunchKernelGGL(up2_relu_head_kernel<128>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, lo, h, w, cin, wgt, bias, cout,
+                           planes, map, n / groups, gy);
+    else
+        hipLaunchKernelGGL(up2_relu_head_kernel<0>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, lo, h, w, cin, wgt, bias, cout,
+                           planes, map, n / groups, gy);
     return egr_launch_status();
 }
 
