@@ -102,13 +102,18 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <int BM, int BN, bool X6 = false, bool PERSIST_ = false>
+constexpr int TAP_HPMAX = 264;                    // halo pixels of a tap-sharing tile: (128 / wo + 2) x (wo + 2), wo in {16, 32, 64}
+constexpr int TAP_PLANE = TAP_HPMAX * 32;          // bytes per bf16 plane (16 channels per pixel)
+constexpr int TAP_HBUF = 3 * TAP_PLANE;            // bytes per halo buffer (hi, mid, lo)
+
+template <int BM, int BN, bool X6 = false, bool PERSIST_ = false, bool TAP = false>
 struct LdsPlan {
     // floats per stage.  fp32 path: BK = 32 deep rows of both operands.  Split-bf16 path: one k16 step of (hi, mid, lo) bf16
     // planes in fragment order, 1 KiB per (32-row fragment, plane)
     static constexpr int TILE = X6 ? (BM / 32 + BN / 32) * 3 * 256 : (BM + BN) * BK;
     static constexpr int CS = BN + 4;                       // epilogue staging row stride
-    static constexpr int ROWOFF = (2 * TILE > BM * CS) ? 2 * TILE : BM * CS;  // row offsets (y, res) live past both
+    static constexpr int STAGES = TAP ? 2 * TAP_HBUF / 4 : 2 * TILE;          // floats of the two stage buffers
+    static constexpr int ROWOFF = (STAGES > BM * CS) ? STAGES : BM * CS;      // row offsets (y, res) live past both
     static constexpr bool PERSIST = X6 && PERSIST_;                           // persistent workgroups, see the tile loop of the split kernel
     static constexpr int TABLES = PERSIST ? 2 : 1;                            // the next tile's table is decoded under the epilogue
     static constexpr int TCOLS = 6;                                           // y / res offset, x offset, tap mask, two bilinear weights (EGR_RES_UP2_BEFORE_ACT)
@@ -134,14 +139,14 @@ __device__ __forceinline__ void* uniform_ptr(const void* p) {
     return (void*)(((uint64_t)hi << 32) | lo);
 }
 
-template <int BM, int BN, int WM, int WN, bool X6, bool PERSIST = false>
+template <int BM, int BN, int WM, int WN, bool X6, bool PERSIST = false, bool TAP = false>
 __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     static_assert(WM * WN == 4, "four waves per workgroup");
     constexpr int NT = 256;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 32, FN = TN / 32;
     constexpr int IA = BM / 32, IB = BN / 32;  // 32 rows per load pass (8 rows per wave-instruction)
-    using P = LdsPlan<BM, BN, X6, PERSIST>;
+    using P = LdsPlan<BM, BN, X6, PERSIST, TAP>;
     static_assert(FM >= 1 && FN >= 1, "wave tile must be >= 32x32");
 
     __shared__ __attribute__((aligned(16))) float lds[P::FLOATS];
@@ -511,7 +516,147 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     stamp(5);  // stores issued
     };
 
-    if constexpr (!X6) {
+    if constexpr (TAP) {
+        // ---- split-bf16, 3x3 / stride 1 / pad 1, taps SHARED (forward and data gradient).  In the generic split loop below every (tap, 16-channel)
+        // stage fetches and splits its own 128 x 16 activation block: each input value is loaded and split nine times, and every
+        // stage ends in a barrier.  Here the tile is BM = 128 consecutive output pixels = 128 / wo whole image rows; for one
+        // 16-channel chunk the input rows around them ((128 / wo + 2) x (wo + 2) pixels, zeros outside the image) are split ONCE
+        // into pixel-major bf16 planes [pixel][16 channels] in LDS, and the nine taps are nine pixel-shifted ds_read_b128 windows
+        // of those planes.  One barrier, one conversion and one activation fetch per 9 x 6 x FM x FN MFMAs; the weights go from
+        // global memory (L2) straight into the B operand registers, one tap ahead.
+        static_assert(X6 && !PERSIST && BM == 128, "tap-sharing tile");
+        constexpr int NFB = BN / 32;
+        constexpr int NUH = (TAP_HPMAX * 4 + NT - 1) / NT;       // halo staging units (4 channels of one pixel) per thread
+        uint8_t* const lb = reinterpret_cast<uint8_t*>(lds);
+        const int wo = d.wo, WP = wo + 2, RT = BM / wo, HP = (RT + 2) * WP;
+        // the tile's image and first row (wave-uniform)
+        const int m0 = tm * BM;
+        int n0, pix0;
+        if (a.howo_shift >= 0) { n0 = m0 >> a.howo_shift; pix0 = m0 & (HoWo - 1); }
+        else { n0 = fdiv(m0, a.dHoWo); pix0 = m0 - n0 * HoWo; }
+        const int y0 = (a.wo_shift >= 0) ? (pix0 >> a.wo_shift) : fdiv(pix0, a.dWo);
+        const int xbase = a.x_plain ? n0 * (int)d.xmap.stride_inner : (int)fmap(d.xmap, a.dXin, n0);
+        const int abias = (d.w + 1) * d.ldx * 4;                 // the window starts one row + one pixel early: halo offsets >= 0
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+            uniform_ptr(reinterpret_cast<const char*>(xg) - abias), 0, 0x80000000u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+            uniform_ptr(reinterpret_cast<const uint8_t*>(a.w) + (int64_t)grp * d.gw * 2), 0, 0x80000000u, 0x00020000);
+        const int so_tile = __builtin_amdgcn_readfirstlane((xbase + y0 * d.w * d.ldx) * 4);
+        int hvo[NUH], hlds[NUH];
+#pragma unroll
+        for (int i = 0; i < NUH; ++i) {
+            const int u = tid + NT * i, hp = u >> 2, seg = u & 3;
+            const int hr = hp / WP, hc = hp - hr * WP;
+            const bool ok = hp < HP && (unsigned)(y0 + hr - 1) < (unsigned)d.h && (unsigned)(hc - 1) < (unsigned)d.w;
+            hvo[i] = ok ? ((hr - 1) * d.w + (hc - 1)) * d.ldx * 4 + seg * 16 + abias : (int)0x80000000;
+            hlds[i] = hp < HP ? hp * 32 + seg * 8 : -1;
+        }
+        int abase[FM], bvo[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int ml = wm * TM + i * 32 + l31, r = ml / wo, c = ml - r * wo;
+            abase[i] = (r * WP + c) * 32 + half * 16;
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bvo[j] = ((tn * NFB + wn * FN + j) * a.ktiles * 6) * 1024 + lane * 16;
+        const int NC = a.cblocks * 2;            // 16-channel chunks
+        u32x4 xr[NUH];
+        auto load_halo = [&](int ck) {           // chunk ck = (32-channel block ck >> 1, half ck & 1)
+            const int so = so_tile + ck * 64;
+#pragma unroll
+            for (int i = 0; i < NUH; ++i) xr[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, hvo[i], so, 0);
+        };
+        unsigned ch_[NUH][2], cm_[NUH][2];
+        // slice k of the conversion: unit k / 3; 0 / 1 = hi + mid + lo of the unit's first / second pair, 2 = the three 8-byte writes
+        unsigned cl_[NUH][2];
+        auto cslice = [&](int base, int k) {
+            const int u = k / 3, q = k % 3;
+            if (q < 2) {
+                const float v0 = __uint_as_float(xr[u][2 * q]), v1 = __uint_as_float(xr[u][2 * q + 1]);
+                ch_[u][q] = cvt_pk_bf16(v0, v1);
+                const float r0 = v0 - bf16_lo_f32(ch_[u][q]), r1 = v1 - bf16_hi_f32(ch_[u][q]);
+                cm_[u][q] = cvt_pk_bf16(r0, r1);
+                cl_[u][q] = cvt_pk_bf16(r0 - bf16_lo_f32(cm_[u][q]), r1 - bf16_hi_f32(cm_[u][q]));
+            } else if (hlds[u] >= 0) {
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                uint8_t* dst = lb + base + hlds[u];
+                *reinterpret_cast<u32x2*>(dst) = u32x2{ch_[u][0], ch_[u][1]};
+                *reinterpret_cast<u32x2*>(dst + TAP_PLANE) = u32x2{cm_[u][0], cm_[u][1]};
+                *reinterpret_cast<u32x2*>(dst + 2 * TAP_PLANE) = u32x2{cl_[u][0], cl_[u][1]};
+            }
+        };
+        constexpr int NSL = 3 * NUH;
+        bf16x8 af[2][FM][3], bf[2][FN][3];
+        auto read_a = [&](int base, int tap, int par) {
+            // (data gradient: tap (kh, kw) reads dy at (y + 1 - kh, x + 1 - kw) - the mirrored window)
+            const int to = d.transposed ? ((2 - tap / 3) * WP + (2 - tap % 3)) * 32 : ((tap / 3) * WP + (tap % 3)) * 32;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    af[par][i][pl] = *reinterpret_cast<const bf16x8*>(lb + base + pl * TAP_PLANE + abase[i] + to);
+        };
+        auto load_b = [&](int ck, int tap, int par) {
+            const int so = (((ck >> 1) * 9 + tap) * 6 + (ck & 1) * 3) * 1024;
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    bf[par][j][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rb, bvo[j] + pl * 1024, so, 0));
+        };
+        // one chunk: nine taps out of halo buffer `cur`; the next chunk's halo is converted into `nxt` behind the taps 2 .. 7.
+        // PAR: operand register set of tap 0 (nine taps flip it, so chunks alternate)
+        auto chunk = [&](auto par_tag, int ck, int cur, int nxt, auto conv_tag) {
+            constexpr int PAR = decltype(par_tag)::value;
+            constexpr bool conv = decltype(conv_tag)::value;
+            if constexpr (conv) load_halo(ck + 1);
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+            constexpr int NMT = 6 * FM * FN;                 // MFMAs per tap
+            constexpr int W0 = 2 * NMT, W1 = 8 * NMT;        // conversion window (in MFMAs of the chunk)
+            int n = 0, done = 0;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int pc = (PAR + tap) & 1, pn = pc ^ 1;
+                if (tap + 1 < 9) { load_b(ck, tap + 1, pn); read_a(cur, tap + 1, pn); }
+                else if (conv) load_b(ck + 1, 0, pn);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j, ++n) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pc][i][PA[t]], bf[pc][j][PB[t]], acc[i][j], 0, 0, 0);
+                            if constexpr (conv) {
+                                const int upto = (n + 1 <= W0) ? 0 : (n + 1 >= W1 ? NSL : ((n + 1 - W0) * NSL + (W1 - W0) - 1) / (W1 - W0));
+                                if (done < upto) { cslice(nxt, done); ++done; }
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if constexpr (conv) read_a(nxt, 0, (PAR + 9) & 1);
+        };
+        using T0 = std::integral_constant<int, 0>;
+        using T1 = std::integral_constant<int, 1>;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // row table visible
+        stamp(1);
+        load_halo(0);
+        load_b(0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) cslice(0, k);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        read_a(0, 0, 0);
+        stamp(2);
+        int ck = 0;
+        for (; ck + 2 < NC; ck += 2) {           // NC is even: chunk pairs, buffers 0 / 1, register parity 0 / 1
+            chunk(T0{}, ck, 0, TAP_HBUF, std::true_type{});
+            chunk(T1{}, ck + 1, TAP_HBUF, 0, std::true_type{});
+        }
+        chunk(T0{}, ck, 0, TAP_HBUF, std::true_type{});
+        chunk(T1{}, ck + 1, TAP_HBUF, 0, std::false_type{});
+        epilogue(tm, tn, s_yoff, s_roff, [] {});
+    } else if constexpr (!X6) {
         const float* wrow[IB];
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
@@ -786,7 +931,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
             if constexpr (conv) write_b(NB{});
             if constexpr (loads) {
                 load_b(kl, sl);
+#ifndef X6_EXP_NOA
                 load_a(kl, sl, CB{});
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
             // smallest terms first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
@@ -809,12 +956,18 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
                             const int upto = (n + 1 <= S0) ? 0 : ((n + 1 - S0) * NS + (NM - S0) - 1) / (NM - S0);
 #pragma unroll
                             for (int k = 0; k < NS; ++k)
+#ifndef X6_EXP_NOA
                                 if (k >= done && k < upto) slice(NB{}, NB{}, k);
+#else
+                                if (k >= done && k < upto && (k % 9) == 8) slice(NB{}, NB{}, k);   // the LDS writes only (stale registers)
+#endif
                             done = upto > done ? upto : done;
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
+#ifndef X6_EXP_NOBAR
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
         };
         using B0 = std::integral_constant<int, 0>;
         using B1 = std::integral_constant<int, 1>;
@@ -926,6 +1079,12 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? X6_OCC_SMALL : X6_OCC_
     conv_igemm_body<BM, BN, WM, WN, true>(a);
 }
 
+// 3x3 / stride 1 / pad 1 with the taps shared (see the TAP branch of conv_igemm_body)
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_tap_kernel(const ConvArgs a) {
+    conv_igemm_body<BM, BN, WM, WN, true, false, true>(a);
+}
+
 // persistent variant (short K: a tile is mostly fixed cost and HBM traffic - the next tile's decode and first loads overlap the
 // stores; measured 106 -> 121 TFLOP/s on 1x1 128 -> 128 at 64x64 pixels, -1.5 % on the long-K layers, which keep the plain launch)
 template <int BM, int BN, int WM, int WN>
@@ -1015,6 +1174,8 @@ enum { CFG_AUTO = -1, CFG_128x128 = 0, CFG_256x64 = 1, CFG_64x64 = 2, CFG_128x32
 const int kBM[CFG_COUNT] = {128, 256, 64, 128, 128};
 const int kBN[CFG_COUNT] = {128, 64, 64, 32, 64};
 int g_force_cfg = CFG_AUTO;
+int g_tap = getenv("EGR_CONV_TAP") ? atoi(getenv("EGR_CONV_TAP")) : 1;   // 0: the generic split kernel everywhere (egr_conv_set_tap)
+int g_last_conv_kernel = 0;   // diagnostic (tests): 0 fp32 MFMA, 1 split-bf16 generic, 2 split-bf16 tap-sharing
 unsigned long long* g_dbg = nullptr;
 
 }  // namespace
@@ -1056,6 +1217,9 @@ extern "C" int egr_conv_set_persist(int slots, int max_ktiles) {
     if (max_ktiles >= 0) g_persist_ktiles = max_ktiles;
     return 0;
 }
+
+extern "C" int egr_conv_last_kernel(void) { return g_last_conv_kernel; }
+extern "C" int egr_conv_set_tap(int on) { g_tap = on; return 0; }
 
 extern "C" int egr_conv_force_config(int cfg) {
     if (cfg < CFG_AUTO || cfg >= CFG_COUNT) return EGR_EINVAL;
@@ -1142,6 +1306,25 @@ static int conv_run(const egr_conv_desc* dd, const float* x, const float* w, con
             return EGR_EINVAL;
         d.split_k = 1;   // the mask is applied in the tile epilogue, not in the split-K reduction
     }
+
+    // ---- 3x3 / stride 1 / pad 1 split launches whose tiles are whole image rows: the tap-sharing kernel
+    if (g_tap && g_force_cfg == CFG_AUTO && d.w_format == EGR_W_BF16X3 && d.kh == 3 && d.kw == 3 && d.stride == 1 && d.pad == 1 &&
+        !a.cls_mode && d.split_k <= 1 && (d.wo == 16 || d.wo == 32 || d.wo == 64) && d.ho == d.h && d.wo == d.w &&
+        (d.ho * d.wo) % 128 == 0 && a.M % 128 == 0 && a.Npad % 64 == 0 && a.M >= 128 * 64) {
+        d.split_k = 1;
+        a.ktiles_per_split = a.ktiles;
+        const int bn = (a.Npad % 128 == 0 && (int64_t)(a.M / 128) * (a.Npad / 128) * d.groups >= 256) ? 128 : 64;
+        a.tilesM = a.M / 128;
+        a.tilesN = a.Npad / bn;
+        a.dTilesN = make_fastdiv(a.tilesN);
+        a.ntiles = a.tilesM * a.tilesN;
+        dim3 grid((unsigned)a.ntiles, 1, (unsigned)d.groups);
+        if (bn == 128) hipLaunchKernelGGL((conv_igemm_tap_kernel<128, 128, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((conv_igemm_tap_kernel<128, 64, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        g_last_conv_kernel = 2;
+        return egr_launch_status();
+    }
+    g_last_conv_kernel = d.w_format == EGR_W_BF16X3 ? 1 : 0;
 
     // ---- tile configuration
     int cfg = g_force_cfg;

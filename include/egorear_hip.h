@@ -139,6 +139,11 @@ int egr_wgrad_last_kernel(void);
 /* Tuning knob for measurements: force the tile configuration of egr_conv2d_nhwc_f32
  * (-1 auto, 0 128x128, 1 256x64, 2 64x64, 3 128x32, 4 128x64).  Process-wide; results do not depend on it. */
 int egr_conv_force_config(int cfg);
+/* diagnostic (tests): the kernel the last egr_conv2d_nhwc_f32 / egr_conv2d_masked_f32 call launched - 0 fp32 MFMA,
+ * 1 split-bf16 generic, 2 split-bf16 tap-sharing (3x3 / stride 1 / pad 1, tiles of whole image rows). */
+int egr_conv_last_kernel(void);
+/* diagnostic / test knob: 0 = 3x3 stride-1 split launches stay on the generic split kernel (default 1, env EGR_CONV_TAP). */
+int egr_conv_set_tap(int on);
 /* Tuning / test knob of the persistent split-bf16 launches (short-K layers: a workgroup walks several tiles and requests the next
  * tile's operands under the current tile's stores): `slots` = resident workgroups a launch is sized for (0: never persistent;
  * default 512 = 2 per CU), `max_ktiles` = largest K in 32-deep chunks that takes them (default 4).  Negative: unchanged.

@@ -214,6 +214,108 @@ def test_wide_dynamic_range_and_zero_padding_rows():
     judge(a.t.permute(0, 3, 1, 2), b.t.permute(0, 3, 1, 2), ref, "dynamic range")
 
 
+TAP_CASES = [
+    # n, h(=w), cin, cout, groups, extras
+    (2, 64, 64, 64, 1, "res_before"),          # layer1 geometry: 64-channel tile, residual + ReLU
+    (8, 32, 128, 128, 2, "scale_relu"),        # layer2 geometry, grouped, BatchNorm affine + ReLU
+    (32, 16, 32, 192, 1, "plain"),             # wo = 16 (a fragment spans two image rows), 32 channels = two chunks, Npad = 192 -> 64-wide tiles
+    (4, 64, 96, 256, 1, "res_after"),          # three 32-channel blocks, residual behind the activation
+    (9, 32, 64, 60, 1, "nchw"),                # cout not a multiple of 32; channel-major planes out; image count odd
+    (32, 64, 64, 128, 1, "scale_relu"),        # enough tiles for the 128 x 128 configuration
+]
+
+
+@pytest.mark.parametrize("case", TAP_CASES)
+def test_tap_sharing_forward_kernel(case):
+    """conv_igemm_tap_kernel (3x3 / stride 1 / pad 1, tiles of whole image rows, input rows split once per 16-channel chunk and the
+    nine taps read as shifted LDS windows) against fp64 and against the generic split kernel (same operands, same products: the
+    two differ only in the order the accumulator receives the taps' products)."""
+    from egorear_amd import hip
+    n, hw, cin, cout, G, extra = case
+    x = rnd(G * n, hw, hw, cin, seed=70)
+    wts = [rnd(cout, cin, 3, 3, seed=71 + g, scale=1.0 / math.sqrt(9 * cin)) for g in range(G)]
+    wp = torch.stack([pack_w(t) for t in wts]) if G > 1 else pack_w(wts[0])
+    npad = wp.shape[-2]
+    kw = dict(groups=G)
+    res = None
+    if extra in ("res_before", "res_after"):
+        res = rnd(G * n, hw, hw, cout, seed=75)
+        kw.update(res=hip.Img(res.to(DEV)), res_mode=hip.RES_BEFORE_ACT if extra == "res_before" else hip.RES_AFTER_ACT, act=hip.ACT_RELU)
+    sc = sh = None
+    if extra == "scale_relu":
+        sc, sh = rnd(G, npad, seed=76) * 0.2 + 1.0, rnd(G, npad, seed=77)
+        if G == 1:
+            sc, sh = sc[0], sh[0]
+        kw.update(scale=sc.to(DEV), shift=sh.to(DEV), act=hip.ACT_RELU)
+    saved = hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS
+    hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = 0, 0.0
+    try:
+        outs = {}
+        for tap in (1, 0):
+            hip.lib.egr_conv_set_tap(tap)
+            if extra == "nchw":
+                planes = torch.full((n, cout, hw, hw), 7.0, device=DEV)
+                hip.conv2d(hip.Img(x.to(DEV)), hip.pack_w6(wp.to(DEV)), cout, 3, 3, 1, 1, out_nchw=planes, ymap=hip.NMap(n, cout * hw * hw, 0), **kw)
+                outs[tap] = planes
+            else:
+                outs[tap] = hip.conv2d(hip.Img(x.to(DEV)), hip.pack_w6(wp.to(DEV)), cout, 3, 3, 1, 1, **kw).t.permute(0, 3, 1, 2)
+            assert hip.lib.egr_conv_last_kernel() == (2 if tap else 1)
+    finally:
+        hip.lib.egr_conv_set_tap(1)
+        hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = saved
+    refs = []
+    for g in range(G):
+        r = F.conv2d(x[g * n:(g + 1) * n].permute(0, 3, 1, 2).double(), wts[g].double(), None, 1, 1)
+        if extra == "scale_relu":
+            s_, b_ = (sc[g], sh[g]) if G > 1 else (sc, sh)
+            r = F.relu(r * s_[:cout].double().view(1, -1, 1, 1) + b_[:cout].double().view(1, -1, 1, 1))
+        if extra == "res_before":
+            r = F.relu(r + res[g * n:(g + 1) * n].permute(0, 3, 1, 2).double())
+        if extra == "res_after":
+            r = F.relu(r) + res[g * n:(g + 1) * n].permute(0, 3, 1, 2).double()
+        refs.append(r)
+    ref = torch.cat(refs)
+    judge(outs[0], outs[1], ref, f"tap {case}")
+    assert float((outs[0] - outs[1]).abs().max()) <= 4e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("case", [(1, 2, 64, 64, 64, False), (2, 8, 32, 128, 128, True), (1, 32, 16, 256, 96, True)])
+def test_tap_sharing_data_gradient(case):
+    """The same kernel in data-gradient mode (mirrored tap windows), plain and with the fused ReLU mask + accumulated gradient."""
+    from egorear_amd import hip
+    G, n, hw, cin, cout, masked = case          # forward conv cin -> cout; the gradient maps dy (cout) to dx (cin)
+    dy = rnd(G * n, hw, hw, cout, seed=81)
+    xs, prev = rnd(G * n, hw, hw, cin, seed=82), rnd(G * n, hw, hw, cin, seed=83)
+    wts = [rnd(cout, cin, 3, 3, seed=84 + g, scale=1.0 / math.sqrt(9 * cin)) for g in range(G)]
+    wt = (torch.stack([pack_w_dgrad(w) for w in wts]) if G > 1 else pack_w_dgrad(wts[0])).to(DEV)
+    kw = dict(transposed_out_hw=(hw, hw), groups=G)
+    if masked:
+        kw.update(res=hip.Img(prev.to(DEV)), res_mode=hip.RES_BEFORE_ACT, mask=hip.Img(xs.to(DEV)))
+    saved = hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS
+    hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = 0, 0.0
+    try:
+        outs = {}
+        for tap in (1, 0):
+            hip.lib.egr_conv_set_tap(tap)
+            outs[tap] = hip.conv2d(hip.Img(dy.to(DEV)), hip.pack_w6(wt), cin, 3, 3, 1, 1, **kw).t.clone()
+            assert hip.lib.egr_conv_last_kernel() == (2 if tap else 1)
+    finally:
+        hip.lib.egr_conv_set_tap(1)
+        hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = saved
+    refs = []
+    for g in range(G):
+        xr = torch.zeros(n, cin, hw, hw, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(xr, wts[g].double(), None, 1, 1)
+        (dx_ref,) = torch.autograd.grad(y, xr, dy[g * n:(g + 1) * n].permute(0, 3, 1, 2).double())
+        r = dx_ref.permute(0, 2, 3, 1)
+        if masked:
+            r = (r + prev[g * n:(g + 1) * n].double()) * (xs[g * n:(g + 1) * n] > 0)
+        refs.append(r)
+    ref = torch.cat(refs)
+    judge(outs[0], outs[1], ref, f"tap dgrad {case}")
+    assert float((outs[0] - outs[1]).abs().max()) <= 4e-6 * float(ref.abs().max())
+
+
 WGRAD_CASES = [
     # n, h, w, cin, cout, k, stride, groups
     (8, 32, 32, 64, 64, 3, 1, 1),        # 64-wide output tile (BCO = 64), 8192 pixels
