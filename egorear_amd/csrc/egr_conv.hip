@@ -102,9 +102,11 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-constexpr int TAP_HPMAX = 264;                    // halo pixels of a tap-sharing tile: (128 / wo + 2) x (wo + 2), wo in {16, 32, 64}
-constexpr int TAP_PLANE = TAP_HPMAX * 32;          // bytes per bf16 plane (16 channels per pixel)
-constexpr int TAP_HBUF = 3 * TAP_PLANE;            // bytes per halo buffer (hi, mid, lo)
+// halo pixels of a tap-sharing tile of BM output pixels: whole rows of one image ((BM / wo + 2) x (wo + 2)) or whole small images
+// (BM / (ho wo) x (ho + 2) x (wo + 2)); wo in {8, 16, 32, 64}: 128 -> 4 x 66, 256 -> 6 x 66
+constexpr int tap_hpmax(int bm) { return bm == 256 ? 396 : 264; }
+constexpr int tap_plane(int bm) { return tap_hpmax(bm) * 32; }      // bytes per bf16 plane (16 channels per pixel)
+constexpr int tap_hbuf(int bm) { return 3 * tap_plane(bm); }        // bytes per halo buffer (hi, mid, lo)
 
 template <int BM, int BN, bool X6 = false, bool PERSIST_ = false, bool TAP = false>
 struct LdsPlan {
@@ -112,11 +114,12 @@ struct LdsPlan {
     // planes in fragment order, 1 KiB per (32-row fragment, plane)
     static constexpr int TILE = X6 ? (BM / 32 + BN / 32) * 3 * 256 : (BM + BN) * BK;
     static constexpr int CS = BN + 4;                       // epilogue staging row stride
-    static constexpr int STAGES = TAP ? 2 * TAP_HBUF / 4 : 2 * TILE;          // floats of the two stage buffers
+    static constexpr int STAGES = TAP ? 2 * tap_hbuf(BM) / 4 : 2 * TILE;          // floats of the two stage buffers
     static constexpr int ROWOFF = (STAGES > BM * CS) ? STAGES : BM * CS;      // row offsets (y, res) live past both
     static constexpr bool PERSIST = X6 && PERSIST_;                           // persistent workgroups, see the tile loop of the split kernel
     static constexpr int TABLES = PERSIST ? 2 : 1;                            // the next tile's table is decoded under the epilogue
-    static constexpr int TCOLS = 6;                                           // y / res offset, x offset, tap mask, two bilinear weights (EGR_RES_UP2_BEFORE_ACT)
+    // row table columns: y / res offset, [x offset, tap mask - not in the tap-sharing kernel,] two bilinear weights (EGR_RES_UP2_BEFORE_ACT)
+    static constexpr int TCOLS = TAP ? 4 : 6, COL_LX = TAP ? 2 : 4, COL_LY = COL_LX + 1;
     static constexpr int FLOATS = ROWOFF + TCOLS * BM * TABLES;
 };
 
@@ -275,15 +278,17 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
                 const int y0 = (int)fy, x0 = (int)fx;
                 const float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f);
                 ro = (a.r_plain ? n * (int)d.rmap.stride_inner : (int)fmap(d.rmap, a.dRin, n)) + (y0 * wl + x0) * d.ldr;
-                s_yoff[4 * BM + r] = (int)(__float_as_uint(lx1) | (x0 + 1 > wl - 1 ? 0x80000000u : 0u));
-                s_yoff[5 * BM + r] = (int)(__float_as_uint(ly1) | (y0 + 1 > hl - 1 ? 0x80000000u : 0u));
+                s_yoff[P::COL_LX * BM + r] = (int)(__float_as_uint(lx1) | (x0 + 1 > wl - 1 ? 0x80000000u : 0u));
+                s_yoff[P::COL_LY * BM + r] = (int)(__float_as_uint(ly1) | (y0 + 1 > hl - 1 ? 0x80000000u : 0u));
             }
         } else if (d.res_mode == EGR_RES_UP2_BEFORE_ACT) {
-            s_yoff[4 * BM + r] = 0;
-            s_yoff[5 * BM + r] = 0;
+            s_yoff[P::COL_LX * BM + r] = 0;
+            s_yoff[P::COL_LY * BM + r] = 0;
         }
-        s_xoff[r] = xo;
-        s_mask[r] = mk;
+        if constexpr (!TAP) {
+            s_xoff[r] = xo;
+            s_mask[r] = mk;
+        }
         s_yoff[r] = yo;
         s_roff[r] = ro;
     }
@@ -398,7 +403,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
             const int row = row0 + it * RPI;
             const int yo = s_yoff[row];
             const int ro = s_roff[row];
-            const unsigned bx = (unsigned)s_yoff[4 * BM + row], by = (unsigned)s_yoff[5 * BM + row];
+            const unsigned bx = (unsigned)s_yoff[P::COL_LX * BM + row], by = (unsigned)s_yoff[P::COL_LY * BM + row];
             const float lx1 = __uint_as_float(bx & 0x7fffffffu), ly1 = __uint_as_float(by & 0x7fffffffu);
             const float lx0 = 1.f - lx1, ly0 = 1.f - ly1;
             const int ox = (bx >> 31) ? 0 : dxo, oy = (by >> 31) ? 0 : dyo;
@@ -518,18 +523,22 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
 
     if constexpr (TAP) {
         // ---- split-bf16, 3x3 / stride 1 / pad 1, taps SHARED (forward and data gradient).  In the generic split loop below every (tap, 16-channel)
-        // stage fetches and splits its own 128 x 16 activation block: each input value is loaded and split nine times, and every
-        // stage ends in a barrier.  Here the tile is BM = 128 consecutive output pixels = 128 / wo whole image rows; for one
-        // 16-channel chunk the input rows around them ((128 / wo + 2) x (wo + 2) pixels, zeros outside the image) are split ONCE
+        // stage fetches and splits its own BM x 16 activation block: each input value is loaded and split nine times, and every
+        // stage ends in a barrier.  Here the tile is BM consecutive output pixels = BM / wo whole rows of one image (or whole small
+        // images); for one 16-channel chunk the input rows around them (+ 1 pixel all around, zeros outside the image) are split ONCE
         // into pixel-major bf16 planes [pixel][16 channels] in LDS, and the nine taps are nine pixel-shifted ds_read_b128 windows
         // of those planes.  One barrier, one conversion and one activation fetch per 9 x 6 x FM x FN MFMAs; the weights go from
         // global memory (L2) straight into the B operand registers, one tap ahead.
-        static_assert(X6 && !PERSIST && BM == 128, "tap-sharing tile");
+        static_assert(X6 && !PERSIST && (BM == 128 || BM == 256), "tap-sharing tile");
+        constexpr int TAP_PLANE = tap_plane(BM), TAP_HBUF = tap_hbuf(BM);
         constexpr int NFB = BN / 32;
-        constexpr int NUH = (TAP_HPMAX * 4 + NT - 1) / NT;       // halo staging units (4 channels of one pixel) per thread
+        constexpr int NUH = (tap_hpmax(BM) * 4 + NT - 1) / NT;   // halo staging units (4 channels of one pixel) per thread
         uint8_t* const lb = reinterpret_cast<uint8_t*>(lds);
-        const int wo = d.wo, WP = wo + 2, RT = BM / wo, HP = (RT + 2) * WP;
-        // the tile's image and first row (wave-uniform)
+        // tile geometry: RTI rows of NI images (one image's rows, or several whole small images)
+        const int wo = d.wo, WP = wo + 2;
+        const int NI = HoWo >= BM ? 1 : BM / HoWo, RTI = HoWo >= BM ? BM / wo : d.ho;
+        const int HPI = (RTI + 2) * WP, HP = NI * HPI, PPI = RTI * wo;
+        // the tile's first image and row (wave-uniform)
         const int m0 = tm * BM;
         int n0, pix0;
         if (a.howo_shift >= 0) { n0 = m0 >> a.howo_shift; pix0 = m0 & (HoWo - 1); }
@@ -542,20 +551,21 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
             uniform_ptr(reinterpret_cast<const uint8_t*>(a.w) + (int64_t)grp * d.gw * 2), 0, 0x80000000u, 0x00020000);
         const int so_tile = __builtin_amdgcn_readfirstlane((xbase + y0 * d.w * d.ldx) * 4);
-        int hvo[NUH], hlds[NUH];
+        int hvo[NUH];
 #pragma unroll
         for (int i = 0; i < NUH; ++i) {
             const int u = tid + NT * i, hp = u >> 2, seg = u & 3;
-            const int hr = hp / WP, hc = hp - hr * WP;
+            const int il = hp / HPI, hq = hp - il * HPI;
+            const int hr = hq / WP, hc = hq - hr * WP;
             const bool ok = hp < HP && (unsigned)(y0 + hr - 1) < (unsigned)d.h && (unsigned)(hc - 1) < (unsigned)d.w;
-            hvo[i] = ok ? ((hr - 1) * d.w + (hc - 1)) * d.ldx * 4 + seg * 16 + abias : (int)0x80000000;
-            hlds[i] = hp < HP ? hp * 32 + seg * 8 : -1;
+            const int ioff = (il == 0) ? 0 : ((a.x_plain ? (n0 + il) * (int)d.xmap.stride_inner : (int)fmap(d.xmap, a.dXin, n0 + il)) - xbase);
+            hvo[i] = ok ? (ioff + ((hr - 1) * d.w + (hc - 1)) * d.ldx) * 4 + seg * 16 + abias : (int)0x80000000;
         }
         int abase[FM], bvo[FN];
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            const int ml = wm * TM + i * 32 + l31, r = ml / wo, c = ml - r * wo;
-            abase[i] = (r * WP + c) * 32 + half * 16;
+            const int ml = wm * TM + i * 32 + l31, il = ml / PPI, mq = ml - il * PPI, r = mq / wo, c = mq - r * wo;
+            abase[i] = (il * HPI + r * WP + c) * 32 + half * 16;
         }
 #pragma unroll
         for (int j = 0; j < FN; ++j) bvo[j] = ((tn * NFB + wn * FN + j) * a.ktiles * 6) * 1024 + lane * 16;
@@ -577,9 +587,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
                 const float r0 = v0 - bf16_lo_f32(ch_[u][q]), r1 = v1 - bf16_hi_f32(ch_[u][q]);
                 cm_[u][q] = cvt_pk_bf16(r0, r1);
                 cl_[u][q] = cvt_pk_bf16(r0 - bf16_lo_f32(cm_[u][q]), r1 - bf16_hi_f32(cm_[u][q]));
-            } else if (hlds[u] >= 0) {
+            } else if (tid + NT * u < 4 * HP) {           // LDS byte (tid + 256 u) * 8 of the plane: pixel hp = unit >> 2, 8 bytes per unit
                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                uint8_t* dst = lb + base + hlds[u];
+                uint8_t* dst = lb + base + (tid + NT * u) * 8;
                 *reinterpret_cast<u32x2*>(dst) = u32x2{ch_[u][0], ch_[u][1]};
                 *reinterpret_cast<u32x2*>(dst + TAP_PLANE) = u32x2{cm_[u][0], cm_[u][1]};
                 *reinterpret_cast<u32x2*>(dst + 2 * TAP_PLANE) = u32x2{cl_[u][0], cl_[u][1]};
@@ -1309,20 +1319,33 @@ static int conv_run(const egr_conv_desc* dd, const float* x, const float* w, con
 
     // ---- 3x3 / stride 1 / pad 1 split launches whose tiles are whole image rows: the tap-sharing kernel
     if (g_tap && g_force_cfg == CFG_AUTO && d.w_format == EGR_W_BF16X3 && d.kh == 3 && d.kw == 3 && d.stride == 1 && d.pad == 1 &&
-        !a.cls_mode && d.split_k <= 1 && (d.wo == 16 || d.wo == 32 || d.wo == 64) && d.ho == d.h && d.wo == d.w &&
-        (d.ho * d.wo) % 128 == 0 && a.M % 128 == 0 && a.Npad % 64 == 0 && a.M >= 128 * 64) {
-        d.split_k = 1;
-        a.ktiles_per_split = a.ktiles;
-        const int bn = (a.Npad % 128 == 0 && (int64_t)(a.M / 128) * (a.Npad / 128) * d.groups >= 256) ? 128 : 64;
-        a.tilesM = a.M / 128;
-        a.tilesN = a.Npad / bn;
-        a.dTilesN = make_fastdiv(a.tilesN);
-        a.ntiles = a.tilesM * a.tilesN;
-        dim3 grid((unsigned)a.ntiles, 1, (unsigned)d.groups);
-        if (bn == 128) hipLaunchKernelGGL((conv_igemm_tap_kernel<128, 128, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((conv_igemm_tap_kernel<128, 64, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream, a);
-        g_last_conv_kernel = 2;
-        return egr_launch_status();
+        !a.cls_mode && d.split_k <= 1 && (d.wo == 8 || d.wo == 16 || d.wo == 32 || d.wo == 64) && d.ho == d.h && d.wo == d.w &&
+        a.Npad % 64 == 0 && a.M >= 128 * 64) {
+        // 256 x 64 tiles for 64 / 192 output channels (as many MFMAs per tap as 128 x 128), 128 x 128 when that fills the chip, else 128 x 64
+        const int P = d.ho * d.wo;
+        auto fits_tile = [&](int bm) {
+            if (a.M % bm != 0 || !((P % bm == 0) || (bm % P == 0))) return false;
+            const int hp = P >= bm ? (bm / d.wo + 2) * (d.wo + 2) : (bm / P) * (d.ho + 2) * (d.wo + 2);
+            return hp <= tap_hpmax(bm);
+        };
+        int bm = 0, bn = 0;
+        if (a.Npad % 128 == 0 && fits_tile(128) && (int64_t)(a.M / 128) * (a.Npad / 128) * d.groups >= 256) { bm = 128; bn = 128; }
+        else if (fits_tile(256) && (int64_t)(a.M / 256) * (a.Npad / 64) * d.groups >= 256) { bm = 256; bn = 64; }
+        else if (fits_tile(128)) { bm = 128; bn = 64; }
+        if (bm) {
+            d.split_k = 1;
+            a.ktiles_per_split = a.ktiles;
+            a.tilesM = a.M / bm;
+            a.tilesN = a.Npad / bn;
+            a.dTilesN = make_fastdiv(a.tilesN);
+            a.ntiles = a.tilesM * a.tilesN;
+            dim3 grid((unsigned)a.ntiles, 1, (unsigned)d.groups);
+            if (bm == 256) hipLaunchKernelGGL((conv_igemm_tap_kernel<256, 64, 4, 1>), grid, dim3(256), 0, (hipStream_t)stream, a);
+            else if (bn == 128) hipLaunchKernelGGL((conv_igemm_tap_kernel<128, 128, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL((conv_igemm_tap_kernel<128, 64, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream, a);
+            g_last_conv_kernel = 2;
+            return egr_launch_status();
+        }
     }
     g_last_conv_kernel = d.w_format == EGR_W_BF16X3 ? 1 : 0;
 

@@ -222,6 +222,10 @@ TAP_CASES = [
     (4, 64, 96, 256, 1, "res_after"),          # three 32-channel blocks, residual behind the activation
     (9, 32, 64, 60, 1, "nchw"),                # cout not a multiple of 32; channel-major planes out; image count odd
     (32, 64, 64, 128, 1, "scale_relu"),        # enough tiles for the 128 x 128 configuration
+    (64, 64, 64, 64, 1, "res_before"),         # 64 output channels, enough tiles for the 256 x 64 configuration (four image rows per tile)
+    (256, 16, 64, 192, 1, "scale_relu"),       # 256 x 64 tiles = one whole 16 x 16 image each, three column tiles
+    (128, 8, 128, 128, 1, "plain"),            # 8 x 8 images: a 128-pixel tile is two whole images
+    (512, 8, 64, 64, 2, "res_after"),          # 8 x 8 images, grouped, 64-wide tiles
 ]
 
 
