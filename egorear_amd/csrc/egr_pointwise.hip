@@ -37,18 +37,17 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* x, float* y, 
 // ------------------------------------------------------------------ bilinear x2, align_corners=True (NHWC)
 // index / weight arithmetic follows ATen's area_pixel_compute_source_index(align_corners=True):
 // src = dst * (in-1)/(out-1) in fp32, i0 = (int)src, i1 = min(i0+1, in-1), l1 = src - i0, l0 = 1 - l1.
+// One output row (img = blockIdx.z, oy = blockIdx.y) per block row: the vertical source rows / weights are wave-uniform, and the
+// thread index only splits into (ox, channel quad) with 32-bit arithmetic (a flat 64-bit index cost three 64-bit divisions per
+// thread - more instructions than the memory system needed time: 202 us for 0.67 GB).
 __global__ __launch_bounds__(256) void upsample2x_kernel(const float* x, int ldx, float* y, int ldy, int n, int h, int w,
-                                                         int c4, int relu) {
+                                                         int c4, int c4_shift, int relu) {
     const int ho = 2 * h, wo = 2 * w;
-    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    int64_t total = (int64_t)n * ho * wo * c4;
-    if (idx >= total) return;
-    int cq = (int)(idx % c4);
-    int64_t p = idx / c4;
-    int ox = (int)(p % wo);
-    p /= wo;
-    int oy = (int)(p % ho);
-    int img = (int)(p / ho);
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= wo * c4) return;
+    const int ox = c4_shift >= 0 ? (t >> c4_shift) : t / c4;
+    const int cq = t - ox * c4;
+    const int oy = blockIdx.y, img = blockIdx.z;
     const float sh = (ho > 1) ? (float)(h - 1) / (float)(ho - 1) : 0.f;
     const float sw = (wo > 1) ? (float)(w - 1) / (float)(wo - 1) : 0.f;
     float fy = sh * (float)oy, fx = sw * (float)ox;
@@ -57,15 +56,15 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* x, int ldx
     float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f);
     float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
     const float* base = x + (int64_t)img * h * w * ldx + cq * 4;
-    f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((int64_t)y0 * w + x0) * ldx);
-    f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((int64_t)y0 * w + x1) * ldx);
-    f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((int64_t)y1 * w + x0) * ldx);
-    f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((int64_t)y1 * w + x1) * ldx);
+    f32x4 v00 = *reinterpret_cast<const f32x4*>(base + (y0 * w + x0) * ldx);
+    f32x4 v01 = *reinterpret_cast<const f32x4*>(base + (y0 * w + x1) * ldx);
+    f32x4 v10 = *reinterpret_cast<const f32x4*>(base + (y1 * w + x0) * ldx);
+    f32x4 v11 = *reinterpret_cast<const f32x4*>(base + (y1 * w + x1) * ldx);
     f32x4 o;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        float t = ly0 * (lx0 * v00[i] + lx1 * v01[i]) + ly1 * (lx0 * v10[i] + lx1 * v11[i]);
-        o[i] = (relu && t < 0.f) ? 0.f : t;
+        float t_ = ly0 * (lx0 * v00[i] + lx1 * v01[i]) + ly1 * (lx0 * v10[i] + lx1 * v11[i]);
+        o[i] = (relu && t_ < 0.f) ? 0.f : t_;
     }
     *reinterpret_cast<f32x4*>(y + (((int64_t)img * ho + oy) * wo + ox) * ldy + cq * 4) = o;
 }
@@ -356,9 +355,16 @@ extern "C" int egr_upsample2x_nhwc_f32(const float* x, int32_t ldx, float* y, in
                                        int32_t w, int32_t c, int32_t relu, void* stream) {
     if (!x || !y) return EGR_ENULL;
     if (n <= 0 || h <= 0 || w <= 0 || c % 4 != 0 || ldx % 4 != 0 || ldy % 4 != 0 || ldx < c || ldy < c) return EGR_EINVAL;
-    int64_t total = (int64_t)n * 4 * h * w * (c / 4);
-    hipLaunchKernelGGL(upsample2x_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, n, h,
-                       w, c / 4, relu);
+    const int c4 = c / 4;
+    int c4_shift = 0;
+    while ((1 << c4_shift) < c4) ++c4_shift;
+    if ((1 << c4_shift) != c4) c4_shift = -1;
+    if (2 * h > 65535 || (int64_t)h * w * ldx >= (1LL << 31) || (int64_t)2 * w * c4 >= (1LL << 31)) return EGR_EINVAL;
+    for (int n0 = 0; n0 < n; n0 += 65535) {       // grid.z is limited to 65535 images per launch
+        const int nn = n - n0 < 65535 ? n - n0 : 65535;
+        hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)((2 * w * c4 + 255) / 256), (unsigned)(2 * h), (unsigned)nn), dim3(256), 0,
+                           (hipStream_t)stream, x + (int64_t)n0 * h * w * ldx, ldx, y + (int64_t)n0 * 4 * h * w * ldy, ldy, nn, h, w, c4, c4_shift, relu);
+    }
     return egr_launch_status();
 }
 
