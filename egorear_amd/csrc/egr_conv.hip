@@ -1371,7 +1371,10 @@ static int conv_run(const egr_conv_desc* dd, const float* x, const float* w, con
     if (d.split_k <= 0) {
         d.split_k = 1;
         // (also: a few hundred blocks each walking a very long K alone - heatmap_proj.0: 240 blocks x 128 chunks, latency-bound)
-        if ((blocks < 128 ? a.ktiles >= 32 : (blocks < 512 && a.ktiles >= 64 && d.w_format == EGR_W_F32)) && workspace) {
+        // (small batches: 128 .. 511 blocks walking 18+ chunks alone leave most CUs idle and are latency-bound as well - layer1 / layer2 at
+        // batch 1: 42 -> ~25 us with the K range split 2-4 ways)
+        static const int mid_kt = getenv("EGR_SPLITK_MID_KT") ? atoi(getenv("EGR_SPLITK_MID_KT")) : 16;   // tuning knob
+        if ((blocks < 128 ? a.ktiles >= 32 : (blocks < 512 && d.w_format == EGR_W_F32 && (a.ktiles >= 64 || (mid_kt > 0 && a.ktiles >= mid_kt)))) && workspace) {
             // skinny GEMM streaming a long weight matrix (mlp_pred.0: 268 MB): a block's two-stage pipeline moves ~8 GB/s,
             // so the HBM rate is set by how many blocks stream at once -> aim at 4 per CU
             static const int target = getenv("EGR_SPLITK_TARGET") ? atoi(getenv("EGR_SPLITK_TARGET")) : 1024;   // tuning knob
