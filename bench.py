@@ -209,7 +209,7 @@ def cpu_train_baseline(batch: int = 4, iters: int = 4):
 
 
 HBM_KERNELS = ("egr_maxpool_nhwc_f32", "egr_upsample2x_nhwc_f32", "egr_argmax_rows_f32", "egr_msda_gather_f32", "egr_avgpool_nhwc_f32",
-               "egr_layernorm_f32", "egr_up2_relu_head_f32", "egr_stem_conv7x7_f32")
+               "egr_layernorm_f32", "egr_up2_relu_head_f32", "egr_stem_conv7x7_f32", "egr_stem_conv7x7_x6_f32[bf16x3]")
 
 
 def roofline_hbm(kernels: dict, pre_leg) -> list:
@@ -224,7 +224,7 @@ def roofline_hbm(kernels: dict, pre_leg) -> list:
                  "peak": PEAK_HBM_GBS, "frac": round(gbs / PEAK_HBM_GBS, 4)}
             if name == "egr_msda_gather_f32":
                 e["note"] = "sampled-corner bytes: a 64x64x128 feature map (2 MB per view) is re-read 60-64 times per frame from L2, so this is an L2 gather rate, not HBM traffic"
-            if name in ("egr_stem_conv7x7_f32", "egr_up2_relu_head_f32"):
+            if name in ("egr_stem_conv7x7_f32", "egr_stem_conv7x7_x6_f32[bf16x3]", "egr_up2_relu_head_f32"):
                 e["note"] = "matrix-core kernel with a memory-bound output side; its MFMA rate is in kernel_ms / DESIGN.md"
             out.append(e)
     if pre_leg:

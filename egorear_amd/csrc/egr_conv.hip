@@ -596,15 +596,16 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
             }
         };
         constexpr int NSL = 3 * NUH;
-        bf16x8 af[2][FM][3], bf[2][FN][3];
-        auto read_a = [&](int base, int tap, int par) {
+        // A fragments: ONE register set, refilled plane by plane behind the last product that uses the plane (lo after product 0,
+        // mid after product 3, hi after product 5) - the next tap's LDS reads overlap this tap's remaining MFMAs at no register cost.
+        // B fragments come from global memory (L2 latency > one tap): two sets, one tap ahead.  (Wave layouts 1 x 4 / 2 x 2 instead of
+        // 2 x 2 / 4 x 1, i.e. fewer redundant weight fetches per workgroup, measured the same within 1 %.)
+        bf16x8 af[FM][3], bf[2][FN][3];
+        auto read_a = [&](int base, int tap, int pl) {
             // (data gradient: tap (kh, kw) reads dy at (y + 1 - kh, x + 1 - kw) - the mirrored window)
             const int to = d.transposed ? ((2 - tap / 3) * WP + (2 - tap % 3)) * 32 : ((tap / 3) * WP + (tap % 3)) * 32;
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    af[par][i][pl] = *reinterpret_cast<const bf16x8*>(lb + base + pl * TAP_PLANE + abase[i] + to);
+            for (int i = 0; i < FM; ++i) af[i][pl] = *reinterpret_cast<const bf16x8*>(lb + base + pl * TAP_PLANE + abase[i] + to);
         };
         auto load_b = [&](int ck, int tap, int par) {
             const int so = (((ck >> 1) * 9 + tap) * 6 + (ck & 1) * 3) * 1024;
@@ -615,7 +616,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
                     bf[par][j][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rb, bvo[j] + pl * 1024, so, 0));
         };
         // one chunk: nine taps out of halo buffer `cur`; the next chunk's halo is converted into `nxt` behind the taps 2 .. 7.
-        // PAR: operand register set of tap 0 (nine taps flip it, so chunks alternate)
+        // PAR: B register set of tap 0 (nine taps flip it, so chunks alternate)
         auto chunk = [&](auto par_tag, int ck, int cur, int nxt, auto conv_tag) {
             constexpr int PAR = decltype(par_tag)::value;
             constexpr bool conv = decltype(conv_tag)::value;
@@ -627,25 +628,32 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int pc = (PAR + tap) & 1, pn = pc ^ 1;
-                if (tap + 1 < 9) { load_b(ck, tap + 1, pn); read_a(cur, tap + 1, pn); }
+                if (tap + 1 < 9) load_b(ck, tap + 1, pn);
                 else if (conv) load_b(ck + 1, 0, pn);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < 6; ++t)
+                for (int t = 0; t < 6; ++t) {
 #pragma unroll
                     for (int i = 0; i < FM; ++i)
 #pragma unroll
                         for (int j = 0; j < FN; ++j, ++n) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pc][i][PA[t]], bf[pc][j][PB[t]], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[pc][j][PB[t]], acc[i][j], 0, 0, 0);
                             if constexpr (conv) {
                                 const int upto = (n + 1 <= W0) ? 0 : (n + 1 >= W1 ? NSL : ((n + 1 - W0) * NSL + (W1 - W0) - 1) / (W1 - W0));
                                 if (done < upto) { cslice(nxt, done); ++done; }
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                         }
+                    if (tap + 1 < 9 && (t == 0 || t == 3 || t == 5)) {
+                        read_a(cur, tap + 1, t == 0 ? 2 : (t == 3 ? 1 : 0));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if constexpr (conv) read_a(nxt, 0, (PAR + 9) & 1);
+            if constexpr (conv) {
+                read_a(nxt, 0, 2); read_a(nxt, 0, 0); read_a(nxt, 0, 1);
+            }
         };
         using T0 = std::integral_constant<int, 0>;
         using T1 = std::integral_constant<int, 1>;
@@ -656,7 +664,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
 #pragma unroll
         for (int k = 0; k < NSL; ++k) cslice(0, k);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        read_a(0, 0, 0);
+        read_a(0, 0, 2); read_a(0, 0, 0); read_a(0, 0, 1);
         stamp(2);
         int ck = 0;
         for (; ck + 2 < NC; ck += 2) {           // NC is even: chunk pairs, buffers 0 / 1, register parity 0 / 1

@@ -6,11 +6,11 @@ import collections, csv, glob, json, sys
 
 
 def classify(nm: str) -> str:
-    if "conv_igemm_x6" in nm: return "conv_igemm_bf16x3"
+    if "conv_igemm_x6" in nm or "conv_igemm_tap" in nm: return "conv_igemm_bf16x3"
     if "conv_igemm" in nm: return "conv_igemm_f32"
-    if "conv_wgrad_x6" in nm: return "conv_wgrad_bf16x3"
+    if "conv_wgrad_x6" in nm or "conv_wgrad3_x6" in nm: return "conv_wgrad_bf16x3"
     if "conv_wgrad" in nm: return "conv_wgrad_f32"
-    for k in ("bn_partial", "bn_bwd_apply", "bn_stats", "scale_shift", "adamw", "msda_gather_bwd", "stem_wgrad", "stem_kernel", "repack", "upsample2x_bwd"):
+    for k in ("bn_partial", "bn_bwd_apply", "bn_stats", "scale_shift", "adamw", "msda_gather_bwd", "stem_wgrad", "stem_x6_kernel", "stem_kernel", "repack", "upsample2x_bwd"):
         if k in nm: return k
     return "other"
 
