@@ -189,7 +189,8 @@ __device__ __forceinline__ void fisheye_one(const float* cam, float x, float y, 
     *v_out = fminf(fmaxf(v, 0.f), 1.f);
 }
 
-__global__ __launch_bounds__(256) void fisheye_kernel(float* pts, const float* ctm, const float* cams, int B, int J,
+// pts_out receives the anchors the later layers add their offsets to: the mutated points in syn mode, a copy in rw mode (may be pts)
+__global__ __launch_bounds__(256) void fisheye_kernel(const float* pts, float* pts_out, const float* ctm, const float* cams, int B, int J,
                                                       float* anchors, uint8_t* valid, float* q4) {
     int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= B * J) return;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) void fisheye_kernel(float* pts, const float* c
         anchors[o * 2 + 1] = v;
         valid[o] = ok;
     }
-    if (!ctm) { pts[idx * 3 + 0] = x; pts[idx * 3 + 1] = y; pts[idx * 3 + 2] = z; }
+    if (!ctm || pts_out != pts) { pts_out[idx * 3 + 0] = x; pts_out[idx * 3 + 1] = y; pts_out[idx * 3 + 2] = z; }
     q4[idx * 4 + 0] = (float)(j + 1) / (float)J;
     q4[idx * 4 + 1] = x; q4[idx * 4 + 2] = y; q4[idx * 4 + 3] = z;
 }
@@ -262,11 +263,16 @@ extern "C" int egr_joint_mha_f32(const float* qkv, float* out, int32_t b, int32_
     return egr_launch_status();
 }
 
-extern "C" int egr_fisheye_project_f32(float* pts, const float* ctm, const float* cams, int32_t b, int32_t joints,
-                                       float* anchors, uint8_t* valid, float* q4, void* stream) {
-    if (!pts || !cams || !anchors || !valid || !q4) return EGR_ENULL;
+extern "C" int egr_fisheye_project2_f32(const float* pts, float* pts_out, const float* ctm, const float* cams, int32_t b, int32_t joints,
+                                        float* anchors, uint8_t* valid, float* q4, void* stream) {
+    if (!pts || !pts_out || !cams || !anchors || !valid || !q4) return EGR_ENULL;
     if (b <= 0 || joints <= 0) return EGR_EINVAL;
-    hipLaunchKernelGGL(fisheye_kernel, dim3((unsigned)((b * joints + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pts,
+    hipLaunchKernelGGL(fisheye_kernel, dim3((unsigned)((b * joints + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pts, pts_out,
                        ctm, cams, b, joints, anchors, valid, q4);
     return egr_launch_status();
+}
+
+extern "C" int egr_fisheye_project_f32(float* pts, const float* ctm, const float* cams, int32_t b, int32_t joints,
+                                       float* anchors, uint8_t* valid, float* q4, void* stream) {
+    return egr_fisheye_project2_f32(pts, pts, ctm, cams, b, joints, anchors, valid, q4, stream);
 }

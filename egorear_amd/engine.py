@@ -707,13 +707,13 @@ def _pose3d(p3, st: State, feat_init: torch.Tensor, feat_final: torch.Tensor, B:
     h = linear(st, flat, P.mlp0, ACT_GELU)
     h = linear(st, h, P.mlp1, ACT_GELU)
     mlp_pred = linear(st, h, P.mlp2).view(B, J, 3)
-    anchors_3d = mlp_pred.clone()                                            # init_anchors_3d = mlp_pred.clone().detach()
+    anchors_3d = torch.empty_like(mlp_pred)                                  # init_anchors_3d = mlp_pred.clone().detach(): written by the projection kernel
     ctm32 = None
     if p3.camera_model.startswith("ego4view_rw"):
         if ctm is None:
             raise RuntimeError("egorear_amd: camera_model ego4view_rw needs coord_trans_mat (B,4,4,4)")
         ctm32 = ctm.to(device=dev, dtype=torch.float32).contiguous()         # any float dtype accepted
-    anchors_2d, valid, q4 = hip.fisheye_project(anchors_3d, ctm32, P.cams)   # syn: anchors_3d mutated in place (F7)
+    anchors_2d, valid, q4 = hip.fisheye_project(mlp_pred, ctm32, P.cams, out=anchors_3d)   # syn: anchors_3d = the points after the in-place chain (F7)
     # --- decoder
     C = p3.embed_dims
     x = hip.linear_smallk(q4, 4, 1, P.qg0_w, P.qg0_b, B * J, C, 4, ACT_RELU)

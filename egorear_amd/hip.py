@@ -26,7 +26,7 @@ EXPORTS = [
     "egr_device_arch", "egr_conv_force_config", "egr_preprocess_u8_f32", "egr_pose_metrics_f32", "egr_gt_heatmap_f32", "egr_conv_debug_stamps", "egr_conv2d_wgrad_f32", "egr_conv2d_masked_f32", "egr_up2_relu_head_f32",
     "egr_msda_fwd_f32", "egr_msda_bwd_f32", "egr_w6_elems", "egr_pack_w6_f32", "egr_pack_w6_many_f32", "egr_joint_layer_f32",
     "egr_preprocess_fused_u8_f32", "egr_preprocess_band_rows", "egr_conv_set_persist", "egr_stem_conv7x7_pool_f32",
-    "egr_stem_w6_bytes", "egr_pack_stem_w6_f32", "egr_stem_conv7x7_x6_f32", "egr_wgrad_last_kernel", "egr_conv_last_kernel", "egr_conv_set_tap",
+    "egr_stem_w6_bytes", "egr_pack_stem_w6_f32", "egr_stem_conv7x7_x6_f32", "egr_wgrad_last_kernel", "egr_conv_last_kernel", "egr_conv_set_tap", "egr_fisheye_project2_f32",
 ]
 
 
@@ -86,6 +86,7 @@ def _load() -> C.CDLL:
     lib.egr_joint_mha_f32.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp]
     lib.egr_msda_gather_f32.argtypes = [vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp]
     lib.egr_fisheye_project_f32.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp]
+    lib.egr_fisheye_project2_f32.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]
     lib.egr_linear_smallk_f32.argtypes = [vp, i64, i64, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.egr_jqa_sum_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.egr_tokens_to_nhwc_f32.argtypes = [vp, vp, i32, i32, i32, vp]
@@ -642,8 +643,9 @@ def msda_gather(feat: torch.Tensor, pos: Optional[torch.Tensor], offs_logits: to
     return g, e, sigma, rowmask
 
 
-def fisheye_project(pts: torch.Tensor, ctm: Optional[torch.Tensor], cams: torch.Tensor):
-    """pts (b, joints, 3) is updated IN PLACE in syn mode (ctm None), as the reference does."""
+def fisheye_project(pts: torch.Tensor, ctm: Optional[torch.Tensor], cams: torch.Tensor, out: Optional[torch.Tensor] = None):
+    """pts (b, joints, 3) is updated IN PLACE in syn mode (ctm None), as the reference does - or, with `out`,
+    left alone and the updated points (syn: mutated, rw: a copy) written there."""
     _cont(pts, "pts")
     b, joints = pts.shape[:2]
     if cams.numel() != 4 * 17:
@@ -656,6 +658,12 @@ def fisheye_project(pts: torch.Tensor, ctm: Optional[torch.Tensor], cams: torch.
     anchors = torch.empty((b, 4, joints, 2), device=dev, dtype=torch.float32)
     valid = torch.empty((b, 4, joints), device=dev, dtype=torch.uint8)
     q4 = torch.empty((b * joints, 4), device=dev, dtype=torch.float32)
+    if out is not None:
+        if out.shape != pts.shape or not out.is_contiguous():
+            raise RuntimeError("egorear_amd.fisheye_project: out must be a contiguous tensor of pts' shape")
+        _launch("egr_fisheye_project_f32", lib.egr_fisheye_project2_f32, _p(pts), _p(out), _p(ctm), _p(cams), b, joints, _p(anchors),
+                _p(valid, torch.uint8), _p(q4), _stream())
+        return anchors, valid, q4
     _launch("egr_fisheye_project_f32", lib.egr_fisheye_project_f32, _p(pts), _p(ctm), _p(cams), b, joints, _p(anchors), _p(valid, torch.uint8), _p(q4),
                                        _stream())
     return anchors, valid, q4

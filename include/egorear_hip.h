@@ -287,6 +287,10 @@ int egr_joint_layer_f32(const egr_layer_desc* d, void* stream);
 int egr_fisheye_project_f32(float* pts, const float* ctm, const float* cams, int32_t b, int32_t joints,
                             float* anchors /* (b, 4, joints, 2) */, uint8_t* valid /* (b, 4, joints) */,
                             float* q4, void* stream);
+/* The same with the updated points written to pts_out (b, joints, 3) instead of in place: the mutated anchors in syn mode, a
+ * copy of pts in rw mode - `init_anchors_3d = mlp_pred.clone()` (egoposeformer_mvf_ex.py:400) without the copy. */
+int egr_fisheye_project2_f32(const float* pts, float* pts_out, const float* ctm, const float* cams, int32_t b, int32_t joints,
+                             float* anchors, uint8_t* valid, float* q4, void* stream);
 
 /* Small dense layer for K not a multiple of 32 (query_gen_mlp.0: K=4; head 1x1 conv: K=15):
  * y[m, n] = act(sum_k x[m*sxm + k*sxk] * w[n*K + k] + bias[n]). */
