@@ -37,36 +37,49 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* x, float* y, 
 // ------------------------------------------------------------------ bilinear x2, align_corners=True (NHWC)
 // index / weight arithmetic follows ATen's area_pixel_compute_source_index(align_corners=True):
 // src = dst * (in-1)/(out-1) in fp32, i0 = (int)src, i1 = min(i0+1, in-1), l1 = src - i0, l0 = 1 - l1.
-// One output row (img = blockIdx.z, oy = blockIdx.y) per block row: the vertical source rows / weights are wave-uniform, and the
-// thread index only splits into (ox, channel quad) with 32-bit arithmetic (a flat 64-bit index cost three 64-bit divisions per
-// thread - more instructions than the memory system needed time: 202 us for 0.67 GB).
+// Two output rows (img = blockIdx.z, oy = 2 blockIdx.y, + 1) per block row: the vertical source rows / weights are wave-uniform,
+// the thread index only splits into (ox, channel quad) with 32-bit arithmetic (a flat 64-bit index cost three 64-bit divisions
+// per thread - more instructions than the memory system needed time: 232 us for 0.67 GB), and a thread's two outputs share their
+// horizontal neighbours' columns and weights - up to eight 16-byte loads in flight per thread before the first use.
 __global__ __launch_bounds__(256) void upsample2x_kernel(const float* x, int ldx, float* y, int ldy, int n, int h, int w,
-                                                         int c4, int c4_shift, int relu) {
+                                                         int c4, int c4_shift, int relu, int nt) {
     const int ho = 2 * h, wo = 2 * w;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= wo * c4) return;
     const int ox = c4_shift >= 0 ? (t >> c4_shift) : t / c4;
     const int cq = t - ox * c4;
-    const int oy = blockIdx.y, img = blockIdx.z;
+    const int oy = 2 * blockIdx.y, img = blockIdx.z;
     const float sh = (ho > 1) ? (float)(h - 1) / (float)(ho - 1) : 0.f;
     const float sw = (wo > 1) ? (float)(w - 1) / (float)(wo - 1) : 0.f;
-    float fy = sh * (float)oy, fx = sw * (float)ox;
-    int y0 = (int)fy, x0 = (int)fx;
-    int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
-    float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f);
-    float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    const float fx = sw * (float)ox;
+    const int x0 = (int)fx, x1 = min(x0 + 1, w - 1);
+    const float lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f), lx0 = 1.f - lx1;
     const float* base = x + (int64_t)img * h * w * ldx + cq * 4;
-    f32x4 v00 = *reinterpret_cast<const f32x4*>(base + (y0 * w + x0) * ldx);
-    f32x4 v01 = *reinterpret_cast<const f32x4*>(base + (y0 * w + x1) * ldx);
-    f32x4 v10 = *reinterpret_cast<const f32x4*>(base + (y1 * w + x0) * ldx);
-    f32x4 v11 = *reinterpret_cast<const f32x4*>(base + (y1 * w + x1) * ldx);
-    f32x4 o;
+    f32x4 v[2][4];
+    float ly0[2], ly1[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float t_ = ly0 * (lx0 * v00[i] + lx1 * v01[i]) + ly1 * (lx0 * v10[i] + lx1 * v11[i]);
-        o[i] = (relu && t_ < 0.f) ? 0.f : t_;
+    for (int r = 0; r < 2; ++r) {
+        const float fy = sh * (float)(oy + r);
+        const int y0 = (int)fy, y1 = min(y0 + 1, h - 1);
+        ly1[r] = fminf(fmaxf(fy - (float)y0, 0.f), 1.f);
+        ly0[r] = 1.f - ly1[r];
+        v[r][0] = *reinterpret_cast<const f32x4*>(base + (y0 * w + x0) * ldx);
+        v[r][1] = *reinterpret_cast<const f32x4*>(base + (y0 * w + x1) * ldx);
+        v[r][2] = *reinterpret_cast<const f32x4*>(base + (y1 * w + x0) * ldx);
+        v[r][3] = *reinterpret_cast<const f32x4*>(base + (y1 * w + x1) * ldx);
     }
-    *reinterpret_cast<f32x4*>(y + (((int64_t)img * ho + oy) * wo + ox) * ldy + cq * 4) = o;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float t_ = ly0[r] * (lx0 * v[r][0][i] + lx1 * v[r][1][i]) + ly1[r] * (lx0 * v[r][2][i] + lx1 * v[r][3][i]);
+            o[i] = (relu && t_ < 0.f) ? 0.f : t_;
+        }
+        // outputs far beyond the last-level cache: non-temporal stores (no write-allocate; 171 -> 103 us for the 537 MB launch)
+        if (nt) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(y + (((int64_t)img * ho + oy + r) * wo + ox) * ldy + cq * 4));
+        else *reinterpret_cast<f32x4*>(y + (((int64_t)img * ho + oy + r) * wo + ox) * ldy + cq * 4) = o;
+    }
 }
 
 // ------------------------------------------------------------------ global average pool (NHWC)
@@ -360,10 +373,12 @@ extern "C" int egr_upsample2x_nhwc_f32(const float* x, int32_t ldx, float* y, in
     while ((1 << c4_shift) < c4) ++c4_shift;
     if ((1 << c4_shift) != c4) c4_shift = -1;
     if (2 * h > 65535 || (int64_t)h * w * ldx >= (1LL << 31) || (int64_t)2 * w * c4 >= (1LL << 31)) return EGR_EINVAL;
+    static const double nt_mb = getenv("EGR_NT_STORE_MB") ? atof(getenv("EGR_NT_STORE_MB")) : 256.0;
+    const int nt = ((double)n * 4 * h * w * c * 4.0 >= nt_mb * 1e6) ? 1 : 0;
     for (int n0 = 0; n0 < n; n0 += 65535) {       // grid.z is limited to 65535 images per launch
         const int nn = n - n0 < 65535 ? n - n0 : 65535;
-        hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)((2 * w * c4 + 255) / 256), (unsigned)(2 * h), (unsigned)nn), dim3(256), 0,
-                           (hipStream_t)stream, x + (int64_t)n0 * h * w * ldx, ldx, y + (int64_t)n0 * 4 * h * w * ldy, ldy, nn, h, w, c4, c4_shift, relu);
+        hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)((2 * w * c4 + 255) / 256), (unsigned)h, (unsigned)nn), dim3(256), 0,
+                           (hipStream_t)stream, x + (int64_t)n0 * h * w * ldx, ldx, y + (int64_t)n0 * 4 * h * w * ldy, ldy, nn, h, w, c4, c4_shift, relu, nt);
     }
     return egr_launch_status();
 }
