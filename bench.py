@@ -392,9 +392,23 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     backend = os.environ.get("EGR_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; "gloo" only for rehearsals on one GPU
+    backend_note = ""
     if world > 1:
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)  # only used for the barrier and the max-over-ranks
+            try:
+                dist.init_process_group("nccl", device_id=dev)  # inference: only the barrier and the max-over-ranks; training: the gradient all-reduce
+                probe = torch.zeros(1, device=dev)
+                dist.all_reduce(probe)                             # the communicator's first collective, before anything is timed
+                torch.cuda.synchronize()
+            except Exception as exc:
+                # RCCL unusable on this node (every rank fails the same way: the eager connect is collective).  The inference line needs
+                # no data-path collective, so it is still measured, with gloo for the barrier / timing; the JSON says so and the
+                # training leg's all-reduce then goes through the host.
+                backend_note = f"gloo (RCCL failed: {type(exc).__name__}: {str(exc)[:200]})"
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                dist.init_process_group("gloo")
+                backend = "gloo"
         else:
             dist.init_process_group(backend)
 
@@ -442,7 +456,7 @@ def main():
                "frames_per_s": round(B * args.steps / own["own_s"], 2)}
         records = gather_rank_records(rec)                       # collective: every rank takes part
         ranks_obj = {"world_size": dist.get_world_size() if world > 1 else 1,
-                     "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else "none (single process)",
+                     "backend": (backend_note or (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else ""))) if world > 1 else "none (single process)",
                      "distinct_devices": check_distinct_devices(records, allow_shared), "per_rank": records}
 
         # ---- roofline leg: per-launch HIP-event timing of one instrumented (eager) step
