@@ -320,6 +320,65 @@ def test_tap_sharing_data_gradient(case):
     assert float((outs[0] - outs[1]).abs().max()) <= 4e-6 * float(ref.abs().max())
 
 
+def test_tap_sharing_randomised_geometry():
+    """Seeded sweep over tap-eligible shapes (image sizes 8-64, 1-3 input chunks, 64-256 output channels, groups, forward and data
+    gradient, every tile configuration the dispatcher can pick): the tap-sharing launch must agree with the generic split launch of
+    the same problem to fp32 rounding (same operands, same products), and the tap-sharing weight gradient with the generic one."""
+    from egorear_amd import hip
+    from egorear_amd.engine import unpack_conv_weight
+    g = torch.Generator().manual_seed(4321)
+
+    def pick(options):
+        return options[int(torch.randint(len(options), (1,), generator=g))]
+
+    saved = hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS
+    hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = 0, 0.0
+    ws = torch.empty(1 << 25, device=DEV)
+    seen = set()
+    try:
+        for it in range(14):
+            hw = pick([8, 16, 32, 64])
+            G = pick([1, 1, 2])
+            cin, cout = pick([32, 64, 96, 128]), pick([64, 128, 192, 256])
+            n = max(1, (8192 * pick([1, 2, 3])) // (hw * hw))          # >= 8192 rows per group, also odd multiples of the tile
+            transposed = pick([False, False, True])
+            x = rnd(G * n, hw, hw, cout if transposed else cin, seed=900 + it)
+            wts = [rnd(cout, cin, 3, 3, seed=950 + it * 2 + q, scale=1.0 / math.sqrt(9 * cin)) for q in range(G)]
+            packer = pack_w_dgrad if transposed else pack_w
+            wp = (torch.stack([packer(t) for t in wts]) if G > 1 else packer(wts[0])).to(DEV)
+            kw = dict(groups=G, transposed_out_hw=(hw, hw)) if transposed else dict(groups=G, act=hip.ACT_RELU)
+            outs = {}
+            n_launch = cin if transposed else cout                      # output channels of the launch
+            eligible = ((n_launch + 31) // 32 * 32) % 64 == 0            # the tap-sharing tiles are 64 / 128 channels wide
+            for tap in (1, 0):
+                hip.lib.egr_conv_set_tap(tap)
+                outs[tap] = hip.conv2d(hip.Img(x.to(DEV)), hip.pack_w6(wp), n_launch, 3, 3, 1, 1, **kw).t.clone()
+                assert hip.lib.egr_conv_last_kernel() == (2 if (tap and eligible) else 1), (it, hw, cin, cout, n, G, transposed)
+            scale = float(outs[0].abs().max())
+            assert float((outs[1] - outs[0]).abs().max()) <= 4e-6 * scale, ("tap vs generic", it, hw, cin, cout, n, G, transposed)
+            if eligible:
+                seen.add((hw, transposed))
+            # weight gradient of the same layer
+            if it % 2 == 0 and cin % 32 == 0:
+                xa = rnd(G * n, cin, hw, hw, seed=1000 + it)
+                dy = rnd(G * n, cout, hw, hw, seed=1100 + it)
+                xi, dyi = hip.Img(xa.permute(0, 2, 3, 1).contiguous().to(DEV)), hip.Img(dy.permute(0, 2, 3, 1).contiguous().to(DEV))
+                import os as _os
+                d1, _ = hip.conv2d_wgrad(xi, dyi, 3, 3, 1, 1, ws, groups=G, x6="force")
+                k1 = hip.lib.egr_wgrad_last_kernel()
+                d1 = d1.clone()
+                d0, _ = hip.conv2d_wgrad(xi, dyi, 3, 3, 1, 1, ws, groups=G, x6=False)
+                assert hip.lib.egr_wgrad_last_kernel() == 0
+                expect = 3 if cout % 128 == 0 else (2 if (cout % 64 == 0 and cin % 64 == 0) else 1)
+                assert k1 == expect, (k1, expect, cin, cout, hw)
+                sc = float(d0.abs().max())
+                assert float((d1 - d0).abs().max()) <= 2e-5 * sc, ("wgrad", it, hw, cin, cout, n, G)
+        assert len({h for h, _ in seen}) >= 3
+    finally:
+        hip.lib.egr_conv_set_tap(1)
+        hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = saved
+
+
 WGRAD_CASES = [
     # n, h, w, cin, cout, k, stride, groups
     (8, 32, 32, 64, 64, 3, 1, 1),        # 64-wide output tile (BCO = 64), 8192 pixels
