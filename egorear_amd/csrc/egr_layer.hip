@@ -38,9 +38,12 @@ __device__ __forceinline__ float gelu_erf(float t) { return 0.5f * t * (1.0f + e
 // across column blocks, so a weight fetch is exposed once per call, not once per block.  NSEG (A, W) segment pairs of depth K
 // each: A segment s starts at A + s*a_seg (row stride lda), W segment s at W + s*w_seg (row stride ldw); K % 128 == 0.
 // epi(nb, acc) consumes a finished block.
+// packed: W is in fragment order (egr_pack_layer_w_f32: [16-column block][128-deep chunk][16-deep k block][lane][4 floats]) - a
+// wave's weight load is then 1 KiB contiguous instead of 16 rows x 64 bytes (the layer kernel streams 0.9 - 3.4 MB of weights per
+// workgroup: -14 % time); the segments of a multi-segment call must be adjacent in K (w_seg == K), which they are.
 template <int RB, int NSEG, typename Epi>
 __device__ __forceinline__ void gemm_cols(const float* __restrict__ A, int lda, int a_seg, const float* __restrict__ W, int ldw, int w_seg, int K,
-                                          int nb0, int nstep, int nb1, int lane, Epi&& epi) {
+                                          int nb0, int nstep, int nb1, int lane, bool packed, Epi&& epi) {
     const int i = lane & 15, q = lane >> 4;
     constexpr int CH = 8;      // 16-deep k blocks per chunk (128 k)
     const int cps = K / (16 * CH);          // chunks per segment
@@ -56,9 +59,15 @@ __device__ __forceinline__ void gemm_cols(const float* __restrict__ A, int lda, 
     int l_blk = 0, l_c = 0;                 // position of the next LOAD
     auto load = [&](f32x4_t (&b)[CH]) {
         const int seg = l_c / cps, cc = l_c - seg * cps;
-        const float* p = wbase + (int64_t)((nb0 + l_blk * nstep) * 16) * ldw + seg * w_seg + cc * (16 * CH);
+        if (packed) {
+            const float* p = W + ((int64_t)((nb0 + l_blk * nstep) * cpb + l_c) * CH) * 256 + lane * 4;
 #pragma unroll
-        for (int u = 0; u < CH; ++u) b[u] = *reinterpret_cast<const f32x4_t*>(p + 16 * u);
+            for (int u = 0; u < CH; ++u) b[u] = *reinterpret_cast<const f32x4_t*>(p + 256 * u);
+        } else {
+            const float* p = wbase + (int64_t)((nb0 + l_blk * nstep) * 16) * ldw + seg * w_seg + cc * (16 * CH);
+#pragma unroll
+            for (int u = 0; u < CH; ++u) b[u] = *reinterpret_cast<const f32x4_t*>(p + 16 * u);
+        }
         if (++l_c == cpb) { l_c = 0; ++l_blk; }
     };
     int c_blk = 0, c_c = 0;                 // position of the next COMPUTE
@@ -195,9 +204,10 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
     const float* const w_f1 = d.w_f1 + (int64_t)grp * C * FF;
     const float* const b_f1 = d.b_f1 + grp * C;
 
+    const bool wpk = d.w_packed != 0;
     // plain "Linear on a 16-row tile": out[16][ldo] = act(A . W^T + bias)
     auto linear16 = [&](const float* A, int lda, const float* W, int K, const float* bias, int N, float* out, int ldo, bool gelu) {
-        gemm_cols<1, 1>(A, lda, 0, W, K, 0, K, wave, NW, N / 16, lane, [&](int nb, const f32x4_t (&acc)[1]) {
+        gemm_cols<1, 1>(A, lda, 0, W, K, 0, K, wave, NW, N / 16, lane, wpk, [&](int nb, const f32x4_t (&acc)[1]) {
             const int col = nb * 16 + i16;
             const float bb = bias[col];
 #pragma unroll
@@ -223,7 +233,7 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
             if (wave * 16 < PW) {
                 const int n0 = ps * PW + wave * 16;    // this wave's output columns [n0, n0 + 16)
                 const int h = n0 / DH, hp = h - ps * HPP;
-                gemm_cols<2, 1>(bufG + hp * 32 * LG, LG, 0, w_fold, CF, 0, CF, n0 / 16, 1, n0 / 16 + 1, lane, [&](int nb, const f32x4_t (&acc)[2]) {
+                gemm_cols<2, 1>(bufG + hp * 32 * LG, LG, 0, w_fold, CF, 0, CF, n0 / 16, 1, n0 / 16 + 1, lane, wpk, [&](int nb, const f32x4_t (&acc)[2]) {
                     const int col = nb * 16 + i16;
                     const float cf_ = c_fold[col];
 #pragma unroll
@@ -243,7 +253,7 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
             __syncthreads();
         }
         // output_proj on the 32 rows of this half; masked_fill(~valid) AFTER it (the bias is zeroed too)
-        gemm_cols<2, 1>(bufA, LC, 0, w_out, C, 0, C, wave, NW, C / 16, lane, [&](int nb, const f32x4_t (&acc)[2]) {
+        gemm_cols<2, 1>(bufA, LC, 0, w_out, C, 0, C, wave, NW, C / 16, lane, wpk, [&](int nb, const f32x4_t (&acc)[2]) {
             const int col = nb * 16 + i16;
             const float bo = b_out[col];
 #pragma unroll
@@ -258,7 +268,7 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
         __syncthreads();
     }
     // ---- cat over views -> fuse_mlp: token j = rows 4j .. 4j+3 of bufO side by side (V segments of K = C)
-    gemm_cols<1, 4>(bufO, V * LC, LC, w_fuse, V * C, C, C, wave, NW, C / 16, lane, [&](int nb, const f32x4_t (&acc)[1]) {
+    gemm_cols<1, 4>(bufO, V * LC, LC, w_fuse, V * C, C, C, wave, NW, C / 16, lane, wpk, [&](int nb, const f32x4_t (&acc)[1]) {
         const int col = nb * 16 + i16;
         const float bb = b_fuse[col];
 #pragma unroll
@@ -340,7 +350,7 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
         const float* const w_ol = d.w_ol + (int64_t)grp * d.ol_n * C;
         const float* const b_ol = d.b_ol + grp * d.ol_n;
         const int oln = d.ol_n;
-        gemm_cols<1, 1>(tile1, LC, 0, w_ol, C, 0, C, wave, NW, oln / 16, lane, [&](int nb, const f32x4_t (&acc)[1]) {
+        gemm_cols<1, 1>(tile1, LC, 0, w_ol, C, 0, C, wave, NW, oln / 16, lane, wpk, [&](int nb, const f32x4_t (&acc)[1]) {
             const int col = nb * 16 + i16;
             const float bb = b_ol[col];
 #pragma unroll
@@ -375,7 +385,31 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
     }
 }
 
+// (rows, k) row-major -> fragment order; one thread per 16 bytes of the output
+__global__ __launch_bounds__(256) void pack_layer_w_kernel(const float* __restrict__ w, float* __restrict__ out, int rows, int k, int64_t total4) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= total4) return;
+    const int64_t per = (int64_t)rows * k / 4;          // float4 per matrix
+    const int64_t m = o / per;
+    int64_t r = o - m * per;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int u = (int)(r & 7); r >>= 3;
+    const int kc = (int)(r % (k / 128)), nb = (int)(r / (k / 128));
+    const int i = lane & 15, q = lane >> 4;
+    *reinterpret_cast<f32x4_t*>(out + o * 4) =
+        *reinterpret_cast<const f32x4_t*>(w + (m * rows + nb * 16 + i) * k + kc * 128 + u * 16 + 4 * q);
+}
+
 }  // namespace
+
+extern "C" int egr_pack_layer_w_f32(const float* w, int32_t matrices, int32_t rows, int32_t k, float* out, void* stream) {
+    if (!w || !out) return EGR_ENULL;
+    if (matrices <= 0 || rows <= 0 || k <= 0 || rows % 16 != 0 || k % 128 != 0 || (((uintptr_t)w | (uintptr_t)out) & 15)) return EGR_EINVAL;
+    const int64_t total4 = (int64_t)matrices * rows * k / 4;
+    if ((total4 + 255) / 256 >= (1LL << 31)) return EGR_EINVAL;
+    hipLaunchKernelGGL(pack_layer_w_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, out, rows, k, total4);
+    return egr_launch_status();
+}
 
 extern "C" int egr_joint_layer_f32(const egr_layer_desc* dd, void* stream) {
     if (!dd) return EGR_ENULL;

@@ -496,6 +496,11 @@ def pack_layers(layers, pres, poss) -> PLayer:
     }
     P.ol_plain = {"w": stk([torch.cat([c.sampling_offsets.weight, c.attention_weights.weight], 0) for c in cas]),
                   "b": stk([torch.cat([c.sampling_offsets.bias, c.attention_weights.bias], 0) for c in cas])}
+    # the kernel streams its weight matrices as 1-KiB contiguous wave loads: fragment order (hip.pack_layer_w), flagged in the dict
+    for k in ("w_fold", "w_out", "w_fuse", "w_qkv", "w_mo", "w_f0", "w_f1"):
+        P.fused[k] = hip.pack_layer_w(P.fused[k])
+    P.fused["packed"] = True
+    P.ol_plain["w"] = hip.pack_layer_w(P.ol_plain["w"])
     return P
 
 
@@ -687,7 +692,7 @@ def _pack_pose3d(p3) -> PPose:
     P.post = [(f32(n.weight), f32(n.bias)) for n in p3.post_norm]
     P.reg0 = [pack_linear_mods([r[0]]) for r in p3.reg_mlp]
     P.reg2 = [pack_linear_mods([r[2]]) for r in p3.reg_mlp]
-    P.reg_plain = [(f32(r[0].weight), f32(r[0].bias), f32(r[2].weight), f32(r[2].bias)) for r in p3.reg_mlp]
+    P.reg_plain = [(hip.pack_layer_w(f32(r[0].weight).contiguous()), f32(r[0].bias), f32(r[2].weight), f32(r[2].bias)) for r in p3.reg_mlp]   # w0 in fragment order
     rec = np.stack([c.packed() for c in p3.cameras()])
     P.cams = torch.from_numpy(rec).to(w0.device)
     return P

@@ -26,7 +26,7 @@ EXPORTS = [
     "egr_device_arch", "egr_conv_force_config", "egr_preprocess_u8_f32", "egr_pose_metrics_f32", "egr_gt_heatmap_f32", "egr_conv_debug_stamps", "egr_conv2d_wgrad_f32", "egr_conv2d_masked_f32", "egr_up2_relu_head_f32",
     "egr_msda_fwd_f32", "egr_msda_bwd_f32", "egr_w6_elems", "egr_pack_w6_f32", "egr_pack_w6_many_f32", "egr_joint_layer_f32",
     "egr_preprocess_fused_u8_f32", "egr_preprocess_band_rows", "egr_conv_set_persist", "egr_stem_conv7x7_pool_f32",
-    "egr_stem_w6_bytes", "egr_pack_stem_w6_f32", "egr_stem_conv7x7_x6_f32", "egr_wgrad_last_kernel", "egr_conv_last_kernel", "egr_conv_set_tap", "egr_fisheye_project2_f32",
+    "egr_stem_w6_bytes", "egr_pack_stem_w6_f32", "egr_stem_conv7x7_x6_f32", "egr_wgrad_last_kernel", "egr_conv_last_kernel", "egr_conv_set_tap", "egr_fisheye_project2_f32", "egr_pack_layer_w_f32",
 ]
 
 
@@ -57,7 +57,7 @@ class LayerDesc(C.Structure):
                                            "w_fold", "c_fold", "w_out", "b_out", "w_fuse", "b_fuse", "ln1_g", "ln1_b",
                                            "w_qkv", "b_qkv", "w_mo", "b_mo", "ln2_g", "ln2_b", "w_f0", "b_f0", "w_f1", "b_f1", "ln3_g", "ln3_b",
                                            "x_out", "w_ol", "b_ol", "ol_out")] +
-                [("ol_n", C.c_int32), ("reserved", C.c_int32)] +
+                [("ol_n", C.c_int32), ("w_packed", C.c_int32)] +
                 [(n, C.c_void_p) for n in ("lnp_g", "lnp_b", "xn_out", "w_r0", "b_r0", "w_r2", "b_r2", "anchors3d", "pred_out")])
 
 
@@ -106,6 +106,7 @@ def _load() -> C.CDLL:
     lib.egr_msda_fwd_f32.argtypes = [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp, vp]
     lib.egr_msda_bwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.egr_joint_layer_f32.argtypes = [C.POINTER(LayerDesc), vp]
+    lib.egr_pack_layer_w_f32.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.egr_preprocess_fused_u8_f32.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]
     lib.egr_preprocess_band_rows.argtypes = [vp, i32]
     lib.egr_preprocess_u8_f32.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
@@ -700,6 +701,17 @@ def tokens_to_nhwc(x: torch.Tensor, b: int, j: int, hw: int) -> torch.Tensor:
     return y
 
 
+def pack_layer_w(w: torch.Tensor) -> torch.Tensor:
+    """(..., rows, k) fp32 weight stack -> the same shape in egr_joint_layer_f32's fragment order (egr_pack_layer_w_f32)."""
+    rows, k = w.shape[-2], w.shape[-1]
+    if w.dtype != torch.float32 or rows % 16 or k % 128:
+        raise RuntimeError("egorear_amd.pack_layer_w: fp32, rows % 16 == 0, k % 128 == 0 expected")
+    w = _cont(w, "layer weight")
+    out = torch.empty_like(w)
+    _launch("egr_pack_layer_w_f32", lib.egr_pack_layer_w_f32, _p(w), w.numel() // (rows * k), rows, k, _p(out), _stream())
+    return out
+
+
 def joint_layer(x: torch.Tensor, g: torch.Tensor, e: Optional[torch.Tensor], sigma: torch.Tensor, rowmask: torch.Tensor, W: dict,
                 B: int, J: int, V: int, Cdim: int, groups: int, *, ol: Optional[dict] = None, post: Optional[dict] = None,
                 reg: Optional[dict] = None, want_xn: bool = False):
@@ -728,6 +740,7 @@ def joint_layer(x: torch.Tensor, g: torch.Tensor, e: Optional[torch.Tensor], sig
         if t.numel() != n or not t.is_contiguous():
             raise RuntimeError(f"egorear_amd.joint_layer: weight {k} has {t.numel()} elements, expected {n}")
         setattr(d, k, _p(t))
+    d.w_packed = 1 if W.get("packed") else 0     # the matrices of W, ol and reg are then all in fragment order (pack_layer_w)
     x_out = torch.empty_like(x)
     d.x_out = _p(x_out)
     ol_out = xn = pred = None

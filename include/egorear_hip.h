@@ -269,7 +269,9 @@ typedef struct egr_layer_desc {
     /* tail: next layer's offsets / logits (NULL = off): ol_out (groups*b*joints, ol_n), ol_n % 16 == 0 */
     const float *w_ol, *b_ol;
     float* ol_out;
-    int32_t ol_n, reserved;
+    int32_t ol_n;
+    int32_t w_packed;   /* != 0: every weight MATRIX (w_fold, w_out, w_fuse, w_qkv, w_mo, w_f0, w_f1, w_ol, w_r0; not w_r2, not the vectors) is in
+                         * the fragment order of egr_pack_layer_w_f32 - 1-KiB contiguous wave loads, what the shipped path passes */
     /* tail: post_norm (lnp_g NULL = off) -> xn_out (or NULL); with it the regression head: w_r0 (groups, c, c), w_r2 (groups, 3, c),
      * pred_out (groups*b*joints, 3) = reg(xn) + anchors3d */
     const float *lnp_g, *lnp_b;
@@ -278,6 +280,10 @@ typedef struct egr_layer_desc {
     float* pred_out;
 } egr_layer_desc;
 int egr_joint_layer_f32(const egr_layer_desc* d, void* stream);
+/* `matrices` row-major (rows, k) fp32 matrices (rows % 16 == 0, k % 128 == 0) -> the fragment order egr_joint_layer_f32 reads with
+ * w_packed: [matrix][16-row block][128-deep chunk][16-deep k block u][lane = 16 q + i][4 floats] = w[16 block + i][128 chunk + 16 u + 4 q ..+3].
+ * Same number of elements; out must not alias w. */
+int egr_pack_layer_w_f32(const float* w, int32_t matrices, int32_t rows, int32_t k, float* out, void* stream);
 
 /* utils/camera_models.py:53-104 + egoposeformer_mvf_ex.py:340-348,400-406: project the (b, joints, 3) proposals
  * into the four fisheye cameras.  cams: 4 records [npoly, cx, cy, W, H, poly[12]] (fp32).  syn mode

@@ -282,6 +282,40 @@ def test_argmax_known_answers(hip):
     assert a[0].tolist() == [20 / 64, 10 / 64] and a[3].tolist() == [63 / 64, 63 / 64]
 
 
+def test_pack_layer_w_layout_and_packed_weights_give_identical_results(hip):
+    """egr_pack_layer_w_f32: [16-row block][128-deep chunk][16-deep block u][lane = 16 q + i][4] = w[16 block + i][128 chunk + 16 u + 4 q ..];
+    egr_joint_layer_f32 with plain and with packed weight matrices: the same bits (only the address pattern of the loads differs)."""
+    w = rnd(3, 48, 256, seed=91).to(DEV)
+    pk = hip.pack_layer_w(w)
+    ref = w.view(3, 3, 16, 2, 8, 4, 4).permute(0, 1, 3, 4, 5, 2, 6).contiguous().view(3, 48, 256)     # (m, nb, i, kc, u, q, t) -> (m, nb, kc, u, q, i, t)
+    assert torch.equal(pk, ref)
+    with pytest.raises(RuntimeError):
+        hip.pack_layer_w(rnd(40, 128, seed=1).to(DEV))            # rows not a multiple of 16
+    # one layer launch, C = 128, two query sets, every tail on
+    G, B, J, V, C = 2, 3, 16, 4, 128
+    r = lambda *s_, seed, scale=0.1: (rnd(*s_, seed=seed) * scale).to(DEV)      # noqa: E731
+    W = {"w_fold": r(G, C, 128, seed=1), "c_fold": r(G, C, seed=2), "w_out": r(G, C, C, seed=3), "b_out": r(G, C, seed=4),
+         "w_fuse": r(G, C, V * C, seed=5), "b_fuse": r(G, C, seed=6), "ln1_g": r(G, C, seed=7) + 1, "ln1_b": r(G, C, seed=8),
+         "w_qkv": r(G, 3 * C, C, seed=9), "b_qkv": r(G, 3 * C, seed=10), "w_mo": r(G, C, C, seed=11), "b_mo": r(G, C, seed=12),
+         "ln2_g": r(G, C, seed=13) + 1, "ln2_b": r(G, C, seed=14), "w_f0": r(G, 512, C, seed=15), "b_f0": r(G, 512, seed=16),
+         "w_f1": r(G, C, 512, seed=17), "b_f1": r(G, C, seed=18), "ln3_g": r(G, C, seed=19) + 1, "ln3_b": r(G, C, seed=20)}
+    ol = {"w": r(G, 192, C, seed=21), "b": r(G, 192, seed=22)}
+    post = {"g": r(G, C, seed=23) + 1, "b": r(G, C, seed=24)}
+    reg = {"w0": r(G, C, C, seed=25), "b0": r(G, C, seed=26), "w2": r(G, 3, C, seed=27), "b2": r(G, 3, seed=28), "anchors": r(G * B * J, 3, seed=29, scale=10.0)}
+    x = r(G * B * J, C, seed=30, scale=1.0)
+    g = r(G * B * J * V, 4, 128, seed=31, scale=1.0)
+    sigma = (rnd(G, 4, B * J * V, seed=32).abs() * 0.5).to(DEV)
+    rowmask = (torch.arange(B * J * V) % 7 != 0).to(torch.uint8).to(DEV)
+    plain = hip.joint_layer(x, g, None, sigma, rowmask, W, B, J, V, C, G, ol=ol, post=post, reg=reg, want_xn=True)
+    mats = ("w_fold", "w_out", "w_fuse", "w_qkv", "w_mo", "w_f0", "w_f1")
+    Wp = {k: (hip.pack_layer_w(v) if k in mats else v) for k, v in W.items()}
+    Wp["packed"] = True
+    packed = hip.joint_layer(x, g, None, sigma, rowmask, Wp, B, J, V, C, G, ol={"w": hip.pack_layer_w(ol["w"]), "b": ol["b"]}, post=post,
+                             reg=dict(reg, w0=hip.pack_layer_w(reg["w0"])), want_xn=True)
+    for a, b in zip(plain, packed):
+        assert a is not None and torch.equal(a, b)
+
+
 def test_layernorm_and_mha_match_torch(hip):
     for c in (128, 256):
         x, r = rnd(45, c, seed=51), rnd(45, c, seed=52)
