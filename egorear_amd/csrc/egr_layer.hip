@@ -149,7 +149,8 @@ struct LayerLds {
     static constexpr int M1 = 64 * LC, M2 = 16 * LQ, M3 = 16 * LF;
     static constexpr int BUFO = (M1 > M2 ? (M1 > M3 ? M1 : M3) : (M2 > M3 ? M2 : M3));
     static constexpr int BUFG = (HPP * 32 * LG > T ? HPP * 32 * LG : T);
-    static constexpr size_t BYTES = sizeof(float) * (size_t)(BUFA + BUFO + BUFG);
+    static constexpr int SIDE = 64 * HEADS + 64;              // sigma of the 64 sampled rows per head, their row mask
+    static constexpr size_t BYTES = sizeof(float) * (size_t)(BUFA + BUFO + BUFG + SIDE);
 };
 
 template <int C>
@@ -164,6 +165,8 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
     float* const bufG = bufO + L::BUFO;
     float* const tile0 = bufA;
     float* const tile1 = bufA + T;
+    float* const s_sig = bufG + L::BUFG;               // [HEADS][64]
+    float* const s_keep = s_sig + 64 * HEADS;          // [64]: 1 = valid sampled row
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, q4 = lane >> 4;
@@ -205,6 +208,12 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
     const float* const b_f1 = d.b_f1 + grp * C;
 
     const bool wpk = d.w_packed != 0;
+    // per-row side inputs of the sampled-row phase, once (they were global loads inside the GEMM epilogues)
+    if (tid < 64 * HEADS) {
+        const int h = tid >> 6, rl = tid & 63;
+        s_sig[tid] = rl < nrow ? sg[(int64_t)h * rows_all + row0 + rl] : 0.f;
+    }
+    if (tid < 64) s_keep[tid] = (tid < nrow && d.rowmask[row0 + tid] != 0) ? 1.f : 0.f;
     // plain "Linear on a 16-row tile": out[16][ldo] = act(A . W^T + bias)
     auto linear16 = [&](const float* A, int lda, const float* W, int K, const float* bias, int N, float* out, int ldo, bool gelu) {
         gemm_cols<1, 1>(A, lda, 0, W, K, 0, K, wave, NW, N / 16, lane, wpk, [&](int nb, const f32x4_t (&acc)[1]) {
@@ -222,12 +231,23 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
     for (int hf = 0; hf < 2; ++hf) {
         for (int ps = 0; ps < C / PW; ++ps) {          // PW output columns per pass: one 16-column block per wave
             // stage the sampled features of the heads behind these columns: bufG[hp][32][LG]
-            for (int idx = tid; idx < HPP * 32 * (CF / 4); idx += NTH) {
+            // (all of a thread's loads first, then the LDS writes: a load -> store loop waits for every load in turn)
+            constexpr int NST = HPP * 32 * (CF / 4) / NTH;
+            static_assert(HPP * 32 * (CF / 4) % NTH == 0, "staging units per thread");
+            f32x4_t stg[NST];
+#pragma unroll
+            for (int it = 0; it < NST; ++it) {
+                const int idx = tid + it * NTH;
                 const int cq = idx % (CF / 4), r = (idx / (CF / 4)) % 32, hp = idx / (32 * (CF / 4));
                 const int rl = hf * 32 + r, h = ps * HPP + hp;
-                f32x4_t v = {0.f, 0.f, 0.f, 0.f};
-                if (rl < nrow) v = *reinterpret_cast<const f32x4_t*>(gq + ((int64_t)(row0 + rl) * HEADS + h) * CF + cq * 4);
-                *reinterpret_cast<f32x4_t*>(bufG + (hp * 32 + r) * LG + cq * 4) = v;
+                stg[it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                if (rl < nrow) stg[it] = *reinterpret_cast<const f32x4_t*>(gq + ((int64_t)(row0 + rl) * HEADS + h) * CF + cq * 4);
+            }
+#pragma unroll
+            for (int it = 0; it < NST; ++it) {
+                const int idx = tid + it * NTH;
+                const int cq = idx % (CF / 4), r = (idx / (CF / 4)) % 32, hp = idx / (32 * (CF / 4));
+                *reinterpret_cast<f32x4_t*>(bufG + (hp * 32 + r) * LG + cq * 4) = stg[it];
             }
             __syncthreads();
             if (wave * 16 < PW) {
@@ -243,7 +263,7 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
                             const int rl32 = rb * 16 + 4 * q4 + r, rl = hf * 32 + rl32;
                             float v = 0.f;
                             if (rl < nrow) {
-                                v = acc[rb][r] + cf_ * sg[(int64_t)h * rows_all + row0 + rl];
+                                v = acc[rb][r] + cf_ * s_sig[h * 64 + rl];
                                 if (eq) v += eq[(int64_t)(row0 + rl) * C + col];
                             }
                             bufA[rl32 * LC + col] = v;
@@ -261,7 +281,7 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int rl = hf * 32 + rb * 16 + 4 * q4 + r;
-                    const bool keep = rl < nrow && d.rowmask[row0 + rl] != 0;
+                    const bool keep = s_keep[rl] != 0.f;
                     bufO[rl * LC + col] = keep ? acc[rb][r] + bo : 0.f;
                 }
         });
@@ -276,9 +296,20 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
     });
     // ---- + residual (the layer input, from global memory) -> norm_cross
     // residual rows of tokens >= J do not exist: point them at token 0 (their results are never stored)
-    for (int idx = tid; idx < 16 * C; idx += NTH) {
-        const int r = idx / C, ch = idx - r * C;
-        bufG[r * LC + ch] = d.x[(xrow0 + (r < J ? r : 0)) * C + ch];
+    {
+        constexpr int NX4 = 16 * C / 4 / NTH;       // float4 per thread (1 or 2)
+        static_assert(16 * C / 4 % NTH == 0, "residual tile");
+        f32x4_t xr[NX4];
+#pragma unroll
+        for (int it = 0; it < NX4; ++it) {
+            const int idx = tid + it * NTH, r = idx / (C / 4), c4 = idx - r * (C / 4);
+            xr[it] = *reinterpret_cast<const f32x4_t*>(d.x + (xrow0 + (r < J ? r : 0)) * C + c4 * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < NX4; ++it) {
+            const int idx = tid + it * NTH, r = idx / (C / 4), c4 = idx - r * (C / 4);
+            *reinterpret_cast<f32x4_t*>(bufG + r * LC + c4 * 4) = xr[it];
+        }
     }
     __syncthreads();
     ln_rows<VPL, NW>(tile0, LC, bufG, LC, d.ln1_g + grp * C, d.ln1_b + grp * C, d.eps, tile1, LC, wave, lane);
