@@ -15,7 +15,7 @@ constexpr int NPTS = 16;  // n_points of MSDeformAttn (heatmap_mvf_ex.py:772, eg
 // The value projection is linear, so sampling first and projecting the 960 sampled rows per frame
 // afterwards (egr_conv2d on g, with the per-row in-bounds mass sigma scaling the bias) gives the same
 // result as projecting all 4096 tokens per view and then sampling — at ~1/70 of the FLOPs.
-template <int CPL>  // feature channels per lane = cf / 64
+template <int CPL, bool POS>  // feature channels per lane = cf / 64; POS: the positional table is read as well
 __global__ __launch_bounds__(256) void msda_gather_kernel(const float* feat, const float* pos, int dh,
                                                           const float* offs_logits, const float* anchors,
                                                           const uint8_t* valid, int B, int V, int J, int heads, int hgt,
@@ -86,26 +86,44 @@ __global__ __launch_bounds__(256) void msda_gather_kernel(const float* feat, con
             for (int c = 0; c < 4; ++c) cw[c] *= aw;
             // ---- gather: (point, corner) list broadcast from the owning lane
             const float* pbase = pos ? pos + (int64_t)v * hw * (heads * dh) + h * dh : nullptr;
-            for (int q = 0; q < NPTS; ++q) {
+            auto corner = [&](float wgt, int idx) {
+                const float* fr = fbase + (int64_t)idx * cf + lane * CPL;
+                if constexpr (CPL == 2) {
+                    f32x2 t = *reinterpret_cast<const f32x2*>(fr);
+                    accf[0] = fmaf(wgt, t[0], accf[0]);
+                    accf[1] = fmaf(wgt, t[1], accf[1]);
+                } else if constexpr (CPL == 4) {
+                    f32x4 t = *reinterpret_cast<const f32x4*>(fr);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float wgt = __shfl(cw[c], q, 64);
-                    int idx = __shfl(ci[c], q, 64);
-                    if (wgt == 0.f) continue;  // wave-uniform (broadcast value)
-                    const float* fr = fbase + (int64_t)idx * cf + lane * CPL;
-                    if constexpr (CPL == 2) {
-                        f32x2 t = *reinterpret_cast<const f32x2*>(fr);
-                        accf[0] = fmaf(wgt, t[0], accf[0]);
-                        accf[1] = fmaf(wgt, t[1], accf[1]);
-                    } else if constexpr (CPL == 4) {
-                        f32x4 t = *reinterpret_cast<const f32x4*>(fr);
+                    for (int i = 0; i < 4; ++i) accf[i] = fmaf(wgt, t[i], accf[i]);
+                } else {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) accf[i] = fmaf(wgt, t[i], accf[i]);
-                    } else {
+                    for (int i = 0; i < CPL; ++i) accf[i] = fmaf(wgt, fr[i], accf[i]);
+                }
+            };
+            if constexpr (POS) {
+                // (with the positional table: zero-weight corners are skipped - the branch-free form below measured slower here,
+                // 173 -> 231 us for the refiners' launch at batch 64)
+                for (int q = 0; q < NPTS; ++q) {
 #pragma unroll
-                        for (int i = 0; i < CPL; ++i) accf[i] = fmaf(wgt, fr[i], accf[i]);
+                    for (int c = 0; c < 4; ++c) {
+                        float wgt = __shfl(cw[c], q, 64);
+                        int idx = __shfl(ci[c], q, 64);
+                        if (wgt == 0.f) continue;  // wave-uniform (broadcast value)
+                        corner(wgt, idx);
+                        if (lane < dh) acce = fmaf(wgt, pbase[(int64_t)idx * (heads * dh) + lane], acce);
                     }
-                    if (pbase && lane < dh) acce = fmaf(wgt, pbase[(int64_t)idx * (heads * dh) + lane], acce);
+                }
+            } else {
+                // corners with zero weight (outside the map) read pixel 0 instead of being skipped: without a branch in the loop
+                // the compiler keeps several of the 64 row reads in flight (with it every read waited for the one before - a chain
+                // of 64 L2 latencies per head: the lifting head's launches 77 -> 52 us at batch 64, 30 -> 10 us at batch 1)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) ci[c] = (cw[c] == 0.f) ? 0 : ci[c];
+#pragma unroll 4
+                for (int q = 0; q < NPTS; ++q) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) corner(__shfl(cw[c], q, 64), __shfl(ci[c], q, 64));
                 }
             }
         }
@@ -240,17 +258,20 @@ extern "C" int egr_msda_gather_f32(const float* feat, int32_t cf, const float* p
     if (rows >= (1LL << 31)) return EGR_EINVAL;
     dim3 grid((unsigned)rows, (unsigned)groups), block(64 * (heads < 4 ? heads : 4));
     hipStream_t s = (hipStream_t)stream;
-    if (cf == 128)
-        hipLaunchKernelGGL(msda_gather_kernel<2>, grid, block, 0, s, feat, pos, dh, offs_logits, anchors, valid, b, views,
-                           joints, heads, hgt, wid, g, e, sigma, rowmask);
-    else if (cf == 64)
-        hipLaunchKernelGGL(msda_gather_kernel<1>, grid, block, 0, s, feat, pos, dh, offs_logits, anchors, valid, b, views,
-                           joints, heads, hgt, wid, g, e, sigma, rowmask);
-    else if (cf == 256)
-        hipLaunchKernelGGL(msda_gather_kernel<4>, grid, block, 0, s, feat, pos, dh, offs_logits, anchors, valid, b, views,
-                           joints, heads, hgt, wid, g, e, sigma, rowmask);
-    else
-        return EGR_EINVAL;
+#define EGR_GATHER(CPL_)                                                                                                            \
+    do {                                                                                                                            \
+        if (pos)                                                                                                                    \
+            hipLaunchKernelGGL((msda_gather_kernel<CPL_, true>), grid, block, 0, s, feat, pos, dh, offs_logits, anchors, valid, b, views, \
+                               joints, heads, hgt, wid, g, e, sigma, rowmask);                                                      \
+        else                                                                                                                        \
+            hipLaunchKernelGGL((msda_gather_kernel<CPL_, false>), grid, block, 0, s, feat, pos, dh, offs_logits, anchors, valid, b, views, \
+                               joints, heads, hgt, wid, g, e, sigma, rowmask);                                                      \
+    } while (0)
+    if (cf == 128) EGR_GATHER(2);
+    else if (cf == 64) EGR_GATHER(1);
+    else if (cf == 256) EGR_GATHER(4);
+    else return EGR_EINVAL;
+#undef EGR_GATHER
     return egr_launch_status();
 }
 
