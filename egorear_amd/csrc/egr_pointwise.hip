@@ -88,7 +88,16 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const float* x, float* y, 
     if (idx >= (int64_t)n * c) return;
     int img = (int)(idx / c), ch = (int)(idx % c);
     float s = 0.f;
-    for (int p = 0; p < hw; ++p) s += x[((int64_t)img * hw + p) * c + ch];
+    const float* xp = x + (int64_t)img * hw * c + ch;
+    int p = 0;
+    for (; p + 8 <= hw; p += 8) {        // eight loads in flight, summed in pixel order (the same chain as the plain loop)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = xp[(int64_t)(p + u) * c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; p < hw; ++p) s += xp[(int64_t)p * c];
     y[idx] = s / (float)hw;
 }
 
