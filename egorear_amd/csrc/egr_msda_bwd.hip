@@ -105,16 +105,28 @@ __global__ __launch_bounds__(256) void msda_gather_bwd_kernel(const float* feat,
         for (int q = 0; q < NPTS; ++q) {
             float s_aw = 0.f, s_w = 0.f, s_h = 0.f;   // per-lane partial dot products
             const float awq = __shfl(aw, q, 64);
+            // the four corners' rows are requested together (a skipped corner reads row 0), then consumed: with the loads behind the
+            // `continue` every corner waited for its own row
+            int cidx[4];
+            float frv[4][CPL], pv[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int idx = __shfl(ci[c], q, 64);
+                cidx[c] = __shfl(ci[c], q, 64);
+                const int ic = cidx[c] < 0 ? 0 : cidx[c];
+                const float* fr = feat + (fimg + ic) * cf + lane * CPL;
+#pragma unroll
+                for (int i = 0; i < CPL; ++i) frv[c][i] = fr[i];
+                pv[c] = pbase ? pbase[(int64_t)ic * C + (lane < dh ? lane : 0)] : 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int idx = cidx[c];
                 if (idx < 0) continue;  // wave-uniform
                 const float b_c = __shfl(bw[c], q, 64), gw_c = __shfl(gw[c], q, 64), gh_c = __shfl(gh[c], q, 64);
-                const float* fr = feat + (fimg + idx) * cf + lane * CPL;
                 float part = 0.f;
 #pragma unroll
-                for (int i = 0; i < CPL; ++i) part = fmaf(dgl[i], fr[i], part);
-                if (pbase && lane < dh) part = fmaf(dal, pbase[(int64_t)idx * C + lane], part);
+                for (int i = 0; i < CPL; ++i) part = fmaf(dgl[i], frv[c][i], part);
+                if (pbase && lane < dh) part = fmaf(dal, pv[c], part);
                 if (lane == 0) part += dsig;  // the bias term of an in-bounds corner
                 s_aw = fmaf(b_c, part, s_aw);
                 s_w = fmaf(gw_c, part, s_w);
