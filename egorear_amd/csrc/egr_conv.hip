@@ -463,6 +463,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
                     if constexpr (RES == EGR_RES_AFTER_ACT) t += rr[e];
                     v[e] = t;
                 }
+#ifdef X6_EXP_NOSTORE
+                if (v[0] == 12345.678f)
+#endif
                 *reinterpret_cast<f32x4*>(yg + (int64_t)yo + co) = v;
             }
         };
