@@ -615,7 +615,7 @@ def backbone_train(S: Step, encs, img: torch.Tensor, view0: int, nviews: int):
         tbl.run()
         S.cache.packs[key] = wp
     # (split-bf16 launch like the other convolutions; the bank is re-split from the refreshed fp32 pack every step: one tiny launch)
-    x = hip.stem_x6(img, view0, nviews, hip.pack_stem_w6(wp), None, None, groups=G).t if engine.STEM_X6 else \
+    x = hip.stem_x6(img, view0, nviews, hip.pack_stem_w6(wp), None, None, groups=G).t if (engine.STEM_X6 and H % 32 == 0 and W % 64 == 0) else \
         hip.stem(img, view0, nviews, wp, None, None, groups=G).t
     wnames = [S.name(w) for w in w7]
 
