@@ -1331,7 +1331,7 @@ static int conv_run(const egr_conv_desc* dd, const float* x, const float* w, con
     // ---- 3x3 / stride 1 / pad 1 split launches whose tiles are whole image rows: the tap-sharing kernel
     if (g_tap && g_force_cfg == CFG_AUTO && d.w_format == EGR_W_BF16X3 && d.kh == 3 && d.kw == 3 && d.stride == 1 && d.pad == 1 &&
         !a.cls_mode && d.split_k <= 1 && (d.wo == 8 || d.wo == 16 || d.wo == 32 || d.wo == 64) && d.ho == d.h && d.wo == d.w &&
-        a.Npad % 64 == 0 && a.M >= 128 * 64) {
+        a.Npad % 64 == 0 && a.M >= 2048) {
         // 256 x 64 tiles for 64 / 192 output channels (as many MFMAs per tap as 128 x 128), 128 x 128 when that fills the chip, else 128 x 64
         const int P = d.ho * d.wo;
         auto fits_tile = [&](int bm) {
