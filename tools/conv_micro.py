@@ -24,6 +24,7 @@ SHAPES = [
     (128, 64, 64, 64, 128, 1, 1, 0, "1x1 64->128 @64 (lateral0)"),
     (128, 64, 64, 128, 128, 1, 1, 3, "fuse 1x1 128->128 @64 (+up2 res)"),
     (128, 32, 32, 128, 128, 1, 1, 3, "fuse 1x1 128->128 @32 (+up2 res)"),
+    (256, 32, 32, 64, 128, 1, 1, 2, "1x1 64->128 @32 (+res after act, head .3)"),
     (256, 64, 64, 128, 64, 1, 1, 0, "1x1 128->64 @64 (conv_frame_feat.0)"),
     (64, 64, 64, 128, 15, 1, 1, 0, "1x1 128->15 @64"),
     (3840, 1, 1, 128, 64, 1, 1, 0, "head value proj M3840"),
