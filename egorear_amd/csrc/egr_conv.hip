@@ -142,7 +142,7 @@ __device__ __forceinline__ void* uniform_ptr(const void* p) {
     return (void*)(((uint64_t)hi << 32) | lo);
 }
 
-template <int BM, int BN, int WM, int WN, bool X6, bool PERSIST = false, bool TAP = false>
+template <int BM, int BN, int WM, int WN, bool X6, bool PERSIST = false, bool TAP = false, bool TAP2 = false>
 __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     static_assert(WM * WN == 4, "four waves per workgroup");
     constexpr int NT = 256;
@@ -524,7 +524,208 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     stamp(5);  // stores issued
     };
 
-    if constexpr (TAP) {
+    if constexpr (TAP2) {
+        // ---- split-bf16, 3x3 / STRIDE 2 / pad 1, taps shared by input-pixel parity class (forward).  Output pixel (y, x), tap (kh, kw)
+        // reads input (2y + kh - 1, 2x + kw - 1): kh = 1 -> even rows (index y), kh = 0 / 2 -> odd rows (index y - 1 / y); the same for
+        // columns.  So the nine taps fall into four classes by the parities of the input pixel they read - (even, even): 1 tap,
+        // (even, odd): 2, (odd, even): 2, (odd, odd): 4 - and inside a class they are unit shifts of ONE plane of (rows + 1) x (wo + 1)
+        // input pixels.  Per 16-channel chunk four such planes are fetched, split and staged (one barrier each) instead of nine
+        // 128 x 16 blocks with nine barriers: activation work and barriers / 2.25.  Loads run two classes ahead (the single-tap
+        // class is too short to cover a memory latency), the conversion one class ahead, weights one tap ahead straight into the
+        // B operand, A fragments refilled plane by plane - as in the stride-1 branch below.
+        static_assert(X6 && !PERSIST && BM == 128, "stride-2 tap-sharing tile");
+        constexpr int HPM = 192;                                 // pixels per class plane: (128 / wo + 1) x (wo + 1) for wo in {8, 16, 32}: <= 165
+        constexpr int T2_PLANE = HPM * 32, T2_HBUF = 3 * T2_PLANE;
+        static_assert(2 * T2_HBUF <= P::ROWOFF * 4, "class planes fit under the staged tile");
+        constexpr int NFB = BN / 32;
+        constexpr int NUH = (HPM * 4 + NT - 1) / NT;             // staging units (4 channels of one pixel) per thread and class
+        uint8_t* const lb = reinterpret_cast<uint8_t*>(lds);
+        const int wo = d.wo, WP = wo + 1;
+        const int NI = HoWo >= BM ? 1 : BM / HoWo, RTI = HoWo >= BM ? BM / wo : d.ho;
+        const int HPI = (RTI + 1) * WP, HP = NI * HPI, PPI = RTI * wo;
+        const int m0 = tm * BM;
+        int n0, pix0;
+        if (a.howo_shift >= 0) { n0 = m0 >> a.howo_shift; pix0 = m0 & (HoWo - 1); }
+        else { n0 = fdiv(m0, a.dHoWo); pix0 = m0 - n0 * HoWo; }
+        const int y0 = (a.wo_shift >= 0) ? (pix0 >> a.wo_shift) : fdiv(pix0, a.dWo);
+        const int xbase = a.x_plain ? n0 * (int)d.xmap.stride_inner : (int)fmap(d.xmap, a.dXin, n0);
+        const int abias = (d.w + 1) * d.ldx * 4;
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+            uniform_ptr(reinterpret_cast<const char*>(xg) - abias), 0, 0x80000000u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+            uniform_ptr(reinterpret_cast<const uint8_t*>(a.w) + (int64_t)grp * d.gw * 2), 0, 0x80000000u, 0x00020000);
+        const int so_tile = __builtin_amdgcn_readfirstlane((xbase + 2 * y0 * d.w * d.ldx) * 4);
+        // class q = 2 * (odd row) + (odd column); plane pixel (pr, pc) = input (2 (y0 + pr) - odd row, 2 pc - odd column)
+        int hvo[4][NUH];
+#pragma unroll
+        for (int i = 0; i < NUH; ++i) {
+            const int u = tid + NT * i, hp = u >> 2, seg = u & 3;
+            const int il = hp / HPI, hq = hp - il * HPI;
+            const int pr = hq / WP, pc = hq - pr * WP;
+            const int ioff = (il == 0) ? 0 : ((a.x_plain ? (n0 + il) * (int)d.xmap.stride_inner : (int)fmap(d.xmap, a.dXin, n0 + il)) - xbase);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int dy = 2 * pr - (q >> 1), ix = 2 * pc - (q & 1);
+                const bool ok = hp < HP && (unsigned)(2 * y0 + dy) < (unsigned)d.h && (unsigned)ix < (unsigned)d.w;
+                hvo[q][i] = ok ? (ioff + (dy * d.w + ix) * d.ldx) * 4 + seg * 16 + abias : (int)0x80000000;
+            }
+        }
+        int abase[FM], bvo[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int ml = wm * TM + i * 32 + l31, il = ml / PPI, mq = ml - il * PPI, r = mq / wo, c = mq - r * wo;
+            abase[i] = (il * HPI + r * WP + c) * 32 + half * 16;
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bvo[j] = ((tn * NFB + wn * FN + j) * a.ktiles * 6) * 1024 + lane * 16;
+        const int NC = a.cblocks * 2;            // 16-channel chunks
+        // the nine taps in class order: weight tap index, class, row / column shift inside the class plane
+        constexpr int TID[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};
+        constexpr int TCL[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
+        constexpr int TDR[9] = {0, 0, 0, 0, 1, 0, 0, 1, 1};
+        constexpr int TDC[9] = {0, 0, 1, 0, 0, 0, 1, 0, 1};
+        u32x4 xr[2][NUH];
+        auto load_class = [&](int ck, auto q_tag) {    // plane of class q of chunk ck -> register set q & 1
+            constexpr int Q = decltype(q_tag)::value;
+            const int so = so_tile + ck * 64;
+#pragma unroll
+            for (int i = 0; i < NUH; ++i) xr[Q & 1][i] = __builtin_amdgcn_raw_buffer_load_b128(ra, hvo[Q][i], so, 0);
+        };
+        unsigned ch_[NUH][2], cm_[NUH][2], cl_[NUH][2];
+        auto cslice = [&](auto set_tag, int base, int k) {
+            constexpr int SET = decltype(set_tag)::value;
+            const int u = k / 3, q = k % 3;
+            if (q < 2) {
+                const float v0 = __uint_as_float(xr[SET][u][2 * q]), v1 = __uint_as_float(xr[SET][u][2 * q + 1]);
+                ch_[u][q] = cvt_pk_bf16(v0, v1);
+                const float r0 = v0 - bf16_lo_f32(ch_[u][q]), r1 = v1 - bf16_hi_f32(ch_[u][q]);
+                cm_[u][q] = cvt_pk_bf16(r0, r1);
+                cl_[u][q] = cvt_pk_bf16(r0 - bf16_lo_f32(cm_[u][q]), r1 - bf16_hi_f32(cm_[u][q]));
+            } else if (tid + NT * u < 4 * HP) {
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                uint8_t* dst = lb + base + (tid + NT * u) * 8;
+                *reinterpret_cast<u32x2*>(dst) = u32x2{ch_[u][0], ch_[u][1]};
+                *reinterpret_cast<u32x2*>(dst + T2_PLANE) = u32x2{cm_[u][0], cm_[u][1]};
+                *reinterpret_cast<u32x2*>(dst + 2 * T2_PLANE) = u32x2{cl_[u][0], cl_[u][1]};
+            }
+        };
+        constexpr int NSL = 3 * NUH;
+        bf16x8 af[FM][3], bf[2][FN][3];
+        auto read_a = [&](int base, int t9, int pl) {       // fragment plane pl of the t9-th tap (class order)
+            const int to = (TDR[t9] * WP + TDC[t9]) * 32;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) af[i][pl] = *reinterpret_cast<const bf16x8*>(lb + base + pl * T2_PLANE + abase[i] + to);
+        };
+        auto load_b = [&](int ck, int t9, int par) {
+            const int so = (((ck >> 1) * 9 + TID[t9]) * 6 + (ck & 1) * 3) * 1024;
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    bf[par][j][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rb, bvo[j] + pl * 1024, so, 0));
+        };
+        using Q0 = std::integral_constant<int, 0>;
+        using Q1 = std::integral_constant<int, 1>;
+        using Q2 = std::integral_constant<int, 2>;
+        using Q3 = std::integral_constant<int, 3>;
+        // one chunk = four classes.  Class q multiplies out of buffer q & 1 while class q + 1's plane (register set (q + 1) & 1, loaded
+        // during class q - 1) is converted into buffer (q + 1) & 1 and class q + 2's plane is requested into set q & 1.
+        // PAR: B register set of the chunk's first tap; LAST: no chunk follows.
+        // one tap (compile-time position T9 in class order) of class Q
+        auto tap_step = [&](auto par_tag, auto last_tag, auto q_tag, auto t9_tag, int ck, int& n, int& done) {
+            constexpr int PAR = decltype(par_tag)::value, Q = decltype(q_tag)::value, T9 = decltype(t9_tag)::value;
+            constexpr bool LAST = decltype(last_tag)::value;
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+            constexpr int NMT = 6 * FM * FN;
+            constexpr int FIRST[4] = {0, 1, 3, 5}, COUNT[4] = {1, 2, 2, 4};
+            constexpr bool conv = !(LAST && Q == 3);              // a next class exists
+            constexpr int cur = (Q & 1) * T2_HBUF, nxt = T2_HBUF - cur;
+            constexpr int nm = COUNT[Q] * NMT;
+            constexpr int pc = (PAR + T9) & 1, pn = pc ^ 1;
+            constexpr bool more_in_class = T9 + 1 < FIRST[Q] + COUNT[Q];
+            if constexpr (T9 + 1 < 9) load_b(ck, T9 + 1, pn);
+            else if constexpr (!LAST) load_b(ck + 1, 0, pn);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j, ++n) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[pc][j][PB[t]], acc[i][j], 0, 0, 0);
+                        if constexpr (conv) {
+                            const int upto = ((n + 1) * NSL + nm - 1) / nm;
+                            if (done < upto) {
+                                cslice(std::integral_constant<int, (Q + 1) & 1>{}, nxt, done);
+                                ++done;
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                if constexpr (more_in_class) {                    // next tap of the same class: same buffer
+                    if (t == 0 || t == 3 || t == 5) {
+                        read_a(cur, T9 + 1, t == 0 ? 2 : (t == 3 ? 1 : 0));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        };
+        // one class of a chunk: request the plane of the class after next, multiply this class's taps (converting the next class's
+        // plane behind them), hand over
+        auto cls = [&](auto par_tag, auto last_tag, auto q_tag, int ck) {
+            constexpr int Q = decltype(q_tag)::value;
+            constexpr bool LAST = decltype(last_tag)::value;
+            constexpr int FIRST[4] = {0, 1, 3, 5};
+            constexpr bool conv = !(LAST && Q == 3);
+            constexpr int nxt = T2_HBUF - (Q & 1) * T2_HBUF;
+            if constexpr (Q == 0) load_class(ck, Q2{});
+            if constexpr (Q == 1) load_class(ck, Q3{});
+            if constexpr (Q == 2 && !LAST) load_class(ck + 1, Q0{});
+            if constexpr (Q == 3 && !LAST) load_class(ck + 1, Q1{});
+            int n = 0, done = 0;
+            using I = std::integral_constant<int, FIRST[Q]>;
+            tap_step(par_tag, last_tag, q_tag, I{}, ck, n, done);
+            if constexpr (Q >= 1) tap_step(par_tag, last_tag, q_tag, std::integral_constant<int, FIRST[Q] + 1>{}, ck, n, done);
+            if constexpr (Q == 3) {
+                tap_step(par_tag, last_tag, q_tag, std::integral_constant<int, FIRST[Q] + 2>{}, ck, n, done);
+                tap_step(par_tag, last_tag, q_tag, std::integral_constant<int, FIRST[Q] + 3>{}, ck, n, done);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if constexpr (conv) {
+                constexpr int t9n = (Q == 3) ? 0 : FIRST[(Q + 1) & 3];
+                read_a(nxt, t9n, 2); read_a(nxt, t9n, 0); read_a(nxt, t9n, 1);
+            }
+        };
+        // PAR: B register set of the chunk's first tap (nine taps flip it, so chunks come in pairs); LAST: no chunk follows
+        auto chunk = [&](auto par_tag, int ck, auto last_tag) {
+            cls(par_tag, last_tag, Q0{}, ck);
+            cls(par_tag, last_tag, Q1{}, ck);
+            cls(par_tag, last_tag, Q2{}, ck);
+            cls(par_tag, last_tag, Q3{}, ck);
+        };
+        using T0 = std::integral_constant<int, 0>;
+        using T1 = std::integral_constant<int, 1>;
+        using TT = std::true_type;
+        using FF = std::false_type;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // row table visible
+        stamp(1);
+        load_class(0, Q0{});
+        load_class(0, Q1{});
+        load_b(0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) cslice(Q0{}, 0, k);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        read_a(0, 0, 2); read_a(0, 0, 0); read_a(0, 0, 1);
+        stamp(2);
+        int ck = 0;
+        for (; ck + 2 < NC; ck += 2) {           // NC is even; nine taps flip the B register parity, so chunks come in pairs
+            chunk(T0{}, ck, FF{});
+            chunk(T1{}, ck + 1, FF{});
+        }
+        chunk(T0{}, ck, FF{});
+        chunk(T1{}, ck + 1, TT{});
+        epilogue(tm, tn, s_yoff, s_roff, [] {});
+    } else if constexpr (TAP) {
         // ---- split-bf16, 3x3 / stride 1 / pad 1, taps SHARED (forward and data gradient).  In the generic split loop below every (tap, 16-channel)
         // stage fetches and splits its own BM x 16 activation block: each input value is loaded and split nine times, and every
         // stage ends in a barrier.  Here the tile is BM consecutive output pixels = BM / wo whole rows of one image (or whole small
@@ -1106,6 +1307,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_tap_kernel(const ConvArgs a
     conv_igemm_body<BM, BN, WM, WN, true, false, true>(a);
 }
 
+// 3x3 / stride 2 / pad 1 with the taps shared by parity class (see the TAP2 branch of conv_igemm_body)
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_tap2_kernel(const ConvArgs a) {
+    conv_igemm_body<BM, BN, WM, WN, true, false, false, true>(a);
+}
+
 // persistent variant (short K: a tile is mostly fixed cost and HBM traffic - the next tile's decode and first loads overlap the
 // stores; measured 106 -> 121 TFLOP/s on 1x1 128 -> 128 at 64x64 pixels, -1.5 % on the long-K layers, which keep the plain launch)
 template <int BM, int BN, int WM, int WN>
@@ -1196,7 +1403,8 @@ const int kBM[CFG_COUNT] = {128, 256, 64, 128, 128};
 const int kBN[CFG_COUNT] = {128, 64, 64, 32, 64};
 int g_force_cfg = CFG_AUTO;
 int g_tap = getenv("EGR_CONV_TAP") ? atoi(getenv("EGR_CONV_TAP")) : 1;   // 0: the generic split kernel everywhere (egr_conv_set_tap)
-int g_last_conv_kernel = 0;   // diagnostic (tests): 0 fp32 MFMA, 1 split-bf16 generic, 2 split-bf16 tap-sharing
+int g_tap2 = getenv("EGR_CONV_TAP2") ? atoi(getenv("EGR_CONV_TAP2")) : 1; // 0: stride-2 3x3 launches stay on the generic split kernel
+int g_last_conv_kernel = 0;   // diagnostic (tests): 0 fp32 MFMA, 1 split-bf16 generic, 2 / 3 split-bf16 tap-sharing (stride 1 / 2)
 unsigned long long* g_dbg = nullptr;
 
 }  // namespace
@@ -1355,6 +1563,27 @@ static int conv_run(const egr_conv_desc* dd, const float* x, const float* w, con
             else if (bn == 128) hipLaunchKernelGGL((conv_igemm_tap_kernel<128, 128, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream, a);
             else hipLaunchKernelGGL((conv_igemm_tap_kernel<128, 64, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream, a);
             g_last_conv_kernel = 2;
+            return egr_launch_status();
+        }
+    }
+    // ---- 3x3 / stride 2 / pad 1 split launches on even images: taps shared by parity class
+    if (g_tap && g_tap2 && g_force_cfg == CFG_AUTO && d.w_format == EGR_W_BF16X3 && d.kh == 3 && d.kw == 3 && d.stride == 2 && d.pad == 1 &&
+        !d.transposed && !a.cls_mode && d.split_k <= 1 && !mask && (d.wo == 8 || d.wo == 16 || d.wo == 32) &&
+        d.h == 2 * d.ho && d.w == 2 * d.wo && a.Npad % 64 == 0 && a.M >= 2048 && a.M % 128 == 0) {
+        const int P = d.ho * d.wo;
+        const int hp = P >= 128 ? (128 / d.wo + 1) * (d.wo + 1) : (128 / P) * (d.ho + 1) * (d.wo + 1);
+        if (((P % 128 == 0) || (128 % P == 0)) && hp <= 192) {
+            const int bn = (a.Npad % 128 == 0 && (int64_t)(a.M / 128) * (a.Npad / 128) * d.groups >= 256) ? 128 : 64;
+            d.split_k = 1;
+            a.ktiles_per_split = a.ktiles;
+            a.tilesM = a.M / 128;
+            a.tilesN = a.Npad / bn;
+            a.dTilesN = make_fastdiv(a.tilesN);
+            a.ntiles = a.tilesM * a.tilesN;
+            dim3 grid((unsigned)a.ntiles, 1, (unsigned)d.groups);
+            if (bn == 128) hipLaunchKernelGGL((conv_igemm_tap2_kernel<128, 128, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL((conv_igemm_tap2_kernel<128, 64, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream, a);
+            g_last_conv_kernel = 3;
             return egr_launch_status();
         }
     }

@@ -379,6 +379,63 @@ def test_tap_sharing_randomised_geometry():
         hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = saved
 
 
+TAP2_CASES = [
+    # n, h(=w, input), cin, cout, groups, extras
+    (8, 64, 64, 128, 1, "scale_relu"),         # layer2 entry: 64 -> 32 pixels, four output rows per tile
+    (16, 32, 128, 256, 2, "scale_relu"),       # layer3 entry, grouped: 16 x 16 outputs, a tile is half an image
+    (64, 16, 256, 512, 1, "plain"),            # layer4 entry: 8 x 8 outputs, a tile is two whole images; enough tiles for 128 x 128
+    (32, 32, 32, 192, 1, "res_after"),         # two chunks only, Npad = 192 -> 64-wide tiles, residual behind the ReLU
+    (9 * 2, 32, 96, 60, 1, "plain"),           # cout not a multiple of 32 (Npad 64), three 32-channel blocks
+    (128, 64, 64, 128, 1, "plain"),            # many tiles: the 128 x 128 configuration on 32-pixel output rows
+]
+
+
+@pytest.mark.parametrize("case", TAP2_CASES)
+def test_tap_sharing_stride2_kernel(case):
+    """conv_igemm_tap2_kernel (3x3 / stride 2 / pad 1 on even images: the input rows of a tile are staged once per 16-channel chunk
+    as four parity-class planes, the nine taps read them as shifted LDS windows) against fp64 and the generic split kernel."""
+    from egorear_amd import hip
+    n, hw, cin, cout, G, extra = case
+    ho = hw // 2
+    x = rnd(G * n, hw, hw, cin, seed=170)
+    wts = [rnd(cout, cin, 3, 3, seed=171 + g, scale=1.0 / math.sqrt(9 * cin)) for g in range(G)]
+    wp = torch.stack([pack_w(t) for t in wts]) if G > 1 else pack_w(wts[0])
+    npad = wp.shape[-2]
+    kw = dict(groups=G)
+    res = sc = sh = None
+    if extra == "res_after":
+        res = rnd(G * n, ho, ho, cout, seed=175)
+        kw.update(res=hip.Img(res.to(DEV)), res_mode=hip.RES_AFTER_ACT, act=hip.ACT_RELU)
+    if extra == "scale_relu":
+        sc, sh = rnd(G, npad, seed=176) * 0.2 + 1.0, rnd(G, npad, seed=177)
+        if G == 1:
+            sc, sh = sc[0], sh[0]
+        kw.update(scale=sc.to(DEV), shift=sh.to(DEV), act=hip.ACT_RELU)
+    saved = hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS
+    hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = 0, 0.0
+    try:
+        outs = {}
+        for tap in (1, 0):
+            hip.lib.egr_conv_set_tap(tap)
+            outs[tap] = hip.conv2d(hip.Img(x.to(DEV)), hip.pack_w6(wp.to(DEV)), cout, 3, 3, 2, 1, **kw).t.permute(0, 3, 1, 2).clone()
+            assert hip.lib.egr_conv_last_kernel() == (3 if tap else 1)
+    finally:
+        hip.lib.egr_conv_set_tap(1)
+        hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = saved
+    refs = []
+    for g in range(G):
+        r = F.conv2d(x[g * n:(g + 1) * n].permute(0, 3, 1, 2).double(), wts[g].double(), None, 2, 1)
+        if extra == "scale_relu":
+            s_, b_ = (sc[g], sh[g]) if G > 1 else (sc, sh)
+            r = F.relu(r * s_[:cout].double().view(1, -1, 1, 1) + b_[:cout].double().view(1, -1, 1, 1))
+        if extra == "res_after":
+            r = F.relu(r) + res[g * n:(g + 1) * n].permute(0, 3, 1, 2).double()
+        refs.append(r)
+    ref = torch.cat(refs)
+    judge(outs[0], outs[1], ref, f"tap2 {case}")
+    assert float((outs[0] - outs[1]).abs().max()) <= 4e-6 * float(ref.abs().max())
+
+
 WGRAD_CASES = [
     # n, h, w, cin, cout, k, stride, groups
     (8, 32, 32, 64, 64, 3, 1, 1),        # 64-wide output tile (BCO = 64), 8192 pixels

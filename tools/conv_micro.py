@@ -17,6 +17,9 @@ SHAPES = [
     (128, 16, 16, 256, 256, 3, 1, 1, "layer3 3x3 256->256 (+res)"),
     (128, 8, 8, 512, 512, 3, 1, 1, "layer4 3x3 512->512 (+res)"),
     (64, 64, 64, 256, 512, 3, 2, 0, "refiner 3x3 s2 256->512"),
+    (128, 64, 64, 64, 128, 3, 2, 0, "layer2.0 3x3 s2 64->128"),
+    (128, 32, 32, 128, 256, 3, 2, 0, "layer3.0 3x3 s2 128->256"),
+    (128, 16, 16, 256, 512, 3, 2, 0, "layer4.0 3x3 s2 256->512"),
     (128, 64, 64, 128, 128, 3, 1, 0, "fpn 3x3 128->128 @64"),
     (128, 64, 64, 256, 128, 1, 1, 0, "1x1 256->128 @64 (fuse / heatmap .7)"),
     (64, 64, 64, 128, 256, 1, 1, 0, "1x1 128->256 @64 (refiner proj .0)"),
