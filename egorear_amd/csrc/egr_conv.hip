@@ -1313,6 +1313,258 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_tap2_kernel(const ConvArgs 
     conv_igemm_body<BM, BN, WM, WN, true, false, false, true>(a);
 }
 
+// ---- 1x1 / stride 1 split-bf16 launches with short K (cin = 64 / 128) over many pixels: the STREAMING kernel.
+// These layers are HBM-bound (K = N = 128: 1 KiB of traffic per pixel against 0.4 us of bf16 MFMA time per 1000 pixels), and
+// in the tiled kernels above they spend their time in per-tile fixed costs: 8 staging barriers, a row-table decode and an LDS
+// round trip of the accumulators for every 64 KiB of input.  Here nothing is tiled across waves:
+//   * the WEIGHTS are stationary: a workgroup (8 waves, one per CU: 96 KiB of LDS) copies the split image of its 64 / 128 output
+//     channels into LDS once and keeps it for the whole launch;
+//   * the operand roles are swapped - A = weights (rows = output channels), B = activations (columns = pixels): lane
+//     (p = lane & 31, h = lane >> 5) of a wave owns pixel p of the wave's 32-pixel tile.  Its B operand of a 16-deep k step is 2 x 16
+//     bytes of the pixel's own NHWC row, so the activations go global memory -> registers -> (split) -> MFMA with no LDS and no
+//     barrier, and the accumulator layout (4 consecutive channels of the lane's pixel per register quad) is stored with 16-byte
+//     stores straight from the registers;
+//   * a wave walks pixel tiles wave_id, + waves, ... on its own; the next tile's 2 * KS loads are issued register by register as the
+//     current tile's k steps release them, a full tile (KS * NCF * 6 MFMAs) ahead of their use.
+// k order inside a step: lane half h holds k = {4h .. 4h+3} u {8+4h .. 8+4h+3}, so one load instruction covers 32 contiguous bytes
+// per pixel; the weight image (pack_w6 order: k = 8h + j) is permuted to match while it is copied into LDS.
+// RESK: 0 no residual, 1 residual of the output's shape (before / behind the activation: run time), 2 half-resolution residual
+// up-sampled on the fly (EGR_RES_UP2_BEFORE_ACT); the ReLU is a run-time clamp bound.
+template <int KS, int NCF, int RESK>
+__global__ __launch_bounds__(512) void conv_pw_x6_kernel(const ConvArgs a) {
+    constexpr int WBYTES = NCF * KS * 3072;
+    constexpr int PATCH = 32 * 144;        // per-wave epilogue patch: 32 pixels x 32 channels, rows padded to 144 bytes
+    __shared__ __attribute__((aligned(16))) uint8_t lds[WBYTES + NCF * 32 * 8 + 8 * PATCH];
+    float* const s_sc = reinterpret_cast<float*>(lds + WBYTES);
+    float* const s_sh = s_sc + NCF * 32;
+    const egr_conv_desc& d = a.d;
+    const int grp = blockIdx.z, tn = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 31, h = lane >> 5;
+    const float* const scg = a.scale ? a.scale + grp * d.gp : nullptr;
+    const float* const shg = a.shift ? a.shift + grp * d.gp : nullptr;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(a.x + grp * d.gx), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(a.y + grp * d.gy), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(a.res ? a.res + grp * d.gr : a.x), 0, 0x80000000u, 0x00020000);
+    const bool masked = a.mask != nullptr;       // data gradient behind a ReLU: dx = (acc [+ res]) * [mask > 0], mask laid out like y
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(masked ? a.mask + grp * d.gy : a.x), 0, 0x80000000u, 0x00020000);
+    const int HoWo = d.ho * d.wo;
+    constexpr int OOB = (int)0x80000000;
+    const int T = (a.M + 31) >> 5, NW = gridDim.x * 8;
+    int t = blockIdx.x * 8 + wave;
+
+    // byte offset of the lane's pixel in x (OOB past the last pixel: the loads return zeros)
+    auto x_off = [&](int tile) {
+        const int m = tile * 32 + p;
+        int n, pix;
+        if (a.howo_shift >= 0) { n = m >> a.howo_shift; pix = m & (HoWo - 1); }
+        else { n = fdiv(m, a.dHoWo); pix = m - n * HoWo; }
+        const int xb = a.x_plain ? n * (int)d.xmap.stride_inner : (int)fmap(d.xmap, a.dXin, n);
+        return (tile < T && m < a.M) ? (xb + pix * d.ldx) * 4 + h * 16 : OOB;
+    };
+    // weights -> LDS: 16-byte loads of the image (lane (p, q) of a fragment = k 8q .. 8q+7), each written as two 8-byte pieces:
+    // its half hh goes to the new lane (p, hh), position q  (new lane (p, h): k {4h .. 4h+3} u {8+4h .. 8+4h+3})
+    u32x4 raw[2 * KS];
+    {
+        const uint8_t* const wimg = reinterpret_cast<const uint8_t*>(a.w) + (int64_t)grp * d.gw * 2;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        constexpr int NV = WBYTES / 16 / 512;
+        static_assert(NV * 512 * 16 == WBYTES, "whole staging rounds");
+        u32x4 wv[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + 512 * i;
+            const int cf = v / (KS * 192), rem = v - cf * (KS * 192);
+            wv[i] = *reinterpret_cast<const u32x4*>(wimg + ((int64_t)(tn * NCF + cf) * a.ktiles * 6) * 1024 + rem * 16);
+        }
+        const int xo = x_off(t);
+#pragma unroll
+        for (int i = 0; i < 2 * KS; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo + i * 32, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + 512 * i;
+            const int lo = v & 63, blk = v >> 6;            // (fragment, k step, plane) block of 1 KiB; its lane
+            uint8_t* const dst = lds + blk * 1024 + (lo & 31) * 16 + (lo >> 5) * 8;
+            *reinterpret_cast<u32x2*>(dst) = u32x2{wv[i][0], wv[i][1]};
+            *reinterpret_cast<u32x2*>(dst + 512) = u32x2{wv[i][2], wv[i][3]};
+        }
+        for (int c = tid; c < NCF * 32; c += 512) {
+            const int co = tn * NCF * 32 + c;
+            s_sc[c] = (scg && co < d.cout) ? scg[co] : 1.f;
+            s_sh[c] = (shg && co < d.cout) ? shg[co] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    const float floor_ = (d.act == EGR_ACT_RELU) ? 0.f : -__builtin_inff();
+    const bool res_before = d.res_mode == EGR_RES_BEFORE_ACT;
+    {
+        for (; t < T; t += NW) {
+#ifdef PW_EXP_NOLOAD
+            const int xo_n = OOB;
+#else
+            const int xo_n = x_off(t + NW);
+#endif
+            f32x16 acc[NCF];
+#pragma unroll
+            for (int cf = 0; cf < NCF; ++cf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[cf][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                // split the lane's 8 values of this k step (hi + mid + lo, exact)
+                unsigned xh[4], xm[4], xl[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const u32x4& src = raw[2 * ks + (e >> 1)];
+                    const float v0 = __uint_as_float(src[2 * (e & 1)]), v1 = __uint_as_float(src[2 * (e & 1) + 1]);
+                    xh[e] = cvt_pk_bf16(v0, v1);
+                    const float r0 = v0 - bf16_lo_f32(xh[e]), r1 = v1 - bf16_hi_f32(xh[e]);
+                    xm[e] = cvt_pk_bf16(r0, r1);
+                    xl[e] = cvt_pk_bf16(r0 - bf16_lo_f32(xm[e]), r1 - bf16_hi_f32(xm[e]));
+                }
+                bf16x8 xb[3];
+                xb[0] = __builtin_bit_cast(bf16x8, u32x4{xh[0], xh[1], xh[2], xh[3]});
+                xb[1] = __builtin_bit_cast(bf16x8, u32x4{xm[0], xm[1], xm[2], xm[3]});
+                xb[2] = __builtin_bit_cast(bf16x8, u32x4{xl[0], xl[1], xl[2], xl[3]});
+                // the registers of a k-step pair (one 128-byte line of the pixel's row) are free: request the same pair of the wave's
+                // next tile - four loads back to back, so the line is fetched once
+#ifndef PW_EXP_LOAD2
+                if (ks & 1) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        raw[2 * ks - 2 + i] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo_n + (ks - 1) * 64 + i * 32, 0, 0);
+                }
+#else
+                raw[2 * ks] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo_n + ks * 64, 0, 0);
+                raw[2 * ks + 1] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo_n + ks * 64 + 32, 0, 0);
+#endif
+                bf16x8 wf[NCF][3];
+#pragma unroll
+                for (int cf = 0; cf < NCF; ++cf)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        wf[cf][pl] = *reinterpret_cast<const bf16x8*>(lds + ((cf * KS + ks) * 3 + pl) * 1024 + lane * 16);
+                constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};   // smallest products first
+#pragma unroll
+                for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+                    for (int cf = 0; cf < NCF; ++cf)
+#ifdef PW_EXP_NOMFMA
+                        if (t6 == 0)
+#endif
+                        acc[cf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cf][PW[t6]], xb[PX[t6]], acc[cf], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- epilogue.  Register quad g of fragment cf = channels cf*32 + 8g + 4h .. +3 of pixel p: stored as it is, an instruction
+            // would write 32-byte pieces of 32 rows (measured: 4.2 TB/s write-only against 5.8 TB/s for the reads).  So each fragment goes
+            // through a wave-private 32 x 32 LDS patch (rows padded to 144 bytes; no barrier - one wave's LDS operations execute in
+            // order) and comes back row-major: lane = (row i*8 + lane/8, channel quad lane%8), an instruction writes 8 whole 128-byte lines.
+            const int m = t * 32 + p;
+            int n, pix;
+            if (a.howo_shift >= 0) { n = m >> a.howo_shift; pix = m & (HoWo - 1); }
+            else { n = fdiv(m, a.dHoWo); pix = m - n * HoWo; }
+            const bool live = m < a.M;
+            const int yo_p = live ? ((a.y_plain ? n * (int)d.ymap.stride_inner : (int)fmap(d.ymap, a.dYin, n)) + pix * d.ldy + tn * NCF * 32) * 4 : OOB;
+            int ro_p = OOB, ox_p = 0, oy_p = 0;
+            float lx1_p = 0.f, ly1_p = 0.f;
+            if constexpr (RESK == 1) {
+                if (live) ro_p = ((a.r_plain ? n * (int)d.rmap.stride_inner : (int)fmap(d.rmap, a.dRin, n)) + pix * d.ldr + tn * NCF * 32) * 4;
+            }
+            if constexpr (RESK == 2) {
+                // bilinear x2 (align_corners = True, ATen arithmetic as in upsample2x_kernel) of a half-resolution tensor
+                const int ho = (a.wo_shift >= 0) ? (pix >> a.wo_shift) : fdiv(pix, a.dWo), wo = pix - ho * d.wo;
+                const int hl = d.ho >> 1, wl = d.wo >> 1;
+                const float shh = (d.ho > 1) ? (float)(hl - 1) / (float)(d.ho - 1) : 0.f;
+                const float sww = (d.wo > 1) ? (float)(wl - 1) / (float)(d.wo - 1) : 0.f;
+                const float fy = shh * (float)ho, fx = sww * (float)wo;
+                const int y0 = (int)fy, x0 = (int)fx;
+                // (fused multiply-subtract, as the compiler contracts the same expressions of the tiled kernels' row decode)
+                ly1_p = fminf(fmaxf(__builtin_fmaf(shh, (float)ho, -(float)y0), 0.f), 1.f);
+                lx1_p = fminf(fmaxf(__builtin_fmaf(sww, (float)wo, -(float)x0), 0.f), 1.f);
+                if (live) ro_p = ((a.r_plain ? n * (int)d.rmap.stride_inner : (int)fmap(d.rmap, a.dRin, n)) + (y0 * wl + x0) * d.ldr + tn * NCF * 32) * 4;
+                ox_p = (x0 + 1 > wl - 1) ? 0 : d.ldr * 4;
+                oy_p = (y0 + 1 > hl - 1) ? 0 : wl * d.ldr * 4;
+            }
+            // the four rows this lane stores: their parameters come from the lanes that own those pixels
+            const int qd = lane & 7, rsub = lane >> 3;
+            int yo[4], ro[4], ox[4], oy[4];
+            float lx1[4], ly1[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int src = i * 8 + rsub;
+                yo[i] = __shfl(yo_p, src) + qd * 16;
+                if constexpr (RESK != 0) ro[i] = __shfl(ro_p, src) + qd * 16;
+                if constexpr (RESK == 2) {
+                    ox[i] = __shfl(ox_p, src); oy[i] = __shfl(oy_p, src);
+                    lx1[i] = __shfl(lx1_p, src); ly1[i] = __shfl(ly1_p, src);
+                }
+            }
+            uint8_t* const patch = lds + WBYTES + NCF * 32 * 8 + wave * PATCH;
+#pragma unroll
+            for (int cf = 0; cf < NCF; ++cf) {
+                f32x4 r00[4], r01[4], r10[4], r11[4], mk[4];
+                if constexpr (RESK != 2) {
+                    if (masked) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            mk[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, yo[i] + cf * 128, 0, 0));
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) mk[i] = f32x4{1.f, 1.f, 1.f, 1.f};
+                    }
+                }
+                if constexpr (RESK != 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        r00[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ro[i] + cf * 128, 0, 0));
+                        if constexpr (RESK == 2) {
+                            r01[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ro[i] + ox[i] + cf * 128, 0, 0));
+                            r10[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ro[i] + oy[i] + cf * 128, 0, 0));
+                            r11[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ro[i] + oy[i] + ox[i] + cf * 128, 0, 0));
+                        }
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(patch + p * 144 + g * 32 + h * 16) =
+                        f32x4{acc[cf][4 * g], acc[cf][4 * g + 1], acc[cf][4 * g + 2], acc[cf][4 * g + 3]};
+                __builtin_amdgcn_wave_barrier();
+                const int c = cf * 32 + 4 * qd;
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(s_sc + c), sh = *reinterpret_cast<const f32x4*>(s_sh + c);
+                const bool cok = tn * NCF * 32 + c < d.cout;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(patch + (i * 8 + rsub) * 144 + qd * 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float tt = v[e] * sc[e] + sh[e];
+                        if constexpr (RESK == 1) tt += res_before ? r00[i][e] : 0.f;
+                        if constexpr (RESK == 2) {
+                            const float lx0 = 1.f - lx1[i], ly0 = 1.f - ly1[i];
+                            tt += ly0 * (lx0 * r00[i][e] + lx1[i] * r01[i][e]) + ly1[i] * (lx0 * r10[i][e] + lx1[i] * r11[i][e]);
+                        }
+                        tt = tt > floor_ ? tt : floor_;
+                        if constexpr (RESK == 1) tt += res_before ? 0.f : r00[i][e];
+                        if constexpr (RESK != 2) tt = mk[i][e] > 0.f ? tt : 0.f;
+                        v[e] = tt;
+                    }
+#ifdef PW_EXP_NOSTORE
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, (v[0] == 12345.678f) ? yo[i] + cf * 128 : OOB, 0, 0);
+#else
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, cok ? yo[i] + cf * 128 : OOB, 0, 0);
+#endif
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
 // persistent variant (short K: a tile is mostly fixed cost and HBM traffic - the next tile's decode and first loads overlap the
 // stores; measured 106 -> 121 TFLOP/s on 1x1 128 -> 128 at 64x64 pixels, -1.5 % on the long-K layers, which keep the plain launch)
 template <int BM, int BN, int WM, int WN>
@@ -1404,7 +1656,10 @@ const int kBN[CFG_COUNT] = {128, 64, 64, 32, 64};
 int g_force_cfg = CFG_AUTO;
 int g_tap = getenv("EGR_CONV_TAP") ? atoi(getenv("EGR_CONV_TAP")) : 1;   // 0: the generic split kernel everywhere (egr_conv_set_tap)
 int g_tap2 = getenv("EGR_CONV_TAP2") ? atoi(getenv("EGR_CONV_TAP2")) : 1; // 0: stride-2 3x3 launches stay on the generic split kernel
-int g_last_conv_kernel = 0;   // diagnostic (tests): 0 fp32 MFMA, 1 split-bf16 generic, 2 / 3 split-bf16 tap-sharing (stride 1 / 2)
+int g_last_conv_kernel = 0;   // diagnostic (tests): 0 fp32 MFMA, 1 split-bf16 generic, 2 / 3 split-bf16 tap-sharing (stride 1 / 2), 4 1x1 streaming
+int g_pw = getenv("EGR_CONV_PW") ? atoi(getenv("EGR_CONV_PW")) : 1;     // 0: short-K 1x1 split launches stay on the tiled kernels
+int g_pw_min_rows = getenv("EGR_CONV_PW_MIN_ROWS") ? atoi(getenv("EGR_CONV_PW_MIN_ROWS")) : 65536;   // rows x groups from which the streaming kernel is used
+int g_pw_blocks = getenv("EGR_CONV_PW_BLOCKS") ? atoi(getenv("EGR_CONV_PW_BLOCKS")) : 256;          // resident workgroups (one per CU)
 unsigned long long* g_dbg = nullptr;
 
 }  // namespace
@@ -1586,6 +1841,36 @@ static int conv_run(const egr_conv_desc* dd, const float* x, const float* w, con
             g_last_conv_kernel = 3;
             return egr_launch_status();
         }
+    }
+    // ---- 1x1 / stride 1 split launches with cin = 64 / 128 over many pixels: weights stationary in LDS, activations streamed
+    if (g_tap && g_pw && g_force_cfg == CFG_AUTO && d.w_format == EGR_W_BF16X3 && d.kh == 1 && d.kw == 1 && d.stride == 1 && d.pad == 0 &&
+        !a.cls_mode && d.split_k <= 1 && !d.out_nchw && !rowscale && !rowmask && a.vec_ok && d.cout % 4 == 0 &&
+        d.act != EGR_ACT_GELU && (d.cin == 64 || d.cin == 128) && a.Npad % 64 == 0 && d.h == d.ho && d.w == d.wo &&
+        (int64_t)a.M * d.groups >= g_pw_min_rows && (span(d.ymap, d.n) + ypix) * 4 < (1LL << 31) &&
+        (!d.res_mode || (span(d.rmap, d.n) + (int64_t)d.ho * d.wo * d.ldr) * 4 < (1LL << 31))) {
+        const int ncf = (a.Npad % 128 == 0) ? 4 : 2;
+        const int tiles_n = a.Npad / (ncf * 32);
+        int nblk = g_pw_blocks / (tiles_n * d.groups);
+        if (nblk < 1) nblk = 1;
+        const int t32 = (a.M + 31) / 32;
+        if (nblk * 8 > t32) nblk = (t32 + 7) / 8;
+        dim3 grid((unsigned)nblk, (unsigned)tiles_n, (unsigned)d.groups);
+        const int resk = d.res_mode == EGR_RES_NONE ? 0 : (d.res_mode == EGR_RES_UP2_BEFORE_ACT ? 2 : 1);
+        auto launch = [&](auto ks_tag, auto ncf_tag) {
+            constexpr int KS = decltype(ks_tag)::value, NCF = decltype(ncf_tag)::value;
+            if (resk == 0) hipLaunchKernelGGL((conv_pw_x6_kernel<KS, NCF, 0>), grid, dim3(512), 0, (hipStream_t)stream, a);
+            else if (resk == 1) hipLaunchKernelGGL((conv_pw_x6_kernel<KS, NCF, 1>), grid, dim3(512), 0, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL((conv_pw_x6_kernel<KS, NCF, 2>), grid, dim3(512), 0, (hipStream_t)stream, a);
+        };
+        using C2 = std::integral_constant<int, 2>;
+        using C4 = std::integral_constant<int, 4>;
+        using C8 = std::integral_constant<int, 8>;
+        if (d.cin == 128 && ncf == 4) launch(C8{}, C4{});
+        else if (d.cin == 128) launch(C8{}, C2{});
+        else if (ncf == 4) launch(C4{}, C4{});
+        else launch(C4{}, C2{});
+        g_last_conv_kernel = 4;
+        return egr_launch_status();
     }
     g_last_conv_kernel = d.w_format == EGR_W_BF16X3 ? 1 : 0;
 

@@ -436,6 +436,107 @@ def test_tap_sharing_stride2_kernel(case):
     assert float((outs[0] - outs[1]).abs().max()) <= 4e-6 * float(ref.abs().max())
 
 
+PW_CASES = [
+    # n, h, w, cin, cout, groups, extras
+    (16, 64, 64, 128, 128, 1, "scale_relu"),       # K = N = 128: the FPN / head 1x1 layers
+    (8, 64, 64, 128, 256, 2, "plain"),             # two channel tiles per group (weights of one tile per workgroup), grouped
+    (16, 64, 64, 64, 128, 1, "res_after"),         # cin = 64 (four k steps), residual behind the ReLU
+    (32, 32, 64, 128, 64, 1, "res_before"),        # 64 output channels (two fragments), non-square image
+    (19, 60, 60, 128, 60, 1, "scale_relu"),        # image size not a power of two, ragged last tile, cout not a multiple of 32
+    (16, 64, 64, 128, 128, 1, "up2"),              # FPN top-down: half-resolution residual up-sampled in the epilogue
+    (8, 64, 64, 64, 64, 2, "up2"),                 # the same, grouped, 64 channels
+    (5, 128, 128, 64, 192, 1, "plain"),            # Npad = 192 -> 64-channel tiles, three of them
+]
+
+
+@pytest.mark.parametrize("case", PW_CASES)
+def test_streaming_1x1_kernel(case):
+    """conv_pw_x6_kernel (1x1 / stride 1, cin 64 / 128, many pixels: weights stationary in LDS, a lane owns a pixel, activations
+    go global -> registers -> MFMA, stores from the accumulator registers) against fp64 and the tiled split kernel."""
+    from egorear_amd import hip
+    n, h, w, cin, cout, G, extra = case
+    x = rnd(G * n, h, w, cin, seed=270)
+    wts = [rnd(cout, cin, 1, 1, seed=271 + g, scale=1.0 / math.sqrt(cin)) for g in range(G)]
+    wp = torch.stack([pack_w(t) for t in wts]) if G > 1 else pack_w(wts[0])
+    npad = wp.shape[-2]
+    kw = dict(groups=G)
+    res = sc = sh = None
+    if extra in ("res_before", "res_after"):
+        res = rnd(G * n, h, w, cout, seed=275)
+        kw.update(res=hip.Img(res.to(DEV)), res_mode=hip.RES_BEFORE_ACT if extra == "res_before" else hip.RES_AFTER_ACT, act=hip.ACT_RELU)
+    if extra == "up2":
+        res = rnd(G * n, h // 2, w // 2, cout, seed=275)
+        kw.update(res=hip.Img(res.to(DEV)), res_mode=hip.RES_UP2_BEFORE_ACT, act=hip.ACT_RELU)
+    if extra == "scale_relu":
+        sc, sh = rnd(G, npad, seed=276) * 0.2 + 1.0, rnd(G, npad, seed=277)
+        if G == 1:
+            sc, sh = sc[0], sh[0]
+        kw.update(scale=sc.to(DEV), shift=sh.to(DEV), act=hip.ACT_RELU)
+    saved = hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS
+    hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = 0, 0.0
+    try:
+        outs = {}
+        for tap in (1, 0):
+            hip.lib.egr_conv_set_tap(tap)
+            outs[tap] = hip.conv2d(hip.Img(x.to(DEV)), hip.pack_w6(wp.to(DEV)), cout, 1, 1, 1, 0, **kw).t.permute(0, 3, 1, 2).clone()
+            assert hip.lib.egr_conv_last_kernel() == (4 if tap else 1)
+    finally:
+        hip.lib.egr_conv_set_tap(1)
+        hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = saved
+    refs = []
+    for g in range(G):
+        r = F.conv2d(x[g * n:(g + 1) * n].permute(0, 3, 1, 2).double(), wts[g].double(), None, 1, 0)
+        rg = res[g * n:(g + 1) * n].permute(0, 3, 1, 2).double() if res is not None else None
+        if extra == "scale_relu":
+            s_, b_ = (sc[g], sh[g]) if G > 1 else (sc, sh)
+            r = F.relu(r * s_[:cout].double().view(1, -1, 1, 1) + b_[:cout].double().view(1, -1, 1, 1))
+        if extra == "res_before":
+            r = F.relu(r + rg)
+        if extra == "res_after":
+            r = F.relu(r) + rg
+        if extra == "up2":
+            r = F.relu(r + F.interpolate(rg, scale_factor=2, mode="bilinear", align_corners=True))
+        refs.append(r)
+    ref = torch.cat(refs)
+    judge(outs[0], outs[1], ref, f"streaming 1x1 {case}")
+    assert float((outs[0] - outs[1]).abs().max()) <= 4e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("case", [(1, 16, 64, 128, 128, True), (2, 8, 64, 64, 128, True), (1, 16, 64, 128, 64, False)])
+def test_streaming_1x1_data_gradient(case):
+    """The streaming kernel as the data gradient of a 1x1 convolution (the same launch with the transposed matrix), plain and with the
+    fused ReLU mask + accumulated gradient of the training step."""
+    from egorear_amd import hip
+    G, n, hw, cin, cout, masked = case          # forward conv cin -> cout; the gradient maps dy (cout) to dx (cin)
+    dy = rnd(G * n, hw, hw, cout, seed=281)
+    xs, prev = rnd(G * n, hw, hw, cin, seed=282), rnd(G * n, hw, hw, cin, seed=283)
+    wts = [rnd(cout, cin, 1, 1, seed=284 + g, scale=1.0 / math.sqrt(cin)) for g in range(G)]
+    wt = (torch.stack([pack_w_dgrad(w) for w in wts]) if G > 1 else pack_w_dgrad(wts[0])).to(DEV)
+    kw = dict(transposed_out_hw=(hw, hw), groups=G)
+    if masked:
+        kw.update(res=hip.Img(prev.to(DEV)), res_mode=hip.RES_BEFORE_ACT, mask=hip.Img(xs.to(DEV)))
+    saved = hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS
+    hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = 0, 0.0
+    try:
+        outs = {}
+        for tap in (1, 0):
+            hip.lib.egr_conv_set_tap(tap)
+            outs[tap] = hip.conv2d(hip.Img(dy.to(DEV)), hip.pack_w6(wt), cin, 1, 1, 1, 0, **kw).t.clone()
+            assert hip.lib.egr_conv_last_kernel() == (4 if tap else 1)
+    finally:
+        hip.lib.egr_conv_set_tap(1)
+        hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = saved
+    refs = []
+    for g in range(G):
+        r = torch.einsum("nhwo,oi->nhwi", dy[g * n:(g + 1) * n].double(), wts[g][:, :, 0, 0].double())
+        if masked:
+            r = (r + prev[g * n:(g + 1) * n].double()) * (xs[g * n:(g + 1) * n] > 0)
+        refs.append(r)
+    ref = torch.cat(refs)
+    judge(outs[0], outs[1], ref, f"streaming 1x1 dgrad {case}")
+    assert float((outs[0] - outs[1]).abs().max()) <= 4e-6 * float(ref.abs().max())
+
+
 WGRAD_CASES = [
     # n, h, w, cin, cout, k, stride, groups
     (8, 32, 32, 64, 64, 3, 1, 1),        # 64-wide output tile (BCO = 64), 8192 pixels
