@@ -141,7 +141,8 @@ int egr_wgrad_last_kernel(void);
 int egr_conv_force_config(int cfg);
 /* diagnostic (tests): the kernel the last egr_conv2d_nhwc_f32 / egr_conv2d_masked_f32 call launched - 0 fp32 MFMA,
  * 1 split-bf16 generic, 2 split-bf16 tap-sharing (3x3 / stride 1 / pad 1, tiles of whole image rows), 3 the stride-2 tap-sharing
- * kernel (3x3 / stride 2 / pad 1 on even images, taps shared by input parity class; env EGR_CONV_TAP2=0 turns it off). */
+ * kernel (3x3 / stride 2 / pad 1 on even images, taps shared by input parity class; env EGR_CONV_TAP2=0 turns it off), 4 the streaming 1x1 kernel (1x1 / stride 1, cin 64 / 128,
+ * rows x groups >= 65536: weights stationary in LDS; env EGR_CONV_PW=0 turns it off).  egr_conv_set_tap(0) disables 2-4. */
 int egr_conv_last_kernel(void);
 /* diagnostic / test knob: 0 = 3x3 stride-1 split launches stay on the generic split kernel (default 1, env EGR_CONV_TAP). */
 int egr_conv_set_tap(int on);

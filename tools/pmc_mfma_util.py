@@ -10,9 +10,9 @@ f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)[0]
 per = collections.defaultdict(lambda: collections.defaultdict(float)); dur = collections.defaultdict(float); seen = set()
 for r in csv.DictReader(open(f)):
     n = r["Kernel_Name"]
-    x6 = "conv_igemm_x6" in n or "conv_igemm_tap" in n
+    x6 = "conv_igemm_x6" in n or "conv_igemm_tap" in n or "conv_pw_x6" in n
     x6w = "conv_wgrad_x6" in n or "conv_wgrad3_x6" in n
-    k = (("conv_igemm_bf16x3" if x6 else "conv_igemm") if "conv_igemm" in n else
+    k = (("conv_igemm_bf16x3" if x6 else "conv_igemm") if ("conv_igemm" in n or "conv_pw_x6" in n) else
          (("conv_wgrad_bf16x3" if x6w else "conv_wgrad") if "conv_wgrad" in n else
           ("stem_bf16x3" if "stem_x6_kernel" in n else ("stem" if "stem_kernel" in n else "other"))))
     per[k][r["Counter_Name"]] += float(r["Counter_Value"])

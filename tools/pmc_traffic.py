@@ -11,8 +11,8 @@ def load(d, counter):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter: continue
         nm = r["Kernel_Name"]
-        # conv_igemm_x6 / x6p / tap kernels = the split-bf16 launches, conv_igemm_kernel the fp32 ones
-        k = ("conv_x6" if ("conv_igemm_x6" in nm or "conv_igemm_tap" in nm) else "conv") if "conv_igemm" in nm else "other"
+        # conv_igemm_x6 / x6p / tap / tap2 / conv_pw_x6 kernels = the split-bf16 launches, conv_igemm_kernel the fp32 ones
+        k = ("conv_x6" if ("conv_igemm_x6" in nm or "conv_igemm_tap" in nm or "conv_pw_x6" in nm) else "conv") if ("conv_igemm" in nm or "conv_pw_x6" in nm) else "other"
         per[k] += float(r["Counter_Value"]); n[(k, r["Dispatch_Id"])] += 1
     launches = collections.Counter(k for (k, _d) in n)
     return per, launches
@@ -28,7 +28,7 @@ def entry(key, label):
             "write_bytes_per_launch": write[key] * 1024 / lw[key],
             "hbm_bytes_per_launch": (2.0 * fetch[key] * 1024) / n + write[key] * 1024 / lw[key]}
 
-x6 = entry("conv_x6", "conv_igemm_x6 / x6p / tap kernels (egr_conv2d_nhwc_f32, EGR_W_BF16X3 launches)")
+x6 = entry("conv_x6", "conv_igemm_x6 / x6p / tap / tap2 / conv_pw_x6 kernels (egr_conv2d_nhwc_f32, EGR_W_BF16X3 launches)")
 f32 = entry("conv", "conv_igemm_kernel (egr_conv2d_nhwc_f32, fp32-matrix-core launches)")
 main = x6 or f32
 out = {"batch": batch, **main, "by_format": {"bf16x3": x6, "f32": f32},
