@@ -81,6 +81,7 @@ struct ConvArgs {
     unsigned long long* dbg;  // diagnostic only: per-block phase stamps (s_memtime), NULL in normal operation
     int vec_ok;   // NHWC output / residual addresses are 16-byte aligned for every (row, channel quad)
     int cls_mode; // stride-2 data gradient split into the four output-parity classes (blockIdx.y): M, dHoWo, dWo, *_shift describe ONE class
+    int* cnt;     // split-K: arrival counters (groups x tiles, zero between launches) - the last slice of a tile reduces it; NULL = separate pass
 };
 
 constexpr int BK = 32;
@@ -343,14 +344,56 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     stamp(4);  // accumulators staged
     hook();    // (split kernel, persistent: the next tile's first operands are requested here and fly under the stores)
 
-    if (d.split_k > 1) {  // raw partial sums; the epilogue runs in splitk_reduce_kernel
+    if (d.split_k > 1) {  // raw partial sums
         constexpr int QPR = BN / 4;
-        for (int idx = tid; idx < BM * QPR; idx += NT) {
-            int row = idx / QPR, cq = idx - row * QPR;
-            int m = tm * BM + row, co = tn * BN + cq * 4;
+        if (!a.cnt) {     // the epilogue runs in splitk_reduce_kernel
+            for (int idx = tid; idx < BM * QPR; idx += NT) {
+                int row = idx / QPR, cq = idx - row * QPR;
+                int m = tm * BM + row, co = tn * BN + cq * 4;
+                if (m < a.M && co < a.Npad)
+                    *reinterpret_cast<f32x4*>(&wsg[((int64_t)split * a.M + m) * a.Npad + co]) =
+                        *reinterpret_cast<const f32x4*>(&sC[row * P::CS + cq * 4]);
+            }
+            return;
+        }
+        // The K slices of a tile arrive in any order; the LAST one to arrive sums all slabs in slice order (the arithmetic of
+        // splitk_reduce_kernel: deterministic, independent of the arrival order) and applies the epilogue - no second launch.
+        // The slices run on any XCD, whose L2s are not coherent with each other for ordinary accesses; agent-scope FENCES would
+        // write back / invalidate the whole L2 per workgroup (measured: the forward 15.3 -> 16.1 ms, batch 1 1.8 -> 3.7 ms).
+        // Instead the slab accesses themselves are agent-scope atomic (relaxed: `sc1` stores that write through, `sc1` loads that do
+        // not hit stale lines); ordering: every thread waits for its own slab stores (vmcnt(0)) before the barrier that precedes
+        // the counter increment, and the slab loads follow the barrier behind the counter read.
+        for (int idx = tid; idx < BM * BN; idx += NT) {
+            const int row = idx / BN, c = idx - row * BN;
+            const int m = tm * BM + row, co = tn * BN + c;
             if (m < a.M && co < a.Npad)
-                *reinterpret_cast<f32x4*>(&wsg[((int64_t)split * a.M + m) * a.Npad + co]) =
-                    *reinterpret_cast<const f32x4*>(&sC[row * P::CS + cq * 4]);
+                __hip_atomic_store(&wsg[((int64_t)split * a.M + m) * a.Npad + co], sC[row * P::CS + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                   // every slab store of this workgroup has completed; sC is dead
+        int* const flag = reinterpret_cast<int*>(lds);
+        if (tid == 0) {
+            int* const c = a.cnt + (int64_t)grp * a.ntiles + tm * a.tilesN + tn;
+            const int last = atomicAdd(c, 1) == d.split_k - 1;
+            if (last) atomicExch(c, 0);                    // ready for the next launch
+            *flag = last;
+        }
+        __syncthreads();
+        if (!*flag) return;
+        for (int idx = tid; idx < BM * BN; idx += NT) {
+            const int row = idx / BN, c = idx - row * BN;
+            const int m = tm * BM + row, co = tn * BN + c;
+            const int yo = s_yoff[row];
+            if (yo < 0 || co >= d.cout) continue;
+            float sum = 0.f;
+            for (int sp = 0; sp < d.split_k; ++sp)
+                sum += __hip_atomic_load(&wsg[((int64_t)sp * a.M + m) * a.Npad + co], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float v = sum * (scg ? scg[co] : 1.f) + (shg ? shg[co] : 0.f) * (rsg ? rsg[m] : 1.f);
+            if (d.res_mode == EGR_RES_BEFORE_ACT) v += resg[(int64_t)s_roff[row] + co];
+            v = egr_act(v, d.act);
+            if (d.res_mode == EGR_RES_AFTER_ACT) v += resg[(int64_t)s_roff[row] + co];
+            if (rmg && !rmg[m]) v = 0.f;
+            yg[(int64_t)yo + (d.out_nchw ? (int64_t)co * HoWo : (int64_t)co)] = v;
         }
         return;
     }
@@ -1589,6 +1632,7 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
             const int rounds = (a.ntiles + slots - 1) / slots;
             gx = ((a.ntiles + rounds - 1) / rounds + 7) & ~7;
             persist = true;
+            a.cnt = nullptr;    // (short K: never split in practice) the persistent tile loop keeps the two-pass reduction
         }
     }
     dim3 grid((unsigned)gx, (unsigned)ny, (unsigned)a.d.groups);
@@ -1661,6 +1705,16 @@ int g_pw = getenv("EGR_CONV_PW") ? atoi(getenv("EGR_CONV_PW")) : 1;     // 0: sh
 int g_pw_min_rows = getenv("EGR_CONV_PW_MIN_ROWS") ? atoi(getenv("EGR_CONV_PW_MIN_ROWS")) : 65536;   // rows x groups from which the streaming kernel is used
 int g_pw_blocks = getenv("EGR_CONV_PW_BLOCKS") ? atoi(getenv("EGR_CONV_PW_BLOCKS")) : 256;          // resident workgroups (one per CU)
 unsigned long long* g_dbg = nullptr;
+// split-K arrival counters: a ring of regions, one per launch (launches on different streams may overlap); zero at load, every
+// launch leaves its region zero again
+constexpr int SPLITK_REGION = 2048, SPLITK_REGIONS = 8;
+__device__ int g_splitk_cnt[SPLITK_REGION * SPLITK_REGIONS];
+// 1: the last-arriving K slice of a tile reduces it (no second launch).  Correct and deterministic, but measured SLOWER than the
+// second pass (batch 1: 2.36 against 1.76 ms over 25 split launches; batch 64: 15.35 against 15.26 ms): the slabs must then be
+// written and read with agent-scope (`sc1`) accesses that go to memory, and one workgroup sums a tile that the second pass
+// spreads over the chip.  Opt-in (egr_conv_set_splitk_fused / EGR_SPLITK_FUSED=1).
+int g_splitk_fused = getenv("EGR_SPLITK_FUSED") ? atoi(getenv("EGR_SPLITK_FUSED")) : 0;
+unsigned g_splitk_seq = 0;
 
 }  // namespace
 
@@ -1703,6 +1757,7 @@ extern "C" int egr_conv_set_persist(int slots, int max_ktiles) {
 }
 
 extern "C" int egr_conv_last_kernel(void) { return g_last_conv_kernel; }
+extern "C" int egr_conv_set_splitk_fused(int on) { g_splitk_fused = on; return 0; }
 extern "C" int egr_conv_set_tap(int on) { g_tap = on; return 0; }
 
 extern "C" int egr_conv_force_config(int cfg) {
@@ -1748,6 +1803,7 @@ static int conv_run(const egr_conv_desc* dd, const float* x, const float* w, con
     a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.res = res; a.rowscale = rowscale; a.rowmask = rowmask;
     a.y = y; a.ws = workspace;
     a.mask = mask;
+    a.cnt = nullptr;
     a.dbg = g_dbg;
     a.M = (int)M64;
     a.Npad = (d.cout + 31) / 32 * 32;
@@ -1921,6 +1977,15 @@ static int conv_run(const egr_conv_desc* dd, const float* x, const float* w, con
 
     hipStream_t s = (hipStream_t)stream;
     int rc;
+    a.cnt = nullptr;
+    {
+        const int64_t tiles_all = (int64_t)((a.M + bm - 1) / bm) * ((a.Npad + bn - 1) / bn) * d.groups;
+        if (d.split_k > 1 && g_splitk_fused && tiles_all <= SPLITK_REGION) {
+            static int* base = nullptr;
+            if (!base && hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_splitk_cnt)) != hipSuccess) base = nullptr;
+            if (base) a.cnt = base + (g_splitk_seq++ % SPLITK_REGIONS) * SPLITK_REGION;
+        }
+    }
     switch (cfg) {
         case CFG_128x128: rc = launch_cfg<128, 128, 2, 2>(a, s); break;
         case CFG_256x64: rc = launch_cfg<256, 64, 4, 1>(a, s); break;
@@ -1929,7 +1994,7 @@ static int conv_run(const egr_conv_desc* dd, const float* x, const float* w, con
         default: rc = launch_cfg<128, 32, 4, 1>(a, s); break;
     }
     if (rc) return rc;
-    if (d.split_k > 1) {
+    if (d.split_k > 1 && !a.cnt) {
         int64_t total = (int64_t)a.M * d.cout;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)d.groups), dim3(256), 0, s, a);
         rc = egr_launch_status();

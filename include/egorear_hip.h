@@ -144,6 +144,10 @@ int egr_conv_force_config(int cfg);
  * kernel (3x3 / stride 2 / pad 1 on even images, taps shared by input parity class; env EGR_CONV_TAP2=0 turns it off), 4 the streaming 1x1 kernel (1x1 / stride 1, cin 64 / 128,
  * rows x groups >= 65536: weights stationary in LDS; env EGR_CONV_PW=0 turns it off).  egr_conv_set_tap(0) disables 2-4. */
 int egr_conv_last_kernel(void);
+/* diagnostic / test knob: 1 = split-K launches run the reduction + epilogue in the last-arriving K slice of each tile (arrival
+ * counters, agent-scope slab accesses) instead of a second kernel (splitk_reduce_kernel).  Both sum the slices in slice order.
+ * Default 0 (env EGR_SPLITK_FUSED): the fused form saves the launch but measured slower, see DESIGN.md §5d. */
+int egr_conv_set_splitk_fused(int on);
 /* diagnostic / test knob: 0 = 3x3 stride-1 split launches stay on the generic split kernel (default 1, env EGR_CONV_TAP). */
 int egr_conv_set_tap(int on);
 /* Tuning / test knob of the persistent split-bf16 launches (short-K layers: a workgroup walks several tiles and requests the next

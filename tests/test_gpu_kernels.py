@@ -121,6 +121,71 @@ def test_conv_split_k_linear_rowscale_rowmask(hip):
         close(out.t.view(m, n_out), ref)
 
 
+@pytest.mark.parametrize("case", [
+    # n, h, cin, cout, k, stride, groups, split, extras
+    (6, 1, 4096, 96, 1, 1, 1, 7, "rowscale_mask"),       # skinny linear, ragged rows and channels
+    (4, 32, 64, 64, 3, 1, 2, 3, "res_before_relu"),      # grouped 3x3 (the small-batch layers that are split 2-4 ways)
+    (2, 16, 256, 128, 3, 2, 1, 0, "nchw"),               # automatic split, channel-major output
+    (64, 1, 8192, 256, 1, 1, 1, 16, "gelu"),             # 16 slices on four 64-column tiles
+])
+def test_split_k_reduction_in_the_last_slice_equals_the_second_pass(hip, case):
+    """Opt-in form of split-K (egr_conv_set_splitk_fused): a tile is reduced in whichever K slice arrives last (arrival counter,
+    agent-scope slab accesses) - summed in slice order like
+    splitk_reduce_kernel, so the result does not depend on the arrival order: equal to the two-pass form within one rounding of
+    the epilogue's multiply-add, identical from run to run, correct against fp64, and the counters are left at zero (second call)."""
+    n, h, cin, cout, k, stride, G, split, extra = case
+    pad = k // 2
+    x = rnd(G * n, h, h, cin, seed=301)
+    wts = [rnd(cout, cin, k, k, seed=302 + g, scale=1.0 / math.sqrt(cin * k * k)) for g in range(G)]
+    wp = (torch.stack([pack_w(w) for w in wts]) if G > 1 else pack_w(wts[0])).to(DEV)
+    npad = wp.shape[-2]
+    ho = (h + 2 * pad - k) // stride + 1
+    kw = dict(groups=G, workspace=torch.empty(1 << 23, device=DEV), split_k=split)
+    sh = rnd(G, npad, seed=305)
+    kw["shift"] = (sh if G > 1 else sh[0]).to(DEV)
+    res = rs = mask = None
+    if extra == "rowscale_mask":
+        rs, mask = rnd(n, seed=306), torch.tensor([1, 0, 1, 1, 0, 1], dtype=torch.uint8)
+        kw.update(rowscale=rs.to(DEV), rowmask=mask.to(DEV))
+    if extra == "res_before_relu":
+        res = rnd(G * n, ho, ho, cout, seed=307)
+        kw.update(res=hip.Img(res.to(DEV)), res_mode=hip.RES_BEFORE_ACT, act=hip.ACT_RELU)
+    if extra == "gelu":
+        kw["act"] = hip.ACT_GELU
+
+    def run():
+        if extra == "nchw":
+            planes = torch.full((n, cout, ho, ho), 7.0, device=DEV)
+            hip.conv2d(hip.Img(x.to(DEV)), wp, cout, k, k, stride, pad, out_nchw=planes, ymap=hip.NMap(n, cout * ho * ho, 0), **kw)
+            return planes
+        return hip.conv2d(hip.Img(x.to(DEV)), wp, cout, k, k, stride, pad, **kw).t.permute(0, 3, 1, 2).clone()
+
+    try:
+        hip.lib.egr_conv_set_splitk_fused(1)
+        a1, a2 = run(), run()
+        hip.lib.egr_conv_set_splitk_fused(0)
+        b = run()
+    finally:
+        hip.lib.egr_conv_set_splitk_fused(0)
+    assert torch.equal(a1, a2)
+    refs = []
+    for g in range(G):
+        r = F.conv2d(x[g * n:(g + 1) * n].permute(0, 3, 1, 2).double(), wts[g].double(), None, stride, pad)
+        bias = (sh[g] if G > 1 else sh[0])[:cout].double().view(1, -1, 1, 1)
+        r = r + (bias * rs.double().view(-1, 1, 1, 1) if rs is not None else bias)
+        if extra == "res_before_relu":
+            r = F.relu(r + res[g * n:(g + 1) * n].permute(0, 3, 1, 2).double())
+        if extra == "gelu":
+            r = F.gelu(r)
+        if mask is not None:
+            r = r * mask.double().view(-1, 1, 1, 1)
+        refs.append(r)
+    ref = torch.cat(refs)
+    scale = float(ref.abs().max())
+    assert float((a1.double().cpu() - ref).abs().max()) <= 2e-5 * scale
+    assert float((a1 - b).abs().max()) <= 3e-7 * scale
+
+
 def test_grouped_conv_equals_separate_launches(hip):
     """groups > 1: same-shape problems with their own weights / scale / shift / residual in one launch."""
     G, n, h, w, cin, cout = 3, 2, 16, 16, 64, 48
