@@ -815,7 +815,11 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
             abase[i] = (il * HPI + r * WP + c) * 32 + half * 16;
         }
 #pragma unroll
+#ifdef TAP_EXP_BUNIFORM
+        for (int j = 0; j < FN; ++j) bvo[j] = ((tn * NFB + wn * FN + j) * a.ktiles * 6) * 1024;
+#else
         for (int j = 0; j < FN; ++j) bvo[j] = ((tn * NFB + wn * FN + j) * a.ktiles * 6) * 1024 + lane * 16;
+#endif
         const int NC = a.cblocks * 2;            // 16-channel chunks
         u32x4 xr[NUH];
         auto load_halo = [&](int ck) {           // chunk ck = (32-channel block ck >> 1, half ck & 1)
@@ -866,8 +870,15 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
         // PAR: B register set of tap 0 (nine taps flip it, so chunks alternate)
         auto chunk = [&](auto par_tag, int ck, int cur, int nxt, auto conv_tag) {
             constexpr int PAR = decltype(par_tag)::value;
+            // (TAP_EXP_*: elimination builds for tools/build_variant.py - timing only, the results are wrong)
+#ifdef TAP_EXP_NOCONV
+            constexpr bool conv = false;
+#else
             constexpr bool conv = decltype(conv_tag)::value;
+#endif
+#ifndef TAP_EXP_NOHALO
             if constexpr (conv) load_halo(ck + 1);
+#endif
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
             constexpr int NMT = 6 * FM * FN;                 // MFMAs per tap
             constexpr int W0 = 2 * NMT, W1 = 8 * NMT;        // conversion window (in MFMAs of the chunk)
@@ -875,8 +886,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int pc = (PAR + tap) & 1, pn = pc ^ 1;
+#ifndef TAP_EXP_NOB
                 if (tap + 1 < 9) load_b(ck, tap + 1, pn);
                 else if (conv) load_b(ck + 1, 0, pn);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < 6; ++t) {
@@ -891,7 +904,11 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                         }
+#ifndef TAP_EXP_NOA
                     if (tap + 1 < 9 && (t == 0 || t == 3 || t == 5)) {
+#else
+                    if (false) {
+#endif
                         read_a(cur, tap + 1, t == 0 ? 2 : (t == 3 ? 1 : 0));
                         __builtin_amdgcn_sched_barrier(0);
                     }
