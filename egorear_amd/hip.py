@@ -294,10 +294,14 @@ class W6Table:
 
 
 # Launches below these sizes (all groups together) are bound by launch latency or by streaming the weights once, not by the
-# matrix cores: they keep the 4-byte weight format (measured: 3840 rows x K 4096 and 16384 rows x K 576 slower with the split,
-# 8192 rows x N 512 x K 4608 faster)
-X6_MIN_ROWS = int(os.environ.get("EGR_X6_MIN_ROWS", "8192"))
-X6_MIN_FLOPS = float(os.environ.get("EGR_X6_MIN_FLOPS", "4e9"))
+# matrix cores: they keep the 4-byte weight format (measured: 3840 rows x K 4096 slower with the split, 8192 rows x N 512 x K 4608
+# faster).  Thresholds re-swept with the tap-sharing / streaming kernels in place (tools/x6_small_sweep.sh: 8192 rows / 4e9 flops ->
+# 4096 / 5e8: batch 2-16 latency -2 .. -7 %, batch 32 +1.9 % frames/s, batch 1 and 64 unchanged)
+X6_MIN_ROWS = int(os.environ.get("EGR_X6_MIN_ROWS", "4096"))
+X6_MIN_FLOPS = float(os.environ.get("EGR_X6_MIN_FLOPS", "5e8"))
+# the training step keeps the rule its gradient goldens were recorded under (tests/test_gpu_train_step.py; train.py passes x6_min)
+X6_TRAIN_MIN_ROWS = int(os.environ.get("EGR_X6_TRAIN_MIN_ROWS", "8192"))
+X6_TRAIN_MIN_FLOPS = float(os.environ.get("EGR_X6_TRAIN_MIN_FLOPS", "4e9"))
 
 
 def conv2d(x: Img, w, cout: int, kh: int, kw: int, stride: int, pad: int, *, scale=None, shift=None,
@@ -305,7 +309,7 @@ def conv2d(x: Img, w, cout: int, kh: int, kw: int, stride: int, pad: int, *, sca
            out: Optional[Img] = None, out_nchw: Optional[torch.Tensor] = None, ymap: Optional[NMap] = None,
            xmap: Optional[NMap] = None, rmap: Optional[NMap] = None, workspace: Optional[torch.Tensor] = None,
            split_k: int = 1, groups: int = 1, gx: Optional[int] = None, gy: Optional[int] = None,
-           gr: Optional[int] = None, grs: int = 0, grm: int = 0, transposed_out_hw: Optional[tuple] = None,
+           gr: Optional[int] = None, grs: int = 0, grm: int = 0, transposed_out_hw: Optional[tuple] = None, x6_min: Optional[tuple] = None,
            mask: Optional[Img] = None) -> Optional[Img]:
     """Implicit-GEMM conv / linear.  Output goes to `out` (NHWC Img, maybe a channel slice), or to the raw
     tensor `out_nchw` (channel-major planes placed by `ymap`), or to a fresh NHWC tensor.
@@ -337,7 +341,8 @@ def conv2d(x: Img, w, cout: int, kh: int, kw: int, stride: int, pad: int, *, sca
         rows_all = x.n * groups * ho * wo
         # (the split kernel addresses one group's activations through a 2-GiB buffer window)
         x_bytes = 4 * ((x.n - 1) * x.nstride + (x.h * x.w + 2 * (kh * x.w + kw + 1)) * x.ld) + 64
-        if rows_all < X6_MIN_ROWS or 2.0 * rows_all * cout * K < X6_MIN_FLOPS or x_bytes >= (1 << 31):
+        min_rows, min_flops = x6_min if x6_min is not None else (X6_MIN_ROWS, X6_MIN_FLOPS)
+        if rows_all < min_rows or 2.0 * rows_all * cout * K < min_flops or x_bytes >= (1 << 31):
             w = w.f32
     x6 = isinstance(w, W6)
     if x6 and not w.used:

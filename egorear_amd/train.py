@@ -37,6 +37,11 @@ from .hip import ACT_NONE, ACT_RELU, RES_BEFORE_ACT, RES_NONE, Img, NMap
 _WS_FLOATS = 72 << 20   # conv split-K / wgrad slab workspace (288 MB: one slab of mlp_pred.0's 2048 x 32768 gradient)
 
 
+def _conv2d(*a, **k):
+    """hip.conv2d under the training step's split-launch rule (hip.X6_TRAIN_MIN_*)."""
+    return hip.conv2d(*a, x6_min=(hip.X6_TRAIN_MIN_ROWS, hip.X6_TRAIN_MIN_FLOPS), **k)
+
+
 def _ceil32(n: int) -> int:
     return (n + 31) // 32 * 32
 
@@ -308,10 +313,10 @@ class Step:
         kw = dict(transposed_out_hw=(h, w), groups=p.groups, res=Img(prev) if prev is not None else None,
                   res_mode=RES_BEFORE_ACT if prev is not None else RES_NONE, workspace=self.ws, split_k=0)
         if id(x) in self.relu_out:
-            dx = hip.conv2d(Img(dz), p.wtop, p.cin_pad, p.kh, p.kw, p.stride, p.pad, mask=Img(x), **kw).t
+            dx = _conv2d(Img(dz), p.wtop, p.cin_pad, p.kh, p.kw, p.stride, p.pad, mask=Img(x), **kw).t
             self.G.add_masked(x, dx)
         else:
-            self.G.g[id(x)] = hip.conv2d(Img(dz), p.wtop, p.cin_pad, p.kh, p.kw, p.stride, p.pad, **kw).t
+            self.G.g[id(x)] = _conv2d(Img(dz), p.wtop, p.cin_pad, p.kh, p.kw, p.stride, p.pad, **kw).t
 
     # ---- conv / linear ------------------------------------------------------------------------------------------
     def pack(self, mods: Sequence[nn.Module], need_dx=True) -> TPack:
@@ -353,7 +358,7 @@ class Step:
         y = T.zeros((n, ho, wo, cw), self.dev) if (out_pad and cw != p.cout) else torch.empty((n, ho, wo, cw), device=self.dev)
         yo = Img(y[..., :p.cout]) if cw != p.cout else Img(y)
         # res_up2: `res` is a half-resolution tensor that the epilogue up-samples itself (the FPN top-down add)
-        hip.conv2d(Img(x), p.wop, p.cout, p.kh, p.kw, p.stride, p.pad, shift=p.bias, act=act, res=Img(res) if res is not None else None,
+        _conv2d(Img(x), p.wop, p.cout, p.kh, p.kw, p.stride, p.pad, shift=p.bias, act=act, res=Img(res) if res is not None else None,
                    res_mode=(hip.RES_UP2_BEFORE_ACT if res_up2 else RES_BEFORE_ACT) if res is not None else RES_NONE, out=yo,
                    workspace=self.ws, split_k=0, groups=p.groups)
 
@@ -712,7 +717,7 @@ def layer_train(S: Step, L: _LayerPack, x: torch.Tensor, memory: torch.Tensor, a
     e2 = e.view(G * rows, C) if e is not None else None
     sig = sigma.view(G * heads * rows)
     for h in range(heads):
-        hip.conv2d(_rows(g2[:rows, h * cf:(h + 1) * cf]), L.head_w[h] if G > 1 else L.head_w[h][0], dh, 1, 1, 1, 0,
+        _conv2d(_rows(g2[:rows, h * cf:(h + 1) * cf]), L.head_w[h] if G > 1 else L.head_w[h][0], dh, 1, 1, 1, 0,
                    shift=L.head_shift[h] if G > 1 else L.head_shift[h][0], rowscale=sig[h * rows:], grs=heads * rows,
                    res=_rows(e2[:rows, h * dh:(h + 1) * dh]) if e2 is not None else None,
                    res_mode=hip.RES_AFTER_ACT if e2 is not None else RES_NONE, out=_rows(a[:rows, h * dh:(h + 1) * dh]),
@@ -729,7 +734,7 @@ def layer_train(S: Step, L: _LayerPack, x: torch.Tensor, memory: torch.Tensor, a
         dg2 = dg.view(G * rows, heads * cf)
         for h in range(heads):
             hip.conv2d_wgrad(_rows(g2[:, h * cf:(h + 1) * cf]), _rows(da[:, h * dh:(h + 1) * dh]), 1, 1, 1, 0, S.ws, dw=dWh[h], groups=G)
-            hip.conv2d(_rows(da[:rows, h * dh:(h + 1) * dh]), L.head_wt[h] if G > 1 else L.head_wt[h][0], cf, 1, 1, 1, 0,
+            _conv2d(_rows(da[:rows, h * dh:(h + 1) * dh]), L.head_wt[h] if G > 1 else L.head_wt[h][0], cf, 1, 1, 1, 0,
                        out=_rows(dg2[:rows, h * cf:(h + 1) * cf]), workspace=None, split_k=1, groups=G, gx=rows * C, gy=rows * heads * cf)
         dWfold = dWh.permute(1, 0, 2, 3).reshape(G, C, cf)
         # dcfold[g, h*dh + d] = sum_r sigma[g, h, r] * da[g, r, h*dh + d]: all heads in one launch
@@ -788,7 +793,7 @@ def conv_to_planes(S: Step, x: torch.Tensor, p: TPack, planes: torch.Tensor, B: 
     plane = p.cout * h * w
     per_group = n // p.groups
     vpg = per_group // B                       # views per group
-    hip.conv2d(Img(x), p.wop, p.cout, 1, 1, 1, 0, shift=p.bias, out_nchw=planes, ymap=NMap(B, V * plane, plane if vpg > 1 else 0),
+    _conv2d(Img(x), p.wop, p.cout, 1, 1, 1, 0, shift=p.bias, out_nchw=planes, ymap=NMap(B, V * plane, plane if vpg > 1 else 0),
                gy=vpg * plane, groups=p.groups, workspace=S.ws, split_k=0)
 
     def bwd():
@@ -829,7 +834,7 @@ def refiners_train(S: Step, rs, B: int, V: int, hm_init: torch.Tensor, feat_all:
     # --- JQA query: heatmap_proj.0 reads the (B, V, J, hw) heat maps in place, group g = view g
     hp0 = S.pack([r.heatmap_proj[0] for r in rs], need_dx=hm_grad)
     hm_rows = Img(hm_init.view(B * V, J, 1, hw)[0::V])
-    t4 = hip.conv2d(hm_rows, hp0.w, C, 1, 1, 1, 0, shift=hp0.bias, act=ACT_RELU, groups=G, gx=J * hw, workspace=S.ws, split_k=0).t   # (G*B, J, 1, C)
+    t4 = _conv2d(hm_rows, hp0.w, C, 1, 1, 1, 0, shift=hp0.bias, act=ACT_RELU, groups=G, gx=J * hw, workspace=S.ws, split_k=0).t   # (G*B, J, 1, C)
     t = t4.view(G * B * J, C)
 
     def bwd_hp0():
@@ -843,7 +848,7 @@ def refiners_train(S: Step, rs, B: int, V: int, hm_init: torch.Tensor, feat_all:
             S.pacc(hp0.wmeta[g][0][0], dw)
             S.pacc(hp0.bmeta[g][0][0], db)
         if hm_grad:     # gradient w.r.t. the heat-map rows, back into the (B, V, J, H, W) layout (group g = view g)
-            dxr = hip.conv2d(Img(dz), hp0.wt, hw, 1, 1, 1, 0, transposed_out_hw=(J, 1), groups=G, workspace=S.ws, split_k=0).t
+            dxr = _conv2d(Img(dz), hp0.wt, hw, 1, 1, 1, 0, transposed_out_hw=(J, 1), groups=G, workspace=S.ws, split_k=0).t
             dhm = torch.empty_like(hm_init)
             T.nhwc_to_planes(dxr.view(G * B, 1, J * hw), dhm, NMap(B, V * J * hw, J * hw), J * hw)
             S.G.add(hm_init, dhm)
