@@ -738,6 +738,30 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial,
     }
 }
 
+// bias gradient of a few rows (<= 4096: the token-sized Linear layers) in ONE launch: 16 channels x 16 row lanes per workgroup,
+// double accumulation like colsum_final_kernel
+__global__ __launch_bounds__(256) void colsum_small_kernel(const float* x, int rows, int c, int ld, float* out, int accumulate, int64_t gx, int64_t gb) {
+    __shared__ double red[256];
+    const int ch = blockIdx.x * 16 + (threadIdx.x & 15), sl = threadIdx.x >> 4;
+    x += (int64_t)blockIdx.y * gx;
+    out += (int64_t)blockIdx.y * gb;
+    double s = 0.0;
+    if (ch < c) {
+        int r = sl;
+        for (; r + 48 < rows; r += 64) {
+            const float v0 = x[(int64_t)r * ld + ch], v1 = x[(int64_t)(r + 16) * ld + ch], v2 = x[(int64_t)(r + 32) * ld + ch], v3 = x[(int64_t)(r + 48) * ld + ch];
+            s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+        }
+        for (; r < rows; r += 16) s += x[(int64_t)r * ld + ch];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (sl == 0 && ch < c) {
+        for (int k = 1; k < 16; ++k) s += red[k * 16 + (threadIdx.x & 15)];
+        out[ch] = (float)s + (accumulate ? out[ch] : 0.f);
+    }
+}
+
 int g_last_kernel = 0;
 
 }  // namespace
@@ -838,6 +862,11 @@ extern "C" int egr_conv2d_wgrad_f32(const egr_conv_desc* dd, const float* x, con
     if (rc || !db) return rc;
     // bias gradient: column sums of dy (plain batch only)
     if (d.ymap.n_inner < d.n || d.ymap.stride_inner != (int64_t)d.ho * d.wo * d.ldy) return EGR_EINVAL;
+    if (M64 <= 4096) {
+        hipLaunchKernelGGL(colsum_small_kernel, dim3((unsigned)((d.cout + 15) / 16), (unsigned)G), dim3(256), 0, s, dy, (int)M64, d.cout, d.ldy, db,
+                           accumulate, d.gy, d.gp);
+        return egr_launch_status();
+    }
     int nblk = (int)((M64 + 255) / 256);          // >= 256 rows per block, at most 256 blocks
     if (nblk > 256) nblk = 256;
     const int rpb = (int)((M64 + nblk - 1) / nblk);
