@@ -502,6 +502,43 @@ def test_streaming_1x1_kernel(case):
     assert float((outs[0] - outs[1]).abs().max()) <= 4e-6 * float(ref.abs().max())
 
 
+def test_streaming_1x1_kernel_operand_placement():
+    """The streaming kernel with every operand placed the way the engine places them: input and residual as channel slices of wider
+    tensors (row stride > channels), the output written into a channel slice of a wider buffer (its neighbours untouched), and a
+    (view, frame) -> (frame, view) image map on the input and the output."""
+    from egorear_amd import hip
+    V, B, h, cin, cout = 4, 4, 64, 128, 128           # n = v * B + b; 65536 pixels
+    n = V * B
+    wide = rnd(n, h, h, 2 * cin, seed=401).to(DEV)                      # the conv reads channels cin .. 2 cin
+    reswide = rnd(n, h, h, cout + 64, seed=402).to(DEV)                 # the residual is channels 32 .. 32 + cout
+    wt = rnd(cout, cin, 1, 1, seed=403, scale=1.0 / math.sqrt(cin))
+    sh = rnd(cout, seed=404).to(DEV)
+    ref = F.relu(F.conv2d(wide[..., cin:].permute(0, 3, 1, 2).cpu().double(), wt.double()) + sh.cpu().double().view(1, -1, 1, 1)
+                 + reswide[..., 32:32 + cout].permute(0, 3, 1, 2).cpu().double())
+    saved = hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS
+    hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = 0, 0.0
+    try:
+        cat = torch.full((n, h, h, 3 * cout), 5.0, device=DEV)
+        hip.conv2d(hip.Img(wide[..., cin:]), hip.pack_w6(pack_w(wt).to(DEV)), cout, 1, 1, 1, 0, shift=sh, act=hip.ACT_RELU,
+                   res=hip.Img(reswide[..., 32:32 + cout]), res_mode=hip.RES_BEFORE_ACT, out=hip.Img(cat[..., cout:2 * cout]))
+        assert hip.lib.egr_conv_last_kernel() == 4
+        err = float((cat[..., cout:2 * cout].permute(0, 3, 1, 2).double().cpu() - ref).abs().max()) / float(ref.abs().max())
+        assert err <= 2e-5, err
+        assert float((cat[..., :cout] - 5.0).abs().max()) == 0 and float((cat[..., 2 * cout:] - 5.0).abs().max()) == 0
+        # image maps: the input batch is stored frame-major (b, v), the launch enumerates view-major (n = v * B + b) and writes view-major
+        xbv = wide[..., cin:].reshape(V, B, h, h, cin).permute(1, 0, 2, 3, 4).contiguous()      # (B, V, ...)
+        img = h * h * cin
+        out = torch.zeros(n, h, h, cout, device=DEV)
+        hip.conv2d(hip.Img(xbv.view(n, h, h, cin)), hip.pack_w6(pack_w(wt).to(DEV)), cout, 1, 1, 1, 0, shift=sh,
+                   xmap=hip.NMap(B, V * img, img), out=hip.Img(out))
+        assert hip.lib.egr_conv_last_kernel() == 4
+        ref2 = F.conv2d(wide[..., cin:].permute(0, 3, 1, 2).cpu().double(), wt.double()) + sh.cpu().double().view(1, -1, 1, 1)
+        err = float((out.permute(0, 3, 1, 2).double().cpu() - ref2).abs().max()) / float(ref2.abs().max())
+        assert err <= 2e-5, err
+    finally:
+        hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = saved
+
+
 @pytest.mark.parametrize("case", [(1, 16, 64, 128, 128, True), (2, 8, 64, 64, 128, True), (1, 16, 64, 128, 64, False)])
 def test_streaming_1x1_data_gradient(case):
     """The streaming kernel as the data gradient of a 1x1 convolution (the same launch with the transposed matrix), plain and with the
