@@ -502,6 +502,34 @@ def test_streaming_1x1_kernel(case):
     assert float((outs[0] - outs[1]).abs().max()) <= 4e-6 * float(ref.abs().max())
 
 
+def test_tap_sharing_stride2_operand_placement():
+    """The stride-2 tap-sharing kernel with the input as a channel slice of a wider tensor stored frame-major behind a
+    (view, frame) -> (frame, view) image map, 8 x 8 outputs (a tile spans two images), the output into a channel slice."""
+    from egorear_amd import hip
+    V, B, h, cin, cout = 4, 8, 16, 64, 128            # n = v * B + b = 32 images of 16 x 16 -> 8 x 8: 2048 output pixels
+    n = V * B
+    x = rnd(n, h, h, cin, seed=411)                                       # launch order (view-major)
+    stored = torch.zeros(B, V, h, h, 2 * cin)
+    stored[..., cin:] = x.view(V, B, h, h, cin).permute(1, 0, 2, 3, 4)
+    stored[..., :cin] = 9.0
+    stored = stored.to(DEV)
+    wt = rnd(cout, cin, 3, 3, seed=412, scale=1.0 / math.sqrt(9 * cin))
+    ref = F.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), wt.double(), None, 2, 1))
+    img = h * h * 2 * cin
+    saved = hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS
+    hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = 0, 0.0
+    try:
+        cat = torch.full((n, h // 2, h // 2, 2 * cout), 5.0, device=DEV)
+        hip.conv2d(hip.Img(stored.view(n, h, h, 2 * cin)[..., cin:]), hip.pack_w6(pack_w(wt).to(DEV)), cout, 3, 3, 2, 1, act=hip.ACT_RELU,
+                   xmap=hip.NMap(B, V * img, img), out=hip.Img(cat[..., cout:]))
+        assert hip.lib.egr_conv_last_kernel() == 3
+    finally:
+        hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = saved
+    err = float((cat[..., cout:].permute(0, 3, 1, 2).double().cpu() - ref).abs().max()) / float(ref.abs().max())
+    assert err <= 2e-5, err
+    assert float((cat[..., :cout] - 5.0).abs().max()) == 0
+
+
 def test_streaming_1x1_kernel_operand_placement():
     """The streaming kernel with every operand placed the way the engine places them: input and residual as channel slices of wider
     tensors (row stride > channels), the output written into a channel slice of a wider buffer (its neighbours untouched), and a
