@@ -6,7 +6,7 @@ import collections, csv, glob, json, sys
 
 
 def classify(nm: str) -> str:
-    if "conv_igemm_x6" in nm or "conv_igemm_tap" in nm: return "conv_igemm_bf16x3"
+    if "conv_igemm_x6" in nm or "conv_igemm_tap" in nm or "conv_pw_x6" in nm: return "conv_igemm_bf16x3"
     if "conv_igemm" in nm: return "conv_igemm_f32"
     if "conv_wgrad_x6" in nm or "conv_wgrad3_x6" in nm: return "conv_wgrad_bf16x3"
     if "conv_wgrad" in nm: return "conv_wgrad_f32"
