@@ -1423,7 +1423,12 @@ __global__ __launch_bounds__(512) void conv_pw_x6_kernel(const ConvArgs a) {
         if (a.howo_shift >= 0) { n = m >> a.howo_shift; pix = m & (HoWo - 1); }
         else { n = fdiv(m, a.dHoWo); pix = m - n * HoWo; }
         const int xb = a.x_plain ? n * (int)d.xmap.stride_inner : (int)fmap(d.xmap, a.dXin, n);
-        return (tile < T && m < a.M) ? (xb + pix * d.ldx) * 4 + h * 16 : OOB;
+        int ipix = pix;
+        if (d.stride == 2) {             // 1x1 / stride 2 (the residual blocks' down-sampling convs): input pixel (2 ho, 2 wo)
+            const int ho = (a.wo_shift >= 0) ? (pix >> a.wo_shift) : fdiv(pix, a.dWo), wo = pix - ho * d.wo;
+            ipix = 2 * ho * d.w + 2 * wo;
+        }
+        return (tile < T && m < a.M) ? (xb + ipix * d.ldx) * 4 + h * 16 : OOB;
     };
     // weights -> LDS: 16-byte loads of the image (lane (p, q) of a fragment = k 8q .. 8q+7), each written as two 8-byte pieces:
     // its half hh goes to the new lane (p, hh), position q  (new lane (p, h): k {4h .. 4h+3} u {8+4h .. 8+4h+3})
@@ -1916,9 +1921,10 @@ static int conv_run(const egr_conv_desc* dd, const float* x, const float* w, con
         }
     }
     // ---- 1x1 / stride 1 split launches with cin = 64 / 128 over many pixels: weights stationary in LDS, activations streamed
-    if (g_tap && g_pw && g_force_cfg == CFG_AUTO && d.w_format == EGR_W_BF16X3 && d.kh == 1 && d.kw == 1 && d.stride == 1 && d.pad == 0 &&
+    if (g_tap && g_pw && g_force_cfg == CFG_AUTO && d.w_format == EGR_W_BF16X3 && d.kh == 1 && d.kw == 1 && d.pad == 0 &&
+        (d.stride == 1 || (d.stride == 2 && !d.transposed && d.ho == (d.h - 1) / 2 + 1 && d.wo == (d.w - 1) / 2 + 1)) &&
         !a.cls_mode && d.split_k <= 1 && !d.out_nchw && !rowscale && !rowmask && a.vec_ok && d.cout % 4 == 0 &&
-        d.act != EGR_ACT_GELU && (d.cin == 64 || d.cin == 128) && a.Npad % 64 == 0 && d.h == d.ho && d.w == d.wo &&
+        d.act != EGR_ACT_GELU && (d.cin == 64 || d.cin == 128) && a.Npad % 64 == 0 && (d.stride == 2 || (d.h == d.ho && d.w == d.wo)) &&
         (int64_t)a.M * d.groups >= g_pw_min_rows && (span(d.ymap, d.n) + ypix) * 4 < (1LL << 31) &&
         (!d.res_mode || (span(d.rmap, d.n) + (int64_t)d.ho * d.wo * d.ldr) * 4 < (1LL << 31))) {
         const int ncf = (a.Npad % 128 == 0) ? 4 : 2;

@@ -446,6 +446,8 @@ PW_CASES = [
     (16, 64, 64, 128, 128, 1, "up2"),              # FPN top-down: half-resolution residual up-sampled in the epilogue
     (8, 64, 64, 64, 64, 2, "up2"),                 # the same, grouped, 64 channels
     (5, 128, 128, 64, 192, 1, "plain"),            # Npad = 192 -> 64-channel tiles, three of them
+    (64, 64, 64, 64, 128, 1, "stride2_scale"),     # 1x1 / stride 2 (the residual blocks' down-sampling convs), BatchNorm affine, no ReLU
+    (37, 62, 62, 128, 256, 2, "stride2_scale"),    # the same: odd-sized output grid (31 x 31), grouped, ragged last tile
 ]
 
 
@@ -455,6 +457,7 @@ def test_streaming_1x1_kernel(case):
     go global -> registers -> MFMA, stores from the accumulator registers) against fp64 and the tiled split kernel."""
     from egorear_amd import hip
     n, h, w, cin, cout, G, extra = case
+    stride = 2 if extra.startswith("stride2") else 1
     x = rnd(G * n, h, w, cin, seed=270)
     wts = [rnd(cout, cin, 1, 1, seed=271 + g, scale=1.0 / math.sqrt(cin)) for g in range(G)]
     wp = torch.stack([pack_w(t) for t in wts]) if G > 1 else pack_w(wts[0])
@@ -467,29 +470,31 @@ def test_streaming_1x1_kernel(case):
     if extra == "up2":
         res = rnd(G * n, h // 2, w // 2, cout, seed=275)
         kw.update(res=hip.Img(res.to(DEV)), res_mode=hip.RES_UP2_BEFORE_ACT, act=hip.ACT_RELU)
-    if extra == "scale_relu":
+    if extra in ("scale_relu", "stride2_scale"):
         sc, sh = rnd(G, npad, seed=276) * 0.2 + 1.0, rnd(G, npad, seed=277)
         if G == 1:
             sc, sh = sc[0], sh[0]
-        kw.update(scale=sc.to(DEV), shift=sh.to(DEV), act=hip.ACT_RELU)
+        kw.update(scale=sc.to(DEV), shift=sh.to(DEV), act=hip.ACT_RELU if extra == "scale_relu" else hip.ACT_NONE)
     saved = hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS
     hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = 0, 0.0
     try:
         outs = {}
         for tap in (1, 0):
             hip.lib.egr_conv_set_tap(tap)
-            outs[tap] = hip.conv2d(hip.Img(x.to(DEV)), hip.pack_w6(wp.to(DEV)), cout, 1, 1, 1, 0, **kw).t.permute(0, 3, 1, 2).clone()
+            outs[tap] = hip.conv2d(hip.Img(x.to(DEV)), hip.pack_w6(wp.to(DEV)), cout, 1, 1, stride, 0, **kw).t.permute(0, 3, 1, 2).clone()
             assert hip.lib.egr_conv_last_kernel() == (4 if tap else 1)
     finally:
         hip.lib.egr_conv_set_tap(1)
         hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = saved
     refs = []
     for g in range(G):
-        r = F.conv2d(x[g * n:(g + 1) * n].permute(0, 3, 1, 2).double(), wts[g].double(), None, 1, 0)
+        r = F.conv2d(x[g * n:(g + 1) * n].permute(0, 3, 1, 2).double(), wts[g].double(), None, stride, 0)
         rg = res[g * n:(g + 1) * n].permute(0, 3, 1, 2).double() if res is not None else None
-        if extra == "scale_relu":
+        if extra in ("scale_relu", "stride2_scale"):
             s_, b_ = (sc[g], sh[g]) if G > 1 else (sc, sh)
-            r = F.relu(r * s_[:cout].double().view(1, -1, 1, 1) + b_[:cout].double().view(1, -1, 1, 1))
+            r = r * s_[:cout].double().view(1, -1, 1, 1) + b_[:cout].double().view(1, -1, 1, 1)
+            if extra == "scale_relu":
+                r = F.relu(r)
         if extra == "res_before":
             r = F.relu(r + rg)
         if extra == "res_after":
