@@ -22,9 +22,9 @@ constexpr int WIMG = 2 << 20;            // weight image bytes walked by the B l
 // BSRC: 0 = B from global memory (one tap ahead), 1 = B from LDS, 2 = no B loads (registers only), AOFF: 1 = no A reads
 template <int FM, int FN, int OCC, int BSRC, int AOFF>
 __global__ __launch_bounds__(256, OCC) void feed_kernel(const uint8_t* __restrict__ wimg, float* __restrict__ out, int taps) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[ABYTES + 16384];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[ABYTES + 24576];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < (ABYTES + 16384) / 16; i += 256) reinterpret_cast<u32x4*>(lds)[i] = u32x4{0x3f803f80u + i, 0x3f003f80u, 0x3e803f80u ^ (unsigned)i, 0x3f803e80u};
+    for (int i = tid; i < (ABYTES + 24576) / 16; i += 256) reinterpret_cast<u32x4*>(lds)[i] = u32x4{0x3f803f80u + i, 0x3f003f80u, 0x3e803f80u ^ (unsigned)i, 0x3f803e80u};
     __syncthreads();
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(wimg), 0, WIMG, 0x00020000);
     int abase[FM];
@@ -63,10 +63,35 @@ __global__ __launch_bounds__(256, OCC) void feed_kernel(const uint8_t* __restric
     load_b(0, 0);
     read_a(0, 2); read_a(0, 0); read_a(0, 1);
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    // BSRC == 3: the tap's weights (4 fragments x 3 planes = 12 KiB for the 128 columns of the workgroup) go through LDS: every wave
+    // fetches a quarter (3 KiB) two taps ahead, writes it one tap ahead, ONE BARRIER PER TAP hands it over, every wave reads its FN
+    // fragments back.  (The real cost of sharing the weights between waves: the synchronisation.)
+    u32x4 stage[3];
+    auto fetch_q = [&](int tap) {
+        const int so = ((tap * 18432) & (WIMG - 1)) & ~1023;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) stage[pl] = __builtin_amdgcn_raw_buffer_load_b128(rb, wave * 3072 + pl * 1024 + lane * 16, so, 0);
+    };
+    auto write_q = [&](int tap) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(lds + ABYTES + (tap & 1) * 12288 + wave * 3072 + pl * 1024 + lane * 16) = stage[pl];
+    };
+    auto read_b = [&](int tap, int par) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                bf[par][j][pl] = *reinterpret_cast<const bf16x8*>(lds + ABYTES + (tap & 1) * 12288 + (((wave & 1) * FN + j) % 4) * 3072 + pl * 1024 + lane * 16);
+    };
+    if (BSRC == 3) { fetch_q(1); }
     for (int tap = 0; tap < taps; tap += 2) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            if (BSRC != 2) load_b(tap + u + 1, u ^ 1);
+            if (BSRC == 3) {
+                write_q(tap + u + 1);            // the quarter fetched during the previous tap
+                fetch_q(tap + u + 2);
+            }
+            if (BSRC != 2 && BSRC != 3) load_b(tap + u + 1, u ^ 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 6; ++t) {
@@ -78,6 +103,11 @@ __global__ __launch_bounds__(256, OCC) void feed_kernel(const uint8_t* __restric
                 if (!AOFF && (t == 0 || t == 3 || t == 5)) {
                     __builtin_amdgcn_sched_barrier(0);
                     read_a(tap + u + 1, t == 0 ? 2 : (t == 3 ? 1 : 0));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (BSRC == 3 && t == 3) {       // two thirds into the tap: hand the next tap's weights over, read them behind the rest
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    read_b(tap + u + 1, u ^ 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -124,6 +154,8 @@ int main() {
     run<2, 2, 2, 2, 1>("wave tile  64 x  64, 2 workgroups / CU, registers only", w, out);
     run<4, 2, 1, 0, 0>("wave tile 128 x  64, 1 workgroup  / CU, A from LDS, B from L2", w, out);
     run<4, 2, 1, 1, 0>("wave tile 128 x  64, 1 workgroup  / CU, A from LDS, B from LDS", w, out);
+    run<4, 2, 1, 3, 0>("wave tile 128 x  64, 1 workgroup  / CU, A from LDS, B staged through LDS (barrier per tap)", w, out);
+    run<2, 2, 2, 3, 0>("wave tile  64 x  64, 2 workgroups / CU, A from LDS, B staged through LDS (barrier per tap)", w, out);
     run<4, 4, 1, 0, 0>("wave tile 128 x 128, 1 workgroup  / CU, A from LDS, B from L2", w, out);
     run<4, 4, 1, 1, 0>("wave tile 128 x 128, 1 workgroup  / CU, A from LDS, B from LDS", w, out);
     run<4, 4, 1, 2, 1>("wave tile 128 x 128, 1 workgroup  / CU, registers only", w, out);
