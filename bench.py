@@ -80,13 +80,19 @@ def _host_cores() -> int:
     return max(1, min(n, int(os.environ.get("EGR_CPU_THREADS", "16"))))
 
 
+def _natural(path: str):
+    """Sort key that orders r02_v10 after r02_v9 (digits compared as numbers)."""
+    import re
+    return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(path))]
+
+
 def _pmc_traffic(batch: int, fmt: str = ""):
     """HBM bytes per launch of the conv kernel from the committed rocprofv3 PMC passes (profiles/*pmc_traffic.json,
     produced by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command, with the
     gfx950 x2 correction on FETCH_SIZE).  Counters cannot be collected from inside the timed run; null if the file
     is absent or was measured at another batch size."""
     import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*pmc_traffic.json")), key=_natural)
     if not files:
         return None
     try:
@@ -106,7 +112,7 @@ def _pmc_traffic_train(batch: int, key: str):
     """HBM bytes per launch of a training-step kernel from the committed PMC passes (profiles/*pmc_traffic_train.json, produced by
     tools/pmc_traffic_train.py from separate FETCH_SIZE / WRITE_SIZE runs of tools/train_bench.py); null if absent / other batch."""
     import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*pmc_traffic_train.json")))
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*pmc_traffic_train.json")), key=_natural)
     if not files:
         return None
     try:
