@@ -420,19 +420,26 @@ def _exchange_leg(tr, world: int, backend: str, dev):
     from egorear_amd.dist import allreduce_gradients_
     stages = []
     names = ["lifting head", "refiners", "initial heat-map heads", "encoders"]
-    for st, (b, e) in enumerate(tr.opt.stage_range):
+    for st, (b, e) in sorted(tr.opt.stage_range.items()):      # {gradient stage: [begin, end)} of the flat gradient buffer
         buf = tr.opt.flat_g[b:e]
         for _ in range(2):
             allreduce_gradients_(buf, tr.opt.pg)
-        torch.cuda.synchronize()
-        dist.barrier()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            allreduce_gradients_(buf, tr.opt.pg)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 5
+        if buf.is_cuda:
+            torch.cuda.synchronize()
+            dist.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                allreduce_gradients_(buf, tr.opt.pg)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+        else:                                            # host tensors (the gloo tests): wall clock
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                allreduce_gradients_(buf, tr.opt.pg)
+            ms = max((time.perf_counter() - t0) * 1e3 / 5, 1e-6)
         nbytes = 4 * (e - b)
         stages.append({"stage": names[st] if st < len(names) else str(st), "bytes": nbytes, "allreduce_ms": round(ms, 3),
                        "busbw_GBps": round(2.0 * (world - 1) / world * nbytes / ms / 1e6, 1)})

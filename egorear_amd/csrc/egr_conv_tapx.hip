@@ -1,0 +1,436 @@
+// 3x3 / pad 1 convolutions of the fp16 scheme (EGR_W_F16X2) on ROLE-SPLIT, persistent workgroups whose epilogue runs
+// under the next tile's K loop.  Forward launches, stride 1 and stride 2 (models/backbones/resnet.py:43-74, 121-137;
+// models/estimator/egoposeformer_heatmap_mvf_ex.py:101-126, 525-532, 570-584 in the reference).
+//
+// Why (profiles/r03_v2_tap_kernel_experiments.txt): vector-memory operations of a wave complete in order (one vmcnt).  In
+// conv_igemm_tap_kernel every wave requests the next chunk's activations (HBM, microseconds under load) and, behind them, the next
+// taps' weight fragments (L2): no weight fragment can be consumed before the older activation loads have landed, which costs that
+// kernel a fifth of its time.  Round 3's role-split prototype put the two streams into different waves and its K loop ran at 88 %
+// of the matrix pipe - but with every CU in lockstep its 128-KB tile epilogue was an exposed, HBM-write-bound phase.  Here:
+//   * waves 0-3 MULTIPLY (one per SIMD): wave tile 128 x 64 (4 x 2 accumulators of v_mfma_f32_32x32x16_f16, three products per
+//     fp32 product), weights from L2 straight into the B operand two taps ahead, A fragments from the fp16 planes in LDS.  At the
+//     end of a tile they park the accumulators (descaled) in a 64-KB LDS staging area, half a tile at a time, and go on with the
+//     next tile: ~3 k cycles per tile instead of the whole epilogue;
+//   * waves 4-7 LOAD: the activations of chunk c + 2 are requested while chunk c is multiplied, chunk c + 1 is split into the
+//     fp16 planes of the other LDS buffer - AND they run the previous tile's epilogue (BatchNorm scale / shift, residual,
+//     activation, abs-max record, 16-byte row stores) in slices behind the first four chunks of the current tile, the first half
+//     out of registers (so that the staging area is free for the second half after a few hundred cycles), the second out of LDS.
+//     The stores of a CU are spread over four chunk periods instead of arriving as one burst from all CUs.
+// One workgroup per CU walks tiles b, b + grid, ... in an XCD-contiguous order: the N tiles of one M tile run at the same time on
+// neighbouring CUs of ONE XCD, so the activations they share are fetched into one L2 once.
+// Stride 2: the nine taps fall into four classes by the parity of the input pixel they read (see conv_igemm_tap2_kernel); the
+// four class planes of a chunk are staged together and the taps are unit shifts inside their class plane - the multiplying waves
+// run the same code with another tap table.
+#include "egr_conv_shared.h"
+
+using namespace egrc;
+
+namespace {
+
+constexpr int XOOB = (int)0x80000000;   // buffer offset beyond every descriptor's range: loads return 0, stores are dropped
+
+// pixels of one 16-bit plane of a chunk
+//   stride 1: whole image rows ((BM / wo + 2) x (wo + 2)) or whole small images, wo in {8, 16, 32, 64}
+//   stride 2: four class planes of (BM / wo + 1) x (wo + 1) pixels (or whole small images), wo in {8, 16, 32}
+constexpr int tapx_cls(int bm) { return bm == 128 ? 168 : 336; }
+constexpr int tapx_hp(int bm, int stride) { return stride == 2 ? 4 * tapx_cls(bm) : (bm == 128 ? 264 : (bm == 256 ? 400 : 664)); }
+
+template <int WM, int WN, int STRIDE>
+__global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
+    static_assert(WM * WN == 4 && (STRIDE == 1 || STRIDE == 2), "four multiplying waves");
+    constexpr int NPL = 2, NPR = 3, FM = 4, FN = 2;
+    constexpr int BM = WM * 128, BN = WN * 64, NFB = BN / 32;
+    constexpr int HPX = tapx_hp(BM, STRIDE), CLS = tapx_cls(BM);
+    constexpr int PLANE = HPX * 32, HBUF = NPL * PLANE;
+    constexpr int STG = (BM / 2) * BN * 4;                    // half a tile of fp32 accumulators
+    constexpr int NUH = (HPX * 4 + 255) / 256;                // staging units (4 channels of one pixel) per loading thread and chunk
+    constexpr int QPR = BN / 4, RPE = 256 / QPR;              // epilogue: channel quads per row, rows covered by the 256 loading threads per step
+    static_assert(2 * HBUF + STG <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * HBUF + STG];
+    uint8_t* const lb = lds;
+    float* const stg = reinterpret_cast<float*>(lds + 2 * HBUF);
+
+    const egr_conv_desc& d = a.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int HoWo = d.ho * d.wo, wo = d.wo;
+    const int WP = wo + (STRIDE == 1 ? 2 : 1);
+    const int NI = HoWo >= BM ? 1 : BM / HoWo, RTI = HoWo >= BM ? BM / wo : d.ho;
+    const int HPI = (RTI + (STRIDE == 1 ? 2 : 1)) * WP, HP = NI * HPI, PPI = RTI * wo;
+    const int NC = a.cblocks * 2;                             // 16-channel chunks per tile (>= 4)
+    const int T_all = a.ntiles * d.groups;
+    // tile order: XCD x owns the contiguous run [x T/8, (x + 1) T/8) and deals it to its workgroups in order (blocks b and b + 8 share
+    // an XCD); the N tiles of an M tile are adjacent in a run.  Falls back to b, b + grid, ... when the counts do not divide.
+    const int grid = (int)gridDim.x, bid = (int)blockIdx.x;
+    const bool xmap = ((grid | T_all) & 7) == 0;
+    const int t_first = xmap ? (bid & 7) * (T_all >> 3) + (bid >> 3) : bid;
+    const int t_step = xmap ? (grid >> 3) : grid;
+    const int t_end = xmap ? ((bid & 7) + 1) * (T_all >> 3) : T_all;
+    if (t_first >= t_end) return;
+    const int my_tiles = (t_end - t_first + t_step - 1) / t_step;
+    const int abias = (d.w + 1) * d.ldx * 4;                  // the window starts one row + one pixel early: activation offsets >= 0
+
+    struct Tile { int grp, tm, tn, n0, y0, xbase; };
+    auto tile_of = [&](int t) __attribute__((always_inline)) {
+        Tile T;
+        T.grp = t / a.ntiles;
+        const int rem = t - T.grp * a.ntiles;
+        T.tm = (a.tilesN == 1) ? rem : fdiv(rem, a.dTilesN);
+        T.tn = rem - T.tm * a.tilesN;
+        const int m0 = T.tm * BM;
+        int pix0;
+        T.n0 = m0 >> a.howo_shift;                            // (the host sends power-of-two image sizes only: shifts, no division)
+        pix0 = m0 & (HoWo - 1);
+        T.y0 = pix0 >> a.wo_shift;
+        T.xbase = (int)fmap(d.xmap, a.dXin, T.n0);
+        return T;
+    };
+    const auto barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ loading waves
+        const int lt = tid - 256;
+        float sa, ads;
+        act_prescale(a.amax_in, lane, sa, ads);
+        int hvo[NUH];
+        u32x4 xr[2][NUH];                                     // two chunks of activations in flight
+        __amdgpu_buffer_rsrc_t ra;
+        int so_tile = 0;
+        auto setup = [&](int t) __attribute__((always_inline)) {    // the load cursor enters tile t
+            const Tile T = tile_of(t);
+            ra = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(reinterpret_cast<const char*>(a.x + T.grp * d.gx) - abias), 0, 0x80000000u, 0x00020000);
+            so_tile = __builtin_amdgcn_readfirstlane((T.xbase + STRIDE * T.y0 * d.w * d.ldx) * 4);
+#pragma unroll
+            for (int i = 0; i < NUH; ++i) {
+                // unit -> pixel of the chunk's planes: class | image of the tile | row | column
+                const int seg = (lt + 256 * i) & 3, pxl = (lt + 256 * i) >> 2;
+                const int q = STRIDE == 2 ? pxl / CLS : 0, hp = STRIDE == 2 ? pxl - q * CLS : pxl;
+                const int il = hp / HPI, hq = hp - il * HPI, hr = hq / WP, hc = hq - hr * WP;
+                // input pixel relative to (first output row's input row, column 0)
+                const int dy = STRIDE == 1 ? hr - 1 : 2 * hr - (q >> 1), ix = STRIDE == 1 ? hc - 1 : 2 * hc - (q & 1);
+                const bool ok = hp < HP && q < 4 && (unsigned)(STRIDE * T.y0 + dy) < (unsigned)d.h && (unsigned)ix < (unsigned)d.w;
+                const int ioff = (int)fmap(d.xmap, a.dXin, T.n0 + il) - T.xbase;
+                hvo[i] = ok ? (ioff + (dy * d.w + ix) * d.ldx) * 4 + seg * 16 + abias : XOOB;
+            }
+        };
+        auto issue = [&](const int SET, int ck) __attribute__((always_inline)) {      // (SET: a literal at every call site)
+            const int so = so_tile + ck * 64;
+#pragma unroll
+            for (int i = 0; i < NUH; ++i) xr[SET][i] = __builtin_amdgcn_raw_buffer_load_b128(ra, hvo[i], so, 0);
+        };
+        auto convert = [&](const int SET, int buf) __attribute__((always_inline)) {   // register set -> the fp16 planes of LDS buffer `buf`
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int i = 0; i < NUH; ++i) {
+                unsigned h0, l0, h1, l1;
+                split4_f16(__uint_as_float(xr[SET][i][0]), __uint_as_float(xr[SET][i][1]), __uint_as_float(xr[SET][i][2]), __uint_as_float(xr[SET][i][3]), sa, h0, l0, h1, l1);
+                if (lt + 256 * i < 4 * HPX) {
+                    uint8_t* dst = lb + buf * HBUF + (lt + 256 * i) * 8;
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+                    *reinterpret_cast<u32x2*>(dst + PLANE) = u32x2{l0, l1};
+                }
+            }
+        };
+        // load cursor (tile k of this workgroup, chunk); saturates at the very last chunk, which is then requested again (the same
+        // vector-memory operations on every path keep the compiler's vmcnt counts exact)
+        int lk = 0, lck = 0;
+        auto advance = [&]() __attribute__((always_inline)) {
+            if (lck + 1 < NC) ++lck;
+            else if (lk + 1 < my_tiles) { lck = 0; ++lk; setup(t_first + lk * t_step); }
+        };
+
+        // ---- epilogue state: the tile whose accumulators are parked (P), this thread's channel quad and its 16 + 16 rows
+        struct Pend { int grp, tm, tn, valid; };
+        Pend P = {0, 0, 0, 0};
+        f32x4 hold[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) hold[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 rr[8];                                          // residual quads of the NEXT drain step (requested one step ahead)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rr[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int cq = lt % QPR, sr0 = lt / QPR;
+        float amx = 0.f;
+        __amdgpu_buffer_rsrc_t ry, rr_;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        int co = 0;
+        bool live = false;
+        auto pend_setup = [&](const Pend& Q) __attribute__((always_inline)) {
+            ry = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.y + Q.grp * d.gy), 0, 0x80000000u, 0x00020000);
+            rr_ = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.res ? a.res + Q.grp * d.gr : a.y), 0, 0x80000000u, 0x00020000);
+            co = Q.tn * BN + cq * 4;
+            live = Q.valid && co < d.cout;
+            sc = f32x4{1.f, 1.f, 1.f, 1.f};
+            sh = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (live) {
+                if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + Q.grp * d.gp + co);
+                if (a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + Q.grp * d.gp + co);
+            }
+        };
+        // row of quad step e (0..15) of half H inside the tile, and its output / residual byte offsets
+        auto row_offsets = [&](int H, int e, int& yo, int& ro) __attribute__((always_inline)) {
+            const int sr = e * RPE + sr0;                                  // row of the half tile
+            const int R = (sr >> 6) * 128 + H * 64 + (sr & 63);
+            const int m = P.tm * BM + R;
+            const int n = m >> a.howo_shift, pix = m & (HoWo - 1);
+            yo = live ? ((int)fmap(d.ymap, a.dYin, n) + pix * d.ldy + co) * 4 : XOOB;
+            ro = (live && d.res_mode) ? ((int)fmap(d.rmap, a.dRin, n) + pix * d.ldr + co) * 4 : XOOB;
+        };
+        auto res_load = [&](int H, int es) __attribute__((always_inline)) {      // residual quad of step es of half H
+            int yo, ro;
+            row_offsets(H, es, yo, ro);
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr_, ro, 0, 0));
+        };
+        auto finish = [&](f32x4 v, const f32x4& rr, int yo) __attribute__((always_inline)) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float t = v[c] * sc[c] + sh[c];
+                if (d.res_mode == EGR_RES_BEFORE_ACT) t += rr[c];
+                if (d.act == EGR_ACT_RELU) t = t > 0.f ? t : 0.f;
+                if (d.res_mode == EGR_RES_AFTER_ACT) t += rr[c];
+                v[c] = t;
+            }
+            if (live) amx = fmaxf(fmaxf(amx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, yo, 0, 0);
+        };
+        // drain step K of the parked tile: K = 0, 1 out of the registers (first half), K = 2, 3 out of the staging area (second half);
+        // behind every quad the residual of the same slot of the NEXT step is requested (a whole chunk period to land)
+        auto drain = [&](const int K) __attribute__((always_inline)) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int H = K >> 1, es = (K & 1) * 8 + e;
+                int yo, ro;
+                row_offsets(H, es, yo, ro);
+                f32x4 v;
+                if (K < 2) v = hold[es];
+                else v = *reinterpret_cast<const f32x4*>(stg + (es * RPE + sr0) * BN + cq * 4);
+                finish(v, rr[e], yo);
+                if (K < 3) rr[e] = res_load((K + 1) >> 1, ((K + 1) & 1) * 8 + e);
+            }
+        };
+
+        setup(t_first);
+        issue(0, 0);                                          // chunks 0, 1 -> sets 0, 1
+        advance(); issue(1, lck);
+        convert(0, 0);
+        advance(); issue(0, lck);                             // chunk 2
+        barrier();                                            // chunk 0 staged
+        // chunk step (the multiplying waves work on chunk ck of the current tile): the chunk after it (register set SET) -> the other
+        // LDS buffer, then the set is reloaded with the chunk three after it
+        int it = 0;
+        const int total = my_tiles * NC;
+        auto step = [&](const int SET) __attribute__((always_inline)) {
+            if (it + 1 < total) convert(SET, (it + 1) & 1);
+            advance(); issue(SET, lck);
+            ++it;
+        };
+        for (int k = 0; k < my_tiles; ++k) {
+            // the first four chunks of a tile carry the parked tile's epilogue (NC is even: chunk ck converts set (ck + 1) & 1)
+            step(1); drain(0); barrier();
+            step(0); drain(1); barrier();
+            step(1); drain(2); barrier();
+            step(0); drain(3); barrier();
+            for (int ck = 4; ck < NC; ck += 2) {
+                step(1); barrier();
+                step(0); barrier();
+            }
+            // ---- tile k is complete: its accumulators arrive through the staging area, half a tile at a time
+            const Tile Tk = tile_of(t_first + k * t_step);
+            P = Pend{Tk.grp, Tk.tm, Tk.tn, 1};
+            pend_setup(P);
+            barrier();                                        // X1: first half staged
+#pragma unroll
+            for (int e = 0; e < 16; ++e) hold[e] = *reinterpret_cast<const f32x4*>(stg + (e * RPE + sr0) * BN + cq * 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rr[e] = res_load(0, e);
+            barrier();                                        // X2: staging area free again
+            barrier();                                        // X3: second half staged
+        }
+        drain(0);
+        drain(1);
+        drain(2);
+        drain(3);
+        if (a.amax_out) amax_flush(a.amax_out, amx, bid * 4 + wave);
+        return;
+    }
+
+    // ---------------------------------------------------------------------- multiplying waves
+    const int wm = wave / WN, wn = wave % WN;
+    float sa_unused, ads;
+    act_prescale(a.amax_in, lane, sa_unused, ads);
+    int abase[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int ml = wm * 128 + i * 32 + l31, il = ml / PPI, mq = ml - il * PPI, r = mq / wo, c = mq - r * wo;
+        abase[i] = (il * HPI + r * WP + c) * 32 + half * 16;
+    }
+    // the nine taps in the order they are multiplied: byte offset of the tap's window inside a plane, index of its weights
+    //   stride 1: tap (kh, kw) = the window shifted by (kh, kw) pixels
+    //   stride 2: class order (even, even) | (even, odd) x 2 | (odd, even) x 2 | (odd, odd) x 4; unit shifts inside the class plane
+    constexpr int TID[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};
+    constexpr int TCL[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
+    constexpr int TDR[9] = {0, 0, 0, 0, 1, 0, 0, 1, 1};
+    constexpr int TDC[9] = {0, 0, 1, 0, 0, 0, 1, 0, 1};
+    auto tap_off = [&](int tap) __attribute__((always_inline)) {
+        return STRIDE == 1 ? ((tap / 3) * WP + (tap % 3)) * 32 : TCL[tap] * CLS * 32 + (TDR[tap] * WP + TDC[tap]) * 32;
+    };
+    auto tap_w = [&](int tap) __attribute__((always_inline)) { return STRIDE == 1 ? tap : TID[tap]; };
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    u32x4 af[FM][NPL], bf[3][FN][NPL];
+
+    const int FSTR = a.ktiles * 2 * NPL * 1024;              // bytes between column fragments of the weight image
+    struct WTile { __amdgpu_buffer_rsrc_t rb; int bvo; };
+    auto wtile_of = [&](const Tile& T) __attribute__((always_inline)) {
+        WTile W;
+        W.rb = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(reinterpret_cast<const uint8_t*>(a.w) + (int64_t)T.grp * d.gw * 2), 0, 0x80000000u, 0x00020000);
+        W.bvo = (T.tn * NFB + wn * FN) * FSTR + lane * 16;
+        return W;
+    };
+    auto load_b = [&](const WTile& W, int ck, int tap, int set) __attribute__((always_inline)) {
+        const int so = (((ck >> 1) * 9 + tap_w(tap)) * 2 * NPL + (ck & 1) * NPL) * 1024;
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) bf[set][j][pl] = __builtin_amdgcn_raw_buffer_load_b128(W.rb, W.bvo + j * FSTR + pl * 1024, so, 0);
+    };
+    auto read_a = [&](int base, int tap, int pl) __attribute__((always_inline)) {
+        const int to = tap_off(tap);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[i][pl] = *reinterpret_cast<const u32x4*>(lb + base + pl * PLANE + abase[i] + to);
+    };
+    // one chunk out of LDS buffer `base`; the weights of the position two taps ahead are requested in front of each tap's MFMAs
+    // (X: the tile the chunk after this one belongs to, ckn its index there; behind the very last chunk they re-read the first
+    // weights, harmlessly)
+    auto chunk = [&](int base, int ck, const WTile& W, const WTile& X, int ckn) __attribute__((always_inline)) {
+        read_a(base, 0, 1);
+        read_a(base, 0, 0);
+        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int pc = tap % 3, pn = (tap + 2) % 3;
+            if (tap + 2 < 9) load_b(W, ck, tap + 2, pn);
+            else load_b(X, ckn, tap + 2 - 9, pn);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NPR; ++t) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        acc[i][j] = mfma_split<NPL>(af[i][PA[t]], bf[pc][j][PB[t]], acc[i][j]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                if (tap + 1 < 9 && split_free_a(NPL, t) >= 0) {
+                    read_a(base, tap + 1, split_free_a(NPL, t));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    };
+    // park half H (fragment rows 2H, 2H + 1 of every wave) of the accumulators in the staging area, descaled; clear them
+    auto park = [&](const Tile& T, const int H) __attribute__((always_inline)) {
+        const float* const wdsg = a.wds + T.grp * d.gp;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int col = wn * 64 + j * 32 + l31;
+            const float dsc = ads * wdsg[T.tn * BN + col];
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int sr = wm * 64 + ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    stg[sr * BN + col] = acc[2 * H + ii][j][r] * dsc;
+                    acc[2 * H + ii][j][r] = 0.f;
+                }
+        }
+    };
+
+    Tile T = tile_of(t_first);
+    WTile W = wtile_of(T);
+    load_b(W, 0, 0, 0);
+    load_b(W, 0, 1, 1);
+    barrier();                                                // chunk 0 staged
+    int it = 0;
+    for (int k = 0; k < my_tiles; ++k) {
+        const bool has_next = k + 1 < my_tiles;
+        const Tile Tn = has_next ? tile_of(t_first + (k + 1) * t_step) : T;
+        const WTile Wn = wtile_of(Tn);
+        for (int ck = 0; ck + 1 < NC; ++ck) {
+            chunk((it & 1) * HBUF, ck, W, W, ck + 1);
+            barrier();
+            ++it;
+        }
+        chunk((it & 1) * HBUF, NC - 1, W, Wn, 0);
+        barrier();
+        ++it;
+        park(T, 0);
+        barrier();                                            // X1
+        barrier();                                            // X2: the loading waves hold the first half in registers
+        park(T, 1);
+        barrier();                                            // X3
+        T = Tn;
+        W = Wn;
+    }
+}
+
+int g_tapx = getenv("EGR_CONV_TAPX") ? atoi(getenv("EGR_CONV_TAPX")) : 1;                          // 0: the 3x3 launches stay on conv_igemm_tap[2]_kernel
+int g_tapx_min_tiles = getenv("EGR_CONV_TAPX_MIN_TILES") ? atoi(getenv("EGR_CONV_TAPX_MIN_TILES")) : 256; // tiles (all groups) from which the role-split kernel is used
+int g_tapx_blocks = getenv("EGR_CONV_TAPX_BLOCKS") ? atoi(getenv("EGR_CONV_TAPX_BLOCKS")) : 256;    // resident workgroups (one per CU)
+
+}  // namespace
+
+namespace egrc {
+
+int tapx_set(int on, int min_tiles, int blocks) {
+    if (on >= 0) g_tapx = on;
+    if (min_tiles >= 0) g_tapx_min_tiles = min_tiles;
+    if (blocks > 0) g_tapx_blocks = blocks;
+    return 0;
+}
+
+// Launch conv_tapx_kernel if the problem is one it covers: returns TAPX_NO (nothing launched) or the launch status.
+// `a` arrives from conv_run with the geometry fields filled in (M, Npad, K, cblocks, ktiles, *_shift, *_plain, vec_ok, cls_mode).
+int tapx_try(ConvArgs& a, int64_t yspan_floats, int64_t rspan_floats, hipStream_t stream) {
+    egr_conv_desc& d = a.d;
+    if (!g_tapx || d.w_format != EGR_W_F16X2 || d.kh != 3 || d.kw != 3 || d.pad != 1 || d.transposed || a.cls_mode || d.split_k > 1 ||
+        d.out_nchw || a.rowscale || a.rowmask || a.mask || a.bn_part || !a.vec_ok || d.cout % 4 != 0 || d.cin < 64 ||
+        (d.act != EGR_ACT_NONE && d.act != EGR_ACT_RELU) || d.res_mode == EGR_RES_UP2_BEFORE_ACT || a.dbg)
+        return TAPX_NO;
+    if (yspan_floats * 4 >= (1LL << 31) || (d.res_mode && rspan_floats * 4 >= (1LL << 31))) return TAPX_NO;   // 32-bit byte offsets in the epilogue
+    const int P = d.ho * d.wo;
+    int wm = 0, wn = 0;
+    if (d.stride == 1) {
+        if (!(d.wo == 8 || d.wo == 16 || d.wo == 32 || d.wo == 64) || d.ho != d.h || d.wo != d.w) return TAPX_NO;
+        if (a.Npad % 128 == 0) { wm = 2; wn = 2; }
+        else if (a.Npad % 64 == 0) { wm = 4; wn = 1; }
+        else return TAPX_NO;
+    } else if (d.stride == 2) {
+        if (!(d.wo == 8 || d.wo == 16 || d.wo == 32) || d.h != 2 * d.ho || d.w != 2 * d.wo || a.Npad % 256 != 0) return TAPX_NO;
+        wm = 1; wn = 4;
+    } else return TAPX_NO;
+    const int bm = wm * 128, bn = wn * 64;
+    if (a.M % bm != 0 || !((P % bm == 0) || (bm % P == 0)) || a.howo_shift < 0 || a.wo_shift < 0) return TAPX_NO;
+    const int ext = d.stride == 1 ? 2 : 1;
+    const int hp = P >= bm ? (bm / d.wo + ext) * (d.wo + ext) : (bm / P) * (d.ho + ext) * (d.wo + ext);
+    if (hp > (d.stride == 1 ? tapx_hp(bm, 1) : tapx_cls(bm)) || (bm / P) > 15) return TAPX_NO;
+    const int64_t tiles = (int64_t)(a.M / bm) * (a.Npad / bn) * d.groups;
+    if (tiles < g_tapx_min_tiles || tiles >= (1 << 30)) return TAPX_NO;
+    d.split_k = 1;
+    a.ktiles_per_split = a.ktiles;
+    a.tilesM = a.M / bm;
+    a.tilesN = a.Npad / bn;
+    a.dTilesN = make_fastdiv(a.tilesN);
+    a.ntiles = a.tilesM * a.tilesN;
+    const unsigned grid = (unsigned)(tiles < g_tapx_blocks ? tiles : g_tapx_blocks);
+    if (d.stride == 2) hipLaunchKernelGGL((conv_tapx_kernel<1, 4, 2>), dim3(grid), dim3(512), 0, stream, a);
+    else if (wn == 2) hipLaunchKernelGGL((conv_tapx_kernel<2, 2, 1>), dim3(grid), dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((conv_tapx_kernel<4, 1, 1>), dim3(grid), dim3(512), 0, stream, a);
+    return egr_launch_status();
+}
+
+}  // namespace egrc

@@ -27,7 +27,7 @@ EXPORTS = [
     "egr_device_arch", "egr_conv_force_config", "egr_preprocess_u8_f32", "egr_pose_metrics_f32", "egr_gt_heatmap_f32", "egr_conv_debug_stamps", "egr_conv2d_wgrad_f32", "egr_conv2d_masked_f32", "egr_up2_relu_head_f32",
     "egr_msda_fwd_f32", "egr_msda_bwd_f32", "egr_w6_elems", "egr_pack_w6_f32", "egr_pack_w6_many_f32", "egr_joint_layer_f32",
     "egr_preprocess_fused_u8_f32", "egr_preprocess_band_rows", "egr_conv_set_persist", "egr_stem_conv7x7_pool_f32",
-    "egr_stem_w6_bytes", "egr_pack_stem_w6_f32", "egr_stem_conv7x7_x6_f32", "egr_wgrad_last_kernel", "egr_conv_last_kernel", "egr_conv_set_tap", "egr_conv_set_splitk_fused", "egr_fisheye_project2_f32", "egr_pack_layer_w_f32",
+    "egr_stem_w6_bytes", "egr_pack_stem_w6_f32", "egr_stem_conv7x7_x6_f32", "egr_wgrad_last_kernel", "egr_conv_last_kernel", "egr_conv_set_tap", "egr_conv_set_tapx", "egr_conv_set_splitk_fused", "egr_fisheye_project2_f32", "egr_pack_layer_w_f32",
     "egr_conv2d_nhwc_ex_f32", "egr_wh2_elems", "egr_pack_wh2_f32", "egr_absmax_f32", "egr_stem_conv7x7_x6_ex_f32", "egr_stem_wh2_bytes", "egr_pack_stem_wh2_f32", "egr_stem_conv7x7_h2_f32",
     "egr_pack_wh2_many_f32", "egr_conv2d_masked_ex_f32", "egr_conv2d_wgrad_ex_f32", "egr_wgrad_last_h2",
     "egr_wstream_image_bytes", "egr_pack_wstream_f32", "egr_linear_wstream_workspace_bytes", "egr_linear_wstream_f32",
@@ -91,6 +91,7 @@ def _load() -> C.CDLL:
     lib.egr_wgrad_last_kernel.argtypes = []
     lib.egr_conv_last_kernel.argtypes = []
     lib.egr_conv_set_tap.argtypes = [i32]
+    lib.egr_conv_set_tapx.argtypes = [i32, i32, i32]
     lib.egr_conv_set_splitk_fused.argtypes = [i32]
     lib.egr_stem_w6_bytes.restype = C.c_int64
     lib.egr_stem_w6_bytes.argtypes = []

@@ -102,6 +102,12 @@ class PipelinedForward:
         self.k += 1
         s = self.streams[i]
         s.wait_stream(torch.cuda.current_stream())          # the inputs were produced on the caller's stream
+        if self.forwards[i].copy_inputs:
+            # the copy into the lane's static input runs on the LANE's stream, up to two replays later: keep the caching allocator
+            # from handing the caller's tensor to someone else before that copy has read it
+            for a in args:
+                if isinstance(a, torch.Tensor) and a.is_cuda:
+                    a.record_stream(s)
         with torch.cuda.stream(s):
             return self.forwards[i](*args)
 

@@ -1,6 +1,7 @@
 """N > 1 plumbing on CPU: two gloo ranks, frame sharding without a collective, barrier-fenced timing with max over ranks."""
 import os
 import socket
+import sys
 
 import torch
 import torch.distributed as dist
@@ -296,3 +297,43 @@ def test_two_skewed_ranks_exchange_the_stage_buckets_in_tape_order_without_deadl
     assert g0[1] == g0[2] == g1[1] == g1[2] == 3.0                # every element of every bucket summed exactly once (1 + 2)
     assert g0[3] == g1[3] == N_GRAD_STAGES                        # one asynchronous all-reduce per stage
     assert g1[4] > g0[4] + 0.5                                    # rank 1 really was late; rank 0 did not wait to ISSUE its buckets
+
+
+# --------------------------------------------------------------------------- bench.py's gradient-exchange leg
+
+def _exchange_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import types
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        # a stand-in for train.Trainer: the flat gradient buffer and its {stage: [begin, end)} buckets (train.flat_layout)
+        flat = torch.full((1000,), float(rank + 1))
+        tr = types.SimpleNamespace(opt=types.SimpleNamespace(stage_range={2: [600, 1000], 0: [0, 100], 1: [100, 600], 3: [1000, 1000]},
+                                                             flat_g=flat, pg=None))
+        rec = bench._exchange_leg(tr, world, "gloo", torch.device("cpu"))
+        if rank == 0:
+            out.put(rec)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_exchange_leg_walks_the_stage_buckets():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    rec = out.get(timeout=60)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [st["bytes"] for st in rec["stages"]] == [400, 2000, 1600, 0]          # stage order 0, 1, 2, 3
+    assert [st["stage"] for st in rec["stages"]] == ["lifting head", "refiners", "initial heat-map heads", "encoders"]
+    assert rec["bytes_per_step"] == 4000 and rec["communicator_size"] == 2
+    assert all(st["allreduce_ms"] > 0 for st in rec["stages"])

@@ -18,6 +18,16 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True, scope="module")
+def _tap_kernels_only():
+    """This module pins the tap-sharing kernels (ids 2 / 3); the role-split kernel that takes their large launches has its own
+    module (test_gpu_conv_tapx.py)."""
+    from egorear_amd import hip
+    hip.lib.egr_conv_set_tapx(0, -1, -1)
+    yield
+    hip.lib.egr_conv_set_tapx(1, -1, -1)
+
+
 def record_of(t: torch.Tensor, slot: int = 0) -> torch.Tensor:
     """An abs-max record (64 int32 slots of float bits) holding max |t| in one slot, as a producing launch would leave it."""
     rec = torch.zeros(64, dtype=torch.int32)

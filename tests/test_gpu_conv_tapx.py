@@ -1,0 +1,138 @@
+"""conv_tapx_kernel (egorear_amd/csrc/egr_conv_tapx.hip): the fp16 scheme's 3x3 / pad 1 forward launches on role-split persistent
+workgroups - four multiplying waves, four waves that load / split the activations and run the PREVIOUS tile's epilogue under the
+current tile's K loop (accumulators handed over through a 64-KB LDS staging area, half a tile at a time).  Forced here from one
+tile up and with fewer workgroups than tiles, so that a workgroup walks several tiles, groups and column tiles, with the
+XCD-contiguous tile order (8 workgroups) and the plain one (5).  Against fp64, the fp32 launch, the bf16 scheme - and bit for bit
+against the tap-sharing kernels it replaces (same products in the same order)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_gpu_conv_h2 import DEV, _epilogue_kw, _reference, check, record_of, record_value, three
+from test_gpu_conv_x6 import pack_w, rnd
+
+pytestmark = pytest.mark.gpu
+
+S1_CASES = [
+    # n, h(=w), cin, cout, groups, extras
+    (2, 64, 64, 64, 1, "res_before"),          # 512 x 64 tiles (eight image rows), residual + ReLU, four chunks = the epilogue slices fill the K loop
+    (8, 32, 128, 128, 2, "scale_relu"),        # 256 x 128 tiles, grouped, BatchNorm affine + ReLU
+    (4, 64, 96, 256, 1, "res_after"),          # six chunks, two column tiles per row tile, residual behind the activation
+    (32, 64, 64, 128, 1, "scale_relu"),        # 512 tiles
+    (16, 64, 64, 64, 1, "res_before"),         # 128 tiles of 512 x 64
+    (256, 16, 64, 192, 1, "scale_relu"),       # 512 x 64 tiles = two whole 16 x 16 images, three column tiles
+    (128, 8, 128, 128, 1, "plain"),            # 8 x 8 images: a 256-pixel tile is four whole images
+    (24, 16, 256, 512, 2, "res_before"),       # layer3 / layer4 like: sixteen chunks, four column tiles, grouped, tile count not a multiple of 8
+    (6, 32, 64, 128, 1, "plain"),              # 24 tiles: the last round of the walk is ragged
+]
+S2_CASES = [
+    # n, h(=w, input), cin, cout, groups, extras
+    (16, 32, 128, 256, 2, "scale_relu"),       # layer3 entry, grouped: 16 x 16 outputs, a tile is half an image
+    (64, 16, 256, 512, 1, "plain"),            # layer4 entry: 8 x 8 outputs, a tile is two whole images, two column tiles
+    (4, 64, 64, 256, 1, "scale_relu"),         # 32-pixel output rows: four rows per tile
+    (8, 64, 128, 512, 2, "res_after"),         # the refiners' 256 -> 512 geometry (narrower), residual behind the ReLU
+    (6, 32, 96, 256, 1, "plain"),              # six chunks, 12 tiles
+]
+
+
+@pytest.fixture(params=[5, 8], ids=["5wg", "8wg"])
+def tapx(request):
+    from egorear_amd import hip
+    hip.lib.egr_conv_set_tapx(1, 1, request.param)
+    yield hip
+    hip.lib.egr_conv_set_tapx(1, 256, 256)
+
+
+def _run(hip, case, stride, seed):
+    n, hw, cin, cout, G, extra = case
+    ho = hw // stride
+    x = rnd(G * n, hw, hw, cin, seed=seed)
+    wts = [rnd(cout, cin, 3, 3, seed=seed + 1 + g, scale=1.0 / math.sqrt(9 * cin)) for g in range(G)]
+    wp = torch.stack([pack_w(t) for t in wts]) if G > 1 else pack_w(wts[0])
+    kw, res, sc, sh = _epilogue_kw(hip, extra, G, n, ho, ho, cout, wp.shape[-2], seed + 5)
+    a, b, c, kern, rec = three(hip, hip.Img(x.to(DEV)), wp, cout, 3, 3, stride, 1, **kw)
+    assert kern == 6, "the role-split kernel must carry this launch"
+    ref = _reference(x, wts, G, n, stride, 1, extra, res, sc, sh, cout)
+    check(a.t.permute(0, 3, 1, 2), b.t.permute(0, 3, 1, 2), c.t.permute(0, 3, 1, 2), ref, rec, f"tapx s{stride} {case}")
+    # the kernels it replaces: same products, same order
+    hip.lib.egr_conv_set_tapx(0, -1, -1)
+    try:
+        _, _, c0, kern0, rec0 = three(hip, hip.Img(x.to(DEV)), wp, cout, 3, 3, stride, 1, **kw)
+    finally:
+        hip.lib.egr_conv_set_tapx(1, -1, -1)
+    assert kern0 in (1, 2, 3)
+    if kern0 == 1:        # (too few rows for the tap-sharing kernels: the generic split kernel walks the taps in another order)
+        assert float((c.t - c0.t).abs().max()) <= 2e-6 * float(c0.t.abs().max()), case
+    else:
+        assert torch.equal(c.t, c0.t), (case, float((c.t - c0.t).abs().max()))
+        assert record_value(rec) == record_value(rec0)
+
+
+@pytest.mark.parametrize("case", S1_CASES)
+def test_role_split_stride1(tapx, case):
+    _run(tapx, case, 1, 70)
+
+
+@pytest.mark.parametrize("case", S2_CASES)
+def test_role_split_stride2(tapx, case):
+    _run(tapx, case, 2, 170)
+
+
+def test_launches_outside_its_cover_stay_on_the_tap_kernels(tapx):
+    hip = tapx
+    for (n, hw, cin, cout, stride, want) in [(32, 16, 32, 192, 1, 2),      # two chunks only
+                                             (512, 8, 64, 64, 1, 2),      # 512 x 64 tiles would need eight whole images' halo
+                                             (8, 64, 64, 128, 2, 3),      # stride 2 with 128 output channels
+                                             (9, 32, 64, 62, 1, 2)]:      # channel count not a multiple of four
+        x = rnd(n, hw, hw, cin, seed=1)
+        wt = rnd(cout, cin, 3, 3, seed=2, scale=1.0 / math.sqrt(9 * cin))
+        a, b, c, kern, rec = three(hip, hip.Img(x.to(DEV)), pack_w(wt), cout, 3, 3, stride, 1)
+        assert kern == want, (n, hw, cin, cout, stride, kern)
+        ref = F.conv2d(x.permute(0, 3, 1, 2).double(), wt.double(), None, stride, 1)
+        check(a.t.permute(0, 3, 1, 2), b.t.permute(0, 3, 1, 2), c.t.permute(0, 3, 1, 2), ref, rec, "fallback")
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_operand_placement_nan_and_scales(tapx, stride):
+    """Input as a channel slice behind an image map, output into a channel slice of a wider tensor (its neighbours untouched); a NaN
+    reaches exactly the outputs that see it; operands far outside fp16's range."""
+    hip = tapx
+    V, B, h, cin, cout = 4, 8, 32, 64, 256
+    n, ho = V * B, h // stride
+    x = rnd(n, h, h, cin, seed=411) * 3e-5
+    stored = torch.zeros(B, V, h, h, 2 * cin)
+    stored[..., cin:] = x.view(V, B, h, h, cin).permute(1, 0, 2, 3, 4)
+    stored[..., :cin] = 9.0
+    stored = stored.to(DEV)
+    wt = rnd(cout, cin, 3, 3, seed=412, scale=1.0 / math.sqrt(9 * cin)) * 2e3
+    ref = F.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), wt.double(), None, stride, 1))
+    img = h * h * 2 * cin
+    saved = hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS
+    hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = 0, 0.0
+    try:
+        w6 = hip.add_wh2(hip.pack_w6(pack_w(wt).to(DEV)))
+        cat = torch.full((n, ho, ho, 2 * cout), 5.0, device=DEV)
+        rec = torch.zeros(64, dtype=torch.int32, device=DEV)
+        out = hip.Img(cat[..., cout:])
+        hip.conv2d(hip.Img(stored.view(n, h, h, 2 * cin)[..., cin:], amax=record_of(x)), w6, cout, 3, 3, stride, 1, act=hip.ACT_RELU,
+                   xmap=hip.NMap(B, V * img, img), out=out, amax_out=rec)
+        assert hip.lib.egr_conv_last_kernel() == 6
+        got = cat[..., cout:].permute(0, 3, 1, 2).double().cpu()
+        assert float((got - ref).abs().max()) / float(ref.abs().max()) <= 2e-5
+        assert float((cat[..., :cout] - 5.0).abs().max()) == 0
+        assert record_value(rec) == float(got.abs().max())
+        xn = x.clone()
+        xn[3, 10, 10, 5] = float("nan")
+        y = hip.conv2d(hip.Img(xn.to(DEV), amax=record_of(x)), w6, cout, 3, 3, stride, 1).t.cpu()
+        assert hip.lib.egr_conv_last_kernel() == 6
+        bad = torch.isnan(y).any(-1)
+        want = torch.zeros_like(bad)
+        for oy in range(ho):
+            for ox in range(ho):
+                if abs(oy * stride - 10) <= 1 and abs(ox * stride - 10) <= 1:
+                    want[3, oy, ox] = True
+        assert torch.equal(bad, want)
+    finally:
+        hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = saved
