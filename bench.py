@@ -50,6 +50,9 @@ X6_TERMS = 6                   # bf16 products per fp32 product in the split-bf1
 H2_TERMS = 3                   # fp16 products per fp32 product in the fp16-scheme launches; v_mfma_f32_32x32x16_f16 has the bf16 form's rate
 W_FORMAT = os.environ.get("EGR_W_FORMAT", "f16x2")
 PEAK_HBM_GBS = 8000.0
+# the arithmetic type the path computes in (fp32 tensors and accumulators; what the large contractions multiply in follows EGR_W_FORMAT)
+DTYPE_NOTE = {"f16x2": "f32 (fp16x2 split, 22-bit operands, fp32 accumulate)", "bf16x3": "f32 (bf16x3 split, exact operands, fp32 accumulate)"}.get(
+    os.environ.get("EGR_W_FORMAT", "f16x2"), "f32")
 ARITHMETIC = {
     "f16x2": ("fp32 tensors, fp32 accumulation; conv / linear contractions with >= 4096 rows run on the fp16 matrix cores: both operands as two "
               "fp16 planes of the value times an exact power of two (22 significant bits; pre-scale from the producing launch's abs-max record), "
@@ -72,6 +75,39 @@ def _kernel_key(name: str, tag: str) -> str:
     if tag.startswith("x6 ") or " x6 " in tag:
         return name + "[bf16x3]"
     return name
+
+
+def _family(key: str, tag: str):
+    """The implicit-GEMM entry point's split launches fall into two families with different roofs: the 3x3 convolutions (matrix-core
+    bound: conv_tapx_kernel / conv_igemm_tap[2]_kernel) and the 1x1 convolutions / linears (HBM bound at these channel counts:
+    conv_pw_x6_kernel and the tiled kernels)."""
+    if not (key.endswith("[f16x2]") or key.endswith("[bf16x3]")):
+        return None
+    fmt = key[key.index("["):]
+    if " k3s" in tag:
+        return "conv3x3" + fmt
+    if " k1s" in tag:
+        return "conv1x1" + fmt
+    return "other" + fmt
+
+
+def _family_roofs(fams: dict) -> dict:
+    """Each family of the dominant entry point against ITS OWN roof, from the same instrumented forward as `roofline`."""
+    out = {}
+    for name, k in sorted(fams.items()):
+        if k["ms"] <= 0:
+            continue
+        terms = H2_TERMS if name.endswith("[f16x2]") else X6_TERMS
+        alg = k["flops"] / (k["ms"] * 1e-3) / 1e12
+        gbs = k["bytes"] / (k["ms"] * 1e-3) / 1e9
+        mfma = {"achieved": round(alg * terms, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(alg * terms / PEAK_BF16_MFMA_TFLOPS, 4),
+                "algorithmic_tflops": round(alg, 1), "frac_algorithmic": round(alg / PEAK_BF16_MFMA_TFLOPS, 4)}
+        hbm = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+               "what": "algorithmic bytes (input once, output once, weights once) / measured time"}
+        bound = "mfma" if name.startswith("conv3x3") else "hbm"
+        out[name] = {"bound": bound, **(mfma if bound == "mfma" else hbm), "other_roof": hbm if bound == "mfma" else mfma,
+                     "launches_per_step": k["launches"], "kernel_ms_per_step": round(k["ms"], 3)}
+    return out
 
 
 def parse():
@@ -111,6 +147,9 @@ def _natural(path: str):
     return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(path))]
 
 
+_TRAFFIC_SOURCE = {}
+
+
 def _pmc_traffic(batch: int, fmt: str = "", launches_per_step: int = 0):
     """HBM bytes per launch of the conv kernel from the committed rocprofv3 PMC passes (profiles/*pmc_traffic.json,
     produced by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command, with the
@@ -133,6 +172,9 @@ def _pmc_traffic(batch: int, fmt: str = "", launches_per_step: int = 0):
             return None
         if launches_per_step and e.get("launches_per_forward") not in (None, launches_per_step):
             return None
+        # provenance: PMC counters cannot be read inside the timed run - the value is REPLAYED from the committed passes of this command
+        _TRAFFIC_SOURCE["file"] = {"replayed_from": os.path.relpath(files[-1], REPO), "commit": t.get("commit"),
+                                   "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH x 2 on gfx950); null when the launch count of this run differs"}
         return e["hbm_bytes_per_launch"]
     except Exception:
         return None
@@ -171,6 +213,8 @@ def _roofline(key: str, k: dict, traffic):
          "traffic": traffic, "launches_per_step": k["launches"], "avg_launch_us": round(1e3 * k["ms"] / k["launches"], 2),
          "flops_per_launch": round(k["flops"] / k["launches"], 1), "algorithmic_bytes_per_launch": round(k["bytes"] / k["launches"], 1),
          "kernel_ms_per_step": round(k["ms"], 3), "algorithmic_tflops": round(alg, 2),
+         "frac_algorithmic": round(alg / (PEAK_BF16_MFMA_TFLOPS if (x6 or h2) else PEAK_F32_MFMA_TFLOPS), 4),
+         "traffic_source": _TRAFFIC_SOURCE.get("file") if traffic is not None else None,
          # the same computation priced against the roof it faced before (and still faces with EGR_W_FORMAT=f32)
          "algorithmic_frac_of_f32_mfma_peak": round(alg / PEAK_F32_MFMA_TFLOPS, 4)}
     if x6:
@@ -653,16 +697,22 @@ def main():
             step()
             torch.cuda.synchronize()
             prof, hip.PROFILE = hip.PROFILE, None
+            fams = {}
             for name, s, e, flops, nbytes, tag in prof:
                 key = _kernel_key(name, tag)
-                k = kernels.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
-                k["launches"] += 1
-                k["ms"] += s.elapsed_time(e)
-                k["flops"] += flops
-                k["bytes"] += nbytes
+                ms_l = s.elapsed_time(e)
+                for dst, kk in ((kernels, key), (fams, _family(key, tag))):
+                    if kk is None:
+                        continue
+                    k = dst.setdefault(kk, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+                    k["launches"] += 1
+                    k["ms"] += ms_l
+                    k["flops"] += flops
+                    k["bytes"] += nbytes
             dom = max(kernels, key=lambda n: kernels[n]["ms"])
             roof = _roofline(dom, kernels[dom], _pmc_traffic(B, "f16x2" if dom.endswith("[f16x2]") else ("bf16x3" if dom.endswith("[bf16x3]") else "f32"),
                                                              kernels[dom]["launches"]))
+            roof["families"] = _family_roofs(fams)
             roof["all_kernels_ms_per_step"] = round(sum(v["ms"] for v in kernels.values()), 3)
             roof["note"] = ("kernel times come from ONE instrumented eager forward after the timed region (a HIP event pair around every launch, one stream): "
                             "their sum can exceed ms_per_step, which is a hipGraph replay without the events and without host launch gaps"
@@ -747,7 +797,7 @@ def main():
         line = {
             "metric": "4-view frames/sec (heatmap+MVFEx+3D lift)", "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": DTYPE_NOTE, "data": "synthetic",
             "config": {"workload": "ego4view_syn_pose3d full pipeline (2x ResNet18+FPN encoders, 4 MVFEx/JQA refiners, "
                                    "3D lifting head), 4 views x 256x256 fp32 per frame, eval/no_grad",
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"frames sharded over {world} GPU(s), no collective",

@@ -27,6 +27,13 @@ using namespace egrc;
 
 namespace {
 
+#ifdef TAPX_STAMPS       // diagnostic build (tools/tapx_stamps.py): per-wave s_memtime sums of the phases
+#define TAPX_DBG true
+#else
+#define TAPX_DBG false
+#endif
+#define TAPX_T() (TAPX_DBG ? __builtin_amdgcn_s_memtime() : 0ull)
+
 constexpr int XOOB = (int)0x80000000;   // buffer offset beyond every descriptor's range: loads return 0, stores are dropped
 
 // pixels of one 16-bit plane of a chunk
@@ -35,16 +42,23 @@ constexpr int XOOB = (int)0x80000000;   // buffer offset beyond every descriptor
 constexpr int tapx_cls(int bm) { return bm == 128 ? 168 : 336; }
 constexpr int tapx_hp(int bm, int stride) { return stride == 2 ? 4 * tapx_cls(bm) : (bm == 128 ? 264 : (bm == 256 ? 400 : 664)); }
 
-template <int WM, int WN, int STRIDE>
+// FN = 2: wave tile 128 x 64 (128 accumulator registers), the tile goes through the 64-KB staging area in two halves, the first
+//         of which the loading waves take into registers at once (three barriers per tile);
+// FN = 1: wave tile 128 x 32 (64 accumulator registers), the WHOLE tile fits the staging area: one barrier per tile, no register
+//         copy, half the registers in both roles - and tiles of 128 x 128 / 256 x 64 for layers with few pixels.
+template <int WM, int WN, int FN, int STRIDE>
 __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
-    static_assert(WM * WN == 4 && (STRIDE == 1 || STRIDE == 2), "four multiplying waves");
-    constexpr int NPL = 2, NPR = 3, FM = 4, FN = 2;
-    constexpr int BM = WM * 128, BN = WN * 64, NFB = BN / 32;
+    static_assert(WM * WN == 4 && (STRIDE == 1 || STRIDE == 2) && (FN == 1 || FN == 2), "four multiplying waves");
+    constexpr int NPL = 2, NPR = 3, FM = 4;
+    constexpr bool WHOLE = FN == 1;                           // the staging area holds the whole tile
+    constexpr int BM = WM * 128, BN = WN * 32 * FN, NFB = BN / 32;
     constexpr int HPX = tapx_hp(BM, STRIDE), CLS = tapx_cls(BM);
     constexpr int PLANE = HPX * 32, HBUF = NPL * PLANE;
-    constexpr int STG = (BM / 2) * BN * 4;                    // half a tile of fp32 accumulators
+    constexpr int STG = (WHOLE ? BM : BM / 2) * BN * 4;       // the tile (FN = 1) or half of it (FN = 2) in fp32: 64 KB
     constexpr int NUH = (HPX * 4 + 255) / 256;                // staging units (4 channels of one pixel) per loading thread and chunk
     constexpr int QPR = BN / 4, RPE = 256 / QPR;              // epilogue: channel quads per row, rows covered by the 256 loading threads per step
+    constexpr int NQ = WHOLE ? 4 : 8;                         // quads per thread and drain step (four steps per tile)
+    static_assert(STG == 65536, "staging area");
     static_assert(2 * HBUF + STG <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(16))) uint8_t lds[2 * HBUF + STG];
     uint8_t* const lb = lds;
@@ -125,7 +139,10 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
                 unsigned h0, l0, h1, l1;
                 split4_f16(__uint_as_float(xr[SET][i][0]), __uint_as_float(xr[SET][i][1]), __uint_as_float(xr[SET][i][2]), __uint_as_float(xr[SET][i][3]), sa, h0, l0, h1, l1);
                 if (lt + 256 * i < 4 * HPX) {
-                    uint8_t* dst = lb + buf * HBUF + (lt + 256 * i) * 8;
+                    // plane layout [8-channel half][pixel][8 channels]: the lanes of an A fragment (consecutive pixels, one half) read
+                    // consecutive 16-byte slots - no bank conflicts (pixel-major 32-byte rows were 2-way for ds_read_b128)
+                    const int u = lt + 256 * i;
+                    uint8_t* dst = lb + buf * HBUF + ((u >> 1) & 1) * (PLANE / 2) + (u >> 2) * 16 + (u & 1) * 8;
                     *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
                     *reinterpret_cast<u32x2*>(dst + PLANE) = u32x2{l0, l1};
                 }
@@ -142,12 +159,12 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
         // ---- epilogue state: the tile whose accumulators are parked (P), this thread's channel quad and its 16 + 16 rows
         struct Pend { int grp, tm, tn, valid; };
         Pend P = {0, 0, 0, 0};
-        f32x4 hold[16];
+        f32x4 hold[WHOLE ? 1 : 16];                           // FN = 2: the first half of the parked tile
 #pragma unroll
-        for (int e = 0; e < 16; ++e) hold[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 rr[8];                                          // residual quads of the NEXT drain step (requested one step ahead)
+        for (int e = 0; e < (WHOLE ? 1 : 16); ++e) hold[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 rr[NQ];                                         // residual quads of the NEXT drain step (requested one step ahead)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) rr[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < NQ; ++e) rr[e] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int cq = lt % QPR, sr0 = lt / QPR;
         float amx = 0.f;
         __amdgpu_buffer_rsrc_t ry, rr_;
@@ -168,8 +185,8 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
         };
         // row of quad step e (0..15) of half H inside the tile, and its output / residual byte offsets
         auto row_offsets = [&](int H, int e, int& yo, int& ro) __attribute__((always_inline)) {
-            const int sr = e * RPE + sr0;                                  // row of the half tile
-            const int R = (sr >> 6) * 128 + H * 64 + (sr & 63);
+            const int sr = e * RPE + sr0;                                  // row of the staged (half) tile
+            const int R = WHOLE ? sr : (sr >> 6) * 128 + H * 64 + (sr & 63);
             const int m = P.tm * BM + R;
             const int n = m >> a.howo_shift, pix = m & (HoWo - 1);
             yo = live ? ((int)fmap(d.ymap, a.dYin, n) + pix * d.ldy + co) * 4 : XOOB;
@@ -195,16 +212,19 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
         // drain step K of the parked tile: K = 0, 1 out of the registers (first half), K = 2, 3 out of the staging area (second half);
         // behind every quad the residual of the same slot of the NEXT step is requested (a whole chunk period to land)
         auto drain = [&](const int K) __attribute__((always_inline)) {
+#ifdef TAPX_EXP_NOLOADER
+            return;
+#endif
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int H = K >> 1, es = (K & 1) * 8 + e;
+            for (int e = 0; e < NQ; ++e) {
+                const int H = WHOLE ? 0 : K >> 1, es = WHOLE ? K * NQ + e : (K & 1) * 8 + e;
                 int yo, ro;
                 row_offsets(H, es, yo, ro);
                 f32x4 v;
-                if (K < 2) v = hold[es];
+                if (!WHOLE && K < 2) v = hold[es];
                 else v = *reinterpret_cast<const f32x4*>(stg + (es * RPE + sr0) * BN + cq * 4);
                 finish(v, rr[e], yo);
-                if (K < 3) rr[e] = res_load((K + 1) >> 1, ((K + 1) & 1) * 8 + e);
+                if (K < 3) rr[e] = WHOLE ? res_load(0, (K + 1) * NQ + e) : res_load((K + 1) >> 1, ((K + 1) & 1) * 8 + e);
             }
         };
 
@@ -219,31 +239,54 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
         int it = 0;
         const int total = my_tiles * NC;
         auto step = [&](const int SET) __attribute__((always_inline)) {
+#ifndef TAPX_EXP_NOLOADER
             if (it + 1 < total) convert(SET, (it + 1) & 1);
             advance(); issue(SET, lck);
+#endif
             ++it;
         };
+        unsigned long long c_work = 0, c_drain = 0, c_bar = 0, c_hand = 0, c_t0 = TAPX_T(), ts = 0;
+        auto tbar = [&]() __attribute__((always_inline)) {      // barrier, its wait booked apart from the work in front of it
+            const unsigned long long t1 = TAPX_T();
+            c_work += t1 - ts;
+            barrier();
+            ts = TAPX_T();
+            c_bar += ts - t1;
+        };
+        ts = TAPX_T();
         for (int k = 0; k < my_tiles; ++k) {
             // the first four chunks of a tile carry the parked tile's epilogue (NC is even: chunk ck converts set (ck + 1) & 1)
-            step(1); drain(0); barrier();
-            step(0); drain(1); barrier();
-            step(1); drain(2); barrier();
-            step(0); drain(3); barrier();
+            unsigned long long d0;
+            step(1); d0 = TAPX_T(); drain(0); c_drain += TAPX_T() - d0; tbar();
+            step(0); d0 = TAPX_T(); drain(1); c_drain += TAPX_T() - d0; tbar();
+            step(1); d0 = TAPX_T(); drain(2); c_drain += TAPX_T() - d0; tbar();
+            step(0); d0 = TAPX_T(); drain(3); c_drain += TAPX_T() - d0; tbar();
             for (int ck = 4; ck < NC; ck += 2) {
-                step(1); barrier();
-                step(0); barrier();
+                step(1); tbar();
+                step(0); tbar();
             }
+            const unsigned long long h0 = TAPX_T();
             // ---- tile k is complete: its accumulators arrive through the staging area, half a tile at a time
             const Tile Tk = tile_of(t_first + k * t_step);
             P = Pend{Tk.grp, Tk.tm, Tk.tn, 1};
             pend_setup(P);
-            barrier();                                        // X1: first half staged
+            barrier();                                        // X1: the tile (FN = 2: its first half) is staged
+            if constexpr (!WHOLE) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) hold[e] = *reinterpret_cast<const f32x4*>(stg + (e * RPE + sr0) * BN + cq * 4);
+                for (int e = 0; e < 16; ++e) hold[e] = *reinterpret_cast<const f32x4*>(stg + (e * RPE + sr0) * BN + cq * 4);
+            }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) rr[e] = res_load(0, e);
-            barrier();                                        // X2: staging area free again
-            barrier();                                        // X3: second half staged
+            for (int e = 0; e < NQ; ++e) rr[e] = res_load(0, e);
+            if constexpr (!WHOLE) {
+                barrier();                                    // X2: staging area free again
+                barrier();                                    // X3: second half staged
+            }
+            ts = TAPX_T();
+            c_hand += ts - h0;
+        }
+        if (TAPX_DBG && a.dbg && lane == 0) {
+            unsigned long long* o = a.dbg + ((int64_t)bid * 8 + wave) * 8;
+            o[0] = c_work; o[1] = c_bar; o[2] = c_hand; o[3] = TAPX_T() - c_t0; o[4] = (unsigned long long)my_tiles * NC; o[5] = c_drain;
         }
         drain(0);
         drain(1);
@@ -261,7 +304,7 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int ml = wm * 128 + i * 32 + l31, il = ml / PPI, mq = ml - il * PPI, r = mq / wo, c = mq - r * wo;
-        abase[i] = (il * HPI + r * WP + c) * 32 + half * 16;
+        abase[i] = (il * HPI + r * WP + c) * 16 + half * (PLANE / 2);
     }
     // the nine taps in the order they are multiplied: byte offset of the tap's window inside a plane, index of its weights
     //   stride 1: tap (kh, kw) = the window shifted by (kh, kw) pixels
@@ -271,7 +314,7 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
     constexpr int TDR[9] = {0, 0, 0, 0, 1, 0, 0, 1, 1};
     constexpr int TDC[9] = {0, 0, 1, 0, 0, 0, 1, 0, 1};
     auto tap_off = [&](int tap) __attribute__((always_inline)) {
-        return STRIDE == 1 ? ((tap / 3) * WP + (tap % 3)) * 32 : TCL[tap] * CLS * 32 + (TDR[tap] * WP + TDC[tap]) * 32;
+        return STRIDE == 1 ? ((tap / 3) * WP + (tap % 3)) * 16 : TCL[tap] * CLS * 16 + (TDR[tap] * WP + TDC[tap]) * 16;
     };
     auto tap_w = [&](int tap) __attribute__((always_inline)) { return STRIDE == 1 ? tap : TID[tap]; };
     f32x16 acc[FM][FN];
@@ -281,14 +324,23 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
         for (int j = 0; j < FN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    u32x4 af[FM][NPL], bf[3][FN][NPL];
+    // weight fragments: NSET register sets (a divisor of the nine taps, so that a tap's set is a compile-time constant), requested
+    // AHEAD taps before they are multiplied.  L2 latency under load is above one microsecond: two taps of the narrow wave tile
+    // (2 x 12 MFMAs = 768 cycles) do not cover it.
+    constexpr int NSET = FN == 1 ? 9 : 3;
+#ifndef TAPX_AHEAD1
+#define TAPX_AHEAD1 5
+#endif
+    constexpr int AHEAD = FN == 1 ? TAPX_AHEAD1 : 2;
+    static_assert(AHEAD < NSET && 9 % NSET == 0, "weight register sets");
+    u32x4 af[FM][NPL], bf[NSET][FN][NPL];
 
     const int FSTR = a.ktiles * 2 * NPL * 1024;              // bytes between column fragments of the weight image
     struct WTile { __amdgpu_buffer_rsrc_t rb; int bvo; };
     auto wtile_of = [&](const Tile& T) __attribute__((always_inline)) {
         WTile W;
         W.rb = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(reinterpret_cast<const uint8_t*>(a.w) + (int64_t)T.grp * d.gw * 2), 0, 0x80000000u, 0x00020000);
-        W.bvo = (T.tn * NFB + wn * FN) * FSTR + lane * 16;
+        W.bvo = (T.tn * NFB + wn * FN) * FSTR + lane * 16;      // (NFB = BN / 32 column fragments per tile, FN of them per wave)
         return W;
     };
     auto load_b = [&](const WTile& W, int ck, int tap, int set) __attribute__((always_inline)) {
@@ -312,9 +364,11 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
         constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int pc = tap % 3, pn = (tap + 2) % 3;
-            if (tap + 2 < 9) load_b(W, ck, tap + 2, pn);
-            else load_b(X, ckn, tap + 2 - 9, pn);
+            const int pc = tap % NSET, pn = (tap + AHEAD) % NSET;
+#ifndef TAPX_EXP_NOB       // (TAPX_EXP_*: elimination builds for tools/tapx_stamps.py - timing only, the results are wrong)
+            if (tap + AHEAD < 9) load_b(W, ck, tap + AHEAD, pn);
+            else load_b(X, ckn, tap + AHEAD - 9, pn);
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < NPR; ++t) {
@@ -325,69 +379,90 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
                         acc[i][j] = mfma_split<NPL>(af[i][PA[t]], bf[pc][j][PB[t]], acc[i][j]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
+#ifndef TAPX_EXP_NOA
                 if (tap + 1 < 9 && split_free_a(NPL, t) >= 0) {
+#else
+                if (false) {
+#endif
                     read_a(base, tap + 1, split_free_a(NPL, t));
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
     };
-    // park half H (fragment rows 2H, 2H + 1 of every wave) of the accumulators in the staging area, descaled; clear them
+    // park the accumulators in the staging area, descaled, and clear them: FN = 2 half H of them (fragment rows 2H, 2H + 1 of every
+    // wave), FN = 1 all four fragment rows
     auto park = [&](const Tile& T, const int H) __attribute__((always_inline)) {
         const float* const wdsg = a.wds + T.grp * d.gp;
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-            const int col = wn * 64 + j * 32 + l31;
+            const int col = wn * 32 * FN + j * 32 + l31;
             const float dsc = ads * wdsg[T.tn * BN + col];
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
+            for (int ii = 0; ii < (WHOLE ? 4 : 2); ++ii)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int sr = wm * 64 + ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    stg[sr * BN + col] = acc[2 * H + ii][j][r] * dsc;
-                    acc[2 * H + ii][j][r] = 0.f;
+                    const int i = WHOLE ? ii : 2 * H + ii;
+                    const int sr = wm * (WHOLE ? 128 : 64) + ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    stg[sr * BN + col] = acc[i][j][r] * dsc;
+                    acc[i][j][r] = 0.f;
                 }
         }
     };
 
     Tile T = tile_of(t_first);
     WTile W = wtile_of(T);
-    load_b(W, 0, 0, 0);
-    load_b(W, 0, 1, 1);
+#pragma unroll
+    for (int t = 0; t < AHEAD; ++t) load_b(W, 0, t, t);
     barrier();                                                // chunk 0 staged
     int it = 0;
+    unsigned long long c_mul = 0, c_bar = 0, c_park = 0, c_t0 = TAPX_T();
     for (int k = 0; k < my_tiles; ++k) {
         const bool has_next = k + 1 < my_tiles;
         const Tile Tn = has_next ? tile_of(t_first + (k + 1) * t_step) : T;
         const WTile Wn = wtile_of(Tn);
         for (int ck = 0; ck + 1 < NC; ++ck) {
+            const unsigned long long s0 = TAPX_T();
             chunk((it & 1) * HBUF, ck, W, W, ck + 1);
+            const unsigned long long s1 = TAPX_T();
             barrier();
+            if (TAPX_DBG) { c_mul += s1 - s0; c_bar += TAPX_T() - s1; }
             ++it;
         }
+        const unsigned long long s0 = TAPX_T();
         chunk((it & 1) * HBUF, NC - 1, W, Wn, 0);
+        const unsigned long long s1 = TAPX_T();
         barrier();
+        const unsigned long long s2 = TAPX_T();
         ++it;
         park(T, 0);
         barrier();                                            // X1
-        barrier();                                            // X2: the loading waves hold the first half in registers
-        park(T, 1);
-        barrier();                                            // X3
+        if constexpr (!WHOLE) {
+            barrier();                                        // X2: the loading waves hold the first half in registers
+            park(T, 1);
+            barrier();                                        // X3
+        }
+        if (TAPX_DBG) { c_mul += s1 - s0; c_bar += s2 - s1; c_park += TAPX_T() - s2; }
         T = Tn;
         W = Wn;
+    }
+    if (TAPX_DBG && a.dbg && lane == 0) {
+        unsigned long long* o = a.dbg + ((int64_t)bid * 8 + wave) * 8;
+        o[0] = c_mul; o[1] = c_bar; o[2] = c_park; o[3] = TAPX_T() - c_t0; o[4] = (unsigned long long)my_tiles * NC;
     }
 }
 
 int g_tapx = getenv("EGR_CONV_TAPX") ? atoi(getenv("EGR_CONV_TAPX")) : 1;                          // 0: the 3x3 launches stay on conv_igemm_tap[2]_kernel
 int g_tapx_min_tiles = getenv("EGR_CONV_TAPX_MIN_TILES") ? atoi(getenv("EGR_CONV_TAPX_MIN_TILES")) : 256; // tiles (all groups) from which the role-split kernel is used
 int g_tapx_blocks = getenv("EGR_CONV_TAPX_BLOCKS") ? atoi(getenv("EGR_CONV_TAPX_BLOCKS")) : 256;    // resident workgroups (one per CU)
+int g_tapx_fn = getenv("EGR_CONV_TAPX_FN") ? atoi(getenv("EGR_CONV_TAPX_FN")) : 0;                  // wave tile: 0 by shape, 1: 128 x 32, 2: 128 x 64 wherever it exists
 
 }  // namespace
 
 namespace egrc {
 
 int tapx_set(int on, int min_tiles, int blocks) {
-    if (on >= 0) g_tapx = on;
+    if (on >= 0) { g_tapx = on != 0; g_tapx_fn = on >= 2 ? on - 1 : 0; }      // on = 2 / 3: the 128 x 32 / 128 x 64 wave tile wherever it exists (tests)
     if (min_tiles >= 0) g_tapx_min_tiles = min_tiles;
     if (blocks > 0) g_tapx_blocks = blocks;
     return 0;
@@ -399,27 +474,32 @@ int tapx_try(ConvArgs& a, int64_t yspan_floats, int64_t rspan_floats, hipStream_
     egr_conv_desc& d = a.d;
     if (!g_tapx || d.w_format != EGR_W_F16X2 || d.kh != 3 || d.kw != 3 || d.pad != 1 || d.transposed || a.cls_mode || d.split_k > 1 ||
         d.out_nchw || a.rowscale || a.rowmask || a.mask || a.bn_part || !a.vec_ok || d.cout % 4 != 0 || d.cin < 64 ||
-        (d.act != EGR_ACT_NONE && d.act != EGR_ACT_RELU) || d.res_mode == EGR_RES_UP2_BEFORE_ACT || a.dbg)
+        (d.act != EGR_ACT_NONE && d.act != EGR_ACT_RELU) || d.res_mode == EGR_RES_UP2_BEFORE_ACT || (a.dbg && !TAPX_DBG))
         return TAPX_NO;
     if (yspan_floats * 4 >= (1LL << 31) || (d.res_mode && rspan_floats * 4 >= (1LL << 31))) return TAPX_NO;   // 32-bit byte offsets in the epilogue
     const int P = d.ho * d.wo;
-    int wm = 0, wn = 0;
+    if (a.howo_shift < 0 || a.wo_shift < 0) return TAPX_NO;
+    const int ext = d.stride == 1 ? 2 : 1;
+    auto fits = [&](int bm, int bn) {        // tiles of whole image rows / whole small images whose planes fit the kernel's LDS buffers
+        if (a.Npad % bn != 0 || a.M % bm != 0 || !((P % bm == 0) || (bm % P == 0)) || (bm / P) > 15) return false;
+        const int hp = P >= bm ? (bm / d.wo + ext) * (d.wo + ext) : (bm / P) * (d.ho + ext) * (d.wo + ext);
+        return hp <= (d.stride == 1 ? tapx_hp(bm, 1) : tapx_cls(bm)) && (int64_t)(a.M / bm) * (a.Npad / bn) * d.groups >= g_tapx_min_tiles;
+    };
+    // candidate tiles (rows x columns, wave tile width): stride 1: 256 x 128 | 128 x 128, 512 x 64 | 256 x 64; stride 2: 128 x 256 | 128 x 128
+    int cfg = -1;
     if (d.stride == 1) {
         if (!(d.wo == 8 || d.wo == 16 || d.wo == 32 || d.wo == 64) || d.ho != d.h || d.wo != d.w) return TAPX_NO;
-        if (a.Npad % 128 == 0) { wm = 2; wn = 2; }
-        else if (a.Npad % 64 == 0) { wm = 4; wn = 1; }
-        else return TAPX_NO;
+        if (a.Npad % 128 == 0) cfg = (g_tapx_fn != 1 && fits(256, 128)) ? 0 : (g_tapx_fn != 2 && fits(128, 128) ? 1 : (fits(256, 128) ? 0 : -1));
+        else cfg = (g_tapx_fn != 1 && fits(512, 64)) ? 2 : (g_tapx_fn != 2 && fits(256, 64) ? 3 : (fits(512, 64) ? 2 : -1));
     } else if (d.stride == 2) {
-        if (!(d.wo == 8 || d.wo == 16 || d.wo == 32) || d.h != 2 * d.ho || d.w != 2 * d.wo || a.Npad % 256 != 0) return TAPX_NO;
-        wm = 1; wn = 4;
-    } else return TAPX_NO;
-    const int bm = wm * 128, bn = wn * 64;
-    if (a.M % bm != 0 || !((P % bm == 0) || (bm % P == 0)) || a.howo_shift < 0 || a.wo_shift < 0) return TAPX_NO;
-    const int ext = d.stride == 1 ? 2 : 1;
-    const int hp = P >= bm ? (bm / d.wo + ext) * (d.wo + ext) : (bm / P) * (d.ho + ext) * (d.wo + ext);
-    if (hp > (d.stride == 1 ? tapx_hp(bm, 1) : tapx_cls(bm)) || (bm / P) > 15) return TAPX_NO;
+        if (!(d.wo == 8 || d.wo == 16 || d.wo == 32) || d.h != 2 * d.ho || d.w != 2 * d.wo) return TAPX_NO;
+        cfg = (g_tapx_fn != 1 && fits(128, 256)) ? 4 : (g_tapx_fn != 2 && fits(128, 128) ? 5 : (fits(128, 256) ? 4 : -1));
+    }
+    if (cfg < 0) return TAPX_NO;
+    static const int kbm[6] = {256, 128, 512, 256, 128, 128}, kbn[6] = {128, 128, 64, 64, 256, 128};
+    const int bm = kbm[cfg], bn = kbn[cfg];
     const int64_t tiles = (int64_t)(a.M / bm) * (a.Npad / bn) * d.groups;
-    if (tiles < g_tapx_min_tiles || tiles >= (1 << 30)) return TAPX_NO;
+    if (tiles >= (1 << 30)) return TAPX_NO;
     d.split_k = 1;
     a.ktiles_per_split = a.ktiles;
     a.tilesM = a.M / bm;
@@ -427,9 +507,14 @@ int tapx_try(ConvArgs& a, int64_t yspan_floats, int64_t rspan_floats, hipStream_
     a.dTilesN = make_fastdiv(a.tilesN);
     a.ntiles = a.tilesM * a.tilesN;
     const unsigned grid = (unsigned)(tiles < g_tapx_blocks ? tiles : g_tapx_blocks);
-    if (d.stride == 2) hipLaunchKernelGGL((conv_tapx_kernel<1, 4, 2>), dim3(grid), dim3(512), 0, stream, a);
-    else if (wn == 2) hipLaunchKernelGGL((conv_tapx_kernel<2, 2, 1>), dim3(grid), dim3(512), 0, stream, a);
-    else hipLaunchKernelGGL((conv_tapx_kernel<4, 1, 1>), dim3(grid), dim3(512), 0, stream, a);
+    switch (cfg) {
+        case 0: hipLaunchKernelGGL((conv_tapx_kernel<2, 2, 2, 1>), dim3(grid), dim3(512), 0, stream, a); break;
+        case 1: hipLaunchKernelGGL((conv_tapx_kernel<1, 4, 1, 1>), dim3(grid), dim3(512), 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((conv_tapx_kernel<4, 1, 2, 1>), dim3(grid), dim3(512), 0, stream, a); break;
+        case 3: hipLaunchKernelGGL((conv_tapx_kernel<2, 2, 1, 1>), dim3(grid), dim3(512), 0, stream, a); break;
+        case 4: hipLaunchKernelGGL((conv_tapx_kernel<1, 4, 2, 2>), dim3(grid), dim3(512), 0, stream, a); break;
+        default: hipLaunchKernelGGL((conv_tapx_kernel<1, 4, 1, 2>), dim3(grid), dim3(512), 0, stream, a); break;
+    }
     return egr_launch_status();
 }
 

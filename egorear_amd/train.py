@@ -1584,10 +1584,19 @@ def _finish_backward(S: Step):
         S.stage_hook(N_GRAD_STAGES - 1)    # the encoders finish last
 
 
+def _mvfex_grad_free(name: str) -> bool:
+    """Parameters of EgoPoseFormerMVFEX that the reference's graph never reaches under the shipped pose3d flags (_FLAGS_POSE3D): the stereo
+    estimators' own conv_heatmap (the MVFEx model only takes their features, heatmap_mvf_ex.py:212-234) and every refiner's
+    frame_feat_proj_layers (`offset_pred + frame_feat.detach()`, :715).  torch leaves their .grad None, AdamW skips them, and
+    DistributedDataParallel(find_unused_parameters=True) - the strategy the wrapper's Trainer uses - must find them UNUSED: a tensor
+    that is an input of the autograd node but receives no gradient would be reduced as zeros and then decayed by AdamW."""
+    return (".conv_heatmap." in name and "heatmap_estimator_stereo_" in name) or ".frame_feat_proj_layers." in name
+
+
 class _MVFEXTrainFn(torch.autograd.Function):
     """One autograd node for the whole network: forward = training-mode forward on the HIP kernels, backward = the taped
-    reverse pass.  Inputs after `ctm` are the module's parameters (so autograd routes .grad to them; a tensor the
-    reverse pass never reaches gets None, exactly like the reference's untouched parameters)."""
+    reverse pass.  Inputs after `ctm` are the module's parameters that the reverse pass reaches (so autograd routes .grad to
+    them); the others are not part of the graph, exactly like the reference's untouched parameters."""
 
     @staticmethod
     def forward(ctx, net, img, ctm, *params):
@@ -1617,6 +1626,9 @@ class _MVFEXTrainFn(torch.autograd.Function):
         _finish_backward(S)
         pg = S.pgrads
         ctx.S = None
+        if set(pg) != set(ctx.names):      # the static rule (_mvfex_grad_free) and the tape disagree: refuse rather than mis-report to DDP
+            raise RuntimeError(f"egorear_amd.train: the reverse pass reached {len(pg)} parameters, the autograd node declares {len(ctx.names)}: "
+                               f"{sorted(set(pg) ^ set(ctx.names))[:4]}")
         return (None, None, None) + tuple(pg.get(k) for k in ctx.names)
 
 
@@ -1632,7 +1644,7 @@ def mvfex_training_forward(net, img, ctm=None):
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
         if not all(p.requires_grad for p in params):
             raise NotImplementedError("egorear_amd.train: partially frozen parameter sets are not supported (the reference trains all of them)")
-        outs = _MVFEXTrainFn.apply(net, img, ctm, *params)
+        outs = _MVFEXTrainFn.apply(net, img, ctm, *[p for k, p in net.named_parameters() if not _mvfex_grad_free(k)])
         return list(outs[:4]), list(outs[4:])
     with torch.no_grad():
         S = Step(net, img.device)

@@ -14,7 +14,7 @@ reference registers).  None of them computes anything: the compute lives in the
 HIP kernels reached through egorear_amd.hip, driven by egorear_amd.estimator.
 Stacks are described by a small op list (`stack(...)`) that builds an
 nn.Sequential with the reference's child indices, so the same description also
-drives the HIP execution plan (egorear_amd.plan.run_stack).
+drives the HIP execution (egorear_amd.engine.run_stack walks the same op lists).
 """
 from __future__ import annotations
 

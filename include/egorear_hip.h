@@ -225,8 +225,9 @@ int egr_conv_set_tap(int on);
  * models/estimator/egoposeformer_heatmap_mvf_ex.py:101-126, 525-532, 570-584): launches with at least `min_tiles` output tiles over
  * all groups run on role-split persistent workgroups - four multiplying waves + four waves that load, split and run the previous
  * tile's epilogue under the current tile's K loop, `blocks` workgroups (one per CU) - egr_conv_last_kernel() = 6.  on = 0 keeps them
- * on the tap-sharing kernels (2 / 3).  Negative values leave a setting unchanged; defaults 1, 256, 256 (env EGR_CONV_TAPX,
- * EGR_CONV_TAPX_MIN_TILES, EGR_CONV_TAPX_BLOCKS).  Process-wide; results do not depend on it (same products, same summation order). */
+ * on the tap-sharing kernels (2 / 3); on = 2 / 3 force the 128 x 32 / 128 x 64 wave tile wherever that variant exists (1: chosen by
+ * shape).  Negative values leave a setting unchanged; defaults 1, 256, 256 (env EGR_CONV_TAPX, EGR_CONV_TAPX_MIN_TILES,
+ * EGR_CONV_TAPX_BLOCKS, EGR_CONV_TAPX_FN).  Process-wide; results do not depend on it (same products, same summation order). */
 int egr_conv_set_tapx(int32_t on, int32_t min_tiles, int32_t blocks);
 /* Tuning / test knob of the persistent split-bf16 launches (short-K layers: a workgroup walks several tiles and requests the next
  * tile's operands under the current tile's stores): `slots` = resident workgroups a launch is sized for (0: never persistent;

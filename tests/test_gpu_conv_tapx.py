@@ -37,10 +37,14 @@ S2_CASES = [
 ]
 
 
-@pytest.fixture(params=[5, 8], ids=["5wg", "8wg"])
+MODE = {"on": 1}      # egr_conv_set_tapx's first argument in force: 2 = the 128 x 32 wave tile (whole tile through the staging area), 3 = 128 x 64 (two halves)
+
+
+@pytest.fixture(params=[(5, 2), (8, 2), (5, 3), (8, 3)], ids=["5wg-w32", "8wg-w32", "5wg-w64", "8wg-w64"])
 def tapx(request):
     from egorear_amd import hip
-    hip.lib.egr_conv_set_tapx(1, 1, request.param)
+    blocks, MODE["on"] = request.param
+    hip.lib.egr_conv_set_tapx(MODE["on"], 1, blocks)
     yield hip
     hip.lib.egr_conv_set_tapx(1, 256, 256)
 
@@ -61,7 +65,7 @@ def _run(hip, case, stride, seed):
     try:
         _, _, c0, kern0, rec0 = three(hip, hip.Img(x.to(DEV)), wp, cout, 3, 3, stride, 1, **kw)
     finally:
-        hip.lib.egr_conv_set_tapx(1, -1, -1)
+        hip.lib.egr_conv_set_tapx(MODE["on"], -1, -1)
     assert kern0 in (1, 2, 3)
     if kern0 == 1:        # (too few rows for the tap-sharing kernels: the generic split kernel walks the taps in another order)
         assert float((c.t - c0.t).abs().max()) <= 2e-6 * float(c0.t.abs().max()), case
@@ -80,11 +84,22 @@ def test_role_split_stride2(tapx, case):
     _run(tapx, case, 2, 170)
 
 
+@pytest.mark.parametrize("case", [(8, 64, 64, 128, 1, "scale_relu"),      # layer2 entry: 128 output channels exist as 128 x 128 tiles only
+                                  (16, 32, 128, 128, 2, "res_after")])
+def test_role_split_stride2_128_channels(case):
+    from egorear_amd import hip
+    MODE["on"] = 1
+    hip.lib.egr_conv_set_tapx(1, 1, 8)
+    try:
+        _run(hip, case, 2, 270)
+    finally:
+        hip.lib.egr_conv_set_tapx(1, 256, 256)
+
+
 def test_launches_outside_its_cover_stay_on_the_tap_kernels(tapx):
     hip = tapx
     for (n, hw, cin, cout, stride, want) in [(32, 16, 32, 192, 1, 2),      # two chunks only
-                                             (512, 8, 64, 64, 1, 2),      # 512 x 64 tiles would need eight whole images' halo
-                                             (8, 64, 64, 128, 2, 3),      # stride 2 with 128 output channels
+                                             (8, 64, 64, 192, 2, 3),      # stride 2 with 192 output channels
                                              (9, 32, 64, 62, 1, 2)]:      # channel count not a multiple of four
         x = rnd(n, hw, hw, cin, seed=1)
         wt = rnd(cout, cin, 3, 3, seed=2, scale=1.0 / math.sqrt(9 * cin))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the conv backward bricks (dgrad = transposed mode of egr_conv2d_nhwc_f32, wgrad = egr_conv2d_wgrad_f32)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from egorear_amd import hip
 from egorear_amd.engine import pack_conv_weight

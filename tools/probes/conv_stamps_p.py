@@ -3,7 +3,7 @@
     [0] tile's turn begins  [2] first stage staged  [3] K loop done  [4] accumulators staged  [5] stores issued
 python tools/conv_stamps_p.py [cin ...]"""
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from egorear_amd import hip
 hip.lib.egr_conv_debug_stamps.argtypes = [ctypes.c_void_p]

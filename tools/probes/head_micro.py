@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """up2_relu_head timing at the pipeline's shape (batch 64: 256 images of 32 x 32 x 128 -> 15 planes of 64 x 64)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from egorear_amd import hip
 B, V, J, G = 64, 4, 15, 2

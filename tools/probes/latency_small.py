@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Graph-replay latency at small batches (1, 2, 4, 8).   python tools/latency_small.py"""
 import copy, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from egorear_amd import configs, synth
 from egorear_amd.estimator import EgoPoseFormerMVFEX

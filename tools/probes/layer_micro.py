@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time of the fused transformer-layer launches inside one forward (HIP events), batch 64 and 1."""
 import copy, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from egorear_amd import configs, hip, synth
 from egorear_amd.estimator import EgoPoseFormerMVFEX

@@ -2,7 +2,7 @@
 """Per-launch time of small GEMM launches inside a hipGraph (the latency-bound launches of the heads): a chain of dependent launches,
 so the figure is the full launch-to-launch period.   python tools/small_launch_micro.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from egorear_amd import engine, hip, hip_train as T
 

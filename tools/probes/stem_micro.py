@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Stem timing: stem, stem + maxpool, stem_pool at (B, 4 views, 256 x 256).   python tools/stem_micro.py [--batch 64] [--reps 20]"""
 import argparse, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from egorear_amd import hip
 

@@ -4,7 +4,7 @@
 hence one split-K workspace - results of the two-stream replay are NOT valid, this only measures the overlap.
     python tools/two_stream_probe.py [--batch 64] [--parts 2]"""
 import argparse, copy, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from egorear_amd import configs, synth
 from egorear_amd.estimator import EgoPoseFormerMVFEX

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """upsample2x timing at the pipeline's shapes."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from egorear_amd import hip
 for (n, h, c) in ((256, 32, 128), (256, 16, 64)):

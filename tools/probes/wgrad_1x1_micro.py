@@ -2,7 +2,7 @@
 """The 1x1 weight gradients of the training step (HBM-bound: two tensors read once, a tiny result), per launch and in TB/s.
    python tools/wgrad_1x1_micro.py          (under rocprofv3 --kernel-trace --stats for the per-kernel split)"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from egorear_amd import hip
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """mlp_pred[0] (2048 x 32768) at B rows: the weight-stream launch vs the fp32 split-K launch.   python tools/wstream_micro.py [--rows 64]"""
 import argparse, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from egorear_amd import engine, hip
 
