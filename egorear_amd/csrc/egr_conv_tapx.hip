@@ -46,7 +46,8 @@ constexpr int tapx_hp(int bm, int stride) { return stride == 2 ? 4 * tapx_cls(bm
 //         of which the loading waves take into registers at once (three barriers per tile);
 // FN = 1: wave tile 128 x 32 (64 accumulator registers), the WHOLE tile fits the staging area: one barrier per tile, no register
 //         copy, half the registers in both roles - and tiles of 128 x 128 / 256 x 64 for layers with few pixels.
-template <int WM, int WN, int FN, int STRIDE>
+// RES: the launch adds a residual (its quads are requested one drain step ahead: eight / four more quads of registers per loading thread).
+template <int WM, int WN, int FN, int STRIDE, bool RES>
 __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
     static_assert(WM * WN == 4 && (STRIDE == 1 || STRIDE == 2) && (FN == 1 || FN == 2), "four multiplying waves");
     constexpr int NPL = 2, NPR = 3, FM = 4;
@@ -61,8 +62,10 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
     static_assert(STG == 65536, "staging area");
     static_assert(2 * HBUF + STG <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(16))) uint8_t lds[2 * HBUF + STG];
-    uint8_t* const lb = lds;
-    float* const stg = reinterpret_cast<float*>(lds + 2 * HBUF);
+    // the staging area first: every one of a wave's parking stores is then one base register + an immediate offset below 64 KB
+    // (behind the planes the compiler needed a dozen address registers for them - spilled, and every reload waited for vmcnt(0))
+    float* const stg = reinterpret_cast<float*>(lds);
+    uint8_t* const lb = lds + STG;
 
     const egr_conv_desc& d = a.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -107,7 +110,10 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
         float sa, ads;
         act_prescale(a.amax_in, lane, sa, ads);
         int hvo[NUH];
-        u32x4 xr[2][NUH];                                     // two chunks of activations in flight
+        // chunks of activations in flight: two register sets (requested two chunk periods before they are split), or one (one period -
+        // a chunk of the wide wave tile is 3.3 us) where eleven units per thread and the parked half tile do not leave room for two
+        constexpr int NXS = (NUH > 8 && !WHOLE) ? 1 : 2;
+        u32x4 xr[NXS][NUH];
         __amdgpu_buffer_rsrc_t ra;
         int so_tile = 0;
         auto setup = [&](int t) __attribute__((always_inline)) {    // the load cursor enters tile t
@@ -162,13 +168,13 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
         f32x4 hold[WHOLE ? 1 : 16];                           // FN = 2: the first half of the parked tile
 #pragma unroll
         for (int e = 0; e < (WHOLE ? 1 : 16); ++e) hold[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 rr[NQ];                                         // residual quads of the NEXT drain step (requested one step ahead)
+        f32x4 rr[RES ? NQ : 1];                               // residual quads of the NEXT drain step (requested one step ahead)
 #pragma unroll
-        for (int e = 0; e < NQ; ++e) rr[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < (RES ? NQ : 1); ++e) rr[e] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int cq = lt % QPR, sr0 = lt / QPR;
         float amx = 0.f;
         __amdgpu_buffer_rsrc_t ry, rr_;
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, dsq = {1.f, 1.f, 1.f, 1.f};
         int co = 0;
         bool live = false;
         auto pend_setup = [&](const Pend& Q) __attribute__((always_inline)) {
@@ -178,6 +184,8 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
             live = Q.valid && co < d.cout;
             sc = f32x4{1.f, 1.f, 1.f, 1.f};
             sh = f32x4{0.f, 0.f, 0.f, 0.f};
+            // the accumulators arrive with both pre-scales on them: the inverse powers of two (activations: ads, weights: per channel)
+            dsq = *reinterpret_cast<const f32x4*>(a.wds + Q.grp * d.gp + Q.tn * BN + cq * 4) * ads;
             if (live) {
                 if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + Q.grp * d.gp + co);
                 if (a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + Q.grp * d.gp + co);
@@ -190,7 +198,7 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
             const int m = P.tm * BM + R;
             const int n = m >> a.howo_shift, pix = m & (HoWo - 1);
             yo = live ? ((int)fmap(d.ymap, a.dYin, n) + pix * d.ldy + co) * 4 : XOOB;
-            ro = (live && d.res_mode) ? ((int)fmap(d.rmap, a.dRin, n) + pix * d.ldr + co) * 4 : XOOB;
+            ro = (RES && live) ? ((int)fmap(d.rmap, a.dRin, n) + pix * d.ldr + co) * 4 : XOOB;
         };
         auto res_load = [&](int H, int es) __attribute__((always_inline)) {      // residual quad of step es of half H
             int yo, ro;
@@ -200,10 +208,10 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
         auto finish = [&](f32x4 v, const f32x4& rr, int yo) __attribute__((always_inline)) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                float t = v[c] * sc[c] + sh[c];
-                if (d.res_mode == EGR_RES_BEFORE_ACT) t += rr[c];
+                float t = (v[c] * dsq[c]) * sc[c] + sh[c];
+                if (RES && d.res_mode == EGR_RES_BEFORE_ACT) t += rr[c];
                 if (d.act == EGR_ACT_RELU) t = t > 0.f ? t : 0.f;
-                if (d.res_mode == EGR_RES_AFTER_ACT) t += rr[c];
+                if (RES && d.res_mode == EGR_RES_AFTER_ACT) t += rr[c];
                 v[c] = t;
             }
             if (live) amx = fmaxf(fmaxf(amx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
@@ -223,22 +231,26 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
                 f32x4 v;
                 if (!WHOLE && K < 2) v = hold[es];
                 else v = *reinterpret_cast<const f32x4*>(stg + (es * RPE + sr0) * BN + cq * 4);
-                finish(v, rr[e], yo);
-                if (K < 3) rr[e] = WHOLE ? res_load(0, (K + 1) * NQ + e) : res_load((K + 1) >> 1, ((K + 1) & 1) * 8 + e);
+                finish(v, rr[RES ? e : 0], yo);
+                if constexpr (RES) {
+                    if (K < 3) rr[e] = WHOLE ? res_load(0, (K + 1) * NQ + e) : res_load((K + 1) >> 1, ((K + 1) & 1) * 8 + e);
+                }
+                __builtin_amdgcn_sched_barrier(0);        // one quad at a time: interleaving the quads only costs registers here (spills = vmcnt(0) waits)
             }
         };
 
         setup(t_first);
         issue(0, 0);                                          // chunks 0, 1 -> sets 0, 1
-        advance(); issue(1, lck);
+        if constexpr (NXS == 2) { advance(); issue(1, lck); }
         convert(0, 0);
-        advance(); issue(0, lck);                             // chunk 2
+        advance(); issue(0, lck);                             // chunk 2 (one set: chunk 1)
         barrier();                                            // chunk 0 staged
         // chunk step (the multiplying waves work on chunk ck of the current tile): the chunk after it (register set SET) -> the other
         // LDS buffer, then the set is reloaded with the chunk three after it
         int it = 0;
         const int total = my_tiles * NC;
-        auto step = [&](const int SET) __attribute__((always_inline)) {
+        auto step = [&](const int SET_) __attribute__((always_inline)) {
+            const int SET = NXS == 1 ? 0 : SET_;
 #ifndef TAPX_EXP_NOLOADER
             if (it + 1 < total) convert(SET, (it + 1) & 1);
             advance(); issue(SET, lck);
@@ -275,8 +287,10 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) hold[e] = *reinterpret_cast<const f32x4*>(stg + (e * RPE + sr0) * BN + cq * 4);
             }
+            if constexpr (RES) {
 #pragma unroll
-            for (int e = 0; e < NQ; ++e) rr[e] = res_load(0, e);
+                for (int e = 0; e < NQ; ++e) rr[e] = res_load(0, e);
+            }
             if constexpr (!WHOLE) {
                 barrier();                                    // X2: staging area free again
                 barrier();                                    // X3: second half staged
@@ -298,8 +312,6 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
 
     // ---------------------------------------------------------------------- multiplying waves
     const int wm = wave / WN, wn = wave % WN;
-    float sa_unused, ads;
-    act_prescale(a.amax_in, lane, sa_unused, ads);
     int abase[FM];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -390,24 +402,20 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
             }
         }
     };
-    // park the accumulators in the staging area, descaled, and clear them: FN = 2 half H of them (fragment rows 2H, 2H + 1 of every
-    // wave), FN = 1 all four fragment rows
-    auto park = [&](const Tile& T, const int H) __attribute__((always_inline)) {
-        const float* const wdsg = a.wds + T.grp * d.gp;
+    // park the accumulators in the staging area (raw: the loading waves undo the pre-scales) and clear them: FN = 2 half H of them
+    // (fragment rows 2H, 2H + 1 of every wave), FN = 1 all four fragment rows
+    auto park = [&](const int H) __attribute__((always_inline)) {
+        float* const sp = stg + (wm * (WHOLE ? 128 : 64) + 4 * half) * BN + wn * 32 * FN + l31;
 #pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int col = wn * 32 * FN + j * 32 + l31;
-            const float dsc = ads * wdsg[T.tn * BN + col];
+        for (int j = 0; j < FN; ++j)
 #pragma unroll
             for (int ii = 0; ii < (WHOLE ? 4 : 2); ++ii)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int i = WHOLE ? ii : 2 * H + ii;
-                    const int sr = wm * (WHOLE ? 128 : 64) + ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    stg[sr * BN + col] = acc[i][j][r] * dsc;
+                    sp[(ii * 32 + (r & 3) + 8 * (r >> 2)) * BN + j * 32] = acc[i][j][r];
                     acc[i][j][r] = 0.f;
                 }
-        }
     };
 
     Tile T = tile_of(t_first);
@@ -435,11 +443,11 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
         barrier();
         const unsigned long long s2 = TAPX_T();
         ++it;
-        park(T, 0);
+        park(0);
         barrier();                                            // X1
         if constexpr (!WHOLE) {
             barrier();                                        // X2: the loading waves hold the first half in registers
-            park(T, 1);
+            park(1);
             barrier();                                        // X3
         }
         if (TAPX_DBG) { c_mul += s1 - s0; c_bar += s2 - s1; c_park += TAPX_T() - s2; }
@@ -483,14 +491,20 @@ int tapx_try(ConvArgs& a, int64_t yspan_floats, int64_t rspan_floats, hipStream_
     auto fits = [&](int bm, int bn) {        // tiles of whole image rows / whole small images whose planes fit the kernel's LDS buffers
         if (a.Npad % bn != 0 || a.M % bm != 0 || !((P % bm == 0) || (bm % P == 0)) || (bm / P) > 15) return false;
         const int hp = P >= bm ? (bm / d.wo + ext) * (d.wo + ext) : (bm / P) * (d.ho + ext) * (d.wo + ext);
-        return hp <= (d.stride == 1 ? tapx_hp(bm, 1) : tapx_cls(bm)) && (int64_t)(a.M / bm) * (a.Npad / bn) * d.groups >= g_tapx_min_tiles;
+        if (hp > (d.stride == 1 ? tapx_hp(bm, 1) : tapx_cls(bm))) return false;
+        // enough tiles for every CU - and, below two tiles per CU, a K loop long enough to carry the epilogue that then runs exposed
+        // (one tile per workgroup: 128 -> 128 at 32 x 32 pixels measured 0.070 ms against 0.063 on the tap kernel, layer4 0.551 against 0.565)
+        const int64_t tiles = (int64_t)(a.M / bm) * (a.Npad / bn) * d.groups;
+        return tiles >= g_tapx_min_tiles && (tiles >= 2 * (int64_t)g_tapx_min_tiles || a.cblocks >= 16 || g_tapx_min_tiles <= 1);
     };
-    // candidate tiles (rows x columns, wave tile width): stride 1: 256 x 128 | 128 x 128, 512 x 64 | 256 x 64; stride 2: 128 x 256 | 128 x 128
+    // tiles (rows x columns): the 128 x 64 wave tile (FN = 2) wherever the channel count allows it - stride 1: 256 x 128, stride 2:
+    // 128 x 256 - else the 128 x 32 one (FN = 1): stride 1: 256 x 64 (64 / 192 channels; measured in the pipeline at batch 64:
+    // layer1 346 TFLOP/s against 291 on conv_igemm_tap_kernel and 245 on 512 x 64 tiles) or 128 x 128, stride 2: 128 x 128
     int cfg = -1;
     if (d.stride == 1) {
         if (!(d.wo == 8 || d.wo == 16 || d.wo == 32 || d.wo == 64) || d.ho != d.h || d.wo != d.w) return TAPX_NO;
         if (a.Npad % 128 == 0) cfg = (g_tapx_fn != 1 && fits(256, 128)) ? 0 : (g_tapx_fn != 2 && fits(128, 128) ? 1 : (fits(256, 128) ? 0 : -1));
-        else cfg = (g_tapx_fn != 1 && fits(512, 64)) ? 2 : (g_tapx_fn != 2 && fits(256, 64) ? 3 : (fits(512, 64) ? 2 : -1));
+        else cfg = fits(256, 64) ? 3 : -1;
     } else if (d.stride == 2) {
         if (!(d.wo == 8 || d.wo == 16 || d.wo == 32) || d.h != 2 * d.ho || d.w != 2 * d.wo) return TAPX_NO;
         cfg = (g_tapx_fn != 1 && fits(128, 256)) ? 4 : (g_tapx_fn != 2 && fits(128, 128) ? 5 : (fits(128, 256) ? 4 : -1));
@@ -507,14 +521,18 @@ int tapx_try(ConvArgs& a, int64_t yspan_floats, int64_t rspan_floats, hipStream_
     a.dTilesN = make_fastdiv(a.tilesN);
     a.ntiles = a.tilesM * a.tilesN;
     const unsigned grid = (unsigned)(tiles < g_tapx_blocks ? tiles : g_tapx_blocks);
-    switch (cfg) {
-        case 0: hipLaunchKernelGGL((conv_tapx_kernel<2, 2, 2, 1>), dim3(grid), dim3(512), 0, stream, a); break;
-        case 1: hipLaunchKernelGGL((conv_tapx_kernel<1, 4, 1, 1>), dim3(grid), dim3(512), 0, stream, a); break;
-        case 2: hipLaunchKernelGGL((conv_tapx_kernel<4, 1, 2, 1>), dim3(grid), dim3(512), 0, stream, a); break;
-        case 3: hipLaunchKernelGGL((conv_tapx_kernel<2, 2, 1, 1>), dim3(grid), dim3(512), 0, stream, a); break;
-        case 4: hipLaunchKernelGGL((conv_tapx_kernel<1, 4, 2, 2>), dim3(grid), dim3(512), 0, stream, a); break;
-        default: hipLaunchKernelGGL((conv_tapx_kernel<1, 4, 1, 2>), dim3(grid), dim3(512), 0, stream, a); break;
-    }
+    auto launch = [&](auto res_tag) {
+        constexpr bool R = decltype(res_tag)::value;
+        switch (cfg) {
+            case 0: hipLaunchKernelGGL((conv_tapx_kernel<2, 2, 2, 1, R>), dim3(grid), dim3(512), 0, stream, a); break;
+            case 1: hipLaunchKernelGGL((conv_tapx_kernel<1, 4, 1, 1, R>), dim3(grid), dim3(512), 0, stream, a); break;
+            case 3: hipLaunchKernelGGL((conv_tapx_kernel<2, 2, 1, 1, R>), dim3(grid), dim3(512), 0, stream, a); break;
+            case 4: hipLaunchKernelGGL((conv_tapx_kernel<1, 4, 2, 2, R>), dim3(grid), dim3(512), 0, stream, a); break;
+            default: hipLaunchKernelGGL((conv_tapx_kernel<1, 4, 1, 2, R>), dim3(grid), dim3(512), 0, stream, a); break;
+        }
+    };
+    if (d.res_mode != EGR_RES_NONE) launch(std::true_type{});
+    else launch(std::false_type{});
     return egr_launch_status();
 }
 

@@ -7,8 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C
 import torch
 from egorear_amd import hip
-SHAPES = [(128, 64, 128, 128, 1, 0, "fpn 3x3 128->128 @64"), (128, 64, 64, 64, 1, 1, "layer1 64->64 (+res)"), (128, 32, 128, 128, 1, 1, "layer2 (+res)"),
-          (128, 16, 256, 256, 1, 1, "layer3 (+res)"), (64, 64, 256, 512, 2, 0, "refiner s2 256->512")]
+SHAPES = [(128, 64, 128, 128, 1, 0, "fpn 3x3 128->128 @64"), (128, 64, 64, 64, 1, 1, "layer1 64->64 (+res)"), (256, 32, 128, 128, 1, 1, "layer2 (+res)"),
+          (512, 16, 256, 256, 1, 1, "layer3 (+res)"), (64, 64, 256, 512, 2, 0, "refiner s2 256->512")]
 for (n, hw, cin, cout, stride, res, label) in SHAPES:
     ho = hw // stride
     x = torch.randn(n, hw, hw, cin, device="cuda")
