@@ -34,6 +34,15 @@ namespace {
 #endif
 #define TAPX_T() (TAPX_DBG ? __builtin_amdgcn_s_memtime() : 0ull)
 
+#ifndef TAPX_LD_AUX
+#define TAPX_LD_AUX 0      // cache policy bits of the loading waves' activation / residual loads and of the output stores (2 = nt)
+#endif
+#ifndef TAPX_ST_AUX
+#define TAPX_ST_AUX 0
+#endif
+#ifndef TAPX_PRIO
+#define TAPX_PRIO 0        // s_setprio of the multiplying waves
+#endif
 constexpr int XOOB = (int)0x80000000;   // buffer offset beyond every descriptor's range: loads return 0, stores are dropped
 
 // pixels of one 16-bit plane of a chunk
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
         auto issue = [&](const int SET, int ck) __attribute__((always_inline)) {      // (SET: a literal at every call site)
             const int so = so_tile + ck * 64;
 #pragma unroll
-            for (int i = 0; i < NUH; ++i) xr[SET][i] = __builtin_amdgcn_raw_buffer_load_b128(ra, hvo[i], so, 0);
+            for (int i = 0; i < NUH; ++i) xr[SET][i] = __builtin_amdgcn_raw_buffer_load_b128(ra, hvo[i], so, TAPX_LD_AUX);
         };
         auto convert = [&](const int SET, int buf) __attribute__((always_inline)) {   // register set -> the fp16 planes of LDS buffer `buf`
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -203,7 +212,7 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
         auto res_load = [&](int H, int es) __attribute__((always_inline)) {      // residual quad of step es of half H
             int yo, ro;
             row_offsets(H, es, yo, ro);
-            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr_, ro, 0, 0));
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr_, ro, 0, TAPX_LD_AUX));
         };
         auto finish = [&](f32x4 v, const f32x4& rr, int yo) __attribute__((always_inline)) {
 #pragma unroll
@@ -215,7 +224,7 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
                 v[c] = t;
             }
             if (live) amx = fmaxf(fmaxf(amx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, yo, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, yo, 0, TAPX_ST_AUX);
         };
         // drain step K of the parked tile: K = 0, 1 out of the registers (first half), K = 2, 3 out of the staging area (second half);
         // behind every quad the residual of the same slot of the NEXT step is requested (a whole chunk period to land)
@@ -311,6 +320,7 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
     }
 
     // ---------------------------------------------------------------------- multiplying waves
+    if (TAPX_PRIO) __builtin_amdgcn_s_setprio(TAPX_PRIO);
     const int wm = wave / WN, wn = wave % WN;
     int abase[FM];
 #pragma unroll

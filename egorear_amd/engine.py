@@ -642,6 +642,12 @@ def _pack_refiners(rs) -> PRefiners:
     return P
 
 
+# tests only: a dict here receives the refiners' intermediates of the next forward - "query" (G, B, J, C) behind fc_query, "post_norm"
+# (G, B, J, C) behind the transformer layer + post_norm, "head_sum" (G*B, h, w, C) = head offset + own-view projection (NHWC) - the
+# tensors tests/golden/mvfex_mid_s*.npz pin against the reference (heatmap_mvf_ex.py:665, 699-706, 715)
+CAPTURE = None
+
+
 def _run_refiners(st: State, rs, B: int, V: int, hm_init: torch.Tensor, feat_all: torch.Tensor, s32_all: torch.Tensor,
                   anchors, valid, feat_ref: torch.Tensor, hm_ref: torch.Tensor):
     """The four HeatmapMVF refiners (heatmap_mvf_ex.py:652-731), refiner g = view g, as one group of G = V."""
@@ -673,6 +679,8 @@ def _run_refiners(st: State, rs, B: int, V: int, hm_init: torch.Tensor, feat_all
     h0 = hip.linear_smallk(tok, J, 1, P.head0_w, P.head0_b, G * B * C, P.head0_w.shape[1], J, ACT_RELU, groups=G)
     h0 = hip.upsample2x(Img(h0.view(G * B, side, side, -1)))
     summed = conv(st, h0, P.head3, ACT_RELU, res=ff, res_mode=RES_AFTER_ACT)   # offset_pred + frame_feat
+    if CAPTURE is not None:
+        CAPTURE.update(query=x.view(G, B, J, C).clone(), post_norm=xn.view(G, B, J, C).clone(), head_sum=summed.t.clone())
     run_stack(st, [r.frame_feat_refined_proj_layers[0] for r in rs], summed, out=Img(feat_ref))
     # --- refined heatmaps, written as (B, V, 15, 64, 64) planes; group g = view g
     plane = J * hw

@@ -247,7 +247,7 @@ def ffn(sd: SD, p: str, x):
     return _lin(sd, p + ".layers.1", F.gelu(_lin(sd, p + ".layers.0.0", x)))
 
 
-def joint_transformer_layer(sd: SD, p: str, x, memory, anchors_2d, anchors_valid, H: int, W: int):
+def joint_transformer_layer(sd: SD, p: str, x, memory, anchors_2d, anchors_valid, H: int, W: int, cap: Optional[dict] = None):
     """MultiViewTransformerLayer.forward (heatmap_mvf_ex.py:874-935) ==
     EgoPoseFormerTransformerLayer.forward (egoposeformer_mvf_ex.py:546-588).
     memory (B,V,HW,C); anchors_2d (B,V,J,2); anchors_valid (B,V,J) bool."""
@@ -256,6 +256,8 @@ def joint_transformer_layer(sd: SD, p: str, x, memory, anchors_2d, anchors_valid
     for v in range(V):
         ref = anchors_2d[:, v].reshape(B, -1, 1, 2)
         a = ms_deform_attn(sd, p + ".cross_attn", x, ref, memory[:, v].reshape(B, -1, memory.shape[-1]), H, W)
+        if cap is not None:
+            cap.setdefault("msda", []).append(a)          # the deformable attention's own output (before the validity mask): a13
         a = a.masked_fill(~anchors_valid[:, v][..., None].expand_as(a), 0.0)  # after output_proj (App. B-2)
         per_view.append(a)
     x = _ln(sd, p + ".norm_cross", x + _lin(sd, p + ".fuse_mlp", torch.cat(per_view, dim=-1)))
@@ -276,7 +278,8 @@ def init_heatmap_head(sd: SD, p: str, x):
     return _conv(sd, p + ".9", x)
 
 
-def heatmap_mvf(sd: SD, p: str, heatmap, frame_feat, feat_mv, anchors_2d, anchors_valid, s32_own, detach_heatmap_feat: bool = True):
+def heatmap_mvf(sd: SD, p: str, heatmap, frame_feat, feat_mv, anchors_2d, anchors_valid, s32_own, detach_heatmap_feat: bool = True,
+                cap: Optional[dict] = None):
     """HeatmapMVF.forward, JQA branch, one transformer layer, non-1x1 heatmap head
     (heatmap_mvf_ex.py:652-731).  Returns (heatmap_refined, frame_feat_refined).
     Gradient stops follow the source: `frame_feat.detach()` (:715, unconditional) and, with detach_heatmap_feat
@@ -295,13 +298,19 @@ def heatmap_mvf(sd: SD, p: str, heatmap, frame_feat, feat_mv, anchors_2d, anchor
     ff = F.relu(_conv(sd, p + ".frame_feat_proj_layers.0", frame_feat))
     ff = F.relu(_conv(sd, p + ".frame_feat_proj_layers.2", ff, 2, 1))
     ff = F.relu(_conv(sd, p + ".frame_feat_proj_layers.4", ff))
-    x = joint_transformer_layer(sd, p + ".transformer_layers.0", x, mem, anchors_2d, anchors_valid, H, W)
+    if cap is not None:
+        cap["query"] = x                                   # JQA query behind fc_query: a9
+    x = joint_transformer_layer(sd, p + ".transformer_layers.0", x, mem, anchors_2d, anchors_valid, H, W, cap)
     _x = _ln(sd, p + ".post_norm.0", x)
+    if cap is not None:
+        cap["post_norm"] = _x                              # the transformer layer + post_norm: a12
     side = int(math.sqrt(_x.shape[-1]))
     _x = _x.reshape(B, -1, side, side)  # joints as channels (App. B-3)
     hp = p + ".head_layers.0.head"
     off = F.relu(_conv(sd, hp + ".3", _up2(F.relu(_conv(sd, hp + ".0", _x)))))
     rp = p + ".frame_feat_refined_proj_layers.0"
+    if cap is not None:
+        cap["head_sum"] = off + ff                         # TransformerHeadLayer output + frame_feat_proj_layers output: a16 + a11
     refined = F.relu(_conv(sd, rp + ".3", _up2(F.relu(_conv(sd, rp + ".0", off + ff.detach())))))
     cp = p + ".conv_heatmap_layers.0"
     h = F.relu(_conv(sd, cp + ".0", refined.detach() if detach_heatmap_feat else refined, 2, 1))
@@ -313,7 +322,7 @@ def heatmap_mvf(sd: SD, p: str, heatmap, frame_feat, feat_mv, anchors_2d, anchor
 
 def heatmap_mvfex_forward(sd: SD, p: str, img, heatmap_threshold: float = 0.5, heatmap_for_anchor=None,
                           full_training: bool = True, use_pred_heatmap_init: bool = True, no_detach_feat_init: bool = False,
-                          detach_heatmap_feat: bool = True):
+                          detach_heatmap_feat: bool = True, capture: bool = False):
     """EgoPoseFormerHeatmapMVFEX.forward, num_views==4, use_1by1_conv False
     (heatmap_mvf_ex.py:236-352).  In eval/no_grad the detach/clone branches are value-neutral; under autograd they are
     the gradient stops of :262-288 (flag defaults = the shipped pose3d configs).
@@ -342,12 +351,18 @@ def heatmap_mvfex_forward(sd: SD, p: str, img, heatmap_threshold: float = 0.5, h
         pts, maxvals, valid, idx = get_max_preds(src.detach().reshape(B * V, J, H, W), heatmap_threshold, True)
     anchors_2d, anchors_valid = pts.view(B, V, J, 2), valid.view(B, V, J)
     hms, feats = [], []
+    mid = {}
     for v, name in enumerate(REFINERS):
+        cap = {} if capture else None
         h, f = heatmap_mvf(sd, pre + "heatmap_refiner_" + name, hm_init[:, v], feat[:, v], feat, anchors_2d, anchors_valid, s32[:, v],
-                           detach_heatmap_feat)
+                           detach_heatmap_feat, cap)
         hms.append(h)
         feats.append(f)
+        if capture:
+            mid[name] = cap
     aux = {"argmax_idx": idx.view(B, V, J), "maxvals": maxvals.view(B, V, J), "anchors_valid": anchors_valid, "anchors_2d": anchors_2d, "s32": s32}
+    if capture:   # per refiner: the intermediates tests/golden/mvfex_mid_s*.npz pin (queries, MSDA outputs, head offsets)
+        aux["mid"] = mid
     return [hm_init_out, torch.stack(hms, dim=1)], [feat_init, torch.stack(feats, dim=1)], aux
 
 

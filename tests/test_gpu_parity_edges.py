@@ -49,7 +49,7 @@ def test_config2_standalone_heatmap_estimators_at_batch_32_vs_oracle():
     for views, seed in ((slice(0, 2), 42), (slice(2, 4), 43)):
         net = EgoPoseFormerHeatmap(**copy.deepcopy(configs.heatmap_cfg())).eval()
         synth.load_synth(net, seed)
-        sd = {k: v.clone() for k, v in net.state_dict().items()}
+        sd = {"m." + k: v.clone() for k, v in net.state_dict().items()}     # (the oracle addresses a module by a key prefix)
         net = net.to(DEV)
         x = img[:, views].contiguous()
         hip.PROFILE = []
@@ -61,7 +61,7 @@ def test_config2_standalone_heatmap_estimators_at_batch_32_vs_oracle():
         assert h2 >= 15, (h2, total)                   # the large launches went to the fp16 scheme by size
         assert torch.equal(hm, hm2)
         with torch.no_grad():
-            o = O.heatmap_forward(sd, "", x[:n])
+            o = O.heatmap_forward(sd, "m", x[:n])
         assert torch.equal(_am(hm[:n].cpu()), _am(o))
         assert float((hm[:n].cpu() - o).abs().max()) < TOL_HM
 

@@ -120,6 +120,30 @@ def test_mvfex_vs_reference_golden(seed, scale, nets, golden_dir, launch_policy)
     assert pts.shape == (2, 4, 15, 2) and mask.dtype == torch.bool
 
 
+@pytest.mark.parametrize("seed,scale", [(0, 1.0), (2, 0.35)])
+def test_mvfex_intermediates_vs_reference_golden(seed, scale, nets, golden_dir, launch_policy):
+    """SURVEY.md 8c intermediate pins, captured inside the reference's refiners by oracle/make_golden_mid.py: the JQA query behind
+    fc_query (a9: egr_jqa_sum_f32 + the small linears), transformer layer + post_norm (a10 / a12-a15: egr_msda_gather_f32 with the
+    folded value path + egr_joint_layer_f32), head offset + own-view projection (a16 + a11: egr_tokens_to_nhwc_f32, the head convs,
+    frame_feat_proj_layers).  (The per-view MSDA output a13 never exists on the HIP path - sample-then-project, DESIGN.md 4: the
+    operand-for-operand op is pinned in test_gpu_msda_op.py, its restatement against this golden in test_oracle_golden.py.)"""
+    from egorear_amd import engine, synth
+    g = np.load(os.path.join(golden_dir, f"mvfex_mid_s{seed}.npz"))
+    net = nets("mvfex")
+    engine.CAPTURE = cap = {}
+    try:
+        with torch.no_grad():
+            net(synth.synth_images(2, 4, seed=seed, scale=scale).to(DEV))
+    finally:
+        engine.CAPTURE = None
+    for gi, name in enumerate(("front_left", "front_right", "back_left", "back_right")):
+        np.testing.assert_allclose(cap["query"][gi].cpu().numpy(), g[name + "_query"], rtol=0, atol=5e-5)
+        np.testing.assert_allclose(cap["post_norm"][gi].cpu().numpy(), g[name + "_post_norm"], rtol=0, atol=2e-4)
+        hs = cap["head_sum"].view(4, 2, *cap["head_sum"].shape[1:])[gi].permute(0, 3, 1, 2).float().cpu()      # (B, C, h, w)
+        np.testing.assert_allclose(hs[:, ::8, ::4, ::4].numpy(), g[name + "_head_sum_sl"], rtol=0, atol=2e-4)
+        assert abs(hs.double().sum().item() - float(g[name + "_head_sum_sum"])) <= 2e-4 * hs.numel()
+
+
 @pytest.mark.parametrize("cam,seed", [("syn", 0), ("syn", 1), ("rw", 0)])
 def test_pose3d_vs_reference_golden(cam, seed, nets, golden_dir, launch_policy):
     from egorear_amd import synth

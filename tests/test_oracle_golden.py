@@ -112,3 +112,21 @@ def test_pose3d_matches_reference(cam, seed, sd_full, golden_dir, calib_dir):
         np.testing.assert_allclose(delta[..., 1:], 0.0, atol=1e-4)
     else:
         np.testing.assert_array_equal(delta, 0.0)
+
+
+@pytest.mark.parametrize("seed,scale", [(0, 1.0), (2, 0.35)])
+def test_mvfex_intermediates_match_reference(seed, scale, sd_mvfex, golden_dir):
+    """SURVEY.md 8c intermediate pins (oracle/make_golden_mid.py: forward hooks inside the reference's refiners): JQA query (a9),
+    the deformable attention's output per view (a13), transformer layer + post_norm (a12 / a14 / a15), head offset + own-view
+    projection (a16 + a11)."""
+    g = np.load(os.path.join(golden_dir, f"mvfex_mid_s{seed}.npz"))
+    with torch.no_grad():
+        _, _, aux = O.heatmap_mvfex_forward(sd_mvfex, "", synth.synth_images(2, 4, seed=seed, scale=scale), capture=True)
+    for name in ("front_left", "front_right", "back_left", "back_right"):
+        c = aux["mid"][name]
+        np.testing.assert_allclose(c["query"].numpy(), g[name + "_query"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(torch.stack(c["msda"])[..., ::4].numpy(), g[name + "_msda"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(c["post_norm"].numpy(), g[name + "_post_norm"], rtol=0, atol=5e-5)
+        hs = c["head_sum"]
+        np.testing.assert_allclose(hs[:, ::8, ::4, ::4].numpy(), g[name + "_head_sum_sl"], rtol=0, atol=5e-5)
+        assert abs(hs.double().sum().item() - float(g[name + "_head_sum_sum"])) <= 5e-5 * hs.numel()
