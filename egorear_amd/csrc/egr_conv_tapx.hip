@@ -56,16 +56,22 @@ constexpr int tapx_hp(int bm, int stride) { return stride == 2 ? 4 * tapx_cls(bm
 // FN = 1: wave tile 128 x 32 (64 accumulator registers), the WHOLE tile fits the staging area: one barrier per tile, no register
 //         copy, half the registers in both roles - and tiles of 128 x 128 / 256 x 64 for layers with few pixels.
 // RES: the launch adds a residual (its quads are requested one drain step ahead: eight / four more quads of registers per loading thread).
+// STRIDE = 0: the same machinery for 1x1 / stride 1 convolutions with >= 256 input channels (the heads' and refiners' 256 -> 256,
+// 256 -> 128, 512 -> 128: 169 TFLOP/s / 2.7-3.7 TB/s on the tiled kernel): a chunk is 64 channels of the tile's 128 pixels, its four
+// k16 steps play the part of the taps (four weight register sets, requested three steps ahead), no halo.
 template <int WM, int WN, int FN, int STRIDE, bool RES>
 __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
-    static_assert(WM * WN == 4 && (STRIDE == 1 || STRIDE == 2) && (FN == 1 || FN == 2), "four multiplying waves");
+    static_assert(WM * WN == 4 && (STRIDE == 0 || STRIDE == 1 || STRIDE == 2) && (FN == 1 || FN == 2), "four multiplying waves");
     constexpr int NPL = 2, NPR = 3, FM = 4;
+    constexpr bool PW = STRIDE == 0;
     constexpr bool WHOLE = FN == 1;                           // the staging area holds the whole tile
     constexpr int BM = WM * 128, BN = WN * 32 * FN, NFB = BN / 32;
-    constexpr int HPX = tapx_hp(BM, STRIDE), CLS = tapx_cls(BM);
-    constexpr int PLANE = HPX * 32, HBUF = NPL * PLANE;
+    constexpr int NT = PW ? 4 : 9;                            // "taps" of a chunk: filter taps of 16 channels, or k16 steps of 64 channels
+    constexpr int SEGS = PW ? 16 : 4;                         // 4-channel units per pixel and chunk
+    constexpr int HPX = PW ? BM : tapx_hp(BM, STRIDE), CLS = tapx_cls(BM);
+    constexpr int PLANE = HPX * 32, HBUF = (PW ? NT : 1) * NPL * PLANE;
     constexpr int STG = (WHOLE ? BM : BM / 2) * BN * 4;       // the tile (FN = 1) or half of it (FN = 2) in fp32: 64 KB
-    constexpr int NUH = (HPX * 4 + 255) / 256;                // staging units (4 channels of one pixel) per loading thread and chunk
+    constexpr int NUH = (HPX * SEGS + 255) / 256;             // staging units (4 channels of one pixel) per loading thread and chunk
     constexpr int QPR = BN / 4, RPE = 256 / QPR;              // epilogue: channel quads per row, rows covered by the 256 loading threads per step
     constexpr int NQ = WHOLE ? 4 : 8;                         // quads per thread and drain step (four steps per tile)
     static_assert(STG == 65536, "staging area");
@@ -83,7 +89,7 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
     const int WP = wo + (STRIDE == 1 ? 2 : 1);
     const int NI = HoWo >= BM ? 1 : BM / HoWo, RTI = HoWo >= BM ? BM / wo : d.ho;
     const int HPI = (RTI + (STRIDE == 1 ? 2 : 1)) * WP, HP = NI * HPI, PPI = RTI * wo;
-    const int NC = a.cblocks * 2;                             // 16-channel chunks per tile (>= 4)
+    const int NC = PW ? a.cblocks / 2 : a.cblocks * 2;        // chunks per tile (>= 4, even)
     const int T_all = a.ntiles * d.groups;
     // tile order: XCD x owns the contiguous run [x T/8, (x + 1) T/8) and deals it to its workgroups in order (blocks b and b + 8 share
     // an XCD); the N tiles of an M tile are adjacent in a run.  Falls back to b, b + grid, ... when the counts do not divide.
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
         int pix0;
         T.n0 = m0 >> a.howo_shift;                            // (the host sends power-of-two image sizes only: shifts, no division)
         pix0 = m0 & (HoWo - 1);
-        T.y0 = pix0 >> a.wo_shift;
+        T.y0 = PW ? 0 : pix0 >> a.wo_shift;
         T.xbase = (int)fmap(d.xmap, a.dXin, T.n0);
         return T;
     };
@@ -127,10 +133,16 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
         int so_tile = 0;
         auto setup = [&](int t) __attribute__((always_inline)) {    // the load cursor enters tile t
             const Tile T = tile_of(t);
-            ra = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(reinterpret_cast<const char*>(a.x + T.grp * d.gx) - abias), 0, 0x80000000u, 0x00020000);
-            so_tile = __builtin_amdgcn_readfirstlane((T.xbase + STRIDE * T.y0 * d.w * d.ldx) * 4);
+            ra = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(reinterpret_cast<const char*>(a.x + T.grp * d.gx) - (PW ? 0 : abias)), 0, 0x80000000u, 0x00020000);
+            so_tile = PW ? 0 : __builtin_amdgcn_readfirstlane((T.xbase + STRIDE * T.y0 * d.w * d.ldx) * 4);
 #pragma unroll
             for (int i = 0; i < NUH; ++i) {
+                if constexpr (PW) {       // pixel p of the tile = output pixel tm BM + p, read at the same place; 16 units of 4 channels per pixel
+                    const int u = lt + 256 * i, m = T.tm * BM + (u >> 4);
+                    const int n = m >> a.howo_shift, pix = m & (HoWo - 1);
+                    hvo[i] = ((int)fmap(d.xmap, a.dXin, n) + pix * d.ldx) * 4 + (u & 15) * 16;
+                    continue;
+                }
                 // unit -> pixel of the chunk's planes: class | image of the tile | row | column
                 const int seg = (lt + 256 * i) & 3, pxl = (lt + 256 * i) >> 2;
                 const int q = STRIDE == 2 ? pxl / CLS : 0, hp = STRIDE == 2 ? pxl - q * CLS : pxl;
@@ -143,7 +155,7 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
             }
         };
         auto issue = [&](const int SET, int ck) __attribute__((always_inline)) {      // (SET: a literal at every call site)
-            const int so = so_tile + ck * 64;
+            const int so = so_tile + ck * (PW ? 256 : 64);
 #pragma unroll
             for (int i = 0; i < NUH; ++i) xr[SET][i] = __builtin_amdgcn_raw_buffer_load_b128(ra, hvo[i], so, TAPX_LD_AUX);
         };
@@ -153,11 +165,12 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
             for (int i = 0; i < NUH; ++i) {
                 unsigned h0, l0, h1, l1;
                 split4_f16(__uint_as_float(xr[SET][i][0]), __uint_as_float(xr[SET][i][1]), __uint_as_float(xr[SET][i][2]), __uint_as_float(xr[SET][i][3]), sa, h0, l0, h1, l1);
-                if (lt + 256 * i < 4 * HPX) {
+                if (lt + 256 * i < SEGS * HPX) {
                     // plane layout [8-channel half][pixel][8 channels]: the lanes of an A fragment (consecutive pixels, one half) read
-                    // consecutive 16-byte slots - no bank conflicts (pixel-major 32-byte rows were 2-way for ds_read_b128)
-                    const int u = lt + 256 * i;
-                    uint8_t* dst = lb + buf * HBUF + ((u >> 1) & 1) * (PLANE / 2) + (u >> 2) * 16 + (u & 1) * 8;
+                    // consecutive 16-byte slots - no bank conflicts (pixel-major 32-byte rows were 2-way for ds_read_b128).
+                    // 1x1: one (h, l) plane pair per k16 step of the chunk
+                    const int u = lt + 256 * i, px = PW ? u >> 4 : u >> 2, sg = PW ? u & 15 : u & 3;
+                    uint8_t* dst = lb + buf * HBUF + (sg >> 2) * (NPL * PLANE) + ((sg >> 1) & 1) * (PLANE / 2) + px * 16 + (sg & 1) * 8;
                     *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
                     *reinterpret_cast<u32x2*>(dst + PLANE) = u32x2{l0, l1};
                 }
@@ -326,7 +339,7 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int ml = wm * 128 + i * 32 + l31, il = ml / PPI, mq = ml - il * PPI, r = mq / wo, c = mq - r * wo;
-        abase[i] = (il * HPI + r * WP + c) * 16 + half * (PLANE / 2);
+        abase[i] = (PW ? ml : il * HPI + r * WP + c) * 16 + half * (PLANE / 2);
     }
     // the nine taps in the order they are multiplied: byte offset of the tap's window inside a plane, index of its weights
     //   stride 1: tap (kh, kw) = the window shifted by (kh, kw) pixels
@@ -336,6 +349,7 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
     constexpr int TDR[9] = {0, 0, 0, 0, 1, 0, 0, 1, 1};
     constexpr int TDC[9] = {0, 0, 1, 0, 0, 0, 1, 0, 1};
     auto tap_off = [&](int tap) __attribute__((always_inline)) {
+        if (PW) return tap * NPL * PLANE;
         return STRIDE == 1 ? ((tap / 3) * WP + (tap % 3)) * 16 : TCL[tap] * CLS * 16 + (TDR[tap] * WP + TDC[tap]) * 16;
     };
     auto tap_w = [&](int tap) __attribute__((always_inline)) { return STRIDE == 1 ? tap : TID[tap]; };
@@ -349,12 +363,12 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
     // weight fragments: NSET register sets (a divisor of the nine taps, so that a tap's set is a compile-time constant), requested
     // AHEAD taps before they are multiplied.  L2 latency under load is above one microsecond: two taps of the narrow wave tile
     // (2 x 12 MFMAs = 768 cycles) do not cover it.
-    constexpr int NSET = FN == 1 ? 9 : 3;
+    constexpr int NSET = PW ? 4 : (FN == 1 ? 9 : 3);
 #ifndef TAPX_AHEAD1
 #define TAPX_AHEAD1 5
 #endif
-    constexpr int AHEAD = FN == 1 ? TAPX_AHEAD1 : 2;
-    static_assert(AHEAD < NSET && 9 % NSET == 0, "weight register sets");
+    constexpr int AHEAD = PW ? 3 : (FN == 1 ? TAPX_AHEAD1 : 2);
+    static_assert(AHEAD < NSET && NT % NSET == 0, "weight register sets");
     u32x4 af[FM][NPL], bf[NSET][FN][NPL];
 
     const int FSTR = a.ktiles * 2 * NPL * 1024;              // bytes between column fragments of the weight image
@@ -366,7 +380,7 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
         return W;
     };
     auto load_b = [&](const WTile& W, int ck, int tap, int set) __attribute__((always_inline)) {
-        const int so = (((ck >> 1) * 9 + tap_w(tap)) * 2 * NPL + (ck & 1) * NPL) * 1024;
+        const int so = PW ? (ck * 4 + tap) * NPL * 1024 : (((ck >> 1) * 9 + tap_w(tap)) * 2 * NPL + (ck & 1) * NPL) * 1024;
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
@@ -385,11 +399,11 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
         read_a(base, 0, 0);
         constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        for (int tap = 0; tap < NT; ++tap) {
             const int pc = tap % NSET, pn = (tap + AHEAD) % NSET;
 #ifndef TAPX_EXP_NOB       // (TAPX_EXP_*: elimination builds for tools/tapx_stamps.py - timing only, the results are wrong)
-            if (tap + AHEAD < 9) load_b(W, ck, tap + AHEAD, pn);
-            else load_b(X, ckn, tap + AHEAD - 9, pn);
+            if (tap + AHEAD < NT) load_b(W, ck, tap + AHEAD, pn);
+            else load_b(X, ckn, tap + AHEAD - NT, pn);
 #endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -402,7 +416,7 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #ifndef TAPX_EXP_NOA
-                if (tap + 1 < 9 && split_free_a(NPL, t) >= 0) {
+                if (tap + 1 < NT && split_free_a(NPL, t) >= 0) {
 #else
                 if (false) {
 #endif
@@ -473,6 +487,7 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
 int g_tapx = getenv("EGR_CONV_TAPX") ? atoi(getenv("EGR_CONV_TAPX")) : 1;                          // 0: the 3x3 launches stay on conv_igemm_tap[2]_kernel
 int g_tapx_min_tiles = getenv("EGR_CONV_TAPX_MIN_TILES") ? atoi(getenv("EGR_CONV_TAPX_MIN_TILES")) : 256; // tiles (all groups) from which the role-split kernel is used
 int g_tapx_blocks = getenv("EGR_CONV_TAPX_BLOCKS") ? atoi(getenv("EGR_CONV_TAPX_BLOCKS")) : 256;    // resident workgroups (one per CU)
+int g_tapx_pw = getenv("EGR_CONV_TAPX_PW") ? atoi(getenv("EGR_CONV_TAPX_PW")) : 1;                  // 0: 1x1 launches with >= 256 input channels stay on the tiled kernel
 int g_tapx_fn = getenv("EGR_CONV_TAPX_FN") ? atoi(getenv("EGR_CONV_TAPX_FN")) : 0;                  // wave tile: 0 by shape, 1: 128 x 32, 2: 128 x 64 wherever it exists
 
 }  // namespace
@@ -490,7 +505,9 @@ int tapx_set(int on, int min_tiles, int blocks) {
 // `a` arrives from conv_run with the geometry fields filled in (M, Npad, K, cblocks, ktiles, *_shift, *_plain, vec_ok, cls_mode).
 int tapx_try(ConvArgs& a, int64_t yspan_floats, int64_t rspan_floats, hipStream_t stream) {
     egr_conv_desc& d = a.d;
-    if (!g_tapx || d.w_format != EGR_W_F16X2 || d.kh != 3 || d.kw != 3 || d.pad != 1 || d.transposed || a.cls_mode || d.split_k > 1 ||
+    const bool pw = d.kh == 1 && d.kw == 1;
+    if (!g_tapx || d.w_format != EGR_W_F16X2 || !(pw ? (d.pad == 0 && d.stride == 1 && g_tapx_pw) : (d.kh == 3 && d.kw == 3 && d.pad == 1)) ||
+        d.transposed || a.cls_mode || d.split_k > 1 ||
         d.out_nchw || a.rowscale || a.rowmask || a.mask || a.bn_part || !a.vec_ok || d.cout % 4 != 0 || d.cin < 64 ||
         (d.act != EGR_ACT_NONE && d.act != EGR_ACT_RELU) || d.res_mode == EGR_RES_UP2_BEFORE_ACT || (a.dbg && !TAPX_DBG))
         return TAPX_NO;
@@ -499,19 +516,25 @@ int tapx_try(ConvArgs& a, int64_t yspan_floats, int64_t rspan_floats, hipStream_
     if (a.howo_shift < 0 || a.wo_shift < 0) return TAPX_NO;
     const int ext = d.stride == 1 ? 2 : 1;
     auto fits = [&](int bm, int bn) {        // tiles of whole image rows / whole small images whose planes fit the kernel's LDS buffers
-        if (a.Npad % bn != 0 || a.M % bm != 0 || !((P % bm == 0) || (bm % P == 0)) || (bm / P) > 15) return false;
-        const int hp = P >= bm ? (bm / d.wo + ext) * (d.wo + ext) : (bm / P) * (d.ho + ext) * (d.wo + ext);
-        if (hp > (d.stride == 1 ? tapx_hp(bm, 1) : tapx_cls(bm))) return false;
+        if (a.Npad % bn != 0 || a.M % bm != 0) return false;
+        if (!pw) {
+            if (!((P % bm == 0) || (bm % P == 0)) || (bm / P) > 15) return false;
+            const int hp = P >= bm ? (bm / d.wo + ext) * (d.wo + ext) : (bm / P) * (d.ho + ext) * (d.wo + ext);
+            if (hp > (d.stride == 1 ? tapx_hp(bm, 1) : tapx_cls(bm))) return false;
+        }
         // enough tiles for every CU - and, below two tiles per CU, a K loop long enough to carry the epilogue that then runs exposed
         // (one tile per workgroup: 128 -> 128 at 32 x 32 pixels measured 0.070 ms against 0.063 on the tap kernel, layer4 0.551 against 0.565)
         const int64_t tiles = (int64_t)(a.M / bm) * (a.Npad / bn) * d.groups;
-        return tiles >= g_tapx_min_tiles && (tiles >= 2 * (int64_t)g_tapx_min_tiles || a.cblocks >= 16 || g_tapx_min_tiles <= 1);
+        return tiles >= g_tapx_min_tiles && (tiles >= 2 * (int64_t)g_tapx_min_tiles || (!pw && a.cblocks >= 16) || g_tapx_min_tiles <= 1);
     };
     // tiles (rows x columns): the 128 x 64 wave tile (FN = 2) wherever the channel count allows it - stride 1: 256 x 128, stride 2:
     // 128 x 256 - else the 128 x 32 one (FN = 1): stride 1: 256 x 64 (64 / 192 channels; measured in the pipeline at batch 64:
     // layer1 346 TFLOP/s against 291 on conv_igemm_tap_kernel and 245 on 512 x 64 tiles) or 128 x 128, stride 2: 128 x 128
     int cfg = -1;
-    if (d.stride == 1) {
+    if (pw) {      // 1x1 with >= 256 input channels (chunks of 64): 128 x 256 tiles, else 128 x 128
+        if (d.cin % 128 != 0 || d.cin < 256 || d.h != d.ho || d.w != d.wo) return TAPX_NO;      // (an even number of 64-channel chunks, at least four)
+        cfg = (g_tapx_fn != 1 && fits(128, 256)) ? 6 : (g_tapx_fn != 2 && fits(128, 128) ? 7 : (fits(128, 256) ? 6 : -1));
+    } else if (d.stride == 1) {
         if (!(d.wo == 8 || d.wo == 16 || d.wo == 32 || d.wo == 64) || d.ho != d.h || d.wo != d.w) return TAPX_NO;
         if (a.Npad % 128 == 0) cfg = (g_tapx_fn != 1 && fits(256, 128)) ? 0 : (g_tapx_fn != 2 && fits(128, 128) ? 1 : (fits(256, 128) ? 0 : -1));
         else cfg = fits(256, 64) ? 3 : -1;
@@ -520,7 +543,7 @@ int tapx_try(ConvArgs& a, int64_t yspan_floats, int64_t rspan_floats, hipStream_
         cfg = (g_tapx_fn != 1 && fits(128, 256)) ? 4 : (g_tapx_fn != 2 && fits(128, 128) ? 5 : (fits(128, 256) ? 4 : -1));
     }
     if (cfg < 0) return TAPX_NO;
-    static const int kbm[6] = {256, 128, 512, 256, 128, 128}, kbn[6] = {128, 128, 64, 64, 256, 128};
+    static const int kbm[8] = {256, 128, 512, 256, 128, 128, 128, 128}, kbn[8] = {128, 128, 64, 64, 256, 128, 256, 128};
     const int bm = kbm[cfg], bn = kbn[cfg];
     const int64_t tiles = (int64_t)(a.M / bm) * (a.Npad / bn) * d.groups;
     if (tiles >= (1 << 30)) return TAPX_NO;
@@ -538,7 +561,9 @@ int tapx_try(ConvArgs& a, int64_t yspan_floats, int64_t rspan_floats, hipStream_
             case 1: hipLaunchKernelGGL((conv_tapx_kernel<1, 4, 1, 1, R>), dim3(grid), dim3(512), 0, stream, a); break;
             case 3: hipLaunchKernelGGL((conv_tapx_kernel<2, 2, 1, 1, R>), dim3(grid), dim3(512), 0, stream, a); break;
             case 4: hipLaunchKernelGGL((conv_tapx_kernel<1, 4, 2, 2, R>), dim3(grid), dim3(512), 0, stream, a); break;
-            default: hipLaunchKernelGGL((conv_tapx_kernel<1, 4, 1, 2, R>), dim3(grid), dim3(512), 0, stream, a); break;
+            case 5: hipLaunchKernelGGL((conv_tapx_kernel<1, 4, 1, 2, R>), dim3(grid), dim3(512), 0, stream, a); break;
+            case 6: hipLaunchKernelGGL((conv_tapx_kernel<1, 4, 2, 0, R>), dim3(grid), dim3(512), 0, stream, a); break;
+            default: hipLaunchKernelGGL((conv_tapx_kernel<1, 4, 1, 0, R>), dim3(grid), dim3(512), 0, stream, a); break;
         }
     };
     if (d.res_mode != EGR_RES_NONE) launch(std::true_type{});

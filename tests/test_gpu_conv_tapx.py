@@ -96,6 +96,31 @@ def test_role_split_stride2_128_channels(case):
         hip.lib.egr_conv_set_tapx(1, 256, 256)
 
 
+PW_CASES = [
+    # n, h(=w), cin, cout, groups, extras        1x1 convolutions with >= 256 input channels: chunks of 64 channels, four k16 steps each
+    (8, 32, 256, 256, 2, "scale_relu"),        # the heads' 256 -> 256 (egoposeformer_heatmap_mvf_ex.py:101-126), grouped
+    (16, 16, 256, 128, 1, "plain"),            # 256 -> 128: 128 x 128 tiles only
+    (4, 32, 512, 128, 4, "scale_relu"),        # the refiners' 512 -> 128 (:525-532), four groups, eight chunks
+    (2, 64, 320, 256, 1, "res_after"),         # five chunks' worth of channels is not a multiple of ... (320 = 5 x 64: odd chunk count -> stays on the tiled kernel)
+    (6, 32, 384, 512, 1, "res_before"),        # six chunks, two column tiles, residual
+]
+
+
+@pytest.mark.parametrize("case", PW_CASES)
+def test_role_split_1x1(tapx, case):
+    hip = tapx
+    n, hw, cin, cout, G, extra = case
+    x = rnd(G * n, hw, hw, cin, seed=370)
+    wts = [rnd(cout, cin, 1, 1, seed=371 + g, scale=1.0 / math.sqrt(cin)) for g in range(G)]
+    wp = torch.stack([pack_w(t) for t in wts]) if G > 1 else pack_w(wts[0])
+    kw, res, sc, sh = _epilogue_kw(hip, extra, G, n, hw, hw, cout, wp.shape[-2], 375)
+    a, b, c, kern, rec = three(hip, hip.Img(x.to(DEV)), wp, cout, 1, 1, 1, 0, **kw)
+    wide_only = MODE["on"] == 3 and cout % 256 != 0         # the 128 x 64 wave tile forced, but only 128 x 128 tiles exist for this width
+    assert kern == (1 if (cin // 64) % 2 or wide_only else 6), (case, kern)
+    ref = _reference(x, wts, G, n, 1, 0, extra, res, sc, sh, cout)
+    check(a.t.permute(0, 3, 1, 2), b.t.permute(0, 3, 1, 2), c.t.permute(0, 3, 1, 2), ref, rec, f"tapx 1x1 {case}")
+
+
 def test_launches_outside_its_cover_stay_on_the_tap_kernels(tapx):
     hip = tapx
     for (n, hw, cin, cout, stride, want) in [(32, 16, 32, 192, 1, 2),      # two chunks only
