@@ -13,10 +13,13 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- $
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- $PM > $out/write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/mfma -- $PM > $out/mfma.log 2>&1
 python3 tools/pmc_traffic.py $out/fetch $out/write $out/pmc_traffic.json 64 12 $commit > /dev/null
+python3 tools/launch_list.py --batch 64 > $out/launch_list.txt 2>/dev/null
+python3 tools/pmc_traffic_per_launch.py $out/fetch $out/write $out/launch_list.txt 12 > $out/pmc_traffic_per_launch.txt || true
 python3 tools/pmc_mfma_util.py $out/mfma $out/pmc_mfma_util.json > /dev/null
 cp $(ls $out/stats/*/*kernel_stats.csv | head -1) $out/kernel_stats.csv
 grep -h '"metric"' $out/stats.log | tail -1 > $out/bench_profiled.json || true
 echo done $tag
+[ "$3" = "notrain" ] && { rm -rf $out/stats/*/*kernel_trace.csv $out/fetch $out/write $out/mfma; exit 0; }
 # training step (config 5, batch 32): per-kernel breakdown of the eager step + the PMC passes of the same command
 TR="python3 tools/train_bench.py --batch 32 --steps 2 --warmup 1"
 python3 tools/train_bench.py --batch 32 --graph > $out/train_step_breakdown.txt 2>&1 || true

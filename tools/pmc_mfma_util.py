@@ -15,14 +15,28 @@ for r in csv.DictReader(open(f)):
     x6w = "conv_wgrad_x6" in n or "conv_wgrad3_x6" in n
     h2w = x6w and re.search(r",\s*2>\(", n) is not None
     h2s = "stem_x6_kernel" in n and re.search(r",\s*2>\(", n) is not None
-    k = (("conv_igemm_f16x2" if h2 else ("conv_igemm_bf16x3" if x6 else "conv_igemm")) if ("conv_igemm" in n or "conv_pw_x6" in n) else
+    # conv_tapx_kernel<WM, WN, FN, STRIDE, RES> (fp16 scheme only): its own rows - 3x3 (STRIDE 1 / 2) and the wide 1x1 mode (STRIDE 0) -
+    # AND part of the conv_igemm_f16x2 total (the key bench.py's roofline object carries)
+    if "conv_tapx_kernel" in n:
+        m = re.search(r"conv_tapx_kernel<\s*\d+\s*,\s*\d+\s*,\s*\d+\s*,\s*(\d+)", n)
+        kk = "conv_tapx_1x1_f16x2" if (m and m.group(1) == "0") else "conv_tapx_3x3_f16x2"
+        per[kk][r["Counter_Name"]] += float(r["Counter_Value"])
+        if ("t", r["Dispatch_Id"]) not in seen:
+            seen.add(("t", r["Dispatch_Id"])); dur[kk] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    if "conv_tapx_kernel" not in n and ("conv_igemm_tap" in n or "conv_pw_x6" in n or "conv_igemm_x6" in n) and h2:
+        kk = "conv_other_split_f16x2"      # what is left on the tap-sharing / streaming / tiled kernels
+        per[kk][r["Counter_Name"]] += float(r["Counter_Value"])
+        if ("o", r["Dispatch_Id"]) not in seen:
+            seen.add(("o", r["Dispatch_Id"])); dur[kk] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    h2 = h2 or "conv_tapx_kernel" in n
+    k = (("conv_igemm_f16x2" if h2 else ("conv_igemm_bf16x3" if x6 else "conv_igemm")) if ("conv_igemm" in n or "conv_pw_x6" in n or "conv_tapx_kernel" in n) else
          (("conv_wgrad_f16x2" if h2w else ("conv_wgrad_bf16x3" if x6w else "conv_wgrad")) if "conv_wgrad" in n else
           (("stem_f16x2" if h2s else "stem_bf16x3") if "stem_x6_kernel" in n else ("stem" if "stem_kernel" in n else ("wstream_f16x2" if "ws_stream_kernel" in n else "other")))))
     per[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if (r["Dispatch_Id"]) not in seen:
         seen.add(r["Dispatch_Id"]); dur[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 out = {}
-for k in ("conv_igemm_f16x2", "conv_igemm_bf16x3", "conv_igemm", "conv_wgrad_f16x2", "conv_wgrad_bf16x3", "conv_wgrad", "stem_f16x2", "stem_bf16x3", "stem",
+for k in ("conv_igemm_f16x2", "conv_tapx_3x3_f16x2", "conv_tapx_1x1_f16x2", "conv_other_split_f16x2", "conv_igemm_bf16x3", "conv_igemm", "conv_wgrad_f16x2", "conv_wgrad_bf16x3", "conv_wgrad", "stem_f16x2", "stem_bf16x3", "stem",
           "wstream_f16x2"):
     if k not in per:
         continue

@@ -15,9 +15,10 @@ def load(d, counter):
         nm = r["Kernel_Name"]
         # conv_igemm_x6 / x6p / tap / tap2 / conv_pw_x6 kernels = the split launches (last template argument: 3 = bf16 x 3 planes,
         # 2 = fp16 x 2 planes), conv_igemm_kernel the fp32 ones
-        split = "conv_igemm_x6" in nm or "conv_igemm_tap" in nm or "conv_pw_x6" in nm
-        h2 = split and re.search(r",\s*2>\(", nm.replace(") ", ")")) is not None
-        k = (("conv_h2" if h2 else "conv_x6") if split else "conv") if ("conv_igemm" in nm or "conv_pw_x6" in nm) else "other"
+        tapx = "conv_tapx_kernel" in nm                       # role-split persistent workgroups: fp16 scheme only
+        split = "conv_igemm_x6" in nm or "conv_igemm_tap" in nm or "conv_pw_x6" in nm or tapx
+        h2 = tapx or (split and re.search(r",\s*2>\(", nm.replace(") ", ")")) is not None)
+        k = (("conv_h2" if h2 else "conv_x6") if split else "conv") if ("conv_igemm" in nm or "conv_pw_x6" in nm or tapx) else "other"
         per[k] += float(r["Counter_Value"]); n[(k, r["Dispatch_Id"])] += 1
     launches = collections.Counter(k for (k, _d) in n)
     return per, launches
@@ -36,7 +37,7 @@ def entry(key, label):
             "write_bytes_per_launch": write[key] * 1024 / lw[key],
             "hbm_bytes_per_launch": (2.0 * fetch[key] * 1024) / n + write[key] * 1024 / lw[key]}
 
-h2 = entry("conv_h2", "conv_igemm_x6 / x6p / tap / tap2 / conv_pw_x6 kernels, two fp16 planes (egr_conv2d_nhwc_ex_f32, EGR_W_F16X2 launches)")
+h2 = entry("conv_h2", "conv_tapx / conv_igemm_x6 / x6p / tap / tap2 / conv_pw_x6 kernels, two fp16 planes (egr_conv2d_nhwc_ex_f32, EGR_W_F16X2 launches)")
 x6 = entry("conv_x6", "conv_igemm_x6 / x6p / tap / tap2 / conv_pw_x6 kernels, three bf16 planes (egr_conv2d_nhwc_f32, EGR_W_BF16X3 launches)")
 f32 = entry("conv", "conv_igemm_kernel (egr_conv2d_nhwc_f32, fp32-matrix-core launches)")
 main = h2 or x6 or f32
