@@ -19,7 +19,7 @@ python3 tools/pmc_mfma_util.py $out/mfma $out/pmc_mfma_util.json > /dev/null
 cp $(ls $out/stats/*/*kernel_stats.csv | head -1) $out/kernel_stats.csv
 grep -h '"metric"' $out/stats.log | tail -1 > $out/bench_profiled.json || true
 echo done $tag
-[ "$3" = "notrain" ] && { rm -rf $out/stats/*/*kernel_trace.csv $out/fetch $out/write $out/mfma; exit 0; }
+[ "$3" = "notrain" ] && { rm -rf $out/stats/*/*kernel_trace.csv $out/mfma; exit 0; }     # (fetch / write kept: ~20 MB of CSV for re-reductions)
 # training step (config 5, batch 32): per-kernel breakdown of the eager step + the PMC passes of the same command
 TR="python3 tools/train_bench.py --batch 32 --steps 2 --warmup 1"
 python3 tools/train_bench.py --batch 32 --graph > $out/train_step_breakdown.txt 2>&1 || true
