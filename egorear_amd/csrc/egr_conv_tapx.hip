@@ -379,13 +379,23 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
         W.bvo = (T.tn * NFB + wn * FN) * FSTR + lane * 16;      // (NFB = BN / 32 column fragments per tile, FN of them per wave)
         return W;
     };
-    auto load_b = [&](const WTile& W, int ck, int tap, int set) __attribute__((always_inline)) {
+    auto load_b_plane = [&](const WTile& W, int ck, int tap, int set, const int pl) __attribute__((always_inline)) {
         const int so = PW ? (ck * 4 + tap) * NPL * 1024 : (((ck >> 1) * 9 + tap_w(tap)) * 2 * NPL + (ck & 1) * NPL) * 1024;
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) bf[set][j][pl] = __builtin_amdgcn_raw_buffer_load_b128(W.rb, W.bvo + j * FSTR + pl * 1024, so, 0);
+        for (int j = 0; j < FN; ++j) bf[set][j][pl] = __builtin_amdgcn_raw_buffer_load_b128(W.rb, W.bvo + j * FSTR + pl * 1024, so, 0);
     };
+    auto load_b = [&](const WTile& W, int ck, int tap, int set) __attribute__((always_inline)) {
+        load_b_plane(W, ck, tap, set, 0);
+        load_b_plane(W, ck, tap, set, 1);
+    };
+    // EARLY (experiment, off): a weight plane of tap T + NSET requested the moment its last product of tap T has been issued - products
+    // in the order (l,h) (h,h) (h,l), so the h plane is free after the second product: 2 1/3 taps of lead instead of 2 for the wide wave
+    // tile, whose registers stop at three sets.  Measured in the pipeline: no change (3x3 + wide 1x1 launches 6.95-7.03 ms per forward with,
+    // 7.00-7.03 without) - like the nine-set variant of the narrow tile: the weight path is not latency-bound.
+#ifndef TAPX_EARLY
+#define TAPX_EARLY 0
+#endif
+    constexpr bool EARLY = TAPX_EARLY && FN == 2;
     auto read_a = [&](int base, int tap, int pl) __attribute__((always_inline)) {
         const int to = tap_off(tap);
 #pragma unroll
@@ -397,13 +407,15 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
     auto chunk = [&](int base, int ck, const WTile& W, const WTile& X, int ckn) __attribute__((always_inline)) {
         read_a(base, 0, 1);
         read_a(base, 0, 0);
-        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, EARLY ? 0 : 1, EARLY ? 1 : 0};
 #pragma unroll
         for (int tap = 0; tap < NT; ++tap) {
             const int pc = tap % NSET, pn = (tap + AHEAD) % NSET;
 #ifndef TAPX_EXP_NOB       // (TAPX_EXP_*: elimination builds for tools/tapx_stamps.py - timing only, the results are wrong)
-            if (tap + AHEAD < NT) load_b(W, ck, tap + AHEAD, pn);
-            else load_b(X, ckn, tap + AHEAD - NT, pn);
+            if constexpr (!EARLY) {
+                if (tap + AHEAD < NT) load_b(W, ck, tap + AHEAD, pn);
+                else load_b(X, ckn, tap + AHEAD - NT, pn);
+            }
 #endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -415,6 +427,15 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
                         acc[i][j] = mfma_split<NPL>(af[i][PA[t]], bf[pc][j][PB[t]], acc[i][j]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
+#ifndef TAPX_EXP_NOB
+                if constexpr (EARLY) {
+                    if (t >= 1) {       // plane t - 1 of this tap's set is dead: the same plane of tap + NSET
+                        if (tap + NSET < NT) load_b_plane(W, ck, tap + NSET, pc, t - 1);
+                        else load_b_plane(X, ckn, tap + NSET - NT, pc, t - 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#endif
 #ifndef TAPX_EXP_NOA
                 if (tap + 1 < NT && split_free_a(NPL, t) >= 0) {
 #else
@@ -445,7 +466,7 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
     Tile T = tile_of(t_first);
     WTile W = wtile_of(T);
 #pragma unroll
-    for (int t = 0; t < AHEAD; ++t) load_b(W, 0, t, t);
+    for (int t = 0; t < (EARLY ? NSET : AHEAD); ++t) load_b(W, 0, t, t);
     barrier();                                                // chunk 0 staged
     int it = 0;
     unsigned long long c_mul = 0, c_bar = 0, c_park = 0, c_t0 = TAPX_T();
