@@ -190,9 +190,15 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
         f32x4 hold[WHOLE ? 1 : 16];                           // FN = 2: the first half of the parked tile
 #pragma unroll
         for (int e = 0; e < (WHOLE ? 1 : 16); ++e) hold[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 rr[RES ? NQ : 1];                               // residual quads of the NEXT drain step (requested one step ahead)
+        // residual quads, requested ahead of the drain step that adds them: one step on the wide wave tile (registers), two on the narrow
+        // one (layer1 at 64 channels is HBM-heavy - one chunk period of 3456 cycles did not cover the loads: the loading waves spent 60 % of
+        // their time in the slices and the multiplying waves 8.8 % at the chunk barriers)
+        constexpr int RD = WHOLE ? 2 : 1;
+        f32x4 rr[RES ? RD : 1][RES ? NQ : 1];
 #pragma unroll
-        for (int e = 0; e < (RES ? NQ : 1); ++e) rr[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < (RES ? RD : 1); ++q)
+#pragma unroll
+            for (int e = 0; e < (RES ? NQ : 1); ++e) rr[q][e] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int cq = lt % QPR, sr0 = lt / QPR;
         float amx = 0.f;
         __amdgpu_buffer_rsrc_t ry, rr_;
@@ -253,9 +259,9 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
                 f32x4 v;
                 if (!WHOLE && K < 2) v = hold[es];
                 else v = *reinterpret_cast<const f32x4*>(stg + (es * RPE + sr0) * BN + cq * 4);
-                finish(v, rr[RES ? e : 0], yo);
+                finish(v, rr[RES ? K % RD : 0][RES ? e : 0], yo);
                 if constexpr (RES) {
-                    if (K < 3) rr[e] = WHOLE ? res_load(0, (K + 1) * NQ + e) : res_load((K + 1) >> 1, ((K + 1) & 1) * 8 + e);
+                    if (K + RD < 4) rr[K % RD][e] = WHOLE ? res_load(0, (K + RD) * NQ + e) : res_load((K + RD) >> 1, ((K + RD) & 1) * 8 + e);
                 }
                 __builtin_amdgcn_sched_barrier(0);        // one quad at a time: interleaving the quads only costs registers here (spills = vmcnt(0) waits)
             }
@@ -311,7 +317,9 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
             }
             if constexpr (RES) {
 #pragma unroll
-                for (int e = 0; e < NQ; ++e) rr[e] = res_load(0, e);
+                for (int q = 0; q < RD; ++q)
+#pragma unroll
+                    for (int e = 0; e < NQ; ++e) rr[q][e] = WHOLE ? res_load(0, q * NQ + e) : res_load(0, e);
             }
             if constexpr (!WHOLE) {
                 barrier();                                    // X2: staging area free again

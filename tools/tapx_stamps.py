@@ -7,18 +7,20 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C
 import torch
 from egorear_amd import hip
-SHAPES = [(128, 64, 128, 128, 1, 0, "fpn 3x3 128->128 @64"), (128, 64, 64, 64, 1, 1, "layer1 64->64 (+res)"), (256, 32, 128, 128, 1, 1, "layer2 (+res)"),
+SHAPES = [(128, 64, 256, 256, 0, 0, "1x1 256->256 @64"), (256, 32, 512, 128, 0, 0, "1x1 512->128 @32"), (128, 64, 128, 128, 1, 0, "fpn 3x3 128->128 @64"), (128, 64, 64, 64, 1, 1, "layer1 64->64 (+res)"), (256, 32, 128, 128, 1, 1, "layer2 (+res)"),
           (512, 16, 256, 256, 1, 1, "layer3 (+res)"), (64, 64, 256, 512, 2, 0, "refiner s2 256->512")]
 for (n, hw, cin, cout, stride, res, label) in SHAPES:
+    k = 1 if stride == 0 else 3
+    stride = max(stride, 1)
     ho = hw // stride
     x = torch.randn(n, hw, hw, cin, device="cuda")
-    wt = hip.add_wh2(hip.pack_w6(torch.randn(cout, 9 * cin, device="cuda") * 0.05))
+    wt = hip.add_wh2(hip.pack_w6(torch.randn(cout, k * k * cin, device="cuda") * 0.05))
     rec = torch.zeros(64, dtype=torch.int32, device="cuda"); rec[0] = x.abs().max().reshape(1).view(torch.int32)[0]
     r = torch.randn(n, ho, ho, cout, device="cuda") if res else None
     buf = torch.zeros(256 * 8 * 8, dtype=torch.int64, device="cuda")
     hip.H2 = True
     def run():
-        return hip.conv2d(hip.Img(x, amax=rec), wt, cout, 3, 3, stride, 1, act=1, res=hip.Img(r) if res else None, res_mode=1 if res else 0)
+        return hip.conv2d(hip.Img(x, amax=rec), wt, cout, k, k, stride, k // 2, act=1, res=hip.Img(r) if res else None, res_mode=1 if res else 0)
     for _ in range(3): run()
     torch.cuda.synchronize()
     hip.lib.egr_conv_debug_stamps(C.c_void_p(buf.data_ptr()))
