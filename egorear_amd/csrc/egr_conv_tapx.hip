@@ -432,7 +432,18 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
                     for (int j = 0; j < FN; ++j) {
+#ifdef TAPX_EXP_SHAPE16     // timing experiment (wrong results): the same MACs as two v_mfma_f32_16x16x32_f16 - which clock does the chip hold on that shape?
+                        {
+                            typedef float f32x4m __attribute__((ext_vector_type(4)));
+                            f32x4m c0 = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]}, c1 = {acc[i][j][4], acc[i][j][5], acc[i][j][6], acc[i][j][7]};
+                            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[i][PA[t]]), __builtin_bit_cast(f16x8, bf[pc][j][PB[t]]), c0, 0, 0, 0);
+                            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[i][PA[t]]), __builtin_bit_cast(f16x8, bf[pc][j][PB[t]]), c1, 0, 0, 0);
+                            acc[i][j][0] = c0[0]; acc[i][j][1] = c0[1]; acc[i][j][2] = c0[2]; acc[i][j][3] = c0[3];
+                            acc[i][j][4] = c1[0]; acc[i][j][5] = c1[1]; acc[i][j][6] = c1[2]; acc[i][j][7] = c1[3];
+                        }
+#else
                         acc[i][j] = mfma_split<NPL>(af[i][PA[t]], bf[pc][j][PB[t]], acc[i][j]);
+#endif
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #ifndef TAPX_EXP_NOB
@@ -466,7 +477,11 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int i = WHOLE ? ii : 2 * H + ii;
+#ifdef TAPX_EXP_SHAPE16     // (registers 8-15 never accumulate in that build: park copies of 0-7 so that the data downstream keeps its statistics)
+                    sp[(ii * 32 + (r & 3) + 8 * (r >> 2)) * BN + j * 32] = acc[i][j][r & 7];
+#else
                     sp[(ii * 32 + (r & 3) + 8 * (r >> 2)) * BN + j * 32] = acc[i][j][r];
+#endif
                     acc[i][j][r] = 0.f;
                 }
     };
@@ -517,6 +532,7 @@ int g_tapx = getenv("EGR_CONV_TAPX") ? atoi(getenv("EGR_CONV_TAPX")) : 1;       
 int g_tapx_min_tiles = getenv("EGR_CONV_TAPX_MIN_TILES") ? atoi(getenv("EGR_CONV_TAPX_MIN_TILES")) : 256; // tiles (all groups) from which the role-split kernel is used
 int g_tapx_blocks = getenv("EGR_CONV_TAPX_BLOCKS") ? atoi(getenv("EGR_CONV_TAPX_BLOCKS")) : 256;    // resident workgroups (one per CU)
 int g_tapx_pw = getenv("EGR_CONV_TAPX_PW") ? atoi(getenv("EGR_CONV_TAPX_PW")) : 1;                  // 0: 1x1 launches with >= 256 input channels stay on the tiled kernel
+int g_tapx_tpw = getenv("EGR_CONV_TAPX_TPW") ? atoi(getenv("EGR_CONV_TAPX_TPW")) : 0;               // > 0: tiles per workgroup of a non-persistent launch (experiment)
 int g_tapx_fn = getenv("EGR_CONV_TAPX_FN") ? atoi(getenv("EGR_CONV_TAPX_FN")) : 0;                  // wave tile: 0 by shape, 1: 128 x 32, 2: 128 x 64 wherever it exists
 
 }  // namespace
@@ -582,7 +598,11 @@ int tapx_try(ConvArgs& a, int64_t yspan_floats, int64_t rspan_floats, hipStream_
     a.tilesN = a.Npad / bn;
     a.dTilesN = make_fastdiv(a.tilesN);
     a.ntiles = a.tilesM * a.tilesN;
-    const unsigned grid = (unsigned)(tiles < g_tapx_blocks ? tiles : g_tapx_blocks);
+    // workgroups: one per CU walking tiles / blocks tiles each - or, with g_tapx_tpw > 0 (experiment), more workgroups of about that many
+    // tiles each, handed to CUs as they free up: measured 6647 frames/s persistent, 6588 / 6511-6520 / 6334 with 8 / 4 / 2 tiles per workgroup
+    int64_t wgs = g_tapx_blocks;
+    if (g_tapx_tpw > 0 && tiles / g_tapx_tpw > wgs) wgs = (tiles / g_tapx_tpw + 7) / 8 * 8;
+    const unsigned grid = (unsigned)(tiles < wgs ? tiles : wgs);
     auto launch = [&](auto res_tag) {
         constexpr bool R = decltype(res_tag)::value;
         switch (cfg) {

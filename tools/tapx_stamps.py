@@ -31,10 +31,12 @@ for (n, hw, cin, cout, stride, res, label) in SHAPES:
     m, l = b[:, :4].reshape(-1, 8), b[:, 4:].reshape(-1, 8)
     m, l = m[m[:, 3] > 0], l[l[:, 3] > 0]
     mul, bar, park, tot, chunks = [float(m[:, i].mean()) for i in range(5)]
+    spread = f"per-workgroup total: min {float(m[:, 3].min()):.0f} / mean {tot:.0f} / max {float(m[:, 3].max()):.0f} (+{100 * (float(m[:, 3].max()) / tot - 1):.1f} %)"
     tiles_m = n * ho * ho // (cout if False else 1)      # (unused)
     bound = 9 * 3 * 4 * 32 * (2 if os.environ.get("EGR_CONV_TAPX_FN", "0") == "2" else (1 if os.environ.get("EGR_CONV_TAPX_FN", "0") == "1" else 0))
     print(f"{label:24s} multiplying waves {len(m)}: total {tot:9.0f} cyc = multiply {mul:9.0f} ({100*mul/tot:.1f} %) + chunk-barrier wait {bar:8.0f} ({100*bar/tot:.1f} %) + "
           f"park/hand-over {park:8.0f} ({100*park/tot:.1f} %); {chunks:.0f} chunks -> {mul/chunks:.0f} cyc per chunk (MFMA-bound: {bound if bound else '3456 / 6912'})")
+    print(f"{'':24s} {spread}")
     work, lbar, hand, ltot, _, drain = [float(l[:, i].mean()) for i in range(6)]
     print(f"{'':24s} loading waves     {len(l)}: total {ltot:9.0f} cyc = work {work:9.0f} ({100*work/ltot:.1f} %, of it epilogue slices {drain:8.0f}) + barrier wait {lbar:8.0f} "
           f"({100*lbar/ltot:.1f} %) + hand-over {hand:8.0f} ({100*hand/ltot:.1f} %); work per chunk {work/chunks:.0f} cyc", flush=True)
