@@ -813,6 +813,8 @@ def main():
             "configs": cfg_legs,
             "preprocess": pre_leg,
             "train": train,
+            # abs-max records refused because an arena ran out (each one a launch that silently left the fp16 scheme): 0 when healthy
+            "amax_arena_exhausted": int(hip.ARENA_EXHAUSTED),
         }
         if kernels:
             line["kernel_ms"] = {n: round(v["ms"], 3) for n, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])}

@@ -25,6 +25,7 @@
 //    fp32 operand is the exact sum of three bf16 numbers, the six partial products of order <= 2 are accumulated in fp32
 //    (the dropped ones are below fp32 rounding).  Weights arrive pre-split in fragment order (egr_pack_w6_f32), the
 //    activations are split while they are staged.  Same row table, modes and epilogue as the fp32 main loop.
+#include <mutex>
 #include <type_traits>
 
 #include <cstdlib>
@@ -2104,8 +2105,9 @@ int g_small_rows = getenv("EGR_CONV_SMALL_ROWS") ? atoi(getenv("EGR_CONV_SMALL_R
 int g_pw_min_rows = getenv("EGR_CONV_PW_MIN_ROWS") ? atoi(getenv("EGR_CONV_PW_MIN_ROWS")) : 65536;   // rows x groups from which the streaming kernel is used
 int g_pw_blocks = getenv("EGR_CONV_PW_BLOCKS") ? atoi(getenv("EGR_CONV_PW_BLOCKS")) : 256;          // resident workgroups (one per CU)
 unsigned long long* g_dbg = nullptr;
-// split-K arrival counters: a ring of regions, one per launch (launches on different streams may overlap); zero at load, every
-// launch leaves its region zero again
+// split-K arrival counters: one region per launch STREAM (launches of one stream never overlap, launches of two streams may - e.g.
+// the graphs of two engine lanes replaying side by side); zero at load, every launch leaves its region zero again.  The stream a
+// launch is issued (or captured) on picks the region; a ninth stream gets no region and its launches take the second pass.
 constexpr int SPLITK_REGION = 2048, SPLITK_REGIONS = 8;
 __device__ int g_splitk_cnt[SPLITK_REGION * SPLITK_REGIONS];
 // 1: the last-arriving K slice of a tile reduces it (no second launch).  Correct and deterministic, but measured SLOWER than the
@@ -2113,7 +2115,18 @@ __device__ int g_splitk_cnt[SPLITK_REGION * SPLITK_REGIONS];
 // written and read with agent-scope (`sc1`) accesses that go to memory, and one workgroup sums a tile that the second pass
 // spreads over the chip.  Opt-in (egr_conv_set_splitk_fused / EGR_SPLITK_FUSED=1).
 int g_splitk_fused = getenv("EGR_SPLITK_FUSED") ? atoi(getenv("EGR_SPLITK_FUSED")) : 0;
-unsigned g_splitk_seq = 0;
+hipStream_t g_splitk_streams[SPLITK_REGIONS];
+int g_splitk_nstreams = 0;
+std::mutex g_splitk_mu;
+
+int splitk_region_of(hipStream_t s) {   // -1: every region belongs to another stream
+    std::lock_guard<std::mutex> lk(g_splitk_mu);
+    for (int i = 0; i < g_splitk_nstreams; ++i)
+        if (g_splitk_streams[i] == s) return i;
+    if (g_splitk_nstreams == SPLITK_REGIONS) return -1;
+    g_splitk_streams[g_splitk_nstreams] = s;
+    return g_splitk_nstreams++;
+}
 
 }  // namespace
 
@@ -2469,7 +2482,8 @@ static int conv_run(const egr_conv_desc* dd, const float* x, const float* w, con
         if (d.split_k > 1 && g_splitk_fused && tiles_all <= SPLITK_REGION) {
             static int* base = nullptr;
             if (!base && hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_splitk_cnt)) != hipSuccess) base = nullptr;
-            if (base) a.cnt = base + (g_splitk_seq++ % SPLITK_REGIONS) * SPLITK_REGION;
+            const int region = base ? splitk_region_of(s) : -1;
+            if (region >= 0) a.cnt = base + region * SPLITK_REGION;
         }
     }
     switch (cfg) {

@@ -156,9 +156,21 @@ lib = _load()
 _ERR = {-1: "EGR_EINVAL (unsupported shape/alignment)", -2: "EGR_ENULL (missing pointer)", -3: "EGR_EWORKSPACE"}
 
 
+class LaunchError(RuntimeError):
+    """A C-ABI entry point returned non-zero: `code` is its return value (-1 EGR_EINVAL, -2 EGR_ENULL, -3 EGR_EWORKSPACE, > 0 a
+    hipError_t), so that a caller with a second way to run the launch can tell "this shape is not supported here" from a device fault."""
+
+    def __init__(self, name: str, code: int):
+        super().__init__(f"{name} failed: {_ERR.get(code, 'hipError_t %d' % code)}")
+        self.name, self.code = name, code
+
+
+EINVAL, ENULL, EWORKSPACE = -1, -2, -3
+
+
 def _check(rc: int, name: str):
     if rc != 0:
-        raise RuntimeError(f"{name} failed: {_ERR.get(rc, 'hipError_t %d' % rc)}")
+        raise LaunchError(name, rc)
 
 
 # When PROFILE is a list, every launch is bracketed by HIP events recorded on the launch stream (torch's current
@@ -345,6 +357,9 @@ def add_wh2(w6: W6) -> W6:
 H2 = os.environ.get("EGR_W_FORMAT", "f16x2") == "f16x2"
 
 
+ARENA_EXHAUSTED = 0      # over every AmaxArena of the process (bench.py reports it: a non-zero count means silent fallbacks)
+
+
 class AmaxArena:
     """Abs-max records of one forward: 64 uint32 slots per recorded tensor in ONE buffer, zeroed by one launch when the forward
     begins (egr_fill_f32: all-zero bits), handed out in launch order.  A graph replay re-runs the fill and every producer."""
@@ -352,13 +367,17 @@ class AmaxArena:
     def __init__(self, device, records: int = 192):
         self.buf = torch.zeros(records * 64, device=device, dtype=torch.int32)
         self.records, self.k = records, 0
+        self.exhausted = 0        # requests refused since construction: each one is a launch that left the fp16 scheme
 
     def begin(self):
         self.k = 0
         _launch("egr_fill_f32", lib.egr_fill_f32, _p(self.buf, torch.int32), 0.0, self.buf.numel(), _stream())
 
     def new(self) -> Optional[torch.Tensor]:
+        global ARENA_EXHAUSTED
         if self.k >= self.records:
+            self.exhausted += 1
+            ARENA_EXHAUSTED += 1
             return None
         self.k += 1
         return self.buf[(self.k - 1) * 64:self.k * 64]

@@ -488,10 +488,12 @@ class Step:
             _conv2d(Img(x), p.wop, p.cout, p.kh, p.kw, p.stride, p.pad, shift=p.bias, act=act, res=Img(res) if res is not None else None,
                     res_mode=(hip.RES_UP2_BEFORE_ACT if res_up2 else RES_BEFORE_ACT) if res is not None else RES_NONE, out=yo,
                     workspace=self.ws, split_k=0, groups=p.groups, amax_arena=self.amax, amax_out=rec, **kw_bn)
-        except RuntimeError:
-            if not kw_bn:
+        except hip.LaunchError as exc:
+            # only "this launch shape has no statistics epilogue" (EINVAL) and "the slabs do not fit" (EWORKSPACE) have a second way:
+            # the plain launch + the statistics pass.  Anything else (a device fault, a missing pointer) is raised as it is.
+            if not kw_bn or exc.code not in (hip.EINVAL, hip.EWORKSPACE):
                 raise
-            slabs = None          # (a launch shape without the statistics epilogue, or slabs that do not fit: the plain launch + the pass)
+            slabs = None
             _conv2d(Img(x), p.wop, p.cout, p.kh, p.kw, p.stride, p.pad, shift=p.bias, act=act, out=yo, workspace=self.ws, split_k=0,
                     groups=p.groups, amax_arena=self.amax, amax_out=rec)
         if slabs:

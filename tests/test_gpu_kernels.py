@@ -169,6 +169,31 @@ def test_small_linear_kernel(hip, m, k, n_out, groups, extra):
     assert float((outs[0] - outs[1]).abs().max()) <= 4e-6 * float(ref.abs().max())
 
 
+def test_split_k_in_the_last_slice_on_two_streams_side_by_side(hip):
+    """The arrival counters are one region per launch stream: two streams running the fused split-K form at the same time (two engine
+    lanes do) each get the result of a lone launch, bit for bit, over many overlapped launches."""
+    n, h, cin, cout, k = 2, 16, 256, 128, 3
+    xs = [rnd(n, h, h, cin, seed=320 + i).to(DEV) for i in range(2)]
+    wp = pack_w(rnd(cout, cin, k, k, seed=322, scale=1.0 / math.sqrt(cin * 9))).to(DEV)
+    wss = [torch.empty(1 << 22, device=DEV) for _ in range(2)]
+    try:
+        hip.lib.egr_conv_set_splitk_fused(1)
+        lone = [hip.conv2d(hip.Img(xs[i]), wp, cout, k, k, 2, 1, workspace=wss[i], split_k=8).t.clone() for i in range(2)]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream() for _ in range(2)]
+        outs = [[], []]
+        for rep in range(40):
+            for i, st in enumerate(streams):
+                with torch.cuda.stream(st):
+                    outs[i].append(hip.conv2d(hip.Img(xs[i]), wp, cout, k, k, 2, 1, workspace=wss[i], split_k=8).t)
+        torch.cuda.synchronize()
+    finally:
+        hip.lib.egr_conv_set_splitk_fused(0)
+    for i in range(2):
+        for o in outs[i]:
+            assert torch.equal(o, lone[i])
+
+
 @pytest.mark.parametrize("case", [
     # n, h, cin, cout, k, stride, groups, split, extras
     (6, 1, 4096, 96, 1, 1, 1, 7, "rowscale_mask"),       # skinny linear, ragged rows and channels
