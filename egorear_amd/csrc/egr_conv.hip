@@ -2324,8 +2324,9 @@ static int conv_run(const egr_conv_desc* dd, const float* x, const float* w, con
         }
     }
 
-    // ---- the fp16 scheme's 3x3 (and wide 1x1) forward launches with enough tiles: role-split persistent workgroups (egr_conv_tapx.hip)
-    if (g_tap && g_force_cfg == CFG_AUTO && h2 && ((d.kh == 3 && d.kw == 3) || (d.kh == 1 && d.kw == 1 && d.cin >= 256)) && !mask && !bnst) {
+    // ---- the fp16 scheme's 3x3 (and wide 1x1) launches with enough tiles - forward, and the training step's statistics-epilogue and
+    // stride-1 data-gradient (plain / masked) ones: role-split persistent workgroups (egr_conv_tapx.hip)
+    if (g_tap && g_force_cfg == CFG_AUTO && h2 && ((d.kh == 3 && d.kw == 3) || (d.kh == 1 && d.kw == 1 && d.cin >= 256))) {
         const int rc = tapx_try(a, span(d.ymap, d.n) + ypix, d.res_mode ? span(d.rmap, d.n) + (int64_t)d.ho * d.wo * d.ldr : 0, (hipStream_t)stream);
         if (rc != TAPX_NO) {
             g_last_conv_kernel = 6;

@@ -1,6 +1,8 @@
 // 3x3 / pad 1 convolutions of the fp16 scheme (EGR_W_F16X2) on ROLE-SPLIT, persistent workgroups whose epilogue runs
 // under the next tile's K loop.  Forward launches, stride 1 and stride 2 (models/backbones/resnet.py:43-74, 121-137;
-// models/estimator/egoposeformer_heatmap_mvf_ex.py:101-126, 525-532, 570-584 in the reference).
+// models/estimator/egoposeformer_heatmap_mvf_ex.py:101-126, 525-532, 570-584 in the reference); of the training step (config 5)
+// the trunk's conv -> train-mode BatchNorm launches (statistics in the epilogue) and the stride-1 data gradients (template
+// parameter TR below).
 //
 // Why (profiles/r03_v2_tap_kernel_experiments.txt): vector-memory operations of a wave complete in order (one vmcnt).  In
 // conv_igemm_tap_kernel every wave requests the next chunk's activations (HBM, microseconds under load) and, behind them, the next
@@ -59,9 +61,15 @@ constexpr int tapx_hp(int bm, int stride) { return stride == 2 ? 4 * tapx_cls(bm
 // STRIDE = 0: the same machinery for 1x1 / stride 1 convolutions with >= 256 input channels (the heads' and refiners' 256 -> 256,
 // 256 -> 128, 512 -> 128: 169 TFLOP/s / 2.7-3.7 TB/s on the tiled kernel): a chunk is 64 channels of the tile's 128 pixels, its four
 // k16 steps play the part of the taps (four weight register sets, requested three steps ahead), no halo.
-template <int WM, int WN, int FN, int STRIDE, bool RES>
+// TR (training launches, narrow wave tile only): 1 = the raw output feeds a train-mode BatchNorm - every tile leaves its per-channel
+// sum / sum of squares (double) and extremes in a slab (egr_conv_aux.bn_partials, the layout of conv_igemm's epilogue: one slab per
+// M tile); 2 = data gradient behind a ReLU: dx = (acc [+ res]) * [mask > 0], the mask quads requested like the residual's.
+// d.transposed (stride 1): the data gradient of a 3x3 / pad 1 conv - the same launch with the taps' windows mirrored.
+template <int WM, int WN, int FN, int STRIDE, bool RES, int TR = 0>
 __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
     static_assert(WM * WN == 4 && (STRIDE == 0 || STRIDE == 1 || STRIDE == 2) && (FN == 1 || FN == 2), "four multiplying waves");
+    static_assert(TR == 0 || (STRIDE != 0 && (FN == 1 || (TR == 1 && STRIDE == 1))), "training epilogues: the narrow wave tile (registers), statistics also on the wide one");
+    constexpr bool BNST = TR == 1, MASK = TR == 2;
     constexpr int NPL = 2, NPR = 3, FM = 4;
     constexpr bool PW = STRIDE == 0;
     constexpr bool WHOLE = FN == 1;                           // the staging area holds the whole tile
@@ -75,8 +83,9 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
     constexpr int QPR = BN / 4, RPE = 256 / QPR;              // epilogue: channel quads per row, rows covered by the 256 loading threads per step
     constexpr int NQ = WHOLE ? 4 : 8;                         // quads per thread and drain step (four steps per tile)
     static_assert(STG == 65536, "staging area");
-    static_assert(2 * HBUF + STG <= 160 * 1024, "LDS");
-    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * HBUF + STG];
+    constexpr int RED = BNST ? 4 * QPR * 96 : 0;              // statistics: eight doubles + eight floats per loading wave and channel quad
+    static_assert(2 * HBUF + STG + RED <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * HBUF + STG + RED];
     // the staging area first: every one of a wave's parking stores is then one base register + an immediate offset below 64 KB
     // (behind the planes the compiler needed a dozen address registers for them - spilled, and every reload waited for vmcnt(0))
     float* const stg = reinterpret_cast<float*>(lds);
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
         int hvo[NUH];
         // chunks of activations in flight: two register sets (requested two chunk periods before they are split), or one (one period -
         // a chunk of the wide wave tile is 3.3 us) where eleven units per thread and the parked half tile do not leave room for two
-        constexpr int NXS = (NUH > 8 && !WHOLE) ? 1 : 2;
+        constexpr int NXS = ((NUH > 8 || BNST) && !WHOLE) ? 1 : 2;      // (the statistics' 24 registers: one set on the wide tile)
         u32x4 xr[NXS][NUH];
         __amdgpu_buffer_rsrc_t ra;
         int so_tile = 0;
@@ -199,15 +208,29 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
         for (int q = 0; q < (RES ? RD : 1); ++q)
 #pragma unroll
             for (int e = 0; e < (RES ? NQ : 1); ++e) rr[q][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 mk[MASK ? RD : 1][MASK ? NQ : 1];             // TR = 2: the ReLU mask's quads, like rr
+#pragma unroll
+        for (int q = 0; q < (MASK ? RD : 1); ++q)
+#pragma unroll
+            for (int e = 0; e < (MASK ? NQ : 1); ++e) mk[q][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // TR = 1: this thread's share of the parked tile's statistics (its channel quad, its rows)
+        double bs[BNST ? 4 : 1], bq[BNST ? 4 : 1];
+        float blo[BNST ? 4 : 1], bhi[BNST ? 4 : 1];
+        auto stats_clear = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int c = 0; c < (BNST ? 4 : 1); ++c) { bs[c] = 0.0; bq[c] = 0.0; blo[c] = INFINITY; bhi[c] = -INFINITY; }
+        };
+        stats_clear();
         const int cq = lt % QPR, sr0 = lt / QPR;
         float amx = 0.f;
-        __amdgpu_buffer_rsrc_t ry, rr_;
+        __amdgpu_buffer_rsrc_t ry, rr_, rm_;
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, dsq = {1.f, 1.f, 1.f, 1.f};
         int co = 0;
         bool live = false;
         auto pend_setup = [&](const Pend& Q) __attribute__((always_inline)) {
             ry = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.y + Q.grp * d.gy), 0, 0x80000000u, 0x00020000);
             rr_ = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.res ? a.res + Q.grp * d.gr : a.y), 0, 0x80000000u, 0x00020000);
+            if constexpr (MASK) rm_ = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.mask + Q.grp * d.gy), 0, 0x80000000u, 0x00020000);
             co = Q.tn * BN + cq * 4;
             live = Q.valid && co < d.cout;
             sc = f32x4{1.f, 1.f, 1.f, 1.f};
@@ -233,14 +256,26 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
             row_offsets(H, es, yo, ro);
             return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr_, ro, 0, TAPX_LD_AUX));
         };
-        auto finish = [&](f32x4 v, const f32x4& rr, int yo) __attribute__((always_inline)) {
+        auto mask_load = [&](int H, int es) __attribute__((always_inline)) {     // (the mask is laid out like y)
+            int yo, ro;
+            row_offsets(H, es, yo, ro);
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm_, yo, 0, TAPX_LD_AUX));
+        };
+        auto finish = [&](f32x4 v, const f32x4& rr, const f32x4& mq, int yo) __attribute__((always_inline)) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 float t = (v[c] * dsq[c]) * sc[c] + sh[c];
                 if (RES && d.res_mode == EGR_RES_BEFORE_ACT) t += rr[c];
                 if (d.act == EGR_ACT_RELU) t = t > 0.f ? t : 0.f;
                 if (RES && d.res_mode == EGR_RES_AFTER_ACT) t += rr[c];
+                if (MASK) t = mq[c] > 0.f ? t : 0.f;
                 v[c] = t;
+                if constexpr (BNST) {
+                    bs[c] += (double)t;
+                    bq[c] += (double)t * (double)t;
+                    blo[c] = fminf(blo[c], t);
+                    bhi[c] = fmaxf(bhi[c], t);
+                }
             }
             if (live) amx = fmaxf(fmaxf(amx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, yo, 0, TAPX_ST_AUX);
@@ -259,11 +294,69 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
                 f32x4 v;
                 if (!WHOLE && K < 2) v = hold[es];
                 else v = *reinterpret_cast<const f32x4*>(stg + (es * RPE + sr0) * BN + cq * 4);
-                finish(v, rr[RES ? K % RD : 0][RES ? e : 0], yo);
+                finish(v, rr[RES ? K % RD : 0][RES ? e : 0], mk[MASK ? K % RD : 0][MASK ? e : 0], yo);
                 if constexpr (RES) {
                     if (K + RD < 4) rr[K % RD][e] = WHOLE ? res_load(0, (K + RD) * NQ + e) : res_load((K + RD) >> 1, ((K + RD) & 1) * 8 + e);
                 }
+                if constexpr (MASK) {
+                    if (K + RD < 4) mk[K % RD][e] = mask_load(0, (K + RD) * NQ + e);
+                }
                 __builtin_amdgcn_sched_barrier(0);        // one quad at a time: interleaving the quads only costs registers here (spills = vmcnt(0) waits)
+            }
+        };
+
+        // TR = 1: after the last drain step the lanes of a wave that share a channel quad add up their shares (butterfly over the lane
+        // bits above the quad index: the same sum in every lane) and the wave leaves one entry per quad in LDS (stats_publish, in front
+        // of a barrier); behind the barrier the first QPR threads add the four waves' entries in wave order and write the slab
+        double* const red_d = reinterpret_cast<double*>(lds + STG + 2 * HBUF);
+        float* const red_f = reinterpret_cast<float*>(lds + STG + 2 * HBUF + 4 * QPR * 64);
+        auto stats_publish = [&]() __attribute__((always_inline)) {
+            if constexpr (BNST) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                    for (int m = 32; m >= QPR; m >>= 1) {
+                        bs[c] += __shfl_xor(bs[c], m);
+                        bq[c] += __shfl_xor(bq[c], m);
+                        blo[c] = fminf(blo[c], __shfl_xor(blo[c], m));
+                        bhi[c] = fmaxf(bhi[c], __shfl_xor(bhi[c], m));
+                    }
+                }
+                if (lane < QPR) {
+                    const int slot = ((wave - 4) * QPR + lane) * 8;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        red_d[slot + c] = bs[c];
+                        red_d[slot + 4 + c] = bq[c];
+                        red_f[slot + c] = blo[c];
+                        red_f[slot + 4 + c] = bhi[c];
+                    }
+                }
+            }
+        };
+        auto stats_reduce = [&]() __attribute__((always_inline)) {
+            if constexpr (BNST) {
+                if (P.valid && lt < QPR) {          // (wave 4: its own entry is in the registers)
+#pragma unroll
+                    for (int k = 1; k < 4; ++k)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            bs[c] += red_d[(k * QPR + lt) * 8 + c];
+                            bq[c] += red_d[(k * QPR + lt) * 8 + 4 + c];
+                            blo[c] = fminf(blo[c], red_f[(k * QPR + lt) * 8 + c]);
+                            bhi[c] = fmaxf(bhi[c], red_f[(k * QPR + lt) * 8 + 4 + c]);
+                        }
+                    const int64_t slab = ((int64_t)P.grp * a.tilesM + P.tm) * 2 * d.cout + co;
+                    float* const mm = reinterpret_cast<float*>(a.bn_part + (int64_t)d.groups * a.tilesM * 2 * d.cout);   // the extremes sit behind the sums
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        a.bn_part[slab + c] = bs[c];
+                        a.bn_part[slab + d.cout + c] = bq[c];
+                        mm[slab + c] = blo[c];
+                        mm[slab + d.cout + c] = bhi[c];
+                    }
+                }
+                stats_clear();
             }
         };
 
@@ -300,7 +393,8 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
             step(1); d0 = TAPX_T(); drain(0); c_drain += TAPX_T() - d0; tbar();
             step(0); d0 = TAPX_T(); drain(1); c_drain += TAPX_T() - d0; tbar();
             step(1); d0 = TAPX_T(); drain(2); c_drain += TAPX_T() - d0; tbar();
-            step(0); d0 = TAPX_T(); drain(3); c_drain += TAPX_T() - d0; tbar();
+            step(0); d0 = TAPX_T(); drain(3); c_drain += TAPX_T() - d0; stats_publish(); tbar();
+            stats_reduce();
             for (int ck = 4; ck < NC; ck += 2) {
                 step(1); tbar();
                 step(0); tbar();
@@ -321,6 +415,12 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int e = 0; e < NQ; ++e) rr[q][e] = WHOLE ? res_load(0, q * NQ + e) : res_load(0, e);
             }
+            if constexpr (MASK) {
+#pragma unroll
+                for (int q = 0; q < RD; ++q)
+#pragma unroll
+                    for (int e = 0; e < NQ; ++e) mk[q][e] = mask_load(0, q * NQ + e);
+            }
             if constexpr (!WHOLE) {
                 barrier();                                    // X2: staging area free again
                 barrier();                                    // X3: second half staged
@@ -336,6 +436,11 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
         drain(1);
         drain(2);
         drain(3);
+        if constexpr (BNST) {
+            stats_publish();
+            barrier();                                        // (the multiplying waves come to this one too)
+            stats_reduce();
+        }
         if (a.amax_out) amax_flush(a.amax_out, amx, bid * 4 + wave);
         return;
     }
@@ -356,9 +461,11 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
     constexpr int TCL[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
     constexpr int TDR[9] = {0, 0, 0, 0, 1, 0, 0, 1, 1};
     constexpr int TDC[9] = {0, 0, 1, 0, 0, 0, 1, 0, 1};
+    // (data gradient, stride 1: tap (kh, kw) reads dy at (y + 1 - kh, x + 1 - kw) - the mirrored window)
+    const int tmir = (STRIDE == 1 && d.transposed) ? (2 * WP + 2) * 16 : 0, tsgn = (STRIDE == 1 && d.transposed) ? -1 : 1;
     auto tap_off = [&](int tap) __attribute__((always_inline)) {
         if (PW) return tap * NPL * PLANE;
-        return STRIDE == 1 ? ((tap / 3) * WP + (tap % 3)) * 16 : TCL[tap] * CLS * 16 + (TDR[tap] * WP + TDC[tap]) * 16;
+        return STRIDE == 1 ? tmir + tsgn * ((tap / 3) * WP + (tap % 3)) * 16 : TCL[tap] * CLS * 16 + (TDR[tap] * WP + TDC[tap]) * 16;
     };
     auto tap_w = [&](int tap) __attribute__((always_inline)) { return STRIDE == 1 ? tap : TID[tap]; };
     f32x16 acc[FM][FN];
@@ -522,6 +629,7 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
         T = Tn;
         W = Wn;
     }
+    if constexpr (BNST) barrier();                            // the loading waves' last statistics hand-over
     if (TAPX_DBG && a.dbg && lane == 0) {
         unsigned long long* o = a.dbg + ((int64_t)bid * 8 + wave) * 8;
         o[0] = c_mul; o[1] = c_bar; o[2] = c_park; o[3] = TAPX_T() - c_t0; o[4] = (unsigned long long)my_tiles * NC;
@@ -533,6 +641,7 @@ int g_tapx_min_tiles = getenv("EGR_CONV_TAPX_MIN_TILES") ? atoi(getenv("EGR_CONV
 int g_tapx_blocks = getenv("EGR_CONV_TAPX_BLOCKS") ? atoi(getenv("EGR_CONV_TAPX_BLOCKS")) : 256;    // resident workgroups (one per CU)
 int g_tapx_pw = getenv("EGR_CONV_TAPX_PW") ? atoi(getenv("EGR_CONV_TAPX_PW")) : 1;                  // 0: 1x1 launches with >= 256 input channels stay on the tiled kernel
 int g_tapx_tpw = getenv("EGR_CONV_TAPX_TPW") ? atoi(getenv("EGR_CONV_TAPX_TPW")) : 0;               // > 0: tiles per workgroup of a non-persistent launch (experiment)
+int g_tapx_train = getenv("EGR_CONV_TAPX_TRAIN") ? atoi(getenv("EGR_CONV_TAPX_TRAIN")) : 1;         // 0: statistics-epilogue / masked launches stay on conv_igemm_tap_kernel
 int g_tapx_fn = getenv("EGR_CONV_TAPX_FN") ? atoi(getenv("EGR_CONV_TAPX_FN")) : 0;                  // wave tile: 0 by shape, 1: 128 x 32, 2: 128 x 64 wherever it exists
 
 }  // namespace
@@ -552,11 +661,21 @@ int tapx_try(ConvArgs& a, int64_t yspan_floats, int64_t rspan_floats, hipStream_
     egr_conv_desc& d = a.d;
     const bool pw = d.kh == 1 && d.kw == 1;
     if (!g_tapx || d.w_format != EGR_W_F16X2 || !(pw ? (d.pad == 0 && d.stride == 1 && g_tapx_pw) : (d.kh == 3 && d.kw == 3 && d.pad == 1)) ||
-        d.transposed || a.cls_mode || d.split_k > 1 ||
-        d.out_nchw || a.rowscale || a.rowmask || a.mask || a.bn_part || !a.vec_ok || d.cout % 4 != 0 || d.cin < 64 ||
+        (d.transposed && (pw || d.stride != 1)) || a.cls_mode || d.split_k > 1 ||
+        d.out_nchw || a.rowscale || a.rowmask || (a.mask && a.bn_part) || !a.vec_ok || d.cout % 4 != 0 || d.cin < 64 ||
         (d.act != EGR_ACT_NONE && d.act != EGR_ACT_RELU) || d.res_mode == EGR_RES_UP2_BEFORE_ACT || (a.dbg && !TAPX_DBG))
         return TAPX_NO;
     if (yspan_floats * 4 >= (1LL << 31) || (d.res_mode && rspan_floats * 4 >= (1LL << 31))) return TAPX_NO;   // 32-bit byte offsets in the epilogue
+    // training launches (statistics epilogue: raw output of a 3x3 conv; masked data gradient: 3x3 / stride 1): the narrow wave tile
+    const int tr = a.bn_part ? 1 : (a.mask ? 2 : 0);
+    if (tr && (pw || !g_tapx_train)) return TAPX_NO;
+    if (tr == 1 && (d.act != EGR_ACT_NONE || d.res_mode != EGR_RES_NONE || d.transposed || d.cout % 64 != 0)) return TAPX_NO;
+    if (tr == 2 && (d.stride != 1 || a.scale || a.shift || d.act != EGR_ACT_NONE || d.res_mode == EGR_RES_AFTER_ACT)) return TAPX_NO;
+    // (the wide wave tile has no registers left for the mask quads; at >= 128 channels the narrow one is no faster than
+    // conv_igemm_tap_kernel - 345 against 340 TFLOP/s at 128 channels, 346 against 358 at 256 - so masked launches come here for 64-channel
+    // outputs only.  The statistics epilogue exists on both wave tiles for stride 1, on the narrow one for stride 2.)
+    if (tr == 2 && a.Npad % 128 == 0 && g_tapx_train < 2 && g_tapx_min_tiles > 1) return TAPX_NO;     // (forced from one tile up: tests)
+    const int fn = (tr == 2 || (tr == 1 && d.stride == 2)) ? 1 : g_tapx_fn;
     const int P = d.ho * d.wo;
     if (a.howo_shift < 0 || a.wo_shift < 0) return TAPX_NO;
     const int ext = d.stride == 1 ? 2 : 1;
@@ -570,6 +689,10 @@ int tapx_try(ConvArgs& a, int64_t yspan_floats, int64_t rspan_floats, hipStream_
         // enough tiles for every CU - and, below two tiles per CU, a K loop long enough to carry the epilogue that then runs exposed
         // (one tile per workgroup: 128 -> 128 at 32 x 32 pixels measured 0.070 ms against 0.063 on the tap kernel, layer4 0.551 against 0.565)
         const int64_t tiles = (int64_t)(a.M / bm) * (a.Npad / bn) * d.groups;
+        // training launches (config 5 at batch 32 has 256-1024 tiles per trunk launch): from four tiles per CU - measured per launch,
+        // statistics epilogue, role-split against tap-sharing kernel: 64 channels / 2048 tiles 0.538 against 0.573 ms, 128 channels /
+        // 1024 narrow tiles 0.448 against 0.471 (512 wide tiles: 0.478), 256 channels / 512 tiles 0.335-0.349 against 0.324
+        if (tr) return tiles >= 4 * (int64_t)g_tapx_min_tiles || g_tapx_min_tiles <= 1;
         return tiles >= g_tapx_min_tiles && (tiles >= 2 * (int64_t)g_tapx_min_tiles || (!pw && a.cblocks >= 16) || g_tapx_min_tiles <= 1);
     };
     // tiles (rows x columns): the 128 x 64 wave tile (FN = 2) wherever the channel count allows it - stride 1: 256 x 128, stride 2:
@@ -581,11 +704,11 @@ int tapx_try(ConvArgs& a, int64_t yspan_floats, int64_t rspan_floats, hipStream_
         cfg = (g_tapx_fn != 1 && fits(128, 256)) ? 6 : (g_tapx_fn != 2 && fits(128, 128) ? 7 : (fits(128, 256) ? 6 : -1));
     } else if (d.stride == 1) {
         if (!(d.wo == 8 || d.wo == 16 || d.wo == 32 || d.wo == 64) || d.ho != d.h || d.wo != d.w) return TAPX_NO;
-        if (a.Npad % 128 == 0) cfg = (g_tapx_fn != 1 && fits(256, 128)) ? 0 : (g_tapx_fn != 2 && fits(128, 128) ? 1 : (fits(256, 128) ? 0 : -1));
+        if (a.Npad % 128 == 0) cfg = (fn != 1 && fits(256, 128)) ? 0 : (fn != 2 && fits(128, 128) ? 1 : (fn != 1 && fits(256, 128) ? 0 : -1));
         else cfg = fits(256, 64) ? 3 : -1;
     } else if (d.stride == 2) {
         if (!(d.wo == 8 || d.wo == 16 || d.wo == 32) || d.h != 2 * d.ho || d.w != 2 * d.wo) return TAPX_NO;
-        cfg = (g_tapx_fn != 1 && fits(128, 256)) ? 4 : (g_tapx_fn != 2 && fits(128, 128) ? 5 : (fits(128, 256) ? 4 : -1));
+        cfg = (fn != 1 && fits(128, 256)) ? 4 : (fn != 2 && fits(128, 128) ? 5 : (fn != 1 && fits(128, 256) ? 4 : -1));
     }
     if (cfg < 0) return TAPX_NO;
     static const int kbm[8] = {256, 128, 512, 256, 128, 128, 128, 128}, kbn[8] = {128, 128, 64, 64, 256, 128, 256, 128};
@@ -598,6 +721,7 @@ int tapx_try(ConvArgs& a, int64_t yspan_floats, int64_t rspan_floats, hipStream_
     a.tilesN = a.Npad / bn;
     a.dTilesN = make_fastdiv(a.tilesN);
     a.ntiles = a.tilesM * a.tilesN;
+    if (const int rcb = bn_slabs(a)) return rcb;
     // workgroups: one per CU walking tiles / blocks tiles each - or, with g_tapx_tpw > 0 (experiment), more workgroups of about that many
     // tiles each, handed to CUs as they free up: measured 6647 frames/s persistent, 6588 / 6511-6520 / 6334 with 8 / 4 / 2 tiles per workgroup
     int64_t wgs = g_tapx_blocks;
@@ -615,7 +739,24 @@ int tapx_try(ConvArgs& a, int64_t yspan_floats, int64_t rspan_floats, hipStream_
             default: hipLaunchKernelGGL((conv_tapx_kernel<1, 4, 1, 0, R>), dim3(grid), dim3(512), 0, stream, a); break;
         }
     };
-    if (d.res_mode != EGR_RES_NONE) launch(std::true_type{});
+    auto launch_tr = [&](auto res_tag, auto tr_tag) {
+        constexpr bool R = decltype(res_tag)::value;
+        constexpr int T = decltype(tr_tag)::value;
+        switch (cfg) {
+            case 0:
+                if constexpr (T == 1) hipLaunchKernelGGL((conv_tapx_kernel<2, 2, 2, 1, R, T>), dim3(grid), dim3(512), 0, stream, a);
+                break;
+            case 1: hipLaunchKernelGGL((conv_tapx_kernel<1, 4, 1, 1, R, T>), dim3(grid), dim3(512), 0, stream, a); break;
+            case 3: hipLaunchKernelGGL((conv_tapx_kernel<2, 2, 1, 1, R, T>), dim3(grid), dim3(512), 0, stream, a); break;
+            default:
+                if constexpr (T == 1) hipLaunchKernelGGL((conv_tapx_kernel<1, 4, 1, 2, R, T>), dim3(grid), dim3(512), 0, stream, a);
+                break;
+        }
+    };
+    if (tr == 1) launch_tr(std::false_type{}, std::integral_constant<int, 1>{});
+    else if (tr == 2 && d.res_mode != EGR_RES_NONE) launch_tr(std::true_type{}, std::integral_constant<int, 2>{});
+    else if (tr == 2) launch_tr(std::false_type{}, std::integral_constant<int, 2>{});
+    else if (d.res_mode != EGR_RES_NONE) launch(std::true_type{});
     else launch(std::false_type{});
     return egr_launch_status();
 }

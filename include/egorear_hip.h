@@ -150,7 +150,8 @@ int egr_conv2d_nhwc_f32(const egr_conv_desc* d, const float* x, const float* w,
  *             interpolation inherits x's record); the launch scales x by 2^k with max |x| 2^k in [2^14, 2^15), k clamped to +-60;
  *   w_descale (EGR_W_F16X2) the per-channel descale egr_pack_wh2_f32 wrote ((groups,) round_up(cout, 32) floats, group stride gp).
  * w: the fp32 matrix, the egr_pack_w6_f32 image or the egr_pack_wh2_f32 image as w_format says (gw in 16-bit elements for both
- * images).  EGR_W_F16X2 is a forward-only format (no transposed / masked launches); amax_out does not go with out_nchw. */
+ * images).  EGR_W_F16X2 covers forward, transposed (data-gradient) and masked launches alike (the training step runs all three on
+ * it); amax_out does not go with out_nchw. */
 typedef struct {
     const float* w_descale;
     const uint32_t* amax_in;
@@ -229,7 +230,10 @@ int egr_conv_set_tap(int on);
  * tile's epilogue under the current tile's K loop, `blocks` workgroups (one per CU) - egr_conv_last_kernel() = 6.  on = 0 keeps them
  * on the tap-sharing kernels (2 / 3); on = 2 / 3 force the 128 x 32 / 128 x 64 wave tile wherever that variant exists (1: chosen by
  * shape).  Negative values leave a setting unchanged; defaults 1, 256, 256 (env EGR_CONV_TAPX, EGR_CONV_TAPX_MIN_TILES,
- * EGR_CONV_TAPX_BLOCKS, EGR_CONV_TAPX_FN).  Process-wide; results do not depend on it (same products, same summation order). */
+ * EGR_CONV_TAPX_BLOCKS, EGR_CONV_TAPX_FN).  Process-wide; results do not depend on it (same products, same summation order).
+ * Training launches take the same kernel where it measured faster (env EGR_CONV_TAPX_TRAIN=0: never): a 3x3 conv with the
+ * statistics epilogue (egr_conv_aux.bn_partials; slabs = M tiles of the tile height chosen, 256 or 128 rows) and the stride-1 data
+ * gradient (transposed, plain or through egr_conv2d_masked_f32) - from four tiles per CU, masked launches for 64-channel outputs only. */
 int egr_conv_set_tapx(int32_t on, int32_t min_tiles, int32_t blocks);
 /* Tuning / test knob of the persistent split-bf16 launches (short-K layers: a workgroup walks several tiles and requests the next
  * tile's operands under the current tile's stores): `slots` = resident workgroups a launch is sized for (0: never persistent;

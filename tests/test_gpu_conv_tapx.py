@@ -176,3 +176,151 @@ def test_operand_placement_nan_and_scales(tapx, stride):
         assert torch.equal(bad, want)
     finally:
         hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = saved
+
+
+# ---- training launches on the role-split kernel (template parameter TR): the data gradient of a 3x3 / stride-1 conv (mirrored taps),
+# with the fused ReLU mask + accumulated gradient; the train-mode BatchNorm statistics of a raw conv output in the epilogue
+@pytest.fixture(params=[(5, 2), (8, 3), (8, 2), (5, 3)], ids=["5wg-w32", "8wg-w64", "8wg-w32", "5wg-w64"])
+def tapx_train(request):
+    from egorear_amd import hip
+    blocks, MODE["on"] = request.param          # (the wide wave tile exists for the statistics epilogue at stride 1 only: other training launches take the narrow one)
+    hip.lib.egr_conv_set_tapx(MODE["on"], 1, blocks)
+    yield hip
+    hip.lib.egr_conv_set_tapx(1, 256, 256)
+
+
+DGRAD_CASES = [
+    # groups, n, h(=w), forward cin, forward cout, mode
+    (2, 8, 32, 128, 128, "masked_res"),        # 128 x 128 tiles, grouped, mask + the gradient accumulated so far
+    (1, 4, 64, 64, 64, "masked_res"),          # 256 x 64 tiles (layer1)
+    (1, 4, 64, 64, 64, "masked"),              # mask only
+    (1, 32, 16, 256, 256, "masked_res"),       # eight chunks, two column tiles
+    (2, 32, 8, 512, 512, "plain"),             # plain data gradient, 8 x 8 images (two per tile), four column tiles
+    (1, 16, 64, 128, 64, "res"),               # gradient into a 64-channel tensor from 128 channels, accumulated, no mask
+    (1, 6, 32, 64, 128, "masked_res"),         # 24 tiles of 256 x 64: ragged last round
+]
+
+
+@pytest.mark.parametrize("case", DGRAD_CASES)
+def test_role_split_data_gradient(tapx_train, case):
+    from test_gpu_conv_x6 import pack_w_dgrad
+    hip = tapx_train
+    G, n, hw, cin, cout, mode = case           # forward conv cin -> cout; the gradient maps dy (cout channels) to dx (cin)
+    dy = rnd(G * n, hw, hw, cout, seed=481)
+    xs, prev = rnd(G * n, hw, hw, cin, seed=482), rnd(G * n, hw, hw, cin, seed=483)
+    wts = [rnd(cout, cin, 3, 3, seed=484 + g, scale=1.0 / math.sqrt(9 * cin)) for g in range(G)]
+    wt = torch.stack([pack_w_dgrad(w) for w in wts]) if G > 1 else pack_w_dgrad(wts[0])
+    kw = dict(transposed_out_hw=(hw, hw), groups=G)
+    if "res" in mode:
+        kw.update(res=hip.Img(prev.to(DEV)), res_mode=hip.RES_BEFORE_ACT)
+    if "masked" in mode:
+        kw.update(mask=hip.Img(xs.to(DEV)))
+    a, b, c, kern, rec = three(hip, hip.Img(dy.to(DEV)), wt, cin, 3, 3, 1, 1, **kw)
+    assert kern == 6, "the role-split kernel must carry this launch"
+    refs = []
+    for g in range(G):
+        xr = torch.zeros(n, cin, hw, hw, dtype=torch.float64, requires_grad=True)
+        (dx_ref,) = torch.autograd.grad(F.conv2d(xr, wts[g].double(), None, 1, 1), xr, dy[g * n:(g + 1) * n].permute(0, 3, 1, 2).double())
+        r = dx_ref.permute(0, 2, 3, 1)
+        if "res" in mode:
+            r = r + prev[g * n:(g + 1) * n].double()
+        if "masked" in mode:
+            r = r * (xs[g * n:(g + 1) * n] > 0)
+        refs.append(r)
+    check(a.t, b.t, c.t, torch.cat(refs), rec, f"tapx dgrad {case}")
+    hip.lib.egr_conv_set_tapx(0, -1, -1)
+    try:
+        _, _, c0, kern0, rec0 = three(hip, hip.Img(dy.to(DEV)), wt, cin, 3, 3, 1, 1, **kw)
+    finally:
+        hip.lib.egr_conv_set_tapx(MODE["on"], -1, -1)
+    assert kern0 == 2
+    assert torch.equal(c.t, c0.t), (case, float((c.t - c0.t).abs().max()))
+    assert record_value(rec) == record_value(rec0)
+
+
+BN_CASES = [
+    # n, h(=w), cin, cout, stride, groups
+    (8, 32, 64, 64, 1, 2),                     # 256 x 64 tiles, grouped
+    (16, 64, 64, 64, 1, 1),                    # layer1 geometry
+    (4, 32, 128, 128, 1, 1),                   # 128 x 128 tiles
+    (32, 8, 256, 512, 1, 2),                   # 8 x 8 images: two per tile, four column tiles
+    (8, 32, 64, 128, 2, 2),                    # stride 2 (layer2 entry): four chunks - the slab goes out right in front of the next hand-over
+    (8, 32, 128, 256, 2, 1),                   # stride 2, two column tiles
+]
+
+
+@pytest.mark.parametrize("case", BN_CASES)
+def test_role_split_batchnorm_statistics(tapx_train, case):
+    """egr_conv_aux.bn_partials on the role-split kernel: the same output tile, and per-tile slabs that finalise to the statistics,
+    running buffers, normalised output and bounds of the tap-sharing kernels' epilogue and of the pass over the tensor."""
+    from egorear_amd import hip_train as T
+    hip = tapx_train
+    n, hw, cin, cout, s, G = case
+    x = rnd(G * n, hw, hw, cin, seed=531).to(DEV)
+    x[:, :, :, 3] += 7.0                       # (a channel far from zero mean on the input side)
+    wts = [rnd(cout, cin, 3, 3, seed=532 + g, scale=1.0 / math.sqrt(9 * cin)) for g in range(G)]
+    wp = (torch.stack([pack_w(t) for t in wts]) if G > 1 else pack_w(wts[0])).to(DEV)
+    gamma, beta = (rnd(G, cout, seed=535) + 1.5).to(DEV), rnd(G, cout, seed=536).to(DEV)
+    ws = T.bn_workspace(DEV)
+    saved = hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS
+    hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = 0, 0.0
+    outs = []
+    try:
+        w = hip.add_wh2(hip.pack_w6(wp))
+        xin = hip.Img(x, amax=record_of(x))
+        for route in ("tapx", "tap", "pass"):
+            hip.lib.egr_conv_set_tapx(MODE["on"] if route == "tapx" else 0, -1, -1)
+            slabs = []
+            rec = torch.zeros(64, dtype=torch.int32, device=DEV)
+            kw = dict(bn_ws=ws, bn_slabs=slabs) if route != "pass" else {}
+            y = hip.conv2d(xin, w, cout, 3, 3, s, 1, groups=G, amax_out=rec, **kw).t
+            kern = hip.lib.egr_conv_last_kernel()
+            assert kern == (6 if route == "tapx" else (2 if s == 1 else 3)), (route, kern)
+            rm, rv = torch.zeros(G, cout, device=DEV), torch.ones(G, cout, device=DEV)
+            r = torch.zeros(64, dtype=torch.int32, device=DEV)
+            o, ctx = T.bn_train(y, gamma, beta, rm, rv, G, ws, relu=True, amax_out=r, slabs=slabs[0] if slabs else None)
+            torch.cuda.synchronize()
+            outs.append((y.clone(), o.clone(), ctx.mean.clone(), ctx.invstd.clone(), rm, rv, ctx.xhat_max.clone(), r, record_value(rec)))
+    finally:
+        hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = saved
+        hip.lib.egr_conv_set_tapx(MODE["on"], -1, -1)
+    t = outs[0]
+    for u, what in ((outs[1], "tap-sharing epilogue"), (outs[2], "statistics pass")):
+        assert torch.equal(t[0], u[0]), what                                     # the conv output itself
+        assert t[8] == u[8]
+        for i, name in ((2, "mean"), (3, "invstd"), (4, "running_mean"), (5, "running_var"), (1, "y")):
+            scale = float(u[i].abs().max())
+            assert float((t[i] - u[i]).abs().max()) <= 2e-6 * scale, (what, name, float((t[i] - u[i]).abs().max()), scale)
+        assert torch.equal(t[6], u[6]) and torch.equal(t[7], u[7]), what         # extremes are exact on every route
+    # against fp64 statistics of the stored tensor
+    yv = t[0].double().view(G, -1, cout)
+    assert float((t[2].double().view(G, cout) - yv.mean(1)).abs().max()) <= 1e-6 * float(yv.abs().max())
+
+
+def test_training_launch_refusals_and_the_forced_wave_tile(tapx_train):
+    """A launch with both a statistics epilogue request and an activation is refused (EINVAL) before any kernel is chosen, slabs that
+    do not fit with EWORKSPACE; the statistics epilogue runs on either wave tile."""
+    hip = tapx_train
+    from egorear_amd import hip_train as T
+    x = rnd(8, 32, 32, 64, seed=601).to(DEV)
+    wp = pack_w(rnd(128, 64, 3, 3, seed=602, scale=0.05)).to(DEV)
+    saved = hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS
+    hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = 0, 0.0
+    try:
+        w = hip.add_wh2(hip.pack_w6(wp))
+        xin = hip.Img(x, amax=record_of(x))
+        ws = T.bn_workspace(DEV)
+        with pytest.raises(hip.LaunchError) as ei:
+            hip.conv2d(xin, w, 128, 3, 3, 1, 1, act=hip.ACT_RELU, bn_ws=ws, bn_slabs=[])
+        assert ei.value.code == hip.EINVAL
+        with pytest.raises(hip.LaunchError) as ei:
+            hip.conv2d(xin, w, 128, 3, 3, 1, 1, bn_ws=ws[:64], bn_slabs=[])
+        assert ei.value.code == hip.EWORKSPACE
+        for on, bm in ((2, 128), (3, 256)):                 # slabs: one per M tile of the wave tile in force
+            hip.lib.egr_conv_set_tapx(on, -1, -1)
+            slabs = []
+            hip.conv2d(xin, w, 128, 3, 3, 1, 1, bn_ws=ws, bn_slabs=slabs)
+            assert hip.lib.egr_conv_last_kernel() == 6 and slabs[0] == 8 * 32 * 32 // bm
+    finally:
+        hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = saved
+        hip.lib.egr_conv_set_tapx(1, -1, -1)
