@@ -19,7 +19,17 @@
 // summed exactly once.  Weight loads run one 8-block chunk ahead of the MFMAs.  A wave owns 16-column output blocks.
 // LayerNorm is the arithmetic of layernorm_kernel (same lane -> channel map, same shuffle tree), the attention core that of
 // joint_mha_kernel (one wave per head).
+//
+// w_packed = 2 (round 4, the shipped path under EGR_W_FORMAT=f16x2): the contractions run in the fp16 scheme of the conv launches
+//  instead - half of a workgroup's time was the fp32 matrix pipe itself (64 FLOP / cycle / SIMD: 8 x 32 cycles per
+// 32-deep block; the three v_mfma_f32_16x16x32_f16 products take 3 x 16).  Weights: egr_pack_layer_wh2_f32 (per-row power-of-two
+// scale, two fp16 planes in fragment order, the descales behind the image).  Activations: every tile that feeds a contraction is
+// produced inside this kernel, its producers fold max |v| into an LDS slot (one atomic per wave), the consumer scales by the
+// power of two that puts that maximum into [2^14, 2^15) and splits its A fragments on the fly (8 floats of a row -> 2 x 8 fp16).
+#include <type_traits>
+
 #include "egr_common.h"
+#include "egr_conv_shared.h"
 
 namespace {
 
@@ -102,11 +112,91 @@ __device__ __forceinline__ void gemm_cols(const float* __restrict__ A, int lda, 
     }
 }
 
+// The same pipeline in the fp16 scheme: W is an egr_pack_layer_wh2_f32 image ([16-column block][128-deep chunk][32-deep k block]
+// [plane h | l][lane][8 fp16] - the eight 1-KiB units of a chunk where the fp32 order has its eight 16-deep blocks), wds the per-row
+// descales behind it; sa / inv the tile's pre-scale and its inverse.  Lane (i, q) holds A[row i][32 kb + 8 q ..+7] and
+// W[column i][the same k]; products (l,h) (h,l) (h,h) as in the conv kernels.  The accumulators reach epi() descaled.
+template <int RB, int NSEG, typename Epi>
+__device__ __forceinline__ void gemm_cols_h2(const float* __restrict__ A, int lda, int a_seg, const float* __restrict__ W, const float* __restrict__ wds,
+                                             int K, int nb0, int nstep, int nb1, int lane, float sa, float inv, Epi&& epi) {
+    using namespace egrc;
+    const int i = lane & 15, q = lane >> 4;
+    constexpr int CH = 8;
+    const int cps = K / 128, cpb = NSEG * cps;
+    const int nblk = (nb1 - nb0 + nstep - 1) / nstep;
+    if (nblk <= 0) return;
+    const int steps = nblk * cpb;
+    const float* const arow = A + i * lda + 8 * q;
+    u32x4 b0[CH], b1[CH];
+    f32x4_t acc[RB];
+    int l_blk = 0, l_c = 0;
+    auto load = [&](u32x4 (&b)[CH]) {
+        const float* p = W + ((int64_t)((nb0 + l_blk * nstep) * cpb + l_c) * CH) * 256 + lane * 4;
+#pragma unroll
+        for (int u = 0; u < CH; ++u) b[u] = *reinterpret_cast<const u32x4*>(p + 256 * u);
+        if (++l_c == cpb) { l_c = 0; ++l_blk; }
+    };
+    int c_blk = 0, c_c = 0;
+    auto compute = [&](const u32x4 (&b)[CH]) {
+        if (c_c == 0) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+        const int seg = c_c / cps, cc = c_c - seg * cps;
+        const float* p = arow + seg * a_seg + cc * 128;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const f32x4_t x0 = *reinterpret_cast<const f32x4_t*>(p + rb * 16 * lda + 32 * kb);
+                const f32x4_t x1 = *reinterpret_cast<const f32x4_t*>(p + rb * 16 * lda + 32 * kb + 4);
+                unsigned h0, l0, h1, l1, h2, l2, h3, l3;
+                split4_f16(x0[0], x0[1], x0[2], x0[3], sa, h0, l0, h1, l1);
+                split4_f16(x1[0], x1[1], x1[2], x1[3], sa, h2, l2, h3, l3);
+                const u32x4 ah = {h0, h1, h2, h3}, al = {l0, l1, l2, l3};
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al), __builtin_bit_cast(f16x8, b[2 * kb]), acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, b[2 * kb + 1]), acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, b[2 * kb]), acc[rb], 0, 0, 0);
+            }
+        }
+        if (++c_c == cpb) {
+            const int nb = nb0 + c_blk * nstep;
+            const float dsc = wds[nb * 16 + i] * inv;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[rb] *= dsc;
+            epi(nb, acc);
+            c_c = 0;
+            ++c_blk;
+        }
+    };
+    load(b0);
+    for (int s = 0; s < steps; s += 2) {
+        if (s + 1 < steps) load(b1);
+        compute(b0);
+        if (s + 2 < steps) load(b0);
+        if (s + 1 < steps) compute(b1);
+    }
+}
+
+// abs-max slot of a tile (LDS, float bits): producers fold their values in, the consumer derives the power-of-two pre-scale
+__device__ __forceinline__ void tile_track(unsigned* slot, float m) {
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.f) __hip_atomic_fetch_max(slot, __float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void tile_prescale(unsigned bits, float& sa, float& inv) {
+    const int e = (int)(__builtin_amdgcn_readfirstlane(bits) >> 23);
+    int k = 141 - e;
+    k = k > 60 ? 60 : (k < -60 ? -60 : k);
+    sa = __uint_as_float((unsigned)(127 + k) << 23);
+    inv = __uint_as_float((unsigned)(127 - k) << 23);
+}
+
 // rows of a 16-row tile owned by this wave: y = LayerNorm(t [+ res]) * gamma + beta, lane -> channels i*64 + lane (layernorm_kernel)
 template <int VPL, int NW>
 __device__ __forceinline__ void ln_rows(const float* t, int ldt, const float* res, int ldr, const float* gamma, const float* beta, float eps,
-                                        float* y, int ldy, int wave, int lane) {
+                                        float* y, int ldy, int wave, int lane, unsigned* slot = nullptr) {
     constexpr int c = VPL * 64;
+    float amx = 0.f;
     for (int rr = 0; rr < 16 / NW; ++rr) {
         const int row = wave * (16 / NW) + rr;
         float v[VPL];
@@ -130,9 +220,12 @@ __device__ __forceinline__ void ln_rows(const float* t, int ldt, const float* re
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int ch = i * 64 + lane;
-            y[row * ldy + ch] = (v[i] - mean) * rstd * gamma[ch] + beta[ch];
+            const float o = (v[i] - mean) * rstd * gamma[ch] + beta[ch];
+            y[row * ldy + ch] = o;
+            amx = fmaxf(amx, fabsf(o));
         }
     }
+    if (slot) tile_track(slot, amx);
 }
 
 constexpr int NW = 8;            // waves per workgroup (two per SIMD: one's weight fetches hide under the other's MFMAs)
@@ -149,11 +242,11 @@ struct LayerLds {
     static constexpr int M1 = 64 * LC, M2 = 16 * LQ, M3 = 16 * LF;
     static constexpr int BUFO = (M1 > M2 ? (M1 > M3 ? M1 : M3) : (M2 > M3 ? M2 : M3));
     static constexpr int BUFG = (HPP * 32 * LG > T ? HPP * 32 * LG : T);
-    static constexpr int SIDE = 64 * HEADS + 64;              // sigma of the 64 sampled rows per head, their row mask
+    static constexpr int SIDE = 64 * HEADS + 64 + 16;         // sigma of the 64 sampled rows per head, their row mask, the tiles' abs-max slots
     static constexpr size_t BYTES = sizeof(float) * (size_t)(BUFA + BUFO + BUFG + SIDE);
 };
 
-template <int C>
+template <int C, bool H2>
 __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
     const egr_layer_desc& d = a.d;
     using L = LayerLds<C>;
@@ -167,6 +260,10 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
     float* const tile1 = bufA + T;
     float* const s_sig = bufG + L::BUFG;               // [HEADS][64]
     float* const s_keep = s_sig + 64 * HEADS;          // [64]: 1 = valid sampled row
+    // fp16 scheme: abs-max (float bits) of every tile that feeds a contraction - slots 0-3 the staged sampled features per (half,
+    // pass), 4-5 the value projection per half, 6 output_proj, 7 norm_cross, 8 attention, 9 norm_spatial, 10 FFN hidden, 11 norm_ffn,
+    // 12 post_norm
+    unsigned* const s_amax = reinterpret_cast<unsigned*>(s_keep + 64);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, q4 = lane >> 4;
@@ -192,19 +289,21 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
     const float* const gq = d.g + (int64_t)grp * rows_all * HEADS * CF;
     const float* const eq = d.e ? d.e + (int64_t)grp * rows_all * C : nullptr;
     const float* const sg = d.sigma + (int64_t)grp * HEADS * rows_all;
-    const float* const w_fold = d.w_fold + (int64_t)grp * C * CF;
+    // a matrix of `rows` x k: rows * k floats; in the fp16 scheme the same bytes as two fp16 planes, the rows' descales behind them
+    auto wsz = [](int rows, int k) { return (int64_t)rows * k + (H2 ? rows : 0); };
+    const float* const w_fold = d.w_fold + grp * wsz(C, CF);
     const float* const c_fold = d.c_fold + grp * C;
-    const float* const w_out = d.w_out + (int64_t)grp * C * C;
+    const float* const w_out = d.w_out + grp * wsz(C, C);
     const float* const b_out = d.b_out + grp * C;
-    const float* const w_fuse = d.w_fuse + (int64_t)grp * C * V * C;
+    const float* const w_fuse = d.w_fuse + grp * wsz(C, 4 * C);
     const float* const b_fuse = d.b_fuse + grp * C;
-    const float* const w_qkv = d.w_qkv + (int64_t)grp * 3 * C * C;
+    const float* const w_qkv = d.w_qkv + grp * wsz(3 * C, C);
     const float* const b_qkv = d.b_qkv + grp * 3 * C;
-    const float* const w_mo = d.w_mo + (int64_t)grp * C * C;
+    const float* const w_mo = d.w_mo + grp * wsz(C, C);
     const float* const b_mo = d.b_mo + grp * C;
-    const float* const w_f0 = d.w_f0 + (int64_t)grp * FF * C;
+    const float* const w_f0 = d.w_f0 + grp * wsz(FF, C);
     const float* const b_f0 = d.b_f0 + grp * FF;
-    const float* const w_f1 = d.w_f1 + (int64_t)grp * C * FF;
+    const float* const w_f1 = d.w_f1 + grp * wsz(C, FF);
     const float* const b_f1 = d.b_f1 + grp * C;
 
     const bool wpk = d.w_packed != 0;
@@ -214,17 +313,42 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
         s_sig[tid] = rl < nrow ? sg[(int64_t)h * rows_all + row0 + rl] : 0.f;
     }
     if (tid < 64) s_keep[tid] = (tid < nrow && d.rowmask[row0 + tid] != 0) ? 1.f : 0.f;
+    if constexpr (H2) {
+        if (tid < 16) s_amax[tid] = 0u;
+        __syncthreads();                                // (the first producers' atomics must find the zeros)
+    }
+    // one contraction in either arithmetic: `rows` x `ktot` is the whole weight matrix (its descales sit behind the image), `slot` the
+    // abs-max slot of the A tile
+    auto gemm = [&](auto rb_tag, auto nseg_tag, const float* A, int lda, int a_seg, const float* W, int rows, int ktot, int ldw, int w_seg, int K,
+                    int nb0, int nstep, int nb1, int slot, auto&& epi) __attribute__((always_inline)) {
+        constexpr int RB = decltype(rb_tag)::value, NSEG = decltype(nseg_tag)::value;
+        if constexpr (H2) {
+            float sa, inv;
+            tile_prescale(s_amax[slot], sa, inv);
+            gemm_cols_h2<RB, NSEG>(A, lda, a_seg, W, W + (int64_t)rows * ktot, K, nb0, nstep, nb1, lane, sa, inv, epi);
+        } else {
+            gemm_cols<RB, NSEG>(A, lda, a_seg, W, ldw, w_seg, K, nb0, nstep, nb1, lane, wpk, epi);
+        }
+    };
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I4 = std::integral_constant<int, 4>;
     // plain "Linear on a 16-row tile": out[16][ldo] = act(A . W^T + bias)
-    auto linear16 = [&](const float* A, int lda, const float* W, int K, const float* bias, int N, float* out, int ldo, bool gelu) {
-        gemm_cols<1, 1>(A, lda, 0, W, K, 0, K, wave, NW, N / 16, lane, wpk, [&](int nb, const f32x4_t (&acc)[1]) {
+    auto linear16 = [&](const float* A, int lda, const float* W, int K, const float* bias, int N, float* out, int ldo, bool gelu, int slot_in,
+                        int slot_out) {
+        float amx = 0.f;
+        gemm(I1{}, I1{}, A, lda, 0, W, N, K, K, 0, K, wave, NW, N / 16, slot_in, [&](int nb, const f32x4_t (&acc)[1]) {
             const int col = nb * 16 + i16;
             const float bb = bias[col];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = acc[0][r] + bb;
-                out[(4 * q4 + r) * ldo + col] = gelu ? gelu_erf(v) : v;
+                float v = acc[0][r] + bb;
+                v = gelu ? gelu_erf(v) : v;
+                out[(4 * q4 + r) * ldo + col] = v;
+                amx = fmaxf(amx, fabsf(v));
             }
         });
+        if (H2 && slot_out >= 0) tile_track(s_amax + slot_out, amx);
     };
 
     // ---- value projection of the sampled rows (sample-then-project) + output_proj, in two 32-row halves
@@ -243,17 +367,21 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
                 stg[it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
                 if (rl < nrow) stg[it] = *reinterpret_cast<const f32x4_t*>(gq + ((int64_t)(row0 + rl) * HEADS + h) * CF + cq * 4);
             }
+            float samx = 0.f;
 #pragma unroll
             for (int it = 0; it < NST; ++it) {
                 const int idx = tid + it * NTH;
                 const int cq = idx % (CF / 4), r = (idx / (CF / 4)) % 32, hp = idx / (32 * (CF / 4));
                 *reinterpret_cast<f32x4_t*>(bufG + (hp * 32 + r) * LG + cq * 4) = stg[it];
+                samx = fmaxf(fmaxf(samx, fmaxf(fabsf(stg[it][0]), fabsf(stg[it][1]))), fmaxf(fabsf(stg[it][2]), fabsf(stg[it][3])));
             }
+            if constexpr (H2) tile_track(s_amax + hf * 2 + ps, samx);
             __syncthreads();
             if (wave * 16 < PW) {
                 const int n0 = ps * PW + wave * 16;    // this wave's output columns [n0, n0 + 16)
                 const int h = n0 / DH, hp = h - ps * HPP;
-                gemm_cols<2, 1>(bufG + hp * 32 * LG, LG, 0, w_fold, CF, 0, CF, n0 / 16, 1, n0 / 16 + 1, lane, wpk, [&](int nb, const f32x4_t (&acc)[2]) {
+                float amx = 0.f;
+                gemm(I2{}, I1{}, bufG + hp * 32 * LG, LG, 0, w_fold, C, CF, CF, 0, CF, n0 / 16, 1, n0 / 16 + 1, hf * 2 + ps, [&](int nb, const f32x4_t (&acc)[2]) {
                     const int col = nb * 16 + i16;
                     const float cf_ = c_fold[col];
 #pragma unroll
@@ -267,28 +395,36 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
                                 if (eq) v += eq[(int64_t)(row0 + rl) * C + col];
                             }
                             bufA[rl32 * LC + col] = v;
+                            amx = fmaxf(amx, fabsf(v));
                         }
                 });
+                if constexpr (H2) tile_track(s_amax + 4 + hf, amx);
             }
             __syncthreads();
         }
         // output_proj on the 32 rows of this half; masked_fill(~valid) AFTER it (the bias is zeroed too)
-        gemm_cols<2, 1>(bufA, LC, 0, w_out, C, 0, C, wave, NW, C / 16, lane, wpk, [&](int nb, const f32x4_t (&acc)[2]) {
-            const int col = nb * 16 + i16;
-            const float bo = b_out[col];
+        {
+            float amx = 0.f;
+            gemm(I2{}, I1{}, bufA, LC, 0, w_out, C, C, C, 0, C, wave, NW, C / 16, 4 + hf, [&](int nb, const f32x4_t (&acc)[2]) {
+                const int col = nb * 16 + i16;
+                const float bo = b_out[col];
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+                for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rl = hf * 32 + rb * 16 + 4 * q4 + r;
-                    const bool keep = s_keep[rl] != 0.f;
-                    bufO[rl * LC + col] = keep ? acc[rb][r] + bo : 0.f;
-                }
-        });
+                    for (int r = 0; r < 4; ++r) {
+                        const int rl = hf * 32 + rb * 16 + 4 * q4 + r;
+                        const bool keep = s_keep[rl] != 0.f;
+                        const float v = keep ? acc[rb][r] + bo : 0.f;
+                        bufO[rl * LC + col] = v;
+                        amx = fmaxf(amx, fabsf(v));
+                    }
+            });
+            if constexpr (H2) tile_track(s_amax + 6, amx);
+        }
         __syncthreads();
     }
     // ---- cat over views -> fuse_mlp: token j = rows 4j .. 4j+3 of bufO side by side (V segments of K = C)
-    gemm_cols<1, 4>(bufO, V * LC, LC, w_fuse, V * C, C, C, wave, NW, C / 16, lane, wpk, [&](int nb, const f32x4_t (&acc)[1]) {
+    gemm(I1{}, I4{}, bufO, V * LC, LC, w_fuse, C, 4 * C, V * C, C, C, wave, NW, C / 16, 6, [&](int nb, const f32x4_t (&acc)[1]) {
         const int col = nb * 16 + i16;
         const float bb = b_fuse[col];
 #pragma unroll
@@ -312,10 +448,10 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
         }
     }
     __syncthreads();
-    ln_rows<VPL, NW>(tile0, LC, bufG, LC, d.ln1_g + grp * C, d.ln1_b + grp * C, d.eps, tile1, LC, wave, lane);
+    ln_rows<VPL, NW>(tile0, LC, bufG, LC, d.ln1_g + grp * C, d.ln1_b + grp * C, d.eps, tile1, LC, wave, lane, H2 ? s_amax + 7 : nullptr);
     __syncthreads();
     // ---- q/k/v projections -> bufO [16][3C]
-    linear16(tile1, LC, w_qkv, C, b_qkv, 3 * C, bufO, LQ, false);
+    linear16(tile1, LC, w_qkv, C, b_qkv, 3 * C, bufO, LQ, false, 7, -1);
     __syncthreads();
     // ---- joint-to-joint attention (joint_mha_kernel's arithmetic): scores by waves 0-3 (one per head), PV by all waves -> tile0
     if (wave < HEADS) {
@@ -351,25 +487,28 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
     {
         const int h = wave & (HEADS - 1), part = wave / HEADS;      // NW / HEADS waves share a head's 16 x DH outputs
         const float* const sp = bufG + h * 256;
+        float amx = 0.f;
         for (int idx = part * 64 + lane; idx < 16 * DH; idx += 64 * (NW / HEADS)) {
             const int t = idx / DH, dd = idx - t * DH;
             float o = 0.f;
             for (int jj = 0; jj < J; ++jj) o = fmaf(sp[t * 16 + jj], bufO[jj * LQ + 2 * C + h * DH + dd], o);
             tile0[t * LC + h * DH + dd] = o;
+            amx = fmaxf(amx, fabsf(o));
         }
+        if constexpr (H2) tile_track(s_amax + 8, amx);
     }
     __syncthreads();
     // ---- out_proj -> bufG, + residual (tile1) -> norm_spatial -> tile0
-    linear16(tile0, LC, w_mo, C, b_mo, C, bufG, LC, false);
+    linear16(tile0, LC, w_mo, C, b_mo, C, bufG, LC, false, 8, -1);
     __syncthreads();
-    ln_rows<VPL, NW>(bufG, LC, tile1, LC, d.ln2_g + grp * C, d.ln2_b + grp * C, d.eps, tile0, LC, wave, lane);
+    ln_rows<VPL, NW>(bufG, LC, tile1, LC, d.ln2_g + grp * C, d.ln2_b + grp * C, d.eps, tile0, LC, wave, lane, H2 ? s_amax + 9 : nullptr);
     __syncthreads();
     // ---- FFN: Linear + GELU -> bufO [16][512]; Linear -> bufG; + residual (tile0) -> norm_ffn -> tile1
-    linear16(tile0, LC, w_f0, C, b_f0, FF, bufO, LF, true);
+    linear16(tile0, LC, w_f0, C, b_f0, FF, bufO, LF, true, 9, 10);
     __syncthreads();
-    linear16(bufO, LF, w_f1, FF, b_f1, C, bufG, LC, false);
+    linear16(bufO, LF, w_f1, FF, b_f1, C, bufG, LC, false, 10, -1);
     __syncthreads();
-    ln_rows<VPL, NW>(bufG, LC, tile0, LC, d.ln3_g + grp * C, d.ln3_b + grp * C, d.eps, tile1, LC, wave, lane);
+    ln_rows<VPL, NW>(bufG, LC, tile0, LC, d.ln3_g + grp * C, d.ln3_b + grp * C, d.eps, tile1, LC, wave, lane, H2 ? s_amax + 11 : nullptr);
     __syncthreads();
     // ---- the layer's output tokens
     for (int idx = tid; idx < J * C; idx += NTH) {
@@ -378,10 +517,10 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
     }
     // ---- tail: the next layer's sampling offsets / attention logits from these tokens (straight to global memory)
     if (d.w_ol) {
-        const float* const w_ol = d.w_ol + (int64_t)grp * d.ol_n * C;
+        const float* const w_ol = d.w_ol + grp * wsz(d.ol_n, C);
         const float* const b_ol = d.b_ol + grp * d.ol_n;
         const int oln = d.ol_n;
-        gemm_cols<1, 1>(tile1, LC, 0, w_ol, C, 0, C, wave, NW, oln / 16, lane, wpk, [&](int nb, const f32x4_t (&acc)[1]) {
+        gemm(I1{}, I1{}, tile1, LC, 0, w_ol, oln, C, C, 0, C, wave, NW, oln / 16, 11, [&](int nb, const f32x4_t (&acc)[1]) {
             const int col = nb * 16 + i16;
             const float bb = b_ol[col];
 #pragma unroll
@@ -393,7 +532,7 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
     }
     // ---- tail: post_norm [+ regression MLP + anchor]
     if (d.lnp_g) {
-        ln_rows<VPL, NW>(tile1, LC, nullptr, 0, d.lnp_g + grp * C, d.lnp_b + grp * C, d.eps, tile0, LC, wave, lane);
+        ln_rows<VPL, NW>(tile1, LC, nullptr, 0, d.lnp_g + grp * C, d.lnp_b + grp * C, d.eps, tile0, LC, wave, lane, H2 ? s_amax + 12 : nullptr);
         __syncthreads();
         if (d.xn_out)
             for (int idx = tid; idx < J * C; idx += NTH) {
@@ -401,7 +540,7 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
                 d.xn_out[(xrow0 + r) * C + ch] = tile0[r * LC + ch];
             }
         if (d.w_r0) {
-            linear16(tile0, LC, d.w_r0 + (int64_t)grp * C * C, C, d.b_r0 + grp * C, C, bufG, LC, true);
+            linear16(tile0, LC, d.w_r0 + grp * wsz(C, C), C, d.b_r0 + grp * C, C, bufG, LC, true, 12, -1);
             __syncthreads();
             // reg_mlp[2]: C -> 3, + init_anchors_3d; one thread per (token, coordinate), sequential k like the GEMM's chain
             if (tid < J * 3) {
@@ -431,7 +570,61 @@ __global__ __launch_bounds__(256) void pack_layer_w_kernel(const float* __restri
         *reinterpret_cast<const f32x4_t*>(w + (m * rows + nb * 16 + i) * k + kc * 128 + u * 16 + 4 * q);
 }
 
+// fp16 scheme: per matrix row the power of two that puts max |w| into [2^14, 2^15) (its inverse goes behind the image) ...
+__global__ __launch_bounds__(256) void layer_wh2_rowscale_kernel(const float* __restrict__ w, float* __restrict__ out, int rows, int k, int64_t rows_all) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= rows_all) return;
+    const float* r = w + row * k;
+    float m = 0.f;
+    for (int c = lane * 4; c < k; c += 256) {
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(r + c);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    m = wave_max(m);
+    if (lane == 0) {
+        const int e = (int)(__float_as_uint(m) >> 23);
+        int kk = 141 - e;
+        kk = kk > 60 ? 60 : (kk < -60 ? -60 : kk);
+        const int64_t mtx = row / rows;
+        out[mtx * ((int64_t)rows * k + rows) + (int64_t)rows * k + (row - mtx * rows)] = __uint_as_float((unsigned)(127 - kk) << 23);
+    }
+}
+// ... and the two fp16 planes in fragment order; one thread per 16 bytes of the image
+__global__ __launch_bounds__(256) void pack_layer_wh2_kernel(const float* __restrict__ w, float* __restrict__ out, int rows, int k, int64_t total4) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= total4) return;
+    const int64_t per = (int64_t)rows * k / 4;          // 16-byte units per matrix
+    const int64_t m = o / per;
+    int64_t r = o - m * per;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int u = (int)(r & 7); r >>= 3;
+    const int kc = (int)(r % (k / 128)), nb = (int)(r / (k / 128));
+    const int i = lane & 15, q = lane >> 4, kb = u >> 1, plane = u & 1;
+    const int64_t mbase = m * ((int64_t)rows * k + rows);
+    const float s = 1.f / out[mbase + (int64_t)rows * k + nb * 16 + i];     // exact: a power of two
+    const float* src = w + (m * rows + nb * 16 + i) * k + kc * 128 + kb * 32 + q * 8;
+    const f32x4_t x0 = *reinterpret_cast<const f32x4_t*>(src), x1 = *reinterpret_cast<const f32x4_t*>(src + 4);
+    unsigned h[4], l[4];
+    egrc::split2_f16(x0[0], x0[1], s, h[0], l[0]);
+    egrc::split2_f16(x0[2], x0[3], s, h[1], l[1]);
+    egrc::split2_f16(x1[0], x1[1], s, h[2], l[2]);
+    egrc::split2_f16(x1[2], x1[3], s, h[3], l[3]);
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<u32x4_t*>(out + mbase + (o - m * per) * 4) = plane ? u32x4_t{l[0], l[1], l[2], l[3]} : u32x4_t{h[0], h[1], h[2], h[3]};
+}
+
 }  // namespace
+
+extern "C" int egr_pack_layer_wh2_f32(const float* w, int32_t matrices, int32_t rows, int32_t k, float* out, void* stream) {
+    if (!w || !out) return EGR_ENULL;
+    if (matrices <= 0 || rows <= 0 || k <= 0 || rows % 16 != 0 || k % 128 != 0 || (((uintptr_t)w | (uintptr_t)out) & 15)) return EGR_EINVAL;
+    const int64_t total4 = (int64_t)matrices * rows * k / 4, rows_all = (int64_t)matrices * rows;
+    if ((total4 + 255) / 256 >= (1LL << 31)) return EGR_EINVAL;
+    hipLaunchKernelGGL(layer_wh2_rowscale_kernel, dim3((unsigned)((rows_all + 3) / 4)), dim3(256), 0, (hipStream_t)stream, w, out, rows, k, rows_all);
+    hipLaunchKernelGGL(pack_layer_wh2_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, out, rows, k, total4);
+    return egr_launch_status();
+}
 
 extern "C" int egr_pack_layer_w_f32(const float* w, int32_t matrices, int32_t rows, int32_t k, float* out, void* stream) {
     if (!w || !out) return EGR_ENULL;
@@ -464,25 +657,24 @@ extern "C" int egr_joint_layer_f32(const egr_layer_desc* dd, void* stream) {
     const dim3 grid((unsigned)(d.B * d.groups)), block(NTH);
     hipStream_t s = (hipStream_t)stream;
     // more than 64 KiB of dynamic LDS must be allowed per kernel and per device (a host-side attribute, not a stream operation)
-    static bool allowed[2][64] = {};
+    static bool allowed[4][64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return EGR_EINVAL;
-    if (d.C == 256) {
-        if (!allowed[0][dev]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(joint_layer_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)LayerLds<256>::BYTES) != hipSuccess)
+    if (d.w_packed < 0 || d.w_packed > 2) return EGR_EINVAL;
+    auto run = [&](auto c_tag, auto h2_tag, int slot) {
+        constexpr int CC = decltype(c_tag)::value;
+        constexpr bool HH = decltype(h2_tag)::value;
+        if (!allowed[slot][dev]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(joint_layer_kernel<CC, HH>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)LayerLds<CC>::BYTES) != hipSuccess)
                 return EGR_EINVAL;
-            allowed[0][dev] = true;
+            allowed[slot][dev] = true;
         }
-        hipLaunchKernelGGL(joint_layer_kernel<256>, grid, block, LayerLds<256>::BYTES, s, a);
-    } else {
-        if (!allowed[1][dev]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(joint_layer_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)LayerLds<128>::BYTES) != hipSuccess)
-                return EGR_EINVAL;
-            allowed[1][dev] = true;
-        }
-        hipLaunchKernelGGL(joint_layer_kernel<128>, grid, block, LayerLds<128>::BYTES, s, a);
-    }
-    return egr_launch_status();
+        hipLaunchKernelGGL((joint_layer_kernel<CC, HH>), grid, block, LayerLds<CC>::BYTES, s, a);
+        return egr_launch_status();
+    };
+    using C256 = std::integral_constant<int, 256>;
+    using C128 = std::integral_constant<int, 128>;
+    if (d.C == 256) return d.w_packed == 2 ? run(C256{}, std::true_type{}, 0) : run(C256{}, std::false_type{}, 1);
+    return d.w_packed == 2 ? run(C128{}, std::true_type{}, 2) : run(C128{}, std::false_type{}, 3);
 }

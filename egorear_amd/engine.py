@@ -476,6 +476,9 @@ class PLayer:
 # One launch per transformer layer behind the sampling (egr_joint_layer_f32) instead of ~14 small ones; EGR_FUSED_LAYER=0 keeps
 # the per-op launches (the training forward always uses those: it needs the intermediates).
 FUSED_LAYER = os.environ.get("EGR_FUSED_LAYER", "1") != "0"
+# the fused layer's contractions in the fp16 scheme (read when a module's layers are packed): follows EGR_W_FORMAT, EGR_LAYER_H2=0 keeps
+# the fp32 matrix cores
+LAYER_H2 = hip.H2 and os.environ.get("EGR_LAYER_H2", "1") != "0"
 
 
 def pack_layers(layers, pres, poss) -> PLayer:
@@ -559,11 +562,14 @@ def pack_layers(layers, pres, poss) -> PLayer:
     if not ok:
         P.fused = P.ol_plain = None
         return P
-    # the kernel streams its weight matrices as 1-KiB contiguous wave loads: fragment order (hip.pack_layer_w), flagged in the dict
+    # the kernel streams its weight matrices as 1-KiB contiguous wave loads: fragment order, flagged in the dict - the fp16 scheme's
+    # images (hip.pack_layer_wh2: the layer's contractions then run like the conv launches') or, with
+    # EGR_W_FORMAT=bf16x3 / EGR_LAYER_H2=0, the fp32 matrices (hip.pack_layer_w: fp32 matrix cores, the reference's arithmetic class)
+    pk = hip.pack_layer_wh2 if LAYER_H2 else hip.pack_layer_w
     for k in ("w_fold", "w_out", "w_fuse", "w_qkv", "w_mo", "w_f0", "w_f1"):
-        P.fused[k] = hip.pack_layer_w(P.fused[k])
-    P.fused["packed"] = True
-    P.ol_plain["w"] = hip.pack_layer_w(P.ol_plain["w"])
+        P.fused[k] = pk(P.fused[k])
+    P.fused["packed"] = 2 if LAYER_H2 else True
+    P.ol_plain["w"] = pk(P.ol_plain["w"])
     return P
 
 
@@ -774,7 +780,8 @@ def _pack_pose3d(p3) -> PPose:
     # the fused layer's regression tail (w0 in fragment order); None when a layer is outside the fused kernel's shapes (pack_layers)
     P.reg_plain = None
     if all(L.fused is not None for L in P.layers):
-        P.reg_plain = [(hip.pack_layer_w(f32(r[0].weight).contiguous()), f32(r[0].bias), f32(r[2].weight), f32(r[2].bias)) for r in p3.reg_mlp]
+        pk = hip.pack_layer_wh2 if LAYER_H2 else hip.pack_layer_w
+        P.reg_plain = [(pk(f32(r[0].weight).contiguous()), f32(r[0].bias), f32(r[2].weight), f32(r[2].bias)) for r in p3.reg_mlp]
     rec = np.stack([c.packed() for c in p3.cameras()])
     P.cams = torch.from_numpy(rec).to(w0.device)
     return P

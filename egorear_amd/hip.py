@@ -27,7 +27,7 @@ EXPORTS = [
     "egr_device_arch", "egr_conv_force_config", "egr_preprocess_u8_f32", "egr_pose_metrics_f32", "egr_gt_heatmap_f32", "egr_conv_debug_stamps", "egr_conv2d_wgrad_f32", "egr_conv2d_masked_f32", "egr_up2_relu_head_f32",
     "egr_msda_fwd_f32", "egr_msda_bwd_f32", "egr_w6_elems", "egr_pack_w6_f32", "egr_pack_w6_many_f32", "egr_joint_layer_f32",
     "egr_preprocess_fused_u8_f32", "egr_preprocess_band_rows", "egr_conv_set_persist", "egr_stem_conv7x7_pool_f32",
-    "egr_stem_w6_bytes", "egr_pack_stem_w6_f32", "egr_stem_conv7x7_x6_f32", "egr_wgrad_last_kernel", "egr_conv_last_kernel", "egr_conv_set_tap", "egr_conv_set_tapx", "egr_conv_set_splitk_fused", "egr_fisheye_project2_f32", "egr_pack_layer_w_f32",
+    "egr_stem_w6_bytes", "egr_pack_stem_w6_f32", "egr_stem_conv7x7_x6_f32", "egr_wgrad_last_kernel", "egr_conv_last_kernel", "egr_conv_set_tap", "egr_conv_set_tapx", "egr_conv_set_splitk_fused", "egr_fisheye_project2_f32", "egr_pack_layer_w_f32", "egr_pack_layer_wh2_f32",
     "egr_conv2d_nhwc_ex_f32", "egr_wh2_elems", "egr_pack_wh2_f32", "egr_absmax_f32", "egr_stem_conv7x7_x6_ex_f32", "egr_stem_wh2_bytes", "egr_pack_stem_wh2_f32", "egr_stem_conv7x7_h2_f32",
     "egr_pack_wh2_many_f32", "egr_conv2d_masked_ex_f32", "egr_conv2d_wgrad_ex_f32", "egr_wgrad_last_h2",
     "egr_wstream_image_bytes", "egr_pack_wstream_f32", "egr_linear_wstream_workspace_bytes", "egr_linear_wstream_f32",
@@ -140,6 +140,7 @@ def _load() -> C.CDLL:
     lib.egr_msda_bwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.egr_joint_layer_f32.argtypes = [C.POINTER(LayerDesc), vp]
     lib.egr_pack_layer_w_f32.argtypes = [vp, i32, i32, i32, vp, vp]
+    lib.egr_pack_layer_wh2_f32.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.egr_preprocess_fused_u8_f32.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]
     lib.egr_preprocess_band_rows.argtypes = [vp, i32]
     lib.egr_preprocess_u8_f32.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
@@ -1028,6 +1029,18 @@ def pack_layer_w(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def pack_layer_wh2(w: torch.Tensor) -> torch.Tensor:
+    """(..., rows, k) fp32 weight stack -> (..., rows * k + rows) floats: per matrix the fp16-scheme image egr_joint_layer_f32 reads with
+    w_packed = 2 (two fp16 planes per weight in fragment order) and the rows' descales behind it (egr_pack_layer_wh2_f32)."""
+    rows, k = w.shape[-2], w.shape[-1]
+    if w.dtype != torch.float32 or rows % 16 or k % 128:
+        raise RuntimeError("egorear_amd.pack_layer_wh2: fp32, rows % 16 == 0, k % 128 == 0 expected")
+    w = _cont(w, "layer weight")
+    out = torch.empty(w.shape[:-2] + (rows * k + rows,), device=w.device, dtype=torch.float32)
+    _launch("egr_pack_layer_wh2_f32", lib.egr_pack_layer_wh2_f32, _p(w), w.numel() // (rows * k), rows, k, _p(out), _stream())
+    return out
+
+
 def joint_layer(x: torch.Tensor, g: torch.Tensor, e: Optional[torch.Tensor], sigma: torch.Tensor, rowmask: torch.Tensor, W: dict,
                 B: int, J: int, V: int, Cdim: int, groups: int, *, ol: Optional[dict] = None, post: Optional[dict] = None,
                 reg: Optional[dict] = None, want_xn: bool = False):
@@ -1042,11 +1055,16 @@ def joint_layer(x: torch.Tensor, g: torch.Tensor, e: Optional[torch.Tensor], sig
         raise RuntimeError("egorear_amd.joint_layer: sampled operands do not match (B, J, V)")
     if e is not None and e.numel() != groups * B * J * V * Cdim:
         raise RuntimeError("egorear_amd.joint_layer: e does not match")
-    need = {"w_fold": groups * Cdim * 128, "c_fold": groups * Cdim, "w_out": groups * Cdim * Cdim, "b_out": groups * Cdim,
-            "w_fuse": groups * Cdim * V * Cdim, "b_fuse": groups * Cdim, "ln1_g": groups * Cdim, "ln1_b": groups * Cdim,
-            "w_qkv": groups * 3 * Cdim * Cdim, "b_qkv": groups * 3 * Cdim, "w_mo": groups * Cdim * Cdim, "b_mo": groups * Cdim,
-            "ln2_g": groups * Cdim, "ln2_b": groups * Cdim, "w_f0": groups * 512 * Cdim, "b_f0": groups * 512,
-            "w_f1": groups * Cdim * 512, "b_f1": groups * Cdim, "ln3_g": groups * Cdim, "ln3_b": groups * Cdim}
+    packed = W.get("packed")
+    packed = 2 if packed == 2 else (1 if packed else 0)     # 2: the fp16-scheme images (pack_layer_wh2), 1: fragment order (pack_layer_w)
+
+    def msz(rows, k):                                       # floats of one weight matrix as passed
+        return rows * k + (rows if packed == 2 else 0)
+    need = {"w_fold": groups * msz(Cdim, 128), "c_fold": groups * Cdim, "w_out": groups * msz(Cdim, Cdim), "b_out": groups * Cdim,
+            "w_fuse": groups * msz(Cdim, V * Cdim), "b_fuse": groups * Cdim, "ln1_g": groups * Cdim, "ln1_b": groups * Cdim,
+            "w_qkv": groups * msz(3 * Cdim, Cdim), "b_qkv": groups * 3 * Cdim, "w_mo": groups * msz(Cdim, Cdim), "b_mo": groups * Cdim,
+            "ln2_g": groups * Cdim, "ln2_b": groups * Cdim, "w_f0": groups * msz(512, Cdim), "b_f0": groups * 512,
+            "w_f1": groups * msz(Cdim, 512), "b_f1": groups * Cdim, "ln3_g": groups * Cdim, "ln3_b": groups * Cdim}
     d = LayerDesc()
     d.B, d.J, d.V, d.C, d.heads, d.cf, d.groups, d.ffn_dim = B, J, V, Cdim, 4, 128, groups, 512
     d.eps, d.mha_scale = 1e-5, float((Cdim // 4) ** -0.5)
@@ -1056,13 +1074,13 @@ def joint_layer(x: torch.Tensor, g: torch.Tensor, e: Optional[torch.Tensor], sig
         if t.numel() != n or not t.is_contiguous():
             raise RuntimeError(f"egorear_amd.joint_layer: weight {k} has {t.numel()} elements, expected {n}")
         setattr(d, k, _p(t))
-    d.w_packed = 1 if W.get("packed") else 0     # the matrices of W, ol and reg are then all in fragment order (pack_layer_w)
+    d.w_packed = packed                          # the matrices of W, ol and reg are then all in that order
     x_out = torch.empty_like(x)
     d.x_out = _p(x_out)
     ol_out = xn = pred = None
     if ol is not None:
-        n = ol["w"].shape[-2]
-        if ol["w"].numel() != groups * n * Cdim or ol["b"].numel() != groups * n or n % 16:
+        n = ol["b"].shape[-1]
+        if ol["w"].numel() != groups * msz(n, Cdim) or ol["b"].numel() != groups * n or n % 16:
             raise RuntimeError("egorear_amd.joint_layer: offsets / logits weights do not match")
         ol_out = torch.empty((rows, n), device=x.device, dtype=torch.float32)
         d.w_ol, d.b_ol, d.ol_out, d.ol_n = _p(_cont(ol["w"], "w_ol")), _p(ol["b"]), _p(ol_out), n
@@ -1076,7 +1094,7 @@ def joint_layer(x: torch.Tensor, g: torch.Tensor, e: Optional[torch.Tensor], sig
     if reg is not None:
         if post is None:
             raise RuntimeError("egorear_amd.joint_layer: the regression head sits behind post_norm")
-        if reg["w0"].numel() != groups * Cdim * Cdim or reg["w2"].numel() != groups * 3 * Cdim or reg["anchors"].numel() != rows * 3:
+        if reg["w0"].numel() != groups * msz(Cdim, Cdim) or reg["w2"].numel() != groups * 3 * Cdim or reg["anchors"].numel() != rows * 3:
             raise RuntimeError("egorear_amd.joint_layer: regression head operands do not match")
         pred = torch.empty((rows, 3), device=x.device, dtype=torch.float32)
         d.w_r0, d.b_r0, d.w_r2, d.b_r2 = _p(_cont(reg["w0"], "w_r0")), _p(reg["b0"]), _p(_cont(reg["w2"], "w_r2")), _p(reg["b2"])

@@ -397,7 +397,9 @@ typedef struct egr_layer_desc {
     float* ol_out;
     int32_t ol_n;
     int32_t w_packed;   /* != 0: every weight MATRIX (w_fold, w_out, w_fuse, w_qkv, w_mo, w_f0, w_f1, w_ol, w_r0; not w_r2, not the vectors) is in
-                         * the fragment order of egr_pack_layer_w_f32 - 1-KiB contiguous wave loads, what the shipped path passes */
+                         * the fragment order of egr_pack_layer_w_f32 (1: fp32, 1-KiB contiguous wave loads) or of egr_pack_layer_wh2_f32
+                         * (2: the fp16 scheme - two fp16 planes per weight, rows * k + rows floats per matrix, the contractions on
+                         * v_mfma_f32_16x16x32_f16 with three products; what the shipped path passes under EGR_W_FORMAT=f16x2) */
     /* tail: post_norm (lnp_g NULL = off) -> xn_out (or NULL); with it the regression head: w_r0 (groups, c, c), w_r2 (groups, 3, c),
      * pred_out (groups*b*joints, 3) = reg(xn) + anchors3d */
     const float *lnp_g, *lnp_b;
@@ -410,6 +412,10 @@ int egr_joint_layer_f32(const egr_layer_desc* d, void* stream);
  * w_packed: [matrix][16-row block][128-deep chunk][16-deep k block u][lane = 16 q + i][4 floats] = w[16 block + i][128 chunk + 16 u + 4 q ..+3].
  * Same number of elements; out must not alias w. */
 int egr_pack_layer_w_f32(const float* w, int32_t matrices, int32_t rows, int32_t k, float* out, void* stream);
+/* The fp16-scheme image of the same matrices (w_packed = 2): per matrix rows * k + rows floats - [16-row block][128-deep chunk]
+ * [32-deep k block][plane h | l][lane = 16 q + i][8 fp16] = plane of w[16 block + i][128 chunk + 32 kb + 8 q ..+7] * 2^e(row), then the
+ * rows' descales 2^-e (fp32; e puts the row's largest magnitude into [2^14, 2^15), clamped to +-60).  Same limits as above. */
+int egr_pack_layer_wh2_f32(const float* w, int32_t matrices, int32_t rows, int32_t k, float* out, void* stream);
 
 /* utils/camera_models.py:53-104 + egoposeformer_mvf_ex.py:340-348,400-406: project the (b, joints, 3) proposals
  * into the four fisheye cameras.  cams: 4 records [npoly, cx, cy, W, H, poly[12]] (fp32).  syn mode

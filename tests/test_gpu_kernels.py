@@ -500,6 +500,63 @@ def test_pack_layer_w_layout_and_packed_weights_give_identical_results(hip):
         assert a is not None and torch.equal(a, b)
 
 
+def _layer_case(hip, C, G, B, J, xs=1.0, gs=1.0):
+    V = 4
+    r = lambda *s_, seed, scale=0.1: (rnd(*s_, seed=seed) * scale).to(DEV)      # noqa: E731
+    W = {"w_fold": r(G, C, 128, seed=1), "c_fold": r(G, C, seed=2), "w_out": r(G, C, C, seed=3), "b_out": r(G, C, seed=4),
+         "w_fuse": r(G, C, V * C, seed=5), "b_fuse": r(G, C, seed=6), "ln1_g": r(G, C, seed=7) + 1, "ln1_b": r(G, C, seed=8),
+         "w_qkv": r(G, 3 * C, C, seed=9), "b_qkv": r(G, 3 * C, seed=10), "w_mo": r(G, C, C, seed=11), "b_mo": r(G, C, seed=12),
+         "ln2_g": r(G, C, seed=13) + 1, "ln2_b": r(G, C, seed=14), "w_f0": r(G, 512, C, seed=15), "b_f0": r(G, 512, seed=16),
+         "w_f1": r(G, C, 512, seed=17), "b_f1": r(G, C, seed=18), "ln3_g": r(G, C, seed=19) + 1, "ln3_b": r(G, C, seed=20)}
+    W["w_out"][0, 5] *= 1e-5                 # a row of tiny weights and a row of large ones: per-row scales
+    W["w_f0"][0, 9] *= 300.0
+    ol = {"w": r(G, 192, C, seed=21), "b": r(G, 192, seed=22)}
+    post = {"g": r(G, C, seed=23) + 1, "b": r(G, C, seed=24)}
+    reg = {"w0": r(G, C, C, seed=25), "b0": r(G, C, seed=26), "w2": r(G, 3, C, seed=27), "b2": r(G, 3, seed=28), "anchors": r(G * B * J, 3, seed=29, scale=10.0)}
+    x = r(G * B * J, C, seed=30, scale=xs)
+    g = r(G * B * J * V, 4, 128, seed=31, scale=gs)
+    sigma = (rnd(G, 4, B * J * V, seed=32).abs() * 0.5).to(DEV)
+    rowmask = (torch.arange(B * J * V) % 7 != 0).to(torch.uint8).to(DEV)
+    mats = ("w_fold", "w_out", "w_fuse", "w_qkv", "w_mo", "w_f0", "w_f1")
+    outs = []
+    for pk, flag in ((hip.pack_layer_w, True), (hip.pack_layer_wh2, 2)):
+        Wp = {k: (pk(v) if k in mats else v) for k, v in W.items()}
+        Wp["packed"] = flag
+        outs.append(hip.joint_layer(x, g, None, sigma, rowmask, Wp, B, J, V, C, G, ol={"w": pk(ol["w"]), "b": ol["b"]}, post=post,
+                                    reg=dict(reg, w0=pk(reg["w0"])), want_xn=True))
+    return outs
+
+
+@pytest.mark.parametrize("C,G,B,J", [(128, 2, 3, 16), (256, 4, 2, 15), (128, 1, 5, 15)])
+def test_layer_in_the_fp16_scheme_matches_the_fp32_matrix_cores(hip, C, G, B, J):
+    """egr_joint_layer_f32 with w_packed = 2 (egr_pack_layer_wh2_f32 images: two fp16 planes per weight, per-row power-of-two scales; the
+    activation tiles scaled from their in-kernel abs-max and split on the fly; three products per fp32 product) against the same launch
+    on the fp32 matrix cores: every output (tokens, next offsets / logits, post_norm, 3-D prediction) within a few 2^-22 of its scale -
+    also with inputs far outside fp16's range."""
+    # image layout: [16-row block][128-deep chunk][32-deep block][plane][lane = 16 q + i][8 fp16] * 2^e(row), descales behind
+    w = rnd(2, 32, 256, seed=93).to(DEV)
+    w[0, 3] *= 1e-4
+    img = hip.pack_layer_wh2(w)
+    assert img.shape == (2, 32 * 256 + 32)
+    ds = img[:, 32 * 256:].double()
+    m, _ = torch.frexp(ds)
+    assert torch.all(m == 0.5)                                               # exact powers of two
+    amax = w.abs().amax(-1).double()
+    assert torch.all(amax / ds >= 2.0 ** 14) and torch.all(amax / ds < 2.0 ** 15)
+    planes = img[:, :32 * 256].contiguous().view(torch.float16).view(2, 2, 2, 4, 2, 4, 16, 8).double()    # (m, nb, kc, kb, plane, q, i, t)
+    back = (planes[:, :, :, :, 0] + planes[:, :, :, :, 1]).permute(0, 1, 5, 2, 3, 4, 6).reshape(2, 32, 256) * ds.view(2, 32, 1)
+    assert float((back - w.double()).abs().max() / w.abs().max()) < 2.0 ** -21      # h + l carries 22 bits of each weight (relative to the row)
+    assert float(((back - w.double()).abs() / amax.view(2, 32, 1)).max()) < 2.0 ** -21
+    for xs, gs in ((1.0, 1.0), (3e4, 1e5), (1e-6, 1e-7)):
+        f32, h2 = _layer_case(hip, C, G, B, J, xs, gs)
+        for name, a, b in zip(("tokens", "offsets/logits", "post_norm", "pred"), f32, h2):
+            assert a is not None and b is not None and torch.isfinite(b).all(), name
+            scale = float(a.abs().max())
+            err = float((a - b).abs().max())
+            # (far from unit scale the residual + LayerNorm in front cancels leading digits: both arithmetics then sit ~1e-5 from fp64)
+            assert err <= (4e-6 if xs == 1.0 else 2e-5) * scale, (name, xs, gs, err, scale)
+
+
 def test_layernorm_and_mha_match_torch(hip):
     for c in (128, 256):
         x, r = rnd(45, c, seed=51), rnd(45, c, seed=52)
