@@ -228,6 +228,13 @@ __device__ __forceinline__ void ln_rows(const float* t, int ldt, const float* re
     if (slot) tile_track(slot, amx);
 }
 
+#ifdef LAYER_STAMPS      // diagnostic build (tools/probes/layer_stamps.py): s_memtime of workgroup 0 at the phase boundaries
+__device__ unsigned long long g_layer_stamps[64];
+#define LSTAMP(n) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_layer_stamps[n] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LSTAMP(n) do { } while (0)
+#endif
+
 constexpr int NW = 8;            // waves per workgroup (two per SIMD: one's weight fetches hide under the other's MFMAs)
 constexpr int NTH = NW * 64;
 
@@ -307,6 +314,7 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
     const float* const b_f1 = d.b_f1 + grp * C;
 
     const bool wpk = d.w_packed != 0;
+    LSTAMP(0);
     // per-row side inputs of the sampled-row phase, once (they were global loads inside the GEMM epilogues)
     if (tid < 64 * HEADS) {
         const int h = tid >> 6, rl = tid & 63;
@@ -423,6 +431,7 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
         }
         __syncthreads();
     }
+    LSTAMP(1);
     // ---- cat over views -> fuse_mlp: token j = rows 4j .. 4j+3 of bufO side by side (V segments of K = C)
     gemm(I1{}, I4{}, bufO, V * LC, LC, w_fuse, C, 4 * C, V * C, C, C, wave, NW, C / 16, 6, [&](int nb, const f32x4_t (&acc)[1]) {
         const int col = nb * 16 + i16;
@@ -430,6 +439,7 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) tile0[(4 * q4 + r) * LC + col] = acc[0][r] + bb;
     });
+    LSTAMP(2);
     // ---- + residual (the layer input, from global memory) -> norm_cross
     // residual rows of tokens >= J do not exist: point them at token 0 (their results are never stored)
     {
@@ -450,9 +460,11 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
     __syncthreads();
     ln_rows<VPL, NW>(tile0, LC, bufG, LC, d.ln1_g + grp * C, d.ln1_b + grp * C, d.eps, tile1, LC, wave, lane, H2 ? s_amax + 7 : nullptr);
     __syncthreads();
+    LSTAMP(3);
     // ---- q/k/v projections -> bufO [16][3C]
     linear16(tile1, LC, w_qkv, C, b_qkv, 3 * C, bufO, LQ, false, 7, -1);
     __syncthreads();
+    LSTAMP(4);
     // ---- joint-to-joint attention (joint_mha_kernel's arithmetic): scores by waves 0-3 (one per head), PV by all waves -> tile0
     if (wave < HEADS) {
         const int h = wave;
@@ -498,11 +510,13 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
         if constexpr (H2) tile_track(s_amax + 8, amx);
     }
     __syncthreads();
+    LSTAMP(5);
     // ---- out_proj -> bufG, + residual (tile1) -> norm_spatial -> tile0
     linear16(tile0, LC, w_mo, C, b_mo, C, bufG, LC, false, 8, -1);
     __syncthreads();
     ln_rows<VPL, NW>(bufG, LC, tile1, LC, d.ln2_g + grp * C, d.ln2_b + grp * C, d.eps, tile0, LC, wave, lane, H2 ? s_amax + 9 : nullptr);
     __syncthreads();
+    LSTAMP(6);
     // ---- FFN: Linear + GELU -> bufO [16][512]; Linear -> bufG; + residual (tile0) -> norm_ffn -> tile1
     linear16(tile0, LC, w_f0, C, b_f0, FF, bufO, LF, true, 9, 10);
     __syncthreads();
@@ -510,6 +524,7 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
     __syncthreads();
     ln_rows<VPL, NW>(bufG, LC, tile0, LC, d.ln3_g + grp * C, d.ln3_b + grp * C, d.eps, tile1, LC, wave, lane, H2 ? s_amax + 11 : nullptr);
     __syncthreads();
+    LSTAMP(7);
     // ---- the layer's output tokens
     for (int idx = tid; idx < J * C; idx += NTH) {
         const int r = idx / C, ch = idx - r * C;
@@ -530,6 +545,7 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
             }
         });
     }
+    LSTAMP(8);
     // ---- tail: post_norm [+ regression MLP + anchor]
     if (d.lnp_g) {
         ln_rows<VPL, NW>(tile1, LC, nullptr, 0, d.lnp_g + grp * C, d.lnp_b + grp * C, d.eps, tile0, LC, wave, lane, H2 ? s_amax + 12 : nullptr);
@@ -553,6 +569,7 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
             }
         }
     }
+    LSTAMP(9);
 }
 
 // (rows, k) row-major -> fragment order; one thread per 16 bytes of the output
@@ -615,6 +632,12 @@ __global__ __launch_bounds__(256) void pack_layer_wh2_kernel(const float* __rest
 }
 
 }  // namespace
+
+#ifdef LAYER_STAMPS
+extern "C" int egr_layer_stamps(unsigned long long* host64) {
+    return (int)hipMemcpyFromSymbol(host64, HIP_SYMBOL(g_layer_stamps), 64 * sizeof(unsigned long long));
+}
+#endif
 
 extern "C" int egr_pack_layer_wh2_f32(const float* w, int32_t matrices, int32_t rows, int32_t k, float* out, void* stream) {
     if (!w || !out) return EGR_ENULL;
