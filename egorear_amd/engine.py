@@ -787,10 +787,15 @@ def _pack_pose3d(p3) -> PPose:
     return P
 
 
-def _pose3d(p3, st: State, feat_init: torch.Tensor, feat_final: torch.Tensor, B: int, V: int, ctm):
-    """EgoPoseFormerPose3D.forward (egoposeformer_mvf_ex.py:422-452).  feat_*: (V*B, 64, 64, 128) view-major NHWC."""
+def _pose3d(p3, st: State, feat_init: torch.Tensor, feat_final: torch.Tensor, B: int, V: int, ctm, behind: Optional[State] = None):
+    """EgoPoseFormerPose3D.forward (egoposeformer_mvf_ex.py:422-452).  feat_*: (V*B, 64, 64, 128) view-major NHWC.
+    behind: the state of the heat-map estimator whose forward has just produced feat_* - the lifting head then goes on in ITS abs-max
+    arena (one clear per forward instead of two; the records of feat_* sit in it anyway)."""
     P: PPose = st.get(p3, lambda: _pack_pose3d(p3))
-    st.begin_forward()
+    if behind is not None and behind.amax is not None and st.amax is not None:
+        st.amax = behind.amax
+    else:
+        st.begin_forward()
     for t in (feat_init, feat_final):      # feature maps handed in by a caller carry no abs-max record: make one (one read each)
         if st.amax is not None and getattr(t, "_egr_amax", None) is None:
             rec = st.new_amax()
@@ -873,6 +878,6 @@ def mvfex_forward_api(mod, img, ctm=None):
     he = mod.heatmap_estimator
     hm_init, hm_ref, feat_all, feat_ref, aux_h = _mvfex(he, img)
     st = _state(mod.pose3d_estimator, img.device)
-    preds, aux_p = _pose3d(mod.pose3d_estimator, st, feat_all, feat_ref, B, V, ctm)
+    preds, aux_p = _pose3d(mod.pose3d_estimator, st, feat_all, feat_ref, B, V, ctm, behind=_state(he, img.device))
     mod.__dict__["_egr_last_aux"] = {"heatmap": aux_h, "pose3d": aux_p}
     return preds, [hm_init, hm_ref]
