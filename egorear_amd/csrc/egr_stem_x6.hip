@@ -28,6 +28,11 @@ constexpr int PW = 2 * TW + 5;           // 69 input columns (+ 1: the padded 8t
 constexpr int PWS = 72;                  // patch row stride (even: 8-byte aligned ds_read_b64)
 constexpr int PATCH = 3 * PH * PWS;      // floats per staged patch
 constexpr int PLOADS = (PATCH + NT - 1) / NT;   // every float of the buffer is (re)written per tile, the pad columns with zeros
+constexpr int PPAIRS = (PATCH / 2 + NT - 1) / NT;   // fp16 scheme: pixel pairs per thread (the patch is parked as two fp16 planes)
+static_assert(PATCH % 2 == 0 && PWS % 2 == 0, "pixel pairs");
+#ifndef STEM_PRESPLIT
+#define STEM_PRESPLIT 1    // fp16 scheme: 1 = the patch is split ONCE while it is parked (two fp16 planes in LDS); 0 = every wave splits its A
+#endif                     // fragments in the K loop (round 3: each patch value was split ~11 times, the K loop ran at 46 % of the MFMA bound)
 #ifndef STEM_KS
 #define STEM_KS 11
 #endif
@@ -74,17 +79,22 @@ struct StemX6Args {
 };
 
 // LDS offset (floats) of the patch row of (ci, kh) pair p; the zero-weight 22nd pair reads the 21st
-__device__ __forceinline__ constexpr int pair_off(int p) {
+template <int PH_>
+__device__ __forceinline__ constexpr int pair_off_t(int p) {
     const int pp = p > 20 ? 20 : p;
-    return (pp / 7) * PH * PWS + (pp % 7) * PWS;
+    return (pp / 7) * PH_ * PWS + (pp % 7) * PWS;
 }
 
 // NPL = 3: three bf16 planes, six products.  NPL = 2: the fp16 scheme - two fp16 planes of the value times an exact power of two, three
 // products; the pre-scale of the activations is PER TILE here (every k of a tile's outputs comes from the one patch in LDS, so a
 // uniform scale per tile is a per-row scale of the GEMM: exact), taken from the patch's largest magnitude while it is parked.
+// (Measured and not kept, profiles/r04_v1_tapx_experiments.txt (17): four-wave workgroups, two per CU, started in or out of step - the
+// kernel is bound by the ~2000 bookkeeping instructions a wave executes per tile around its 132 MFMAs, not by phase overlap.)
 template <bool POOL, int NPL>
 __global__ __launch_bounds__(NT, 1) void stem_x6_kernel(const StemX6Args a) {
+    auto pair_off = [](int p) constexpr { return pair_off_t<PH>(p); };
     constexpr int WB = NPL == 3 ? WBYTES : WBYTES2, NPR = NPL == 3 ? 6 : 3;
+    constexpr bool PRE = NPL == 2 && STEM_PRESPLIT;     // the patch sits in LDS as fp16 planes h | l ([ci][py][px], PATCH halves each)
     __shared__ __attribute__((aligned(16))) float s_patch[2][PATCH];
     __shared__ __attribute__((aligned(16))) uint8_t s_w[WB];
     __shared__ unsigned s_pmax[2][NW];           // NPL = 2: per-wave largest |value| (float bits) of the patch parked in buffer b
@@ -134,6 +144,52 @@ __global__ __launch_bounds__(NT, 1) void stem_x6_kernel(const StemX6Args a) {
             if (lane == 0) s_pmax[buf][wave] = __float_as_uint(m);
         }
     };
+    // ---- PRE: pair slots - LDS pair j = tid + NT*u -> (ci, py, px even); a pair is two global loads (the patch starts at an odd column)
+    int q_geo[PRE ? PPAIRS : 1];            // (ci << 16) | (py << 8) | px, -1 past the patch; the pair's LDS slot is tid + NT*u itself
+    if constexpr (PRE) {
+#pragma unroll
+        for (int u = 0; u < PPAIRS; ++u) {
+            const int i = 2 * (tid + NT * u);
+            const int ci = i / (PH * PWS);
+            const int r = i - ci * PH * PWS;
+            const int py = r / PWS;
+            q_geo[u] = (i < PATCH) ? ((ci << 16) | (py << 8) | (r - py * PWS)) : -1;
+        }
+    }
+    auto fetch2 = [&](int tile, float (&v)[2 * PPAIRS]) {
+        const int n = tile / tpi;
+        const int t = tile - n * tpi;
+        const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+        const int iy0 = 2 * ty * TH - 3, ix0 = 2 * tx * TW - 3;
+        const float* img = xg + egr_map(a.xmap, n);
+#pragma unroll
+        for (int u = 0; u < (PRE ? PPAIRS : 1); ++u) {
+            const int g = q_geo[u], q_ci = g >> 16, q_py = (g >> 8) & 255, q_px = g & 255;
+            const int iy = iy0 + q_py, ix = ix0 + q_px;
+            const bool rowok = g >= 0 && iy >= 0 && iy < a.h;
+            const float* rp = img + ((int64_t)q_ci * a.h + iy) * a.w + ix;
+            v[2 * u] = (rowok && q_px < PW && ix >= 0 && ix < a.w) ? rp[0] : 0.f;
+            v[2 * u + 1] = (rowok && q_px + 1 < PW && ix + 1 >= 0 && ix + 1 < a.w) ? rp[1] : 0.f;
+        }
+    };
+    auto publish_max = [&](int buf, const float (&v)[2 * PPAIRS]) {     // in front of the barrier behind which park2 needs the scale
+        float m = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2 * PPAIRS; ++u) m = fmaxf(m, fabsf(v[u]));
+        m = wave_max(m);
+        if (lane == 0) s_pmax[buf][wave] = __float_as_uint(m);
+    };
+    auto park2 = [&](int buf, const float (&v)[2 * PPAIRS], float psc_) {   // split once, store both planes
+        unsigned* const ph = reinterpret_cast<unsigned*>(s_patch[buf]);
+#pragma unroll
+        for (int u = 0; u < (PRE ? PPAIRS : 1); ++u)
+            if (q_geo[u] >= 0) {
+                unsigned h, l;
+                split2_f16(v[2 * u], v[2 * u + 1], psc_, h, l);
+                ph[tid + NT * u] = h;
+                ph[PATCH / 2 + tid + NT * u] = l;
+            }
+    };
     auto patch_scale = [&](int buf, float& s, float& inv) {    // after the barrier that publishes buffer `buf`
         unsigned m = s_pmax[buf][lane & (NW - 1)];
 #pragma unroll
@@ -148,11 +204,25 @@ __global__ __launch_bounds__(NT, 1) void stem_x6_kernel(const StemX6Args a) {
         const u32x4* src = reinterpret_cast<const u32x4*>(a.w6 + (int64_t)grp * WB);
         for (int i = tid; i < WB / 16; i += NT) reinterpret_cast<u32x4*>(s_w)[i] = src[i];
     }
-    float pv[PLOADS];
+    float pv[PRE ? 1 : PLOADS];
+    float pv2[PRE ? 2 * PPAIRS : 1];
+    float psc = 1.f, pinv = 1.f;                     // NPL = 2: the pre-scale of the patch being multiplied and its inverse
     int tile = blockIdx.x;
-    if (tile < total) {
-        fetch(tile, pv);
-        park(0, pv);
+    if constexpr (PRE) {
+        if (tile < total) {
+            fetch2(tile, pv2);
+            publish_max(0, pv2);
+        }
+        __syncthreads();
+        if (tile < total) {
+            patch_scale(0, psc, pinv);
+            park2(0, pv2, psc);
+        }
+    } else {
+        if (tile < total) {
+            fetch(tile, pv);
+            park(0, pv);
+        }
     }
     __syncthreads();
 
@@ -175,10 +245,13 @@ __global__ __launch_bounds__(NT, 1) void stem_x6_kernel(const StemX6Args a) {
     float amx = 0.f;
     for (; tile < total; tile += gridDim.x, buf ^= 1) {
         const int next = tile + gridDim.x;
-        if (next < total) fetch(next, pv);        // in flight during the MFMA loop below
+        if (next < total) {                       // in flight during the MFMA loop below
+            if constexpr (PRE) fetch2(next, pv2);
+            else fetch(next, pv);
+        }
         const float* sp = s_patch[buf];
-        float psc = 1.f, pinv = 1.f;                 // NPL = 2: this tile's pre-scale and its inverse
-        if constexpr (NPL == 2) patch_scale(buf, psc, pinv);
+        if constexpr (NPL == 2 && !PRE) patch_scale(buf, psc, pinv);
+        const float pinv_cur = pinv;
         f32x16 acc[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -192,6 +265,19 @@ __global__ __launch_bounds__(NT, 1) void stem_x6_kernel(const StemX6Args a) {
         f32x2 raw_a[2][4];
         u32x4 sa[2][2][NPL];      // [parity][row][plane]: split A of the current / next step
         u32x4 bfr[2][2][NPL];     // [parity][channel half][plane]
+        auto read_a_pre = [&](int s, int par) {      // PRE: the eight taps of a row fragment = 16 bytes of each plane (4-byte aligned)
+            const int ao = half ? pair_off(2 * s + 1) : pair_off(2 * s);
+            const unsigned* const ph = reinterpret_cast<const unsigned*>(sp);
+            const unsigned* h0 = ph + ((abase0 + ao) >> 1);
+            const unsigned* h1 = ph + ((abase1 + ao) >> 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sa[par][0][0][e] = h0[e];
+                sa[par][0][1][e] = h0[PATCH / 2 + e];
+                sa[par][1][0][e] = h1[e];
+                sa[par][1][1][e] = h1[PATCH / 2 + e];
+            }
+        };
         auto read_a = [&](int s) {
             const int ao = half ? pair_off(2 * s + 1) : pair_off(2 * s);
             const float* q0 = sp + abase0 + ao;
@@ -225,15 +311,22 @@ __global__ __launch_bounds__(NT, 1) void stem_x6_kernel(const StemX6Args a) {
                 sa[par][i][1][e] = l;
             }
         };
-        read_a(0);
+        if constexpr (PRE) {
+            read_a_pre(0, 0);
+        } else {
+            read_a(0);
+        }
         read_b(0, 0);
+        if constexpr (!PRE) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) split_pair(0, c >> 2, c & 3);
+            for (int c = 0; c < 8; ++c) split_pair(0, c >> 2, c & 3);
+        }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int par = s & 1;
             if (s + 1 < KS) {
-                read_a(s + 1);
+                if constexpr (PRE) read_a_pre(s + 1, par ^ 1);
+                else read_a(s + 1);
                 read_b(s + 1, par ^ 1);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -253,7 +346,7 @@ __global__ __launch_bounds__(NT, 1) void stem_x6_kernel(const StemX6Args a) {
                         else
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, sa[par][i][PA[t]]),
                                                                                __builtin_bit_cast(f16x8, bfr[par][j][PB[t]]), acc[i][j], 0, 0, 0);
-                        if (s + 1 < KS && nm % EVERY == EVERY - 1 && nm / EVERY < 8) {
+                        if (!PRE && s + 1 < KS && nm % EVERY == EVERY - 1 && nm / EVERY < 8) {
                             const int c = nm / EVERY;         // 0..7
                             split_pair(par ^ 1, c >> 2, c & 3);
                             __builtin_amdgcn_sched_barrier(0);
@@ -265,7 +358,7 @@ __global__ __launch_bounds__(NT, 1) void stem_x6_kernel(const StemX6Args a) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const float dsc = pinv * wds[j];
+                    const float dsc = pinv_cur * wds[j];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][j][r] *= dsc;
                 }
@@ -277,16 +370,29 @@ __global__ __launch_bounds__(NT, 1) void stem_x6_kernel(const StemX6Args a) {
         const int oy0 = ty * TH, ox0 = tx * TW;
 #ifdef STEM_SKIP_EPI
         if (acc[0][0][0] + acc[0][1][1] + acc[1][0][2] + acc[1][1][3] == 12345.f) y[tid] = 1.f;
-        if (next < total) park(buf ^ 1, pv);
+        if constexpr (PRE) {
+            if (next < total) publish_max(buf ^ 1, pv2);
+            __syncthreads();
+            if (next < total) { patch_scale(buf ^ 1, psc, pinv); park2(buf ^ 1, pv2, psc); }
+        } else {
+            if (next < total) park(buf ^ 1, pv);
+        }
         __syncthreads();
         continue;
 #endif
         if constexpr (POOL) {
             StemPool<NW> pool;
             pool.reduce(acc, sc, sh, half);
+            if constexpr (PRE) {
+                if (next < total) publish_max(buf ^ 1, pv2);   // (the next patch's largest magnitude: its scale is needed behind A)
+            }
             __syncthreads();                             // A: every wave has left the K loop - the current patch buffer is dead,
             pool.publish(s_patch[buf], wave, l31, half); //    and so is the exchange area of the previous tile in the other one
-            if (next < total) park(buf ^ 1, pv);
+            if constexpr (PRE) {
+                if (next < total) { patch_scale(buf ^ 1, psc, pinv); park2(buf ^ 1, pv2, psc); }
+            } else {
+                if (next < total) park(buf ^ 1, pv);
+            }
             __syncthreads();                             // B: exchange rows and the next patch are visible
             pool.finish(s_patch[buf], wave, l31, half, y, n, oy0, ox0, a.ho >> 1, a.wo >> 1);
             amx = fmaxf(amx, pool.amx);
@@ -307,7 +413,13 @@ __global__ __launch_bounds__(NT, 1) void stem_x6_kernel(const StemX6Args a) {
                     *reinterpret_cast<f32x2*>(&y[(((int64_t)n * a.ho + oy) * a.wo + ox) * 64 + 2 * l31]) = v;
                 }
             }
-            if (next < total) park(buf ^ 1, pv);
+            if constexpr (PRE) {
+                if (next < total) publish_max(buf ^ 1, pv2);
+                __syncthreads();
+                if (next < total) { patch_scale(buf ^ 1, psc, pinv); park2(buf ^ 1, pv2, psc); }
+            } else {
+                if (next < total) park(buf ^ 1, pv);
+            }
             __syncthreads();                           // next patch visible; everybody is done reading the current one
         }
     }
