@@ -64,3 +64,54 @@ def test_launch_switches_to_the_operands_device(monkeypatch):
     assert seen == [("call", (8,))]      # already on the right device: no switch
     with pytest.raises(RuntimeError, match="fake failed"):
         hip._launch("fake", lambda *a: -1)
+
+
+def test_launch_error_carries_the_return_code(monkeypatch):
+    """A non-zero return of a C-ABI entry point becomes hip.LaunchError (a RuntimeError) with the code, so that a caller with a second
+    way to run the launch (train.Step.conv: statistics epilogue -> plain launch + pass) can tell EINVAL / EWORKSPACE from a fault."""
+    from egorear_amd import hip
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    for rc, text in ((hip.EINVAL, "EGR_EINVAL"), (hip.ENULL, "EGR_ENULL"), (hip.EWORKSPACE, "EGR_EWORKSPACE"), (700, "hipError_t 700")):
+        hip._DEV[0] = None
+        with pytest.raises(hip.LaunchError) as ei:
+            hip._launch("egr_fake", lambda *a, rc=rc: rc)
+        assert isinstance(ei.value, RuntimeError) and ei.value.code == rc and ei.value.name == "egr_fake" and text in str(ei.value)
+    hip._DEV[0] = None
+    hip._launch("egr_fake", lambda *a: 0)            # success: nothing raised
+
+
+def test_arena_exhaustion_is_counted(monkeypatch):
+    """hip.AmaxArena hands out 64-slot records in launch order and COUNTS the requests it has to refuse (bench.py reports the
+    process-wide counter: each refusal is a launch that silently left the fp16 scheme)."""
+    from egorear_amd import hip
+
+    class _Arena(hip.AmaxArena):
+        def __init__(self, records):
+            self.buf = torch.zeros(records * 64, dtype=torch.int32)
+            self.records, self.k, self.exhausted = records, 0, 0
+
+    before = hip.ARENA_EXHAUSTED
+    a = _Arena(2)
+    r0, r1 = a.new(), a.new()
+    assert r0.numel() == 64 and r1.numel() == 64 and r0.data_ptr() != r1.data_ptr()
+    assert a.new() is None and a.new() is None
+    assert a.exhausted == 2 and hip.ARENA_EXHAUSTED == before + 2
+    a.k = 0                                           # (begin() rewinds; the counters keep their history)
+    assert a.new() is not None and a.exhausted == 2
+
+
+def test_grad_free_rule_names_real_parameters():
+    """train._mvfex_grad_free: the parameters the reference's graph never reaches (stereo estimators' own conv_heatmap, refiners'
+    frame_feat_proj_layers) exist under those names in the drop-in module - the rule DDP(find_unused_parameters=True) relies on."""
+    import copy
+    from egorear_amd import configs, train
+    from egorear_amd.estimator import EgoPoseFormerMVFEX
+    net = EgoPoseFormerMVFEX(**copy.deepcopy(configs.pose3d_cfg("ego4view_rw")))
+    names = [k for k, _ in net.named_parameters()]
+    free = [k for k in names if train._mvfex_grad_free(k)]
+    heads = [k for k in free if ".conv_heatmap." in k]
+    proj = [k for k in free if ".frame_feat_proj_layers." in k]
+    assert heads and proj and len(heads) + len(proj) == len(free)
+    assert all("heatmap_estimator_stereo_" in k for k in heads)
+    assert len({k.split(".frame_feat_proj_layers.")[0] for k in proj}) == 4          # the four refiners
+    assert len(names) - len(free) == 536                                             # the gradients the golden step holds
