@@ -717,7 +717,7 @@ def main():
             roof["note"] = ("kernel times come from ONE instrumented eager forward after the timed region (a HIP event pair around every launch, one stream): "
                             "their sum can exceed ms_per_step, which is a hipGraph replay without the events and without host launch gaps"
                             + (f" and, with {args.lanes} lanes, overlaps the low-occupancy tail of one step with the convolutions of the next "
-                               "(measured on one box: 5562 frames/s with one lane, 6027 with two, 5826 with three)" if (use_graph and args.lanes > 1) else ""))
+                               "(measured on one box in round 4: 6168 frames/s with one lane, 6511-6516 with two, 6391 with three, 6506 with four)" if (use_graph and args.lanes > 1) else ""))
 
     parity_out = None
     if cpu_sd is not None:  # the HIP path on the frames the CPU oracle will see (checked inside the cpu_baseline leg)
