@@ -853,7 +853,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
         // into pixel-major bf16 planes [pixel][16 channels] in LDS, and the nine taps are nine pixel-shifted ds_read_b128 windows
         // of those planes.  One barrier, one conversion and one activation fetch per 9 x 6 x FM x FN MFMAs; the weights go from
         // global memory (L2) straight into the B operand registers, one tap ahead.
-        static_assert(X6 && !PERSIST && (BM == 128 || BM == 256), "tap-sharing tile");
+        static_assert(X6 && !PERSIST && (BM == 64 || BM == 128 || BM == 256), "tap-sharing tile");
         constexpr int TAP_PLANE = tap_plane(BM), TAP_HBUF = tap_hbuf(BM, NPL);
         constexpr int NFB = BN / 32;
         constexpr int NUH = (tap_hpmax(BM) * 4 + NT - 1) / NT;   // halo staging units (4 channels of one pixel) per thread
@@ -2098,6 +2098,7 @@ int g_tap = getenv("EGR_CONV_TAP") ? atoi(getenv("EGR_CONV_TAP")) : 1;   // 0: t
 int g_tap2 = getenv("EGR_CONV_TAP2") ? atoi(getenv("EGR_CONV_TAP2")) : 1; // 0: stride-2 3x3 launches stay on the generic split kernel
 int g_last_conv_kernel = 0;   // diagnostic (tests): 0 fp32 MFMA, 1 split-bf16 generic, 2 / 3 split-bf16 tap-sharing (stride 1 / 2), 4 1x1 streaming
 int g_pw = getenv("EGR_CONV_PW") ? atoi(getenv("EGR_CONV_PW")) : 1;     // 0: short-K 1x1 split launches stay on the tiled kernels
+int g_tap64 = getenv("EGR_CONV_TAP64") ? atoi(getenv("EGR_CONV_TAP64")) : 1;       // 0: no 64-row tiles for the tap-sharing kernel's small launches
 int g_small = getenv("EGR_CONV_SMALL") ? atoi(getenv("EGR_CONV_SMALL")) : 1;        // 0: small fp32 1x1 launches stay on the tiled kernel
 int g_small_k = getenv("EGR_CONV_SMALL_K") ? atoi(getenv("EGR_CONV_SMALL_K")) : 1024;            // longest K (longer: split-K on the tiled kernel)
 int g_small_tiles = getenv("EGR_CONV_SMALL_TILES") ? atoi(getenv("EGR_CONV_SMALL_TILES")) : 256;  // most 32 x 32 tiles (all groups) for K > 64
@@ -2197,7 +2198,7 @@ extern "C" int egr_conv_set_persist(int slots, int max_ktiles) {
 
 extern "C" int egr_conv_last_kernel(void) { return g_last_conv_kernel; }
 extern "C" int egr_conv_set_splitk_fused(int on) { g_splitk_fused = on; return 0; }
-extern "C" int egr_conv_set_tap(int on) { g_tap = on; return 0; }
+extern "C" int egr_conv_set_tap(int on) { g_tap = on & 1; g_tap64 = (on & 2) ? 0 : 1; return 0; }     // (bit 1: no 64-row tiles)
 extern "C" int egr_conv_set_tapx(int32_t on, int32_t min_tiles, int32_t blocks) { return tapx_set(on, min_tiles, blocks); }
 
 extern "C" int egr_conv_force_config(int cfg) {
@@ -2348,6 +2349,8 @@ static int conv_run(const egr_conv_desc* dd, const float* x, const float* w, con
         if (a.Npad % 128 == 0 && fits_tile(128) && (int64_t)(a.M / 128) * (a.Npad / 128) * d.groups >= 256) { bm = 128; bn = 128; }
         else if (fits_tile(256) && (int64_t)(a.M / 256) * (a.Npad / 64) * d.groups >= 256) { bm = 256; bn = 64; }
         else if (fits_tile(128)) { bm = 128; bn = 64; }
+        // few rows (batch 1: layer1 has 128 tiles of 128 x 64, layer2 64): 64-row tiles put twice the workgroups on the chip
+        if (g_tap64 && h2 && bm == 128 && bn == 64 && !bnst && fits_tile(64) && (int64_t)(a.M / 128) * (a.Npad / 64) * d.groups < 256) bm = 64;
         if (bm) {
             d.split_k = 1;
             a.ktiles_per_split = a.ktiles;
@@ -2358,7 +2361,8 @@ static int conv_run(const egr_conv_desc* dd, const float* x, const float* w, con
             if (const int rcb = bn_slabs(a)) return rcb;
             dim3 grid((unsigned)a.ntiles, 1, (unsigned)d.groups);
             if (h2) {
-                if (bm == 256) hipLaunchKernelGGL((conv_igemm_tap_kernel<256, 64, 4, 1, 2>), grid, dim3(256), 0, (hipStream_t)stream, a);
+                if (bm == 64) hipLaunchKernelGGL((conv_igemm_tap_kernel<64, 64, 2, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream, a);
+                else if (bm == 256) hipLaunchKernelGGL((conv_igemm_tap_kernel<256, 64, 4, 1, 2>), grid, dim3(256), 0, (hipStream_t)stream, a);
                 else if (bn == 128) hipLaunchKernelGGL((conv_igemm_tap_kernel<128, 128, 2, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream, a);
                 else hipLaunchKernelGGL((conv_igemm_tap_kernel<128, 64, 2, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream, a);
             } else if (bm == 256) hipLaunchKernelGGL((conv_igemm_tap_kernel<256, 64, 4, 1>), grid, dim3(256), 0, (hipStream_t)stream, a);

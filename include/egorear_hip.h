@@ -221,7 +221,9 @@ int egr_conv_last_kernel(void);
  * one region per launch stream (the stream a launch is issued or captured on), eight streams at most - a launch on a ninth stream
  * takes the second pass; graphs captured on ONE stream must therefore not be replayed side by side with this knob on. */
 int egr_conv_set_splitk_fused(int on);
-/* diagnostic / test knob: 0 = 3x3 stride-1 split launches stay on the generic split kernel (default 1, env EGR_CONV_TAP). */
+/* diagnostic / test knob: 0 = 3x3 stride-1 split launches stay on the generic split kernel (default 1, env EGR_CONV_TAP); 3 = the
+ * tap-sharing kernels without the 64-row tile that launches below 256 tiles of 128 x 64 take in the fp16 scheme (batch 1: twice the
+ * workgroups; env EGR_CONV_TAP64=0).  Same results either way. */
 int egr_conv_set_tap(int on);
 /* Test / tuning knob of the fp16 scheme's 3x3 / pad 1 forward launches (stride 1 with 64-channel-multiple outputs, stride 2 with
  * 256-channel-multiple outputs; nn.Conv2d 3x3 of models/backbones/resnet.py:43-74 and of the heads / refiners in

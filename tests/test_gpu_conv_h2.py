@@ -499,3 +499,27 @@ def test_fp16_scheme_needs_its_side_operands():
     assert hip.lib.egr_conv2d_nhwc_ex_f32(C.byref(d), x.data_ptr(), pack_w(wt).to(DEV).data_ptr(), None, None, None, None, None, y.data_ptr(), None, 0,
                                           C.byref(hip.ConvAux(None, None, out.data_ptr())), s) == -1
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("case", [(1, 2, 64, 64, 64, "res_before"), (2, 2, 32, 128, 128, "scale_relu"), (1, 8, 16, 256, 64, "plain")])
+def test_tap_sharing_kernel_64_row_tiles_for_small_launches(case):
+    """Launches with fewer than 256 tiles of 128 x 64 (batch 1) take 64-row tiles on conv_igemm_tap_kernel - twice the workgroups on the
+    chip; against fp64 and bit for bit against the 128-row tiling (egr_conv_set_tap(3)): the tile height does not touch the K order."""
+    from egorear_amd import hip
+    G, n, hw, cin, cout, extra = case
+    x = rnd(G * n, hw, hw, cin, seed=901)
+    wts = [rnd(cout, cin, 3, 3, seed=902 + g, scale=1.0 / math.sqrt(9 * cin)) for g in range(G)]
+    wp = torch.stack([pack_w(t) for t in wts]) if G > 1 else pack_w(wts[0])
+    kw, res, sc, sh = _epilogue_kw(hip, extra, G, n, hw, hw, cout, wp.shape[-2], 905)
+    hip.lib.egr_conv_set_tapx(0, -1, -1)
+    try:
+        a, b, c, kern, rec = three(hip, hip.Img(x.to(DEV)), wp, cout, 3, 3, 1, 1, **kw)
+        assert kern == 2
+        ref = _reference(x, wts, G, n, 1, 1, extra, res, sc, sh, cout)
+        check(a.t.permute(0, 3, 1, 2), b.t.permute(0, 3, 1, 2), c.t.permute(0, 3, 1, 2), ref, rec, f"tap 64-row {case}")
+        hip.lib.egr_conv_set_tap(3)
+        _, _, c0, kern0, rec0 = three(hip, hip.Img(x.to(DEV)), wp, cout, 3, 3, 1, 1, **kw)
+        assert kern0 == 2 and torch.equal(c.t, c0.t) and record_value(rec) == record_value(rec0)
+    finally:
+        hip.lib.egr_conv_set_tap(1)
+        hip.lib.egr_conv_set_tapx(1, -1, -1)
