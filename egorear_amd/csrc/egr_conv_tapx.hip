@@ -693,6 +693,9 @@ int tapx_try(ConvArgs& a, int64_t yspan_floats, int64_t rspan_floats, hipStream_
         // statistics epilogue, role-split against tap-sharing kernel: 64 channels / 2048 tiles 0.538 against 0.573 ms, 128 channels /
         // 1024 narrow tiles 0.448 against 0.471 (512 wide tiles: 0.478), 256 channels / 512 tiles 0.335-0.349 against 0.324
         if (tr) return tiles >= 4 * (int64_t)g_tapx_min_tiles || g_tapx_min_tiles <= 1;
+        // below 2048 rows the alternative is the generic split kernel (the tap-sharing ones start there): a quarter of the CUs on this
+        // kernel is still faster - the refiners' 256 -> 512 stride-2 conv at batch 1 (128 tiles) 72 us there
+        if (!pw && a.M < 2048 && tiles >= g_tapx_min_tiles / 4 && a.cblocks >= 4) return true;
         return tiles >= g_tapx_min_tiles && (tiles >= 2 * (int64_t)g_tapx_min_tiles || (!pw && a.cblocks >= 16) || g_tapx_min_tiles <= 1);
     };
     // tiles (rows x columns): the 128 x 64 wave tile (FN = 2) wherever the channel count allows it - stride 1: 256 x 128, stride 2:
@@ -708,7 +711,8 @@ int tapx_try(ConvArgs& a, int64_t yspan_floats, int64_t rspan_floats, hipStream_
         else cfg = fits(256, 64) ? 3 : -1;
     } else if (d.stride == 2) {
         if (!(d.wo == 8 || d.wo == 16 || d.wo == 32) || d.h != 2 * d.ho || d.w != 2 * d.wo) return TAPX_NO;
-        cfg = (fn != 1 && fits(128, 256)) ? 4 : (fn != 2 && fits(128, 128) ? 5 : (fn != 1 && fits(128, 256) ? 4 : -1));
+        if (a.M < 2048 && fn == 0) cfg = fits(128, 128) ? 5 : (fits(128, 256) ? 4 : -1);       // (few rows: the narrower tile = twice the workgroups)
+        else cfg = (fn != 1 && fits(128, 256)) ? 4 : (fn != 2 && fits(128, 128) ? 5 : (fn != 1 && fits(128, 256) ? 4 : -1));
     }
     if (cfg < 0) return TAPX_NO;
     static const int kbm[8] = {256, 128, 512, 256, 128, 128, 128, 128}, kbn[8] = {128, 128, 64, 64, 256, 128, 256, 128};
