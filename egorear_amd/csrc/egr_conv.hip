@@ -2098,7 +2098,8 @@ int g_tap = getenv("EGR_CONV_TAP") ? atoi(getenv("EGR_CONV_TAP")) : 1;   // 0: t
 int g_tap2 = getenv("EGR_CONV_TAP2") ? atoi(getenv("EGR_CONV_TAP2")) : 1; // 0: stride-2 3x3 launches stay on the generic split kernel
 int g_last_conv_kernel = 0;   // diagnostic (tests): 0 fp32 MFMA, 1 split-bf16 generic, 2 / 3 split-bf16 tap-sharing (stride 1 / 2), 4 1x1 streaming
 int g_pw = getenv("EGR_CONV_PW") ? atoi(getenv("EGR_CONV_PW")) : 1;     // 0: short-K 1x1 split launches stay on the tiled kernels
-int g_tap64 = getenv("EGR_CONV_TAP64") ? atoi(getenv("EGR_CONV_TAP64")) : 1;       // 0: no 64-row tiles for the tap-sharing kernel's small launches
+const int g_tap64_env = getenv("EGR_CONV_TAP64") ? atoi(getenv("EGR_CONV_TAP64")) : 1;
+int g_tap64 = g_tap64_env;    // 0: no 64-row tiles for the tap-sharing kernel's small launches
 int g_small = getenv("EGR_CONV_SMALL") ? atoi(getenv("EGR_CONV_SMALL")) : 1;        // 0: small fp32 1x1 launches stay on the tiled kernel
 int g_small_k = getenv("EGR_CONV_SMALL_K") ? atoi(getenv("EGR_CONV_SMALL_K")) : 1024;            // longest K (longer: split-K on the tiled kernel)
 int g_small_tiles = getenv("EGR_CONV_SMALL_TILES") ? atoi(getenv("EGR_CONV_SMALL_TILES")) : 256;  // most 32 x 32 tiles (all groups) for K > 64
@@ -2106,27 +2107,30 @@ int g_small_rows = getenv("EGR_CONV_SMALL_ROWS") ? atoi(getenv("EGR_CONV_SMALL_R
 int g_pw_min_rows = getenv("EGR_CONV_PW_MIN_ROWS") ? atoi(getenv("EGR_CONV_PW_MIN_ROWS")) : 65536;   // rows x groups from which the streaming kernel is used
 int g_pw_blocks = getenv("EGR_CONV_PW_BLOCKS") ? atoi(getenv("EGR_CONV_PW_BLOCKS")) : 256;          // resident workgroups (one per CU)
 unsigned long long* g_dbg = nullptr;
-// split-K arrival counters: one region per launch STREAM (launches of one stream never overlap, launches of two streams may - e.g.
-// the graphs of two engine lanes replaying side by side); zero at load, every launch leaves its region zero again.  The stream a
-// launch is issued (or captured) on picks the region; a ninth stream gets no region and its launches take the second pass.
-constexpr int SPLITK_REGION = 2048, SPLITK_REGIONS = 8;
+// split-K arrival counters: one region per WORKSPACE (the slab buffer the K slices are written to).  Two launches that share a
+// workspace can never overlap (they would race on the slabs themselves), two launches with different workspaces may - the graphs of
+// two engine lanes replaying side by side own one workspace each.  The key survives graph capture (round 4 keyed the region by the
+// launch stream: every graph torch captures is recorded on the same capture stream, so both lanes' graphs shared a region).
+// Zero at load, every launch leaves its region zero again.  Regions are never re-assigned (a captured graph may hold one): the
+// 65th workspace of a process gets none and its launches take the second pass.
+constexpr int SPLITK_REGION = 2048, SPLITK_REGIONS = 64;
 __device__ int g_splitk_cnt[SPLITK_REGION * SPLITK_REGIONS];
 // 1: the last-arriving K slice of a tile reduces it (no second launch).  Correct and deterministic, but measured SLOWER than the
 // second pass (batch 1: 2.36 against 1.76 ms over 25 split launches; batch 64: 15.35 against 15.26 ms): the slabs must then be
 // written and read with agent-scope (`sc1`) accesses that go to memory, and one workgroup sums a tile that the second pass
 // spreads over the chip.  Opt-in (egr_conv_set_splitk_fused / EGR_SPLITK_FUSED=1).
 int g_splitk_fused = getenv("EGR_SPLITK_FUSED") ? atoi(getenv("EGR_SPLITK_FUSED")) : 0;
-hipStream_t g_splitk_streams[SPLITK_REGIONS];
-int g_splitk_nstreams = 0;
+const void* g_splitk_keys[SPLITK_REGIONS];
+int g_splitk_nkeys = 0;
 std::mutex g_splitk_mu;
 
-int splitk_region_of(hipStream_t s) {   // -1: every region belongs to another stream
+int splitk_region_of(const void* workspace) {   // -1: every region belongs to another workspace
     std::lock_guard<std::mutex> lk(g_splitk_mu);
-    for (int i = 0; i < g_splitk_nstreams; ++i)
-        if (g_splitk_streams[i] == s) return i;
-    if (g_splitk_nstreams == SPLITK_REGIONS) return -1;
-    g_splitk_streams[g_splitk_nstreams] = s;
-    return g_splitk_nstreams++;
+    for (int i = 0; i < g_splitk_nkeys; ++i)
+        if (g_splitk_keys[i] == workspace) return i;
+    if (g_splitk_nkeys == SPLITK_REGIONS) return -1;
+    g_splitk_keys[g_splitk_nkeys] = workspace;
+    return g_splitk_nkeys++;
 }
 
 }  // namespace
@@ -2198,7 +2202,7 @@ extern "C" int egr_conv_set_persist(int slots, int max_ktiles) {
 
 extern "C" int egr_conv_last_kernel(void) { return g_last_conv_kernel; }
 extern "C" int egr_conv_set_splitk_fused(int on) { g_splitk_fused = on; return 0; }
-extern "C" int egr_conv_set_tap(int on) { g_tap = on & 1; g_tap64 = (on & 2) ? 0 : 1; return 0; }     // (bit 1: no 64-row tiles)
+extern "C" int egr_conv_set_tap(int on) { g_tap = on & 1; g_tap64 = (on & 2) ? 0 : g_tap64_env; return 0; }     // (bit 1: no 64-row tiles; clear: what EGR_CONV_TAP64 chose)
 extern "C" int egr_conv_set_tapx(int32_t on, int32_t min_tiles, int32_t blocks) { return tapx_set(on, min_tiles, blocks); }
 
 extern "C" int egr_conv_force_config(int cfg) {
@@ -2487,7 +2491,7 @@ static int conv_run(const egr_conv_desc* dd, const float* x, const float* w, con
         if (d.split_k > 1 && g_splitk_fused && tiles_all <= SPLITK_REGION) {
             static int* base = nullptr;
             if (!base && hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_splitk_cnt)) != hipSuccess) base = nullptr;
-            const int region = base ? splitk_region_of(s) : -1;
+            const int region = base ? splitk_region_of(workspace) : -1;
             if (region >= 0) a.cnt = base + region * SPLITK_REGION;
         }
     }

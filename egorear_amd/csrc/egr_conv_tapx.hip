@@ -360,6 +360,7 @@ __global__ __launch_bounds__(512) void conv_tapx_kernel(const ConvArgs a) {
             }
         };
 
+        pend_setup(P);                                        // no tile parked yet: valid descriptors, every offset out of range (the first tile's drains)
         setup(t_first);
         issue(0, 0);                                          // chunks 0, 1 -> sets 0, 1
         if constexpr (NXS == 2) { advance(); issue(1, lck); }
@@ -743,25 +744,29 @@ int tapx_try(ConvArgs& a, int64_t yspan_floats, int64_t rspan_floats, hipStream_
             default: hipLaunchKernelGGL((conv_tapx_kernel<1, 4, 1, 0, R>), dim3(grid), dim3(512), 0, stream, a); break;
         }
     };
-    auto launch_tr = [&](auto res_tag, auto tr_tag) {
+    // (false: no instantiation for this tile / epilogue pair - nothing was launched and the caller's other kernels take the problem)
+    auto launch_tr = [&](auto res_tag, auto tr_tag) -> bool {
         constexpr bool R = decltype(res_tag)::value;
         constexpr int T = decltype(tr_tag)::value;
         switch (cfg) {
             case 0:
-                if constexpr (T == 1) hipLaunchKernelGGL((conv_tapx_kernel<2, 2, 2, 1, R, T>), dim3(grid), dim3(512), 0, stream, a);
-                break;
-            case 1: hipLaunchKernelGGL((conv_tapx_kernel<1, 4, 1, 1, R, T>), dim3(grid), dim3(512), 0, stream, a); break;
-            case 3: hipLaunchKernelGGL((conv_tapx_kernel<2, 2, 1, 1, R, T>), dim3(grid), dim3(512), 0, stream, a); break;
-            default:
-                if constexpr (T == 1) hipLaunchKernelGGL((conv_tapx_kernel<1, 4, 1, 2, R, T>), dim3(grid), dim3(512), 0, stream, a);
-                break;
+                if constexpr (T == 1) { hipLaunchKernelGGL((conv_tapx_kernel<2, 2, 2, 1, R, T>), dim3(grid), dim3(512), 0, stream, a); return true; }
+                return false;
+            case 1: hipLaunchKernelGGL((conv_tapx_kernel<1, 4, 1, 1, R, T>), dim3(grid), dim3(512), 0, stream, a); return true;
+            case 3: hipLaunchKernelGGL((conv_tapx_kernel<2, 2, 1, 1, R, T>), dim3(grid), dim3(512), 0, stream, a); return true;
+            case 5:
+                if constexpr (T == 1) { hipLaunchKernelGGL((conv_tapx_kernel<1, 4, 1, 2, R, T>), dim3(grid), dim3(512), 0, stream, a); return true; }
+                return false;
+            default: return false;
         }
     };
-    if (tr == 1) launch_tr(std::false_type{}, std::integral_constant<int, 1>{});
-    else if (tr == 2 && d.res_mode != EGR_RES_NONE) launch_tr(std::true_type{}, std::integral_constant<int, 2>{});
-    else if (tr == 2) launch_tr(std::false_type{}, std::integral_constant<int, 2>{});
+    bool launched = true;
+    if (tr == 1) launched = launch_tr(std::false_type{}, std::integral_constant<int, 1>{});
+    else if (tr == 2 && d.res_mode != EGR_RES_NONE) launched = launch_tr(std::true_type{}, std::integral_constant<int, 2>{});
+    else if (tr == 2) launched = launch_tr(std::false_type{}, std::integral_constant<int, 2>{});
     else if (d.res_mode != EGR_RES_NONE) launch(std::true_type{});
     else launch(std::false_type{});
+    if (!launched) return TAPX_NO;
     return egr_launch_status();
 }
 

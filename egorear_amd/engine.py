@@ -791,11 +791,19 @@ def _pose3d(p3, st: State, feat_init: torch.Tensor, feat_final: torch.Tensor, B:
     """EgoPoseFormerPose3D.forward (egoposeformer_mvf_ex.py:422-452).  feat_*: (V*B, 64, 64, 128) view-major NHWC.
     behind: the state of the heat-map estimator whose forward has just produced feat_* - the lifting head then goes on in ITS abs-max
     arena (one clear per forward instead of two; the records of feat_* sit in it anyway)."""
-    P: PPose = st.get(p3, lambda: _pack_pose3d(p3))
-    if behind is not None and behind.amax is not None and st.amax is not None:
-        st.amax = behind.amax
+    own = st.amax
+    if behind is not None and behind.amax is not None and own is not None:
+        st.amax = behind.amax          # for THIS call only (restored below): a later stand-alone call clears its own arena, not the estimator's
     else:
         st.begin_forward()
+    try:
+        return _pose3d_body(p3, st, feat_init, feat_final, B, V, ctm)
+    finally:
+        st.amax = own
+
+
+def _pose3d_body(p3, st: State, feat_init: torch.Tensor, feat_final: torch.Tensor, B: int, V: int, ctm):
+    P: PPose = st.get(p3, lambda: _pack_pose3d(p3))
     for t in (feat_init, feat_final):      # feature maps handed in by a caller carry no abs-max record: make one (one read each)
         if st.amax is not None and getattr(t, "_egr_amax", None) is None:
             rec = st.new_amax()

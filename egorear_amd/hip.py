@@ -365,7 +365,7 @@ class AmaxArena:
     """Abs-max records of one forward: 64 uint32 slots per recorded tensor in ONE buffer, zeroed by one launch when the forward
     begins (egr_fill_f32: all-zero bits), handed out in launch order.  A graph replay re-runs the fill and every producer."""
 
-    def __init__(self, device, records: int = 192):
+    def __init__(self, device, records: int = 256):
         self.buf = torch.zeros(records * 64, device=device, dtype=torch.int32)
         self.records, self.k = records, 0
         self.exhausted = 0        # requests refused since construction: each one is a launch that left the fp16 scheme

@@ -14,9 +14,9 @@ from __future__ import annotations
 
 import sys
 import types
+from typing import Tuple
 
 import torch
-from torch.autograd.function import once_differentiable
 
 from . import hip
 
@@ -72,29 +72,68 @@ def msda_backward(value, spatial_shapes, level_start_index, sampling_locations, 
     return gv, gl, ga
 
 
-class MultiScaleDeformableAttnFunction(torch.autograd.Function):
-    """Same call as mmcv's: `apply(value, value_spatial_shapes, value_level_start_index, sampling_locations,
-    attention_weights, im2col_step) -> (N, Lq, heads*D)`; gradients for value, sampling_locations, attention_weights."""
+# ---- the op as a torch.library operator ("wrapped as torch.library ops with ... Meta implementations") ----------
+# `egorear_amd::msda_fwd` / `egorear_amd::msda_bwd`: opaque to Dynamo (the body launches through ctypes), shape-inferred through the
+# fake (Meta) implementations below, differentiable through register_autograd - so a module that keeps the reference's own
+# MSDeformAttn.forward (deform_attn.py:90-168) compiles under run.py:7-9's torch.compile(model.network) WITHOUT a graph break at the
+# op.  Device: the HIP device only; CPU tensors have no kernel (NotImplementedError from the dispatcher) - there is no CPU path.
+
+@torch.library.custom_op("egorear_amd::msda_fwd", mutates_args=(), device_types="cuda")
+def msda_fwd_op(value: torch.Tensor, spatial_shapes: torch.Tensor, level_start_index: torch.Tensor, sampling_locations: torch.Tensor,
+                attention_weights: torch.Tensor) -> torch.Tensor:
+    return msda_forward(value, spatial_shapes, level_start_index, sampling_locations, attention_weights)
+
+
+@msda_fwd_op.register_fake
+def _msda_fwd_fake(value, spatial_shapes, level_start_index, sampling_locations, attention_weights):
+    n, lin, heads, d, lq, levels, points = _check_shapes(value, spatial_shapes, level_start_index, sampling_locations, attention_weights)
+    return value.new_empty((n, lq, heads * d), dtype=torch.float32)
+
+
+@torch.library.custom_op("egorear_amd::msda_bwd", mutates_args=(), device_types="cuda")
+def msda_bwd_op(value: torch.Tensor, spatial_shapes: torch.Tensor, level_start_index: torch.Tensor, sampling_locations: torch.Tensor,
+                attention_weights: torch.Tensor, grad_output: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    return msda_backward(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, grad_output)
+
+
+@msda_bwd_op.register_fake
+def _msda_bwd_fake(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, grad_output):
+    n, lin, heads, d, lq, levels, points = _check_shapes(value, spatial_shapes, level_start_index, sampling_locations, attention_weights)
+    if tuple(grad_output.shape) != (n, lq, heads * d):
+        raise ValueError(f"grad_output must be {(n, lq, heads * d)}, got {tuple(grad_output.shape)}")
+    return (value.new_empty(value.shape, dtype=torch.float32), sampling_locations.new_empty(sampling_locations.shape, dtype=torch.float32),
+            attention_weights.new_empty(attention_weights.shape, dtype=torch.float32))
+
+
+def _msda_setup_context(ctx, inputs, output):
+    ctx.save_for_backward(*inputs)
+
+
+def _msda_autograd(ctx, grad_output):
+    value, shapes, starts, loc, aw = ctx.saved_tensors
+    gv, gl, ga = msda_bwd_op(value, shapes, starts, loc, aw, grad_output.to(torch.float32).contiguous())
+    return gv, None, None, gl, ga
+
+
+msda_fwd_op.register_autograd(_msda_autograd, setup_context=_msda_setup_context)
+
+
+class MultiScaleDeformableAttnFunction:
+    """Same call as mmcv's autograd Function: `apply(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+    attention_weights, im2col_step) -> (N, Lq, heads*D)`; gradients for value, sampling_locations, attention_weights (once
+    differentiable, like mmcv's).  `apply` is a plain function around the `egorear_amd::msda_fwd` operator, so both eager autograd and
+    torch.compile see one differentiable op."""
 
     @staticmethod
-    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights, im2col_step):
+    def apply(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights, im2col_step):
         # mmcv chunks the batch by im2col_step and requires it to divide the batch; the result does not depend on it
         step = min(int(value.shape[0]), int(im2col_step)) if int(value.shape[0]) > 0 else 1
         if step <= 0 or value.shape[0] % step != 0:
             raise RuntimeError(f"batch({value.shape[0]}) must divide im2col_step({step})")
-        value = value.to(torch.float32)
-        sampling_locations = sampling_locations.to(torch.float32)
-        attention_weights = attention_weights.to(torch.float32)
-        out = msda_forward(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights)
-        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights)
-        return out
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, grad_output):
-        value, shapes, starts, loc, aw = ctx.saved_tensors
-        gv, gl, ga = msda_backward(value, shapes, starts, loc, aw, grad_output.to(torch.float32))
-        return gv, None, None, gl, ga, None
+        if not value.is_cuda and value.device.type != "meta":
+            raise RuntimeError("egorear_amd.msda: no CPU path - tensors must live on the HIP device")
+        return msda_fwd_op(value.to(torch.float32), value_spatial_shapes, value_level_start_index, sampling_locations.to(torch.float32),
+                           attention_weights.to(torch.float32))
 
 
 def install_mmcv_shim(force: bool = False) -> None:

@@ -1591,7 +1591,9 @@ def _mvfex_grad_free(name: str) -> bool:
     estimators' own conv_heatmap (the MVFEx model only takes their features, heatmap_mvf_ex.py:212-234) and every refiner's
     frame_feat_proj_layers (`offset_pred + frame_feat.detach()`, :715).  torch leaves their .grad None, AdamW skips them, and
     DistributedDataParallel(find_unused_parameters=True) - the strategy the wrapper's Trainer uses - must find them UNUSED: a tensor
-    that is an input of the autograd node but receives no gradient would be reduced as zeros and then decayed by AdamW."""
+    that is an input of the autograd node but receives no gradient would be reduced as zeros and then decayed by AdamW.
+    The rule is tied to those flags: forward_train refuses every other flag combination with NotImplementedError BEFORE anything runs
+    (so a configuration the rule does not describe never reaches backward), and backward re-checks it against the tape."""
     return (".conv_heatmap." in name and "heatmap_estimator_stereo_" in name) or ".frame_feat_proj_layers." in name
 
 

@@ -218,8 +218,8 @@ int egr_conv_last_kernel(void);
 /* diagnostic / test knob: 1 = split-K launches run the reduction + epilogue in the last-arriving K slice of each tile (arrival
  * counters, agent-scope slab accesses) instead of a second kernel (splitk_reduce_kernel).  Both sum the slices in slice order.
  * Default 0 (env EGR_SPLITK_FUSED): the fused form saves the launch but measured slower, see DESIGN.md §5d.  The counters are
- * one region per launch stream (the stream a launch is issued or captured on), eight streams at most - a launch on a ninth stream
- * takes the second pass; graphs captured on ONE stream must therefore not be replayed side by side with this knob on. */
+ * one region per `workspace` pointer (launches that share a workspace cannot overlap anyway; two engine lanes own one each, also
+ * when their graphs were captured on the same stream), 64 workspaces per process at most - the 65th takes the second pass. */
 int egr_conv_set_splitk_fused(int on);
 /* diagnostic / test knob: 0 = 3x3 stride-1 split launches stay on the generic split kernel (default 1, env EGR_CONV_TAP); 3 = the
  * tap-sharing kernels without the 64-row tile that launches below 256 tiles of 128 x 64 take in the fp16 scheme (batch 1: twice the

@@ -170,8 +170,8 @@ def test_small_linear_kernel(hip, m, k, n_out, groups, extra):
 
 
 def test_split_k_in_the_last_slice_on_two_streams_side_by_side(hip):
-    """The arrival counters are one region per launch stream: two streams running the fused split-K form at the same time (two engine
-    lanes do) each get the result of a lone launch, bit for bit, over many overlapped launches."""
+    """The arrival counters are one region per workspace: two streams running the fused split-K form at the same time (two engine
+    lanes do, each with its own workspace) each get the result of a lone launch, bit for bit, over many overlapped launches."""
     n, h, cin, cout, k = 2, 16, 256, 128, 3
     xs = [rnd(n, h, h, cin, seed=320 + i).to(DEV) for i in range(2)]
     wp = pack_w(rnd(cout, cin, k, k, seed=322, scale=1.0 / math.sqrt(cin * 9))).to(DEV)
@@ -192,6 +192,43 @@ def test_split_k_in_the_last_slice_on_two_streams_side_by_side(hip):
     for i in range(2):
         for o in outs[i]:
             assert torch.equal(o, lone[i])
+
+
+def test_split_k_in_the_last_slice_in_two_captured_graphs_replayed_side_by_side(hip):
+    """What runner.PipelinedForward does with the knob on: both lanes' graphs are captured on torch's ONE capture stream and then
+    replayed on two streams at the same time.  The counter region follows the workspace (one per lane), not the capture stream, so
+    every replay gives the lone launch's bits."""
+    n, h, cin, cout, k = 2, 16, 256, 128, 3
+    xs = [rnd(n, h, h, cin, seed=330 + i).to(DEV) for i in range(2)]
+    wp = pack_w(rnd(cout, cin, k, k, seed=332, scale=1.0 / math.sqrt(cin * 9))).to(DEV)
+    wss = [torch.empty(1 << 22, device=DEV) for _ in range(2)]
+    reps = 12
+    try:
+        hip.lib.egr_conv_set_splitk_fused(1)
+        lone = [hip.conv2d(hip.Img(xs[i]), wp, cout, k, k, 2, 1, workspace=wss[i], split_k=8).t.clone() for i in range(2)]
+        torch.cuda.synchronize()
+        graphs, outs = [], []
+        for i in range(2):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):           # no stream argument: the same capture stream for both, as GraphedForward captures
+                o = [hip.conv2d(hip.Img(xs[i]), wp, cout, k, k, 2, 1, workspace=wss[i], split_k=8).t for _ in range(reps)]
+            graphs.append(g)
+            outs.append(o)
+        streams = [torch.cuda.Stream() for _ in range(2)]
+        for rnd_ in range(6):
+            for o in outs:
+                for t in o:
+                    t.fill_(-7.0)
+            torch.cuda.synchronize()
+            for i, st in enumerate(streams):
+                with torch.cuda.stream(st):
+                    graphs[i].replay()
+            torch.cuda.synchronize()
+            for i in range(2):
+                for t in outs[i]:
+                    assert torch.equal(t, lone[i])
+    finally:
+        hip.lib.egr_conv_set_splitk_fused(0)
 
 
 @pytest.mark.parametrize("case", [

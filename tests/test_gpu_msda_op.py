@@ -172,3 +172,53 @@ def test_reference_module_sequence(msda):
     out = Fn.apply(value.to(torch.float32), shapes, starts, loc, aw, 64)
     got = F.linear(out, d["a.output_proj.weight"], d["a.output_proj.bias"])
     close(got, want, "MSDeformAttn.forward", tol=1e-4)  # rocBLAS vs oneDNN linears around the op
+
+
+@pytest.mark.parametrize("seed,scale", [(0, 1.0), (2, 0.35)])
+def test_op_inside_the_module_sequence_reproduces_the_references_msda_output(msda, seed, scale):
+    """Row a13 against the REFERENCE (not the oracle): tests/golden/mvfex_mid_s*.npz holds what every refiner's
+    `transformer_layers[0].cross_attn` returned inside the real reference for each of the four views
+    (DeformMultiViewAttn.forward, egoposeformer_heatmap_mvf_ex.py:779-796 -> MSDeformAttn.forward, deform_attn.py:90-168, before the
+    validity mask of :909).  Here the same statement sequence runs around egr_msda_fwd_f32 - value_proj, offsets / softmax weights
+    from the golden's own JQA query, reference points = the golden's 2-D anchors, the op, output_proj - on the memory tokens of the
+    same synthetic frames (frame_feat_multi_view_proj + pos_embed of the features the HIP path produced, themselves pinned by the
+    feat_init golden).  2e-5, the tolerance the oracle meets on the same vector."""
+    import copy
+    import os
+    import numpy as np
+    from egorear_amd import configs, synth
+    from egorear_amd.estimator import EgoPoseFormerHeatmapMVFEX
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    mid = np.load(os.path.join(gdir, f"mvfex_mid_s{seed}.npz"))
+    end = np.load(os.path.join(gdir, f"mvfex_s{seed}.npz"))
+    net = EgoPoseFormerHeatmapMVFEX(**copy.deepcopy(configs.heatmap_mvfex_cfg())).eval()
+    synth.load_synth(net, 42)
+    net = net.to(DEV)
+    B, V, J = 2, 4, 15
+    with torch.no_grad():
+        _, fts = net(synth.synth_images(B, V, seed=seed, scale=scale).to(DEV))
+        feat = fts[0].contiguous()                                              # (B, V, 128, 64, 64) initial features of all four views
+        anchors = torch.from_numpy(end["anchors_2d"]).to(DEV)                   # (B, V, 15, 2), bit-equal on the HIP path (test_gpu_pipeline)
+        for name in ("front_left", "front_right", "back_left", "back_right"):
+            r = getattr(net, "heatmap_refiner_" + name)
+            ca = r.transformer_layers[0].cross_attn
+            heads, points, C = ca.n_heads, ca.n_points, ca.d_model
+            # memory tokens: HeatmapMVF.forward :689-693
+            w = r.frame_feat_multi_view_proj.weight.view(C, -1)
+            tok = feat.flatten(3).transpose(2, 3)                                # (B, V, 4096, 128)
+            memory = tok @ w.t() + r.frame_feat_multi_view_proj.bias + r.frame_feat_multi_view_pos_embed
+            query = torch.from_numpy(mid[name + "_query"]).to(DEV)              # (B, 15, 256) from the reference
+            outs = []
+            for v in range(V):
+                # MSDeformAttn.forward, statement by statement (levels = 1)
+                value = F.linear(memory[:, v], ca.value_proj.weight, ca.value_proj.bias).view(B, -1, heads, C // heads)
+                off = F.linear(query, ca.sampling_offsets.weight, ca.sampling_offsets.bias).view(B, J, heads, 1, points, 2)
+                aw = F.softmax(F.linear(query, ca.attention_weights.weight, ca.attention_weights.bias).view(B, J, heads, points), -1)
+                aw = aw.view(B, J, heads, 1, points)
+                normalizer = torch.stack([ca.spatial_shapes[..., 1], ca.spatial_shapes[..., 0]], -1)
+                ref_pts = anchors[:, v].reshape(B, J, 1, 2)
+                loc = ref_pts[:, :, None, :, None, :] + off / normalizer[None, None, None, :, None, :]
+                out = msda.MultiScaleDeformableAttnFunction.apply(value.float(), ca.spatial_shapes, ca.start_index, loc, aw, 64)
+                outs.append(F.linear(out, ca.output_proj.weight, ca.output_proj.bias))
+            got = torch.stack(outs)[..., ::4].cpu().numpy()
+            np.testing.assert_allclose(got, mid[name + "_msda"], rtol=0, atol=2e-5, err_msg=name)

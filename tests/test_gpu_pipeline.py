@@ -277,6 +277,30 @@ def test_pose3d_estimator_standalone_api(nets):
         assert torch.equal(p, q) and torch.equal(p, r)
 
 
+def test_lifting_head_borrows_the_estimators_arena_for_one_call_only(nets):
+    """Inside the pipeline the lifting head goes on in the heat-map estimator's abs-max arena (one clear per forward) - for that call:
+    its own State keeps its own arena, so a stand-alone call afterwards does not zero records of tensors the estimator still exposes
+    (a zero record = pre-scale 2^60 = fp16 overflow in the next consumer), and no forward runs out of records."""
+    from egorear_amd import engine, hip, synth
+    net = nets("syn")
+    img = synth.synth_images(2, 4, seed=24).to(DEV)
+    before = hip.ARENA_EXHAUSTED
+    with torch.no_grad():
+        preds, hms = net(img)
+        st_h = engine._state(net.heatmap_estimator, torch.device(DEV))
+        st_p = engine._state(net.pose3d_estimator, torch.device(DEV))
+        assert st_p.amax is not st_h.amax
+        _, fts = net.heatmap_estimator(img)
+        recs = [t._egr_amax.clone() for t in fts if getattr(t, "_egr_amax", None) is not None]
+        a = net.pose3d_estimator(fts[0].contiguous(), fts[1].contiguous(), hms[1])         # stand-alone: clears ITS arena
+        after = [t._egr_amax for t in fts if getattr(t, "_egr_amax", None) is not None]
+        b = net.pose3d_estimator(fts[0], fts[1], hms[1])                                   # the estimator's tensors, records intact
+    assert len(recs) > 0 and all(torch.equal(x, y) for x, y in zip(recs, after)) and all(int(x.max()) > 0 for x in recs)
+    for p, q, r in zip(preds, a, b):
+        assert torch.equal(p, q) and torch.equal(p, r)
+    assert hip.ARENA_EXHAUSTED == before
+
+
 def test_graphed_forward_replays_identically(nets):
     from egorear_amd import synth
     from egorear_amd.runner import GraphedForward
