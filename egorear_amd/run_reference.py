@@ -56,6 +56,13 @@ def install(checkout: str, chdir: bool = True) -> types.ModuleType:
         setattr(mod, name, getattr(estimator, name))
     mod.__all__ = list(CLASS_NAMES)
     sys.modules[ESTIMATOR_MODULE] = mod
+    # `import pose_estimation.models.estimator as E` walks attributes: bind the module on its parent (a namespace package of the
+    # checkout - importing it executes no reference code)
+    import importlib
+    parent = importlib.import_module(ESTIMATOR_MODULE.rsplit(".", 1)[0])
+    if getattr(parent, "__file__", None) is not None:
+        raise RuntimeError(f"egorear_amd.run_reference: {parent.__name__} has an __init__.py in this checkout; expected a namespace package")
+    parent.estimator = mod
     msda.install_mmcv_shim()
     return mod
 

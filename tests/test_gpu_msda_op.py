@@ -222,3 +222,41 @@ def test_op_inside_the_module_sequence_reproduces_the_references_msda_output(msd
                 outs.append(F.linear(out, ca.output_proj.weight, ca.output_proj.bias))
             got = torch.stack(outs)[..., ::4].cpu().numpy()
             np.testing.assert_allclose(got, mid[name + "_msda"], rtol=0, atol=2e-5, err_msg=name)
+
+
+def test_module_sequence_compiles_as_one_graph_around_the_operator(msda):
+    """SURVEY.md 8(b) / run.py:7-9: with only the op swapped, the reference-shaped MSDeformAttn statement sequence compiles with
+    fullgraph=True (the op is a torch.library operator with a Meta kernel and a registered autograd formula, not a ctypes call Dynamo
+    has to break at); forward and the three input gradients equal the eager run bit for bit (the same kernels run either way)."""
+    torch.manual_seed(0)
+    n, lq, heads, d, points, hw = 2, 15, 4, 64, 16, 64
+    C = heads * d
+    shapes = torch.tensor([[hw, hw]], dtype=torch.int64, device=DEV)
+    starts = torch.tensor([0], dtype=torch.int64, device=DEV)
+    lins = [torch.nn.Linear(C, C).to(DEV), torch.nn.Linear(C, heads * points * 2).to(DEV), torch.nn.Linear(C, heads * points).to(DEV),
+            torch.nn.Linear(C, C).to(DEV)]
+
+    def seq(query, ref_pts, tokens):
+        value = lins[0](tokens).view(n, hw * hw, heads, d)
+        off = lins[1](query).view(n, lq, heads, 1, points, 2)
+        aw = F.softmax(lins[2](query).view(n, lq, heads, points), -1).view(n, lq, heads, 1, points)
+        normalizer = torch.stack([shapes[..., 1], shapes[..., 0]], -1)
+        loc = ref_pts[:, :, None, :, None, :] + off / normalizer[None, None, None, :, None, :]
+        out = msda.MultiScaleDeformableAttnFunction.apply(value.to(dtype=torch.float32), shapes, starts, loc, aw, 64)
+        return lins[3](out)
+
+    query = torch.randn(n, lq, C, device=DEV, requires_grad=True)
+    ref = torch.rand(n, lq, 1, 2, device=DEV)
+    tokens = torch.randn(n, hw * hw, C, device=DEV, requires_grad=True)
+    go = torch.randn(n, lq, C, device=DEV)
+    out_e = seq(query, ref, tokens)
+    ge = torch.autograd.grad(out_e, [query, tokens], go)
+    import torch._dynamo as dynamo
+    dynamo.reset()
+    cseq = torch.compile(seq, fullgraph=True, backend="aot_eager")
+    out_c = cseq(query, ref, tokens)
+    gc = torch.autograd.grad(out_c, [query, tokens], go)
+    assert torch.equal(out_e, out_c)
+    # (the value gradient is accumulated with atomics: order-dependent in the last bits)
+    close(gc[0], ge[0].cpu(), "dquery compiled vs eager", tol=1e-5)
+    close(gc[1], ge[1].cpu(), "dtokens compiled vs eager", tol=1e-5)
