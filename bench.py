@@ -69,7 +69,10 @@ ARITHMETIC = {
 
 def _kernel_key(name: str, tag: str) -> str:
     """Profile key of a launch: the implicit-GEMM entry point runs three kernel families - the fp16 scheme (tag "h2"), the split-bf16
-    one ("x6") and the fp32-matrix-core one."""
+    one ("x6") and the fp32-matrix-core one.  egr_conv1x1_chain_f32 (two 1x1 launches of the fp16 scheme fused into one, round 5) is
+    booked with that entry point: same family, same roofs - its algorithmic bytes no longer contain the intermediate tensor."""
+    if name == "egr_conv1x1_chain_f32":
+        name = "egr_conv2d_nhwc_f32"
     if tag.startswith("h2 ") or " h2 " in tag:
         return name + "[f16x2]"
     if tag.startswith("x6 ") or " x6 " in tag:

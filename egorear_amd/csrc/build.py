@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["egr_conv.hip", "egr_conv_tapx.hip", "egr_stem.hip", "egr_stem_x6.hip", "egr_pointwise.hip", "egr_attn.hip", "egr_preprocess.hip", "egr_metrics.hip", "egr_wgrad.hip", "egr_train.hip", "egr_msda_bwd.hip", "egr_msda_op.hip", "egr_layer.hip", "egr_wstream.hip"]
+SOURCES = ["egr_conv.hip", "egr_conv_tapx.hip", "egr_conv_chain.hip", "egr_stem.hip", "egr_stem_x6.hip", "egr_pointwise.hip", "egr_attn.hip", "egr_preprocess.hip", "egr_metrics.hip", "egr_wgrad.hip", "egr_train.hip", "egr_msda_bwd.hip", "egr_msda_op.hip", "egr_layer.hip", "egr_wstream.hip"]
 LIB = os.path.join(HERE, "libegorear_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(REPO, "include"), "-I" + HERE]
 

@@ -1,0 +1,458 @@
+// Two 1x1 / stride-1 convolutions back to back in ONE launch of the fp16 scheme (EGR_W_F16X2):
+//     y = act2( W2 . act1( W1 . x + b1 ) + b2 [+ res] )
+// for the chains of the path whose 128-channel intermediate used to make a round trip through HBM (round 4's PMC pass:
+// profiles/r04_v3_pmc_traffic_per_launch.txt #28 -> #30, #24 -> #26, #45 -> #46): the FPN's lateral conv -> fuse conv
+// (models/backbones/resnet.py:96-110, 127-133 in the reference; the fuse conv's up-sampled half enters as EGR_RES_UP2_BEFORE_ACT) and
+// the refiners' frame_feat_refined_proj_layers (models/estimator/egoposeformer_heatmap_mvf_ex.py:553-563, 715).
+//
+// The streaming kernel's structure (conv_pw_x6_kernel, egr_conv.hip): operand roles swapped - A = weights (rows = output channels,
+// stationary in LDS for the whole launch), B = activations (columns = pixels); lane (p = lane & 31, h = lane >> 5) of a wave owns
+// pixel p of the wave's 32-pixel tile, its B operand of a k16 step is 2 x 16 bytes of the pixel's own NHWC row.  What makes the
+// chain free of any transposition: the accumulator layout of the FIRST product (register quad g of fragment cf = channels
+// 32 cf + 8 g + 4 h .. + 3 of the lane's pixel) IS the B-operand layout of the second (k16 step s of the second product = quads
+// 2 (s & 1), 2 (s & 1) + 1 of fragment s / 2) - so bias + ReLU run on the accumulator registers, the values are split into their
+// two fp16 planes where they stand and go straight back into the matrix cores.  No LDS, no barrier between the two products.
+//
+// Pre-scale of the intermediate: it has no abs-max record (it never exists as a tensor), and does not need one - a column of the
+// second GEMM is ONE pixel, so each lane scales its own pixel by the power of two that puts the pixel's largest magnitude (over its
+// 128 channels: the lane's 64 values and those of lane ^ 32) into [2^14, 2^15), and multiplies the pixel's accumulators by the inverse
+// (exact).  Finer than the per-tensor scale of the single launches: every pixel keeps its own 22 bits.
+//
+// Registers: both accumulator sets (64 + 64) and two sets of weight fragments (the next k step's are read from LDS in front of the
+// current step's MFMAs) live at the same time; the NEXT tile's activations are requested behind the second product, when the
+// first product's registers are dead, and have the whole epilogue to land.
+// LDS: W1 (cin 64: 32 KB, 128: 64 KB) + W2 (64 KB) + the channel vectors + one 16-row epilogue patch per wave (rows come back as whole
+// 128-byte lines, as in conv_pw_x6_kernel; 16 rows instead of 32 so that the 128 -> 128 -> 128 chain fits 160 KB).
+#include "egr_conv_shared.h"
+
+using namespace egrc;
+
+namespace {
+
+#ifndef CHAIN_SB_G
+#define CHAIN_SB_G 1
+#endif
+#ifndef CHAIN_SB_E
+#define CHAIN_SB_E 1
+#endif
+#define SB_G() do { if (CHAIN_SB_G) __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SB_E() do { if (CHAIN_SB_E) __builtin_amdgcn_sched_barrier(0); } while (0)
+
+struct ChainArgs {
+    ConvArgs a;              // the chain as ONE 1x1 conv cin -> cout (geometry, maps, act = act2, residual, groups); a.w = W1's image, a.wds = its descale
+    const void* w2;          // egr_pack_wh2_f32 image of the second conv (cout x cmid)
+    const float* wds2;       // its descale, (groups,) 128, group stride a.d.gp
+    const float* shift1;     // bias of the first conv, (groups,) 128, group stride gp1; NULL = 0
+    int64_t gw2, gp1;        // group strides: 16-bit elements of w2; floats of shift1 / W1's descale
+    int act1;
+};
+
+constexpr int OOB = (int)0x80000000;
+
+// KS1 = cin / 16 (4 / 8); the intermediate and the output have 128 channels (four 32-row fragments each).
+// RESK: 0 no residual, 1 residual of the output's shape, 2 half-resolution residual up-sampled on the fly (EGR_RES_UP2_BEFORE_ACT)
+template <int KS1, int RESK>
+__global__ __launch_bounds__(512) void conv_pw_chain_kernel(const ChainArgs ca) {
+    constexpr int NCF = 4, KS2 = 8, NPL = 2;
+    constexpr bool PIPE = true;
+    constexpr int W1B = NCF * KS1 * NPL * 1024, W2B = NCF * KS2 * NPL * 1024;
+    constexpr int PR = 16, PATCH = PR * 144;          // per-wave epilogue patch: 16 pixels x 32 channels, rows padded to 144 bytes
+    constexpr int VEC = 4 * 128 * 4;                  // sc1, sh1, sc2, sh2
+    static_assert(W1B + W2B + VEC + 8 * PATCH <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) uint8_t lds[W1B + W2B + VEC + 8 * PATCH];
+    float* const s_sc1 = reinterpret_cast<float*>(lds + W1B + W2B);
+    float* const s_sh1 = s_sc1 + 128;
+    float* const s_sc2 = s_sh1 + 128;
+    float* const s_sh2 = s_sc2 + 128;
+    const ConvArgs& a = ca.a;
+    const egr_conv_desc& d = a.d;
+    const int grp = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 31, h = lane >> 5;
+    float sa, ads;
+    act_prescale(a.amax_in, lane, sa, ads);
+    float amx = 0.f;
+    // ds_read / ds_write take a 16-bit immediate offset: one opaque base register per 64-KB window of the LDS image keeps every weight
+    // fragment read at base + immediate (left to itself the compiler materialised one address register per fragment above 64 KB: 30 registers)
+    unsigned lb0 = lane * 16, lb1 = lane * 16 + 65536;
+    asm volatile("" : "+v"(lb0), "+v"(lb1));
+    auto wfrag = [&](const int off) __attribute__((always_inline)) {      // 16 bytes of this lane at byte offset `off` (a literal) + 16 lane
+        return off < 65536 ? *reinterpret_cast<const u32x4*>(lds + lb0 + off) : *reinterpret_cast<const u32x4*>(lds + lb1 + (off - 65536));
+    };
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.x + grp * d.gx), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.y + grp * d.gy), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.res ? a.res + grp * d.gr : a.x), 0, 0x80000000u, 0x00020000);
+    const int HoWo = d.ho * d.wo;
+    const int T = (a.M + 31) >> 5, NW = gridDim.x * 8;
+    int t = blockIdx.x * 8 + wave;
+
+    auto x_off = [&](int tile) {      // byte offset of the lane's pixel in x (OOB past the last pixel: the loads return zeros)
+        const int m = tile * 32 + p;
+        int n, pix;
+        if (a.howo_shift >= 0) { n = m >> a.howo_shift; pix = m & (HoWo - 1); }
+        else { n = fdiv(m, a.dHoWo); pix = m - n * HoWo; }
+        const int xb = a.x_plain ? n * (int)d.xmap.stride_inner : (int)fmap(d.xmap, a.dXin, n);
+        return (tile < T && m < a.M) ? (xb + pix * d.ldx) * 4 + h * 16 : OOB;
+    };
+    // weights -> LDS, both images, permuted to the lane's k order (lane half h holds k = {4h .. 4h+3} u {8+4h .. 8+4h+3} of a k16 step:
+    // a 16-byte piece of the image (lane (p, q): k 8q .. 8q+7) goes as two 8-byte halves to the new lanes (p, 0) and (p, 1), slot q)
+    u32x4 raw[2 * KS1];
+    {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        // (all of a round's 16-byte pieces in flight at once: a load -> store loop pays one memory latency per piece - 16 of them in
+        // front of a launch whose waves only see a handful of tiles each)
+        auto stage = [&](const uint8_t* img, auto ks_tag, uint8_t* dst0) __attribute__((always_inline)) {
+            constexpr int KS = decltype(ks_tag)::value;
+            constexpr int NV = NCF * KS * NPL * 64 / 512;           // 16-byte pieces per thread
+            u32x4 wv[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int v = tid + 512 * i;
+                const int cf = v / (KS * 64 * NPL), rem = v - cf * (KS * 64 * NPL);
+                wv[i] = *reinterpret_cast<const u32x4*>(img + ((int64_t)cf * (KS / 2) * 2 * NPL) * 1024 + rem * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int v = tid + 512 * i;
+                const int lo = v & 63, blk = v >> 6;
+                uint8_t* const dst = dst0 + blk * 1024 + (lo & 31) * 16 + (lo >> 5) * 8;
+                *reinterpret_cast<u32x2*>(dst) = u32x2{wv[i][0], wv[i][1]};
+                *reinterpret_cast<u32x2*>(dst + 512) = u32x2{wv[i][2], wv[i][3]};
+            }
+        };
+        const int xo = x_off(t);
+#pragma unroll
+        for (int i = 0; i < 2 * KS1; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo + i * 32, 0, 0);
+        stage(reinterpret_cast<const uint8_t*>(a.w) + (int64_t)grp * d.gw * 2, std::integral_constant<int, KS1>{}, lds);
+        stage(reinterpret_cast<const uint8_t*>(ca.w2) + (int64_t)grp * ca.gw2 * 2, std::integral_constant<int, KS2>{}, lds + W1B);
+        if (tid < 128) {
+            // (the exact power-of-two descales ride on the channel scales: first conv = activation pre-scale x W1's row scale; second
+            // conv = W2's row scale - the per-pixel scale of the intermediate is undone in the registers)
+            s_sc1[tid] = ads * a.wds[grp * ca.gp1 + tid];
+            s_sh1[tid] = ca.shift1 ? ca.shift1[grp * ca.gp1 + tid] : 0.f;
+            s_sc2[tid] = (tid < d.cout) ? ca.wds2[grp * d.gp + tid] * ((a.scale && tid < d.cout) ? a.scale[grp * d.gp + tid] : 1.f) : 1.f;
+            s_sh2[tid] = (a.shift && tid < d.cout) ? a.shift[grp * d.gp + tid] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    const float floor1 = (ca.act1 == EGR_ACT_RELU) ? 0.f : -__builtin_inff();
+    const float floor_ = (d.act == EGR_ACT_RELU) ? 0.f : -__builtin_inff();
+    const bool res_before = d.res_mode == EGR_RES_BEFORE_ACT;
+    constexpr int PW[3] = {1, 0, 0}, PX[3] = {0, 1, 0};      // (l,h) (h,l) (h,h): smallest products first
+    for (; t < T; t += NW) {
+#ifdef CHAIN_EXP_NOLOAD      // (CHAIN_EXP_*: elimination builds for tools/chain_micro.py - timing only, the results are wrong)
+        const int xo_n = OOB;
+#else
+        const int xo_n = x_off(t + NW);
+#endif
+        // ---------------------------------------------------------------- first product: acc1 = W1 . x
+        // (PIPE: the weight fragments of k step s + 1 are read from LDS in front of step s's MFMAs - two register sets - so that no step
+        // starts with an exposed LDS round trip; the 128 -> 128 -> 128 chain with the up-sampled residual has no registers for the second set)
+        f32x16 acc1[NCF];
+#pragma unroll
+        for (int cf = 0; cf < NCF; ++cf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[cf][r] = 0.f;
+        u32x4 wf[PIPE ? 2 : 1][NCF][NPL];
+        auto read_w1 = [&](const int set, const int ks) __attribute__((always_inline)) {
+#pragma unroll
+            for (int cf = 0; cf < NCF; ++cf)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl)
+                    wf[PIPE ? set : 0][cf][pl] = wfrag(((cf * KS1 + ks) * NPL + pl) * 1024);
+        };
+        auto read_w2 = [&](const int set, const int ks) __attribute__((always_inline)) {
+#pragma unroll
+            for (int cf = 0; cf < NCF; ++cf)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl)
+                    wf[PIPE ? set : 0][cf][pl] = wfrag(W1B + ((cf * KS2 + ks) * NPL + pl) * 1024);
+        };
+        if constexpr (PIPE) read_w1(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+            unsigned xh[4], xl[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const u32x4& src = raw[2 * ks + (e >> 1)];
+                split2_f16(__uint_as_float(src[2 * (e & 1)]), __uint_as_float(src[2 * (e & 1) + 1]), sa, xh[e], xl[e]);
+            }
+            u32x4 xb[NPL];
+            xb[0] = u32x4{xh[0], xh[1], xh[2], xh[3]};
+            xb[1] = u32x4{xl[0], xl[1], xl[2], xl[3]};
+            if constexpr (PIPE) {
+                if (ks + 1 < KS1) read_w1((ks + 1) & 1, ks + 1);
+                else read_w2((ks + 1) & 1, 0);            // the second product's first step
+            } else {
+                read_w1(0, ks);
+            }
+            SB_G();
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+                for (int cf = 0; cf < NCF; ++cf)
+#ifdef CHAIN_EXP_NOMFMA1
+                    if (t3 == 0 && ks == 0)
+#endif
+                    acc1[cf] = mfma_split<NPL>(wf[PIPE ? (ks & 1) : 0][cf][PW[t3]], xb[PX[t3]], acc1[cf]);
+            SB_G();
+        }
+        // ---------------------------------------------------------------- bias + activation on the accumulators, the pixel's maximum
+        float pmax = 0.f;
+#pragma unroll
+        for (int cf = 0; cf < NCF; ++cf)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(s_sc1 + cf * 32 + 8 * g + 4 * h);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(s_sh1 + cf * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc1[cf][4 * g + e] * sc[e] + sh[e];
+                    v = v > floor1 ? v : floor1;
+                    acc1[cf][4 * g + e] = v;
+                    pmax = fmaxf(pmax, fabsf(v));
+                }
+            }
+        pmax = fmaxf(pmax, __shfl_xor(pmax, 32, 64));
+        // 2^k with pmax 2^k in [2^14, 2^15), k clamped to +-60 (act_prescale's rule, per pixel); NaN / Inf propagate through the products
+        int k2 = 141 - (int)(__float_as_uint(pmax) >> 23);
+        k2 = k2 > 60 ? 60 : (k2 < -60 ? -60 : k2);
+        const float sa2 = __uint_as_float((unsigned)(127 + k2) << 23), inv2 = __uint_as_float((unsigned)(127 - k2) << 23);
+        // ---------------------------------------------------------------- second product: acc2 = W2 . y1 (y1 = acc1, in place)
+        SB_G();
+        f32x16 acc2[NCF];
+#pragma unroll
+        for (int cf = 0; cf < NCF; ++cf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[cf][r] = 0.f;
+        constexpr int S0 = KS1 & 1;              // register set holding step 0 of the second product (read behind the first product's last step)
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) {
+            const int cf1 = ks >> 1, g0 = 2 * (ks & 1);
+            unsigned xh[4], xl[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r0 = 4 * (g0 + (e >> 1)) + 2 * (e & 1);
+                split2_f16(acc1[cf1][r0], acc1[cf1][r0 + 1], sa2, xh[e], xl[e]);
+            }
+            u32x4 xb[NPL];
+            xb[0] = u32x4{xh[0], xh[1], xh[2], xh[3]};
+            xb[1] = u32x4{xl[0], xl[1], xl[2], xl[3]};
+            if constexpr (PIPE) {
+                if (ks + 1 < KS2) read_w2((S0 + ks + 1) & 1, ks + 1);
+            } else {
+                read_w2(0, ks);
+            }
+            SB_G();
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+                for (int cf = 0; cf < NCF; ++cf)
+#ifdef CHAIN_EXP_NOMFMA2
+                    if (t3 == 0 && ks == 0)
+#endif
+                    acc2[cf] = mfma_split<NPL>(wf[PIPE ? ((S0 + ks) & 1) : 0][cf][PW[t3]], xb[PX[t3]], acc2[cf]);
+            SB_G();
+        }
+        // the next tile's activations: requested now that the first product's registers are dead (the whole epilogue to land)
+        SB_G();
+#pragma unroll
+        for (int i = 0; i < 2 * KS1; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo_n + i * 32, 0, 0);
+        SB_G();
+        // ---------------------------------------------------------------- epilogue (conv_pw_x6_kernel's, on 16-row patches)
+        const int m = t * 32 + p;
+        int n, pix;
+        if (a.howo_shift >= 0) { n = m >> a.howo_shift; pix = m & (HoWo - 1); }
+        else { n = fdiv(m, a.dHoWo); pix = m - n * HoWo; }
+        const bool live = m < a.M;
+        const int yo_p = live ? ((a.y_plain ? n * (int)d.ymap.stride_inner : (int)fmap(d.ymap, a.dYin, n)) + pix * d.ldy) * 4 : OOB;
+        int ro_p = OOB, ox_p = 0, oy_p = 0;
+        float lx1_p = 0.f, ly1_p = 0.f;
+        if constexpr (RESK == 1) {
+            if (live) ro_p = ((a.r_plain ? n * (int)d.rmap.stride_inner : (int)fmap(d.rmap, a.dRin, n)) + pix * d.ldr) * 4;
+        }
+        if constexpr (RESK == 2) {
+            // bilinear x2 (align_corners = True, ATen arithmetic as in upsample2x_kernel) of a half-resolution tensor
+            const int ho = (a.wo_shift >= 0) ? (pix >> a.wo_shift) : fdiv(pix, a.dWo), wo = pix - ho * d.wo;
+            const int hl = d.ho >> 1, wl = d.wo >> 1;
+            const float shh = (d.ho > 1) ? (float)(hl - 1) / (float)(d.ho - 1) : 0.f;
+            const float sww = (d.wo > 1) ? (float)(wl - 1) / (float)(d.wo - 1) : 0.f;
+            const float fy = shh * (float)ho, fx = sww * (float)wo;
+            const int y0 = (int)fy, x0 = (int)fx;
+            ly1_p = fminf(fmaxf(__builtin_fmaf(shh, (float)ho, -(float)y0), 0.f), 1.f);
+            lx1_p = fminf(fmaxf(__builtin_fmaf(sww, (float)wo, -(float)x0), 0.f), 1.f);
+            if (live) ro_p = ((a.r_plain ? n * (int)d.rmap.stride_inner : (int)fmap(d.rmap, a.dRin, n)) + (y0 * wl + x0) * d.ldr) * 4;
+            ox_p = (x0 + 1 > wl - 1) ? 0 : d.ldr * 4;
+            oy_p = (y0 + 1 > hl - 1) ? 0 : wl * d.ldr * 4;
+        }
+        const int qd = lane & 7, rsub = lane >> 3;
+        uint8_t* const patch = lds + W1B + W2B + VEC + wave * PATCH;
+        // Eight steps (pixel half hp = it / 4, fragment cf = it % 4).  The residual quads of step it + 1 are requested BEFORE step it's
+        // stores: vector-memory operations retire in order, so a residual load issued behind the previous step's stores would wait for
+        // those stores to be acknowledged as well (measured on the single launches: one exposed round trip per step, 15 us per tile).
+        int yo[2][2], ro[2][2], ox[2][2], oy[2][2];       // [hp][row i]: the two rows this lane stores in each half
+        float lx1[2][2], ly1[2][2];
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int src = hp * 16 + i * 8 + rsub;       // parameters come from the lane that owns that pixel
+                yo[hp][i] = __shfl(yo_p, src) + qd * 16;
+                if constexpr (RESK != 0) ro[hp][i] = __shfl(ro_p, src) + qd * 16;
+                if constexpr (RESK == 2) {
+                    ox[hp][i] = __shfl(ox_p, src); oy[hp][i] = __shfl(oy_p, src);
+                    lx1[hp][i] = __shfl(lx1_p, src); ly1[hp][i] = __shfl(ly1_p, src);
+                }
+            }
+        constexpr int NR = RESK == 2 ? 4 : (RESK == 1 ? 1 : 0);
+        f32x4 rq[2][NR > 0 ? NR : 1];                        // [parity of the step][corner]
+        // sixteen steps: (pixel half hp, fragment cf, row i of the two rows a lane stores per half)
+        auto res_issue = [&](const int st, const int par) __attribute__((always_inline)) {
+            if constexpr (RESK != 0) {
+                const int hp = st >> 3, cf = (st >> 1) & 3, i = st & 1;
+#ifdef CHAIN_EXP_NORES
+                if (st > 0) return;
+#endif
+                rq[par][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ro[hp][i] + cf * 128, 0, 0));
+                if constexpr (RESK == 2) {
+                    rq[par][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ro[hp][i] + ox[hp][i] + cf * 128, 0, 0));
+                    rq[par][2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ro[hp][i] + oy[hp][i] + cf * 128, 0, 0));
+                    rq[par][3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ro[hp][i] + oy[hp][i] + ox[hp][i] + cf * 128, 0, 0));
+                }
+            }
+        };
+        auto patch_write = [&](const int u) __attribute__((always_inline)) {
+            const int hp = u >> 2, cf = u & 3;
+            if ((p >> 4) == hp) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(patch + (p & 15) * 144 + g * 32 + h * 16) =
+                        f32x4{acc2[cf][4 * g] * inv2, acc2[cf][4 * g + 1] * inv2, acc2[cf][4 * g + 2] * inv2, acc2[cf][4 * g + 3] * inv2};
+            }
+        };
+        res_issue(0, 0);
+        patch_write(0);
+        // eight units (pixel half hp, fragment cf) of two rows each: both rows of a unit are read back, then the NEXT unit's accumulators go
+        // into the patch in front of this unit's arithmetic and stores - the write's LDS latency hides behind them
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#ifdef CHAIN_EXP_NOEPI
+            if (u > 0) break;
+#endif
+            const int hp = u >> 2, cf = u & 3;
+            __builtin_amdgcn_wave_barrier();
+            f32x4 vv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) vv[i] = *reinterpret_cast<const f32x4*>(patch + (i * 8 + rsub) * 144 + qd * 16);
+            const int c = cf * 32 + 4 * qd;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(s_sc2 + c), sh = *reinterpret_cast<const f32x4*>(s_sh2 + c);
+            const bool cok = c < d.cout;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (u + 1 < 8) patch_write(u + 1);
+            SB_E();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int st = 2 * u + i, par = st & 1;
+                if (st + 1 < 16) res_issue(st + 1, par ^ 1);
+                SB_E();
+                f32x4 v = vv[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float tt = v[e] * sc[e] + sh[e];
+                    if constexpr (RESK == 1) tt += res_before ? rq[par][0][e] : 0.f;
+                    if constexpr (RESK == 2) {
+                        const float lx0 = 1.f - lx1[hp][i], ly0 = 1.f - ly1[hp][i];
+                        tt += ly0 * (lx0 * rq[par][0][e] + lx1[hp][i] * rq[par][1][e]) + ly1[hp][i] * (lx0 * rq[par][2][e] + lx1[hp][i] * rq[par][3][e]);
+                    }
+                    tt = tt > floor_ ? tt : floor_;
+                    if constexpr (RESK == 1) tt += res_before ? 0.f : rq[par][0][e];
+                    v[e] = tt;
+                }
+                if (cok && yo[hp][i] >= 0) amx = fmaxf(fmaxf(amx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+#ifdef CHAIN_EXP_NOSTORE
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, (v[0] == 12345.678f) ? yo[hp][i] + cf * 128 : OOB, 0, 0);
+#else
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, cok ? yo[hp][i] + cf * 128 : OOB, 0, 0);
+#endif
+                SB_E();
+            }
+        }
+    }
+    if (a.amax_out) amax_flush(a.amax_out, amx, (int)blockIdx.x * 8 + wave);
+}
+
+int g_chain_blocks = getenv("EGR_CONV_CHAIN_BLOCKS") ? atoi(getenv("EGR_CONV_CHAIN_BLOCKS")) : 256;    // resident workgroups (one per CU)
+
+}  // namespace
+
+extern "C" int egr_conv1x1_chain_f32(const egr_conv_desc* dd, const float* x, const void* w1, const float* shift2, const float* res, float* y,
+                                     const egr_conv_aux* aux, const egr_chain_aux* chain, void* stream) {
+    if (!dd || !x || !w1 || !y || !aux || !chain || !aux->w_descale || !aux->amax_in || !chain->w2 || !chain->w2_descale) return EGR_ENULL;
+    ChainArgs ca;
+    ConvArgs& a = ca.a;
+    a = ConvArgs{};
+    a.d = *dd;
+    egr_conv_desc& d = a.d;
+    if (d.groups <= 0) d.groups = 1;
+    if (d.kh != 1 || d.kw != 1 || d.stride != 1 || d.pad != 0 || d.h != d.ho || d.w != d.wo || d.transposed || d.out_nchw || d.split_k > 1) return EGR_EINVAL;
+    if ((d.cin != 64 && d.cin != 128) || chain->cmid != 128 || d.cout <= 0 || d.cout > 128 || d.cout % 4 != 0) return EGR_EINVAL;
+    if (d.w_format != EGR_W_F16X2 || d.n <= 0 || d.ho <= 0 || d.wo <= 0 || d.groups > 65535) return EGR_EINVAL;
+    if ((d.act != EGR_ACT_NONE && d.act != EGR_ACT_RELU) || (chain->act1 != EGR_ACT_NONE && chain->act1 != EGR_ACT_RELU)) return EGR_EINVAL;
+    if (d.res_mode != EGR_RES_NONE && !res) return EGR_ENULL;
+    if (d.res_mode == EGR_RES_UP2_BEFORE_ACT && ((d.ho | d.wo) & 1)) return EGR_EINVAL;
+    if (d.ldx % 4 != 0 || d.ldy % 4 != 0 || (d.res_mode && d.ldr % 4 != 0)) return EGR_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)w1 | (uintptr_t)chain->w2 | (uintptr_t)y | (uintptr_t)res) & 15) return EGR_EINVAL;
+    if (((uintptr_t)aux->amax_in | (uintptr_t)aux->amax_out) & 3) return EGR_EINVAL;
+    if (d.xmap.n_inner <= 0 || d.ymap.n_inner <= 0 || (d.res_mode && d.rmap.n_inner <= 0)) return EGR_EINVAL;
+    if (((d.xmap.stride_inner | d.xmap.stride_outer | d.ymap.stride_inner | d.ymap.stride_outer) % 4) != 0) return EGR_EINVAL;
+    if (d.res_mode && ((d.rmap.stride_inner | d.rmap.stride_outer) % 4) != 0) return EGR_EINVAL;
+    if (d.groups > 1 && (((d.gx | d.gp | d.gy | d.gr | chain->gp1) % 4) != 0 || (d.gw | chain->gw2) % 8 != 0)) return EGR_EINVAL;
+    const int64_t M64 = (int64_t)d.n * d.ho * d.wo;
+    if (M64 >= (1LL << 31)) return EGR_EINVAL;
+    auto span = [](const egr_nmap& m, int n) {
+        const int o = (n - 1) / m.n_inner, i = (n - 1 < m.n_inner ? n - 1 : m.n_inner - 1);
+        return (int64_t)i * m.stride_inner + (int64_t)o * m.stride_outer;
+    };
+    // 32-bit BYTE offsets inside a group's window
+    if ((span(d.xmap, d.n) + (int64_t)d.h * d.w * d.ldx) * 4 + 64 >= (1LL << 31)) return EGR_EINVAL;
+    if ((span(d.ymap, d.n) + (int64_t)d.ho * d.wo * d.ldy) * 4 >= (1LL << 31)) return EGR_EINVAL;
+    if (d.res_mode && (span(d.rmap, d.n) + (int64_t)d.ho * d.wo * d.ldr) * 4 >= (1LL << 31)) return EGR_EINVAL;
+    a.x = x; a.w = static_cast<const float*>(w1); a.shift = shift2; a.res = res; a.y = y;
+    a.wds = aux->w_descale; a.amax_in = aux->amax_in; a.amax_out = aux->amax_out;
+    a.M = (int)M64;
+    a.Npad = 128;
+    a.K = d.cin;
+    auto log2_exact = [](int v) { int l = 0; while ((1 << l) < v) ++l; return ((1 << l) == v) ? l : -1; };
+    a.howo_shift = log2_exact(d.ho * d.wo);
+    a.wo_shift = log2_exact(d.wo);
+    a.x_plain = d.xmap.n_inner >= d.n;
+    a.y_plain = d.ymap.n_inner >= d.n;
+    a.r_plain = d.res_mode ? (d.rmap.n_inner >= d.n) : 1;
+    a.dHoWo = make_fastdiv(d.ho * d.wo);
+    a.dWo = make_fastdiv(d.wo);
+    a.dXin = make_fastdiv(d.xmap.n_inner);
+    a.dYin = make_fastdiv(d.ymap.n_inner);
+    a.dRin = make_fastdiv(d.res_mode ? d.rmap.n_inner : 1);
+    a.cblocks = d.cin / BK;
+    a.taps = 1;
+    a.ktiles = a.cblocks;
+    ca.w2 = chain->w2; ca.wds2 = chain->w2_descale; ca.shift1 = chain->shift1; ca.gw2 = chain->gw2; ca.gp1 = chain->gp1; ca.act1 = chain->act1;
+    int nblk = g_chain_blocks / d.groups;
+    if (nblk < 1) nblk = 1;
+    const int t32 = (a.M + 31) / 32;
+    if (nblk * 8 > t32) nblk = (t32 + 7) / 8;
+    const dim3 grid((unsigned)nblk, 1, (unsigned)d.groups);
+    const int resk = d.res_mode == EGR_RES_NONE ? 0 : (d.res_mode == EGR_RES_UP2_BEFORE_ACT ? 2 : 1);
+    hipStream_t s = (hipStream_t)stream;
+    if (d.cin == 64) {
+        if (resk == 0) hipLaunchKernelGGL((conv_pw_chain_kernel<4, 0>), grid, dim3(512), 0, s, ca);
+        else if (resk == 1) hipLaunchKernelGGL((conv_pw_chain_kernel<4, 1>), grid, dim3(512), 0, s, ca);
+        else hipLaunchKernelGGL((conv_pw_chain_kernel<4, 2>), grid, dim3(512), 0, s, ca);
+    } else {
+        if (resk == 0) hipLaunchKernelGGL((conv_pw_chain_kernel<8, 0>), grid, dim3(512), 0, s, ca);
+        else if (resk == 1) hipLaunchKernelGGL((conv_pw_chain_kernel<8, 1>), grid, dim3(512), 0, s, ca);
+        else hipLaunchKernelGGL((conv_pw_chain_kernel<8, 2>), grid, dim3(512), 0, s, ca);
+    }
+    return egr_launch_status();
+}

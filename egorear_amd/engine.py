@@ -297,6 +297,30 @@ def run_stack(st: State, seqs: Sequence[nn.Sequential], x: Img, out: Optional[Im
             act = ACT_RELU if (i + 1 < len(m0) and isinstance(m0[i + 1], nn.ReLU)) else ACT_NONE
             last = (i + (2 if act else 1)) >= len(m0)
             p = st.get(m, lambda i=i: pack_convs([g[i] for g in mods]))
+            # Conv2d(1x1)[+ReLU] -> [Upsample ->] Conv2d(1x1)[+ReLU]: both convs in ONE launch, the intermediate stays in registers
+            # (egr_conv1x1_chain_f32); with the Upsample in between the second conv commutes in front of it as below
+            j = i + (2 if act else 1)
+            up = j < len(m0) and isinstance(m0[j], nn.Upsample)
+            k = j + 1 if up else j
+            nxt = m0[k] if k < len(m0) else None
+            if (m.kernel_size == (1, 1) and m.stride == (1, 1) and isinstance(nxt, nn.Conv2d) and nxt.kernel_size == (1, 1)
+                    and nxt.stride == (1, 1)):
+                relu2 = k + 1 < len(m0) and isinstance(m0[k + 1], nn.ReLU)
+                end = k + (2 if relu2 else 1)
+                fin = end >= len(m0)
+                ok = (not up) or relu2                                         # ReLU(conv(up(x))) = ReLU(up(conv(x))) needs the ReLU
+                if up and end + 1 == len(m0) and last_kw and "out_nchw" in last_kw:
+                    ok = False                                                 # tail of a heat-map head: egr_up2_relu_head_f32's pattern below
+                if fin and last_kw:
+                    ok = False                                                 # (a placed / channel-major final output stays on the single launches)
+                p2 = st.get(nxt, lambda k=k: pack_convs([g[k] for g in mods])) if ok else None
+                if ok and hip.chain_eligible(x, p.w, p2.w, p.cout, p2.cout, p.groups, p.scale, p2.scale):
+                    y = hip.conv1x1_chain(x, p.w, p2.w, p.cout, p2.cout, shift1=p.shift, shift2=p2.shift, act1=act,
+                                          act2=ACT_NONE if up else (ACT_RELU if relu2 else ACT_NONE), groups=p.groups,
+                                          out=out if (fin and not up) else None, amax_out=st.new_amax())
+                    x = hip.upsample2x(y, out=out if fin else None, relu=True) if up else y
+                    i = end
+                    continue
             kw = dict(last_kw or {}) if last else {}
             if last and out is not None:
                 kw["out"] = out
@@ -413,12 +437,18 @@ def run_backbone(st: State, encs, img: torch.Tensor, view0: int, nviews: int, fe
     lat = conv(st, pyramid[3], st.get(n0.lateral_convs[3], lambda: pack_convs([k.lateral_convs[3][0] for k in necks])), ACT_RELU)
     for i in (3, 2, 1):
         lo = pyramid[i - 1]
-        fine = conv(st, lo, st.get(n0.lateral_convs[i - 1], lambda i=i: pack_convs([k.lateral_convs[i - 1][0] for k in necks])), ACT_RELU)
+        pl = st.get(n0.lateral_convs[i - 1], lambda i=i: pack_convs([k.lateral_convs[i - 1][0] for k in necks]))
         fuse = n0.fuse_convs[i - 1]
         pa = st.get((id(fuse), "a"), lambda i=i: pack_convs_cin_slice([k.fuse_convs[i - 1][0] for k in necks], 0, c, True))
         pb = st.get((id(fuse), "b"), lambda i=i: pack_convs_cin_slice([k.fuse_convs[i - 1][0] for k in necks], c, 2 * c, False))
         coarse_lo = conv(st, lat, pb, ACT_NONE)          # stays at the coarse resolution: the fuse conv's epilogue upsamples it on the fly
-        fused = conv(st, fine, pa, ACT_RELU, res=coarse_lo, res_mode=RES_UP2_BEFORE_ACT)
+        if hip.chain_eligible(lo, pl.w, pa.w, pl.cout, pa.cout, G, pl.scale, pa.scale):
+            # lateral conv + ReLU -> fuse conv (+ up-sampled half, ReLU) in one launch: the lateral tensor is never written
+            fused = hip.conv1x1_chain(lo, pl.w, pa.w, pl.cout, pa.cout, shift1=pl.shift, shift2=pa.shift, act1=ACT_RELU, act2=ACT_RELU,
+                                      res=coarse_lo, res_mode=RES_UP2_BEFORE_ACT, groups=G, amax_out=st.new_amax())
+        else:
+            fine = conv(st, lo, pl, ACT_RELU)
+            fused = conv(st, fine, pa, ACT_RELU, res=coarse_lo, res_mode=RES_UP2_BEFORE_ACT)
         lat = conv(st, fused, st.get(n0.fpn_convs[i - 1], lambda i=i: pack_convs([k.fpn_convs[i - 1][0] for k in necks])), ACT_RELU,
                    out=feat_out if i == 1 else None)
     return pyramid

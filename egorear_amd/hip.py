@@ -30,7 +30,7 @@ EXPORTS = [
     "egr_stem_w6_bytes", "egr_pack_stem_w6_f32", "egr_stem_conv7x7_x6_f32", "egr_wgrad_last_kernel", "egr_conv_last_kernel", "egr_conv_set_tap", "egr_conv_set_tapx", "egr_conv_set_splitk_fused", "egr_fisheye_project2_f32", "egr_pack_layer_w_f32", "egr_pack_layer_wh2_f32",
     "egr_conv2d_nhwc_ex_f32", "egr_wh2_elems", "egr_pack_wh2_f32", "egr_absmax_f32", "egr_stem_conv7x7_x6_ex_f32", "egr_stem_wh2_bytes", "egr_pack_stem_wh2_f32", "egr_stem_conv7x7_h2_f32",
     "egr_pack_wh2_many_f32", "egr_conv2d_masked_ex_f32", "egr_conv2d_wgrad_ex_f32", "egr_wgrad_last_h2",
-    "egr_wstream_image_bytes", "egr_pack_wstream_f32", "egr_linear_wstream_workspace_bytes", "egr_linear_wstream_f32",
+    "egr_wstream_image_bytes", "egr_pack_wstream_f32", "egr_linear_wstream_workspace_bytes", "egr_linear_wstream_f32", "egr_conv1x1_chain_f32",
 ]
 
 
@@ -58,6 +58,12 @@ class ConvAux(C.Structure):
                 ("bn_partials", C.c_void_p), ("bn_tiles_out", C.c_void_p), ("bn_capacity", C.c_int64)]
 
 
+class ChainAux(C.Structure):
+    """egr_chain_aux of include/egorear_hip.h: the second conv of egr_conv1x1_chain_f32."""
+    _fields_ = [("w2", C.c_void_p), ("w2_descale", C.c_void_p), ("shift1", C.c_void_p), ("cmid", C.c_int32), ("act1", C.c_int32),
+                ("gw2", C.c_int64), ("gp1", C.c_int64)]
+
+
 class LayerDesc(C.Structure):
     """egr_layer_desc of include/egorear_hip.h (field for field)."""
     _P = C.c_void_p
@@ -80,6 +86,7 @@ def _load() -> C.CDLL:
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     lib.egr_conv2d_nhwc_f32.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.egr_conv2d_nhwc_ex_f32.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(ConvAux), vp]
+    lib.egr_conv1x1_chain_f32.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, C.POINTER(ConvAux), C.POINTER(ChainAux), vp]
     lib.egr_fill_f32.argtypes = [vp, f32, i64, vp]      # (include/egorear_train.h; zeroes the abs-max records)
     lib.egr_fill_f32.restype = C.c_int
     lib.egr_absmax_f32.argtypes = [vp, i64, vp, vp]
@@ -626,6 +633,82 @@ def conv2d(x: Img, w, cout: int, kh: int, kw: int, stride: int, pad: int, *, sca
     if tiles is not None:
         bn_slabs[:] = [int(tiles.value)]
     return ret
+
+
+# Two 1x1 convolutions back to back in one launch (egr_conv1x1_chain_f32): EGR_CONV_CHAIN=0 keeps the two launches
+CHAIN = os.environ.get("EGR_CONV_CHAIN", "1") != "0"
+CHAIN_MIN_ROWS = int(os.environ.get("EGR_CONV_CHAIN_MIN_ROWS", "65536"))
+
+
+def chain_eligible(x: Img, w1, w2, cmid: int, cout: int, groups: int, scale1=None, scale2=None) -> bool:
+    """Whether conv1x1_chain covers this pair: fp16 scheme on both operands, x carries its abs-max record, cin 64 / 128 -> 128 -> <= 128,
+    bias-only convs, enough pixels for the streaming structure (the rule of the single streaming launches)."""
+    if not (CHAIN and H2 and isinstance(w1, W6) and isinstance(w2, W6) and w1.h2 is not None and w2.h2 is not None):
+        return False
+    if x.amax is None or scale1 is not None or scale2 is not None or x.c not in (64, 128) or cmid != 128 or cout > 128 or cout % 4:
+        return False
+    if x.n % groups or w1.groups != groups or w2.groups != groups or w1.npad != 128 or w2.npad != 128 or w1.K != x.c or w2.K != cmid:
+        return False
+    return x.n * x.h * x.w >= CHAIN_MIN_ROWS
+
+
+def conv1x1_chain(x: Img, w1, w2, cmid: int, cout: int, *, shift1=None, shift2=None, act1: int = ACT_RELU, act2: int = ACT_NONE,
+                  res: Optional[Img] = None, res_mode: int = RES_NONE, out: Optional[Img] = None, groups: int = 1,
+                  amax_out: Optional[torch.Tensor] = None) -> Img:
+    """y = act2(W2 . act1(W1 . x + shift1) + shift2 [+ res]) in one launch; the cmid-channel intermediate never reaches memory.
+    x / out / res hold the images of all groups back to back (as hip.conv2d).  Call chain_eligible first."""
+    if not chain_eligible(x, w1, w2, cmid, cout, groups):
+        raise LaunchError("egr_conv1x1_chain_f32", EINVAL)
+    ng = x.n // groups
+    gx = ng * x.nstride if groups > 1 else 0
+    xg = Img(x.t[:ng], amax=x.amax) if groups > 1 else x
+    for w in (w1, w2):
+        if not w.h2_used:
+            if w.f32 is not None:
+                pack_wh2_into(w)
+            w.h2_used = True
+    d = ConvDesc()
+    d.w_format = 4
+    d.n, d.h, d.w, d.cin, d.cout = xg.n, xg.h, xg.w, xg.c, cout
+    d.kh, d.kw, d.stride, d.pad, d.ho, d.wo = 1, 1, 1, 0, xg.h, xg.w
+    d.ldx, d.xmap = xg.ld, xg.nmap()
+    d.act, d.res_mode, d.split_k, d.transposed, d.out_nchw = act2, res_mode, 1, 0, 0
+    full = out
+    if out is None:
+        full = Img(torch.empty((x.n, x.h, x.w, cout), device=x.t.device, dtype=torch.float32))
+        out = full
+    if out.n != x.n or (out.h, out.w, out.c) != (x.h, x.w, cout):
+        raise RuntimeError("egorear_amd.conv1x1_chain: output shape does not match")
+    gy = ng * out.nstride if groups > 1 else 0
+    og = Img(out.t[:ng]) if groups > 1 else out
+    d.ldy, d.ymap = og.ld, og.nmap()
+    gr = 0
+    if res_mode != RES_NONE:
+        if res is None or res.n != x.n:
+            raise RuntimeError("egorear_amd.conv1x1_chain: res_mode set without a residual of groups x n images")
+        if res_mode == RES_UP2_BEFORE_ACT and (2 * res.h != x.h or 2 * res.w != x.w or res.c < cout):
+            raise RuntimeError("egorear_amd.conv1x1_chain: the upsampled residual must be exactly half the output resolution")
+        gr = ng * res.nstride if groups > 1 else 0
+        rg = Img(res.t[:ng]) if groups > 1 else res
+        d.ldr, d.rmap = rg.ld, rg.nmap()
+    else:
+        d.rmap = NMap(1, 0, 0)
+    d.groups, d.gx, d.gw, d.gp, d.gy, d.gr = groups, gx, (w1.h2_gstride if groups > 1 else 0), (128 if groups > 1 else 0), gy, gr
+    for t, nm, need in ((shift1, "shift1", cmid), (shift2, "shift2", cout)):
+        if t is not None and t.numel() < ((groups - 1) * 128 + need):
+            raise RuntimeError(f"egorear_amd.conv1x1_chain: {nm} shorter than expected")
+    if amax_out is not None and (amax_out.numel() != 64 or amax_out.dtype != torch.int32 or not amax_out.is_contiguous()):
+        raise RuntimeError("egorear_amd.conv1x1_chain: amax_out must be 64 contiguous int32 slots")
+    aux = ConvAux(_p(w1.h2_ds).value, _p(x.amax, torch.int32).value, _p(amax_out, torch.int32).value if amax_out is not None else None, None, None, 0)
+    ch = ChainAux(_p(w2.h2, torch.float16).value, _p(w2.h2_ds).value, _p(shift1).value if shift1 is not None else None, cmid, act1,
+                  (w2.h2_gstride if groups > 1 else 0), (128 if groups > 1 else 0))
+    M = ng * x.h * x.w
+    _launch("egr_conv1x1_chain_f32", lib.egr_conv1x1_chain_f32, C.byref(d), _p(xg.t), _p(w1.h2, torch.float16), _p(shift2),
+            _p(res.t) if res is not None else None, _p(og.t), C.byref(aux), C.byref(ch), _stream(),
+            flops=2.0 * M * groups * (cmid * x.c + cout * cmid), nbytes=4.0 * groups * (M * (cout + x.c) + cmid * x.c + cout * cmid),
+            tag=f"h2 chain G{groups} M{M} N{cout} K{x.c} k1s1 cin{x.c} mid{cmid}" if PROFILE is not None else "")
+    full.tag(amax_out)
+    return full
 
 
 # weight gradients of large layers on the bf16 matrix cores with exact operand splits (the kernel keeps small ones on fp32 MFMA)

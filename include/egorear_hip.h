@@ -171,6 +171,30 @@ int egr_conv2d_nhwc_ex_f32(const egr_conv_desc* d, const float* x, const void* w
                            const float* res, const float* rowscale, const uint8_t* rowmask, float* y, float* workspace,
                            size_t workspace_floats, const egr_conv_aux* aux /* NULL = egr_conv2d_nhwc_f32 */, void* stream);
 
+/* Two 1x1 / stride-1 convolutions back to back in ONE launch (fp16 scheme, round 5):
+ *     y = act2( W2 . act1( W1 . x + shift1 ) + shift2 [+ res] )
+ * with the cmid-channel intermediate kept in the accumulator registers of the lane that owns the pixel (never written to memory) -
+ * it is split into its two fp16 planes under a PER-PIXEL power-of-two scale and fed back to the matrix cores as the second product's
+ * operand.  Replaces the pairs nn.Conv2d(1x1)+ReLU -> nn.Conv2d(1x1)[+ReLU] of the path whose intermediate used to round-trip
+ * through HBM: EfficientFPN's lateral conv -> fuse conv (models/backbones/resnet.py:96-110, 127-133; the fuse conv's up-sampled half
+ * enters as res with EGR_RES_UP2_BEFORE_ACT) and HeatmapMVF.frame_feat_refined_proj_layers
+ * (models/estimator/egoposeformer_heatmap_mvf_ex.py:553-563, 715).
+ * d: the chain described as ONE 1x1 conv cin -> cout (n, h = ho, w = wo, ldx / ldy / ldr, the three maps, act = act2, res_mode,
+ *    groups with gx / gy / gr / gp, gw = 16-bit elements between the groups' W1 images; kh = kw = stride = 1, pad = 0,
+ *    w_format = EGR_W_F16X2); cin 64 or 128, chain->cmid 128, cout <= 128 (cout % 4 == 0).
+ * w1 / aux->w_descale: egr_pack_wh2_f32 image and descale of the first conv (cmid x cin; descale group stride chain->gp1);
+ * aux->amax_in: abs-max record of x; aux->amax_out: record of y (may be NULL); shift2 / chain->w2_descale: (groups,) 128 floats,
+ * group stride d->gp.  EGR_EINVAL for any other shape - the caller then runs the two launches of egr_conv2d_nhwc_ex_f32. */
+typedef struct {
+    const void* w2;            /* egr_pack_wh2_f32 image of the second conv (round_up(cout, 32) padded to 128 rows x cmid) */
+    const float* w2_descale;
+    const float* shift1;       /* bias of the first conv, (groups,) cmid floats, group stride gp1; NULL = 0 */
+    int32_t cmid, act1;        /* 128; EGR_ACT_NONE | EGR_ACT_RELU */
+    int64_t gw2, gp1;          /* group strides: 16-bit elements of w2; floats of shift1 and of aux->w_descale */
+} egr_chain_aux;
+int egr_conv1x1_chain_f32(const egr_conv_desc* d, const float* x, const void* w1, const float* shift2, const float* res, float* y,
+                          const egr_conv_aux* aux, const egr_chain_aux* chain, void* stream);
+
 /* Data gradient behind a ReLU (training row): the conv of `d` (normally in transposed mode) with y = (conv [+ res]) * [mask > 0],
  * mask laid out exactly like y (the forward activation the ReLU produced).  Fuses torch's threshold_backward into the
  * data-gradient launch of the layer above.  No scale / shift / activation; res (may be NULL) is added before the mask. */

@@ -291,11 +291,11 @@ def test_lifting_head_borrows_the_estimators_arena_for_one_call_only(nets):
         st_p = engine._state(net.pose3d_estimator, torch.device(DEV))
         assert st_p.amax is not st_h.amax
         _, fts = net.heatmap_estimator(img)
-        recs = [t._egr_amax.clone() for t in fts if getattr(t, "_egr_amax", None) is not None]
-        a = net.pose3d_estimator(fts[0].contiguous(), fts[1].contiguous(), hms[1])         # stand-alone: clears ITS arena
-        after = [t._egr_amax for t in fts if getattr(t, "_egr_amax", None) is not None]
+        recs = st_h.amax.buf.clone()                                                       # every record the estimator's forward left
+        a = net.pose3d_estimator(fts[0].contiguous(), fts[1].contiguous(), hms[1])         # stand-alone: clears ITS arena, not the estimator's
+        assert torch.equal(st_h.amax.buf, recs) and int(recs.max()) > 0
         b = net.pose3d_estimator(fts[0], fts[1], hms[1])                                   # the estimator's tensors, records intact
-    assert len(recs) > 0 and all(torch.equal(x, y) for x, y in zip(recs, after)) and all(int(x.max()) > 0 for x in recs)
+        assert st_p.amax is not st_h.amax
     for p, q, r in zip(preds, a, b):
         assert torch.equal(p, q) and torch.equal(p, r)
     assert hip.ARENA_EXHAUSTED == before

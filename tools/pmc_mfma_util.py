@@ -23,13 +23,14 @@ for r in csv.DictReader(open(f)):
         per[kk][r["Counter_Name"]] += float(r["Counter_Value"])
         if ("t", r["Dispatch_Id"]) not in seen:
             seen.add(("t", r["Dispatch_Id"])); dur[kk] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-    if "conv_tapx_kernel" not in n and ("conv_igemm_tap" in n or "conv_pw_x6" in n or "conv_igemm_x6" in n) and h2:
+    chain = "conv_pw_chain_kernel" in n          # chained 1x1 pairs (fp16 scheme only): booked with the streaming / tiled kernels
+    if "conv_tapx_kernel" not in n and ((("conv_igemm_tap" in n or "conv_pw_x6" in n or "conv_igemm_x6" in n) and h2) or chain):
         kk = "conv_other_split_f16x2"      # what is left on the tap-sharing / streaming / tiled kernels
         per[kk][r["Counter_Name"]] += float(r["Counter_Value"])
         if ("o", r["Dispatch_Id"]) not in seen:
             seen.add(("o", r["Dispatch_Id"])); dur[kk] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-    h2 = h2 or "conv_tapx_kernel" in n
-    k = (("conv_igemm_f16x2" if h2 else ("conv_igemm_bf16x3" if x6 else "conv_igemm")) if ("conv_igemm" in n or "conv_pw_x6" in n or "conv_tapx_kernel" in n) else
+    h2 = h2 or "conv_tapx_kernel" in n or chain
+    k = (("conv_igemm_f16x2" if h2 else ("conv_igemm_bf16x3" if x6 else "conv_igemm")) if ("conv_igemm" in n or "conv_pw_x6" in n or "conv_tapx_kernel" in n or chain) else
          (("conv_wgrad_f16x2" if h2w else ("conv_wgrad_bf16x3" if x6w else "conv_wgrad")) if "conv_wgrad" in n else
           (("stem_f16x2" if h2s else "stem_bf16x3") if "stem_x6_kernel" in n else ("stem" if "stem_kernel" in n else ("wstream_f16x2" if "ws_stream_kernel" in n else "other")))))
     per[k][r["Counter_Name"]] += float(r["Counter_Value"])

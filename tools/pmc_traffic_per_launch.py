@@ -11,7 +11,7 @@ def per_dispatch(d, counter):
     val = collections.OrderedDict()
     for r in csv.DictReader(open(f)):
         nm = r["Kernel_Name"]
-        if r["Counter_Name"] != counter or not ("conv_igemm" in nm or "conv_pw_x6" in nm or "conv_tapx_kernel" in nm or "linear_small_kernel" in nm):
+        if r["Counter_Name"] != counter or not ("conv_igemm" in nm or "conv_pw_x6" in nm or "conv_tapx_kernel" in nm or "conv_pw_chain_kernel" in nm or "linear_small_kernel" in nm):
             continue
         k = int(r["Dispatch_Id"])
         val[k] = val.get(k, 0.0) + float(r["Counter_Value"])
@@ -22,7 +22,7 @@ fetch, write = per_dispatch(sys.argv[1], "FETCH_SIZE"), per_dispatch(sys.argv[2]
 forwards = int(sys.argv[4]) if len(sys.argv) > 4 else 12
 tags = []
 for l in open(sys.argv[3]):
-    m = re.match(r"\s*\d+\s+([\d.]+) us\s+egr_conv2d_nhwc_f32\s+(.*)", l)
+    m = re.match(r"\s*\d+\s+([\d.]+) us\s+(?:egr_conv2d_nhwc_f32|egr_conv1x1_chain_f32)\s+(.*)", l)
     if m:
         tags.append((float(m.group(1)), m.group(2).strip()))
 per = len(tags)
@@ -33,7 +33,8 @@ tot_a = tot_h = 0.0
 for i, (us, tag) in enumerate(tags):
     m = re.search(r"G(\d+) M(\d+) N(\d+) K(\d+) k(\d)s(\d) cin(\d+)", tag)
     G, M, N, K, k, s_, cin = map(int, m.groups())
-    alg = 4.0 * G * (M * N + M * s_ * s_ * cin + N * K)
+    mid = re.search(r" mid(\d+)", tag)           # chained 1x1 pair: both weight matrices, no intermediate tensor
+    alg = 4.0 * G * (M * N + M * s_ * s_ * cin + N * K + (int(mid.group(1)) * (K + N) - N * K if mid else 0))
     fs = [2.0 * fetch[f_ * per + i] for f_ in range(2, 6)]
     ws = [write[f_ * per + i] for f_ in range(2, 6)]
     fm, wm = sum(fs) / len(fs), sum(ws) / len(ws)
