@@ -10,11 +10,15 @@ batch-of-frames axis with no data-path collective ("weak" scaling: B frames per 
 is printed by rank 0.  A "step" is one forward of B frames.
 
 Extra objects on the line:
-  roofline     — dominant kernel (the implicit-GEMM conv/linear kernel; "[bf16x3]" = its split-bf16 launches, which are
-                 the bulk): FLOPs of its launches / their summed duration, measured with HIP events on the launch stream
-                 in an instrumented pass right after the timed region.  Split launches execute 6 bf16 MFMA products per
-                 fp32 product: achieved = 6 x algorithmic rate against the bf16 dense peak (2516.6 TFLOP/s); the
-                 algorithmic rate is given beside it (`algorithmic_tflops`; the fp32 matrix cores peak at 157.3).
+  roofline     — dominant kernel (the implicit-GEMM conv/linear entry point; "[f16x2]" = its fp16-scheme launches, which are
+                 the bulk; the chained-1x1 launches of round 5 are booked with it): FLOPs of its launches / their summed
+                 duration, measured with HIP events on the launch stream in an instrumented pass right after the timed region.
+                 fp16-scheme launches execute 3 fp16 MFMA products per fp32 product: achieved = 3 x algorithmic rate against the
+                 16-bit dense peak (2516.6 TFLOP/s); the algorithmic rate is given beside it (`algorithmic_tflops`).
+                 `families` prices the 3x3 launches (MFMA-bound) and the 1x1 launches (HBM-bound) each against its own roof;
+                 the same figures as scalars: frac_conv3x3, conv3x3_ms, conv1x1_GBps, frac_conv1x1_hbm, conv1x1_ms;
+                 traffic (+ traffic_commit / traffic_file) = HBM bytes per launch replayed from the committed PMC passes.
+  exact_leg    — the same forward in exact operand arithmetic (bf16x3, six products), 50 steps: prices the 22-bit trade.
   cpu_baseline — the CPU oracle (oracle/egorear_oracle.py, a PyTorch-CPU port of the reference path)
                  timed on this box's host cores on a bounded sample of the same workload.
   parity_vs_cpu_oracle — the metric's "MPJPE vs ref" half: the oracle's warm-up forward of that sample checks the HIP
@@ -113,6 +117,41 @@ def _family_roofs(fams: dict) -> dict:
     return out
 
 
+def exact_leg(net, img, B: int, lanes: int, steps: int = 50):
+    """The 22-bit trade of the headline, priced in the same run: frames/s of the SAME forward (same weights, batch, lanes, hipGraph
+    replay) in exact operand arithmetic - every fp32 operand of the large contractions as the exact sum of three bf16 numbers, six
+    products (EGR_W_FORMAT=bf16x3), the fused transformer layers on the fp32 matrix cores.  Never `value`."""
+    import torch
+    from egorear_amd import engine, hip
+    from egorear_amd.runner import PipelinedForward
+    saved = (hip.H2, engine.LAYER_H2, engine.W_FORMAT)
+    mods = (net, net.heatmap_estimator, net.pose3d_estimator)
+    try:
+        hip.H2, engine.LAYER_H2, engine.W_FORMAT = False, False, "bf16x3"
+        for m in mods:
+            engine.invalidate(m)               # packs and scratch are rebuilt for the other format
+        with torch.no_grad():
+            net(img)
+            torch.cuda.synchronize()
+            if lanes > 1:
+                pipe = PipelinedForward(net, lanes=lanes, copy_inputs=False)
+                pipe.prime(img)
+                ms = _gpu_time_ms(lambda: pipe(img), 5, steps, join=pipe.wait)
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    net(img)
+                ms = _gpu_time_ms(g.replay, 5, steps)
+        return {"value": round(B / ms * 1e3, 2), "unit": "frames/s", "ms_per_step": round(ms, 3), "steps": steps, "batch_per_gpu": B,
+                "dtype": "f32 (bf16x3 split, exact operands, fp32 accumulate)",
+                "what": "same forward, weights, batch and launch mode as `value` with EGR_W_FORMAT=bf16x3 arithmetic: what the fp16 scheme's "
+                        "22-bit operands buy (parity of this leg: tests/test_gpu_bf16x3_leg.py)"}
+    finally:
+        hip.H2, engine.LAYER_H2, engine.W_FORMAT = saved
+        for m in mods:
+            engine.invalidate(m)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,6 +169,7 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=28)      # ~12 s of CPU work on the GPU box's 16 host threads
     ap.add_argument("--no-train", action="store_true", help="skip the training-step leg (config 5)")
     ap.add_argument("--no-configs", action="store_true", help="skip the config 1-3 legs")
+    ap.add_argument("--no-exact", action="store_true", help="skip the exact-arithmetic (bf16x3) leg")
     ap.add_argument("--train-batch", type=int, default=32, help="frames per GPU per optimisation step (config 5: 256 / 8)")
     ap.add_argument("--train-steps", type=int, default=10)
     return ap.parse_args()
@@ -142,6 +182,19 @@ def _host_cores() -> int:
     except AttributeError:
         n = os.cpu_count() or 1
     return max(1, min(n, int(os.environ.get("EGR_CPU_THREADS", "16"))))
+
+
+def _cpu_model() -> str:
+    """Model name of the host CPU the baselines run on ("core count and CPU model printed")."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine() or "unknown"
 
 
 def _natural(path: str):
@@ -268,7 +321,7 @@ def cpu_baseline(state_dict, batch: int, iters: int, gpu_out=None):
         for _ in range(iters):
             O.mvfex_forward(state_dict, cams, img)
         dt = time.perf_counter() - t0
-    return {"value": round(batch * iters / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+    return {"value": round(batch * iters / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
             "sample": f"{iters} forwards of batch {batch} (config ego4view_syn_pose3d, eval/no_grad, torch-CPU fp32, "
                       f"{cores} threads), {dt:.1f} s"}, parity
 
@@ -295,7 +348,7 @@ def cpu_train_baseline(batch: int = 4, iters: int = 7):
     for _ in range(iters):
         ref.step(*args_)
     dt = time.perf_counter() - t0
-    return {"value": round(batch * iters / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+    return {"value": round(batch * iters / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
             "sample": f"{iters} optimisation steps of batch {batch} (train-mode forward, autograd backward, clip, torch AdamW; torch-CPU fp32, {cores} threads), {dt:.1f} s"}
 
 
@@ -315,7 +368,16 @@ def roofline_hbm(kernels: dict, pre_leg) -> list:
             e = {"kernel": name, "launches_per_step": k["launches"], "ms_per_step": round(k["ms"], 3), "algorithmic_GBps": round(gbs, 1),
                  "peak": PEAK_HBM_GBS, "frac": round(gbs / PEAK_HBM_GBS, 4)}
             if name == "egr_msda_gather_f32":
-                e["note"] = "sampled-corner bytes: a 64x64x128 feature map (2 MB per view) is re-read 60-64 times per frame from L2, so this is an L2 gather rate, not HBM traffic"
+                # Priced on UNIQUE bytes (what HBM has to deliver: every feature map once + the per-row operands and outputs); the
+                # sampled-corner rate (every corner of every sample counted) is an L2 gather rate and is reported beside it, against
+                # no HBM peak.  k["unique_bytes"] is filled in from the launch tags by the caller.
+                ub = k.get("unique_bytes", 0.0)
+                e["l2_gather_GBps"] = e.pop("algorithmic_GBps")
+                e["algorithmic_GBps"] = round(ub / k["ms"] / 1e6, 1)
+                e["frac"] = round(ub / k["ms"] / 1e6 / PEAK_HBM_GBS, 4)
+                e["note"] = ("frac / algorithmic_GBps: unique bytes (feature maps once + offsets / logits / anchors + sampled rows out) against the HBM peak - "
+                             "the kernel is not HBM-bound; l2_gather_GBps: sampled-corner bytes (a 64x64x128 map, 2 MB per view, is re-read 60-64 "
+                             "times per frame out of L2) - an L2 gather rate, priced against no HBM roof")
             if name in ("egr_stem_conv7x7_f32", "egr_stem_conv7x7_x6_f32[bf16x3]", "egr_stem_conv7x7_x6_f32[f16x2]", "egr_up2_relu_head_f32"):
                 e["note"] = "matrix-core kernel with a memory-bound output side; its MFMA rate is in kernel_ms / DESIGN.md"
             out.append(e)
@@ -415,7 +477,7 @@ def config_legs(args, dev, with_cpu: bool):
             ms1 = _gpu_time_ms(lambda: front(img_f[:1]), 3, 20)
             legs["config1_heatmap_stereo_front_b1"] = {
                 "workload": "ego4view_syn_heatmap_stereo_front, batch 1, 2 views (13.63 GFLOP per two-view frame)",
-                "cpu_baseline": {"value": round(n_it / dt, 2), "unit": "two-view frames/s", "cores": cores, "kind": "port",
+                "cpu_baseline": {"value": round(n_it / dt, 2), "unit": "two-view frames/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
                                  "sample": f"{n_it} forwards of batch 1 (torch-CPU fp32, {cores} threads), {dt:.2f} s"},
                 "gpu": {"value": round(1e3 / ms1, 1), "unit": "two-view frames/s", "ms_per_step": round(ms1, 3), "launch": "eager"}}
     del net, g_front, g_back, g_net
@@ -545,7 +607,7 @@ def train_leg(args, dev, rank: int, world: int, backend: str):
             k["bytes"] += nbytes
     leg = {"metric": "training 4-view frames/sec (fwd + bwd + grad all-reduce + clip + AdamW)",
            "value": round(world * B * args.train_steps / elapsed, 2), "unit": "frames/s", "ms_per_step": round(1e3 * elapsed / args.train_steps, 3),
-           "steps": args.train_steps, "batch_per_gpu": B, "global_batch": B * world, "dtype": "f32", "data": "synthetic",
+           "steps": args.train_steps, "batch_per_gpu": B, "global_batch": B * world, "dtype": DTYPE_NOTE, "data": "synthetic",
            "workload": "ego4view_rw_pose3d fine-tune step (config 5): train-mode BatchNorm, MPJPE x4 + heat-map row-norm x2 losses, "
                        "all 126 M parameters, gradient-norm clip 5.0, AdamW(1e-3, wd 5e-4, two groups)",
            "parallelism": f"dp{world}: frames sharded, stage-bucketed gradient all-reduce overlapped with backward" if world > 1 else "single GPU",
@@ -712,10 +774,25 @@ def main():
                     k["ms"] += ms_l
                     k["flops"] += flops
                     k["bytes"] += nbytes
+                    if tag.startswith("unique") and tag[6:].isdigit():
+                        k["unique_bytes"] = k.get("unique_bytes", 0.0) + float(tag[6:])
             dom = max(kernels, key=lambda n: kernels[n]["ms"])
             roof = _roofline(dom, kernels[dom], _pmc_traffic(B, "f16x2" if dom.endswith("[f16x2]") else ("bf16x3" if dom.endswith("[bf16x3]") else "f32"),
                                                              kernels[dom]["launches"]))
             roof["families"] = _family_roofs(fams)
+            # the same per-family figures as SCALAR keys (a parser that keeps scalars only loses `families`)
+            f3, f1 = roof["families"].get("conv3x3[f16x2]"), roof["families"].get("conv1x1[f16x2]")
+            if f3:
+                roof["frac_conv3x3"] = f3["frac"]                          # executed fp16 MFMA rate of the 3x3 launches / 2516.6 TFLOP/s
+                roof["conv3x3_algorithmic_tflops"] = f3["algorithmic_tflops"]
+                roof["conv3x3_ms"] = f3["kernel_ms_per_step"]
+            if f1:
+                roof["conv1x1_GBps"] = f1["achieved"]                      # algorithmic bytes / time of the 1x1 launches (HBM roof 8000)
+                roof["frac_conv1x1_hbm"] = f1["frac"]
+                roof["conv1x1_ms"] = f1["kernel_ms_per_step"]
+            ts = roof.get("traffic_source") or {}
+            roof["traffic_commit"] = ts.get("commit")                      # commit the replayed PMC passes were collected at (null: no traffic figure)
+            roof["traffic_file"] = ts.get("replayed_from")
             roof["all_kernels_ms_per_step"] = round(sum(v["ms"] for v in kernels.values()), 3)
             roof["note"] = ("kernel times come from ONE instrumented eager forward after the timed region (a HIP event pair around every launch, one stream): "
                             "their sum can exceed ms_per_step, which is a hipGraph replay without the events and without host launch gaps"
@@ -772,6 +849,13 @@ def main():
             del raw_b
         except Exception as exc:  # never at the expense of the main line
             pre_leg["from_raw_frames"] = {"error": f"{type(exc).__name__}: {exc}"}
+    exact = None
+    if rank == 0 and world == 1 and W_FORMAT == "f16x2" and use_graph and not args.no_exact:
+        _log("exact-arithmetic leg (bf16x3)")
+        try:
+            exact = exact_leg(net, img, B, args.lanes)
+        except Exception as exc:  # never at the expense of the main line
+            exact = {"error": f"{type(exc).__name__}: {exc}"}
     cfg_legs = None
     if rank == 0 and world == 1 and not args.no_configs:
         _log("config 2 / 3 legs (+ config 1 on the CPU)")
@@ -808,6 +892,7 @@ def main():
                                   f"{args.lanes} hipGraphs (one captured forward per lane) replayed round-robin on {args.lanes} streams: consecutive steps overlap"),
                        "arithmetic": ARITHMETIC},
             "steady_state": steady,
+            "exact_leg": exact,
             "path_tflops_per_gpu": round(fps / world * GFLOP_PER_FRAME / 1e3, 2),
             "path_frac_of_f32_mfma_peak": round(fps / world * GFLOP_PER_FRAME / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),  # > 1 is possible: most contractions run on the bf16 matrix cores
             "roofline": roof,

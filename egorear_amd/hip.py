@@ -1040,7 +1040,10 @@ def msda_gather(feat: torch.Tensor, pos: Optional[torch.Tensor], offs_logits: to
                                    joints, heads, hgt, wid, _p(g), _p(e), _p(sigma), _p(rowmask, torch.uint8), groups, _stream(),
             # algorithmic bytes: 16 points x 4 bilinear corners x (cf + dh) floats per (query set, row, head) gathered (served
             # mostly by L2), the offsets / logits read, g / e / sigma written
-            nbytes=4.0 * groups * rows * heads * (64.0 * (cf + (dh if pos is not None else 0)) + 48 + cf + (dh if pos is not None else 0) + 1))
+            nbytes=4.0 * groups * rows * heads * (64.0 * (cf + (dh if pos is not None else 0)) + 48 + cf + (dh if pos is not None else 0) + 1),
+            # unique bytes (what HBM must deliver at least: every operand once, every output once) for bench.py's roofline_hbm entry
+            tag=("unique%d" % (4 * (feat.numel() + (pos.numel() if pos is not None else 0) + offs_logits.numel() + anchors.numel() + g.numel()
+                                    + (e.numel() if e is not None else 0) + sigma.numel()) + valid.numel() + rowmask.numel())) if PROFILE is not None else "")
     return g, e, sigma, rowmask
 
 
