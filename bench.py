@@ -375,8 +375,10 @@ def roofline_hbm(kernels: dict, pre_leg) -> list:
                 e["l2_gather_GBps"] = e.pop("algorithmic_GBps")
                 e["algorithmic_GBps"] = round(ub / k["ms"] / 1e6, 1)
                 e["frac"] = round(ub / k["ms"] / 1e6 / PEAK_HBM_GBS, 4)
-                e["note"] = ("frac / algorithmic_GBps: unique bytes (feature maps once + offsets / logits / anchors + sampled rows out) against the HBM peak - "
-                             "the kernel is not HBM-bound; l2_gather_GBps: sampled-corner bytes (a 64x64x128 map, 2 MB per view, is re-read 60-64 "
+                e["bound"] = "l2 gather"
+                e["note"] = ("frac / algorithmic_GBps: an UPPER bound of the unique bytes (every feature map and positional table once + offsets / logits / "
+                             "anchors + sampled rows out; the samples touch only part of each map, and the maps were written by the launches just before - "
+                             "the 256-MB infinity cache serves most of them) against the HBM peak - the kernel is not HBM-bound; l2_gather_GBps: sampled-corner bytes (a 64x64x128 map, 2 MB per view, is re-read 60-64 "
                              "times per frame out of L2) - an L2 gather rate, priced against no HBM roof")
             if name in ("egr_stem_conv7x7_f32", "egr_stem_conv7x7_x6_f32[bf16x3]", "egr_stem_conv7x7_x6_f32[f16x2]", "egr_up2_relu_head_f32"):
                 e["note"] = "matrix-core kernel with a memory-bound output side; its MFMA rate is in kernel_ms / DESIGN.md"

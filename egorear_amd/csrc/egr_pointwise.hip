@@ -262,8 +262,9 @@ __global__ __launch_bounds__(256) void tokens_to_nhwc_kernel(const float* x, flo
 // 64 x 64 that would sit between them (written by the upsample, read back by a 15-output conv that is pure HBM traffic)
 // never exists.  A workgroup owns 8 x 32 output pixels and stages their (<= 6 x 18) low-resolution source pixels in LDS
 // (pixel stride cin + 4 floats: the 16 pixels of an MFMA group hit different banks).  The 1x1 conv runs on
-// v_mfma_f32_16x16x4_f32 with N = 16 output channels: lane l supplies a[pixel l%16][channel 4s + l/16], computed on the
-// fly (four source reads, the upsample kernel's interpolation arithmetic, ReLU), and b from registers (the filter,
+// v_mfma_f32_16x16x4_f32 with N = 16 output channels: lane l supplies a[pixel l%16][k = l/16] of step s = channel
+// 16 (s/4) + 4 (l/16) + s%4, computed on the fly (four 16-byte source reads per 16-channel block, the upsample kernel's
+// interpolation arithmetic, ReLU), and b from registers (the filter,
 // 32 floats per lane, loaded once); D[pixel][co] leaves as one 16-byte store of 4 consecutive pixels per lane.
 #ifndef HT_ROWS
 #define HT_ROWS 8     // (4-row tiles, four workgroups per CU instead of two: 141 us per launch against 119)
@@ -274,7 +275,7 @@ typedef float f32x4_mfma __attribute__((ext_vector_type(4)));
 
 // CIN > 0: the channel count at compile time (the path's heads: 128) - the 32-step K loop is straight-line code the compiler
 // can software-pipeline (with a run-time trip count it stayed a rolled loop of read -> wait -> interpolate -> MFMA: 160 us
-// per launch).  CIN == 0: any multiple of 4 up to HT_MAXCIN.
+// per launch).  CIN == 0: any multiple of 16 up to HT_MAXCIN.
 template <int CIN>
 __global__ __launch_bounds__(256) void up2_relu_head_kernel(const float* lo, int h, int w, int cin_rt, const float* wgt, const float* bias,
                                                             int cout, float* planes, egr_nmap map, int npg, int64_t gy) {
@@ -318,12 +319,15 @@ __global__ __launch_bounds__(256) void up2_relu_head_kernel(const float* lo, int
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pj = lane & 15, kq = lane >> 4;                   // MFMA roles: A row / B column pj, k index kq
-    // filter: b[s] = W[co = pj][channel 4s + kq] (zero rows above cout)
+    // K order: step s = 4j + r multiplies channel 16j + 4kq + r of lane kq (any bijection of (step, kq) onto the channels serves - the
+    // sum runs over all of them): a lane's four steps of a block j are FOUR CONSECUTIVE channels, so every source corner is one 16-byte
+    // LDS read per block instead of four 4-byte ones (round 5: the loop was bound by LDS instruction issue, not bytes)
+    // filter: b[s] = W[co = pj][channel 16 (s / 4) + 4 kq + s % 4] (zero rows above cout)
     const float* wg = wgt + (int64_t)grp * cout * cin;
     float bw[HT_MAXCIN / 4];
     const int ksteps = cin >> 2;
 #pragma unroll
-    for (int s_ = 0; s_ < HT_MAXCIN / 4; ++s_) bw[s_] = (s_ < ksteps && pj < cout) ? wg[pj * cin + 4 * s_ + kq] : 0.f;
+    for (int s_ = 0; s_ < HT_MAXCIN / 4; ++s_) bw[s_] = (s_ < ksteps && pj < cout) ? wg[pj * cin + 16 * (s_ >> 2) + 4 * kq + (s_ & 3)] : 0.f;
     __syncthreads();
 
     const float* bg = bias ? bias + grp * cout : nullptr;
@@ -342,50 +346,46 @@ __global__ __launch_bounds__(256) void up2_relu_head_kernel(const float* lo, int
         const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
         wy1[mg] = fminf(fmaxf(fy - (float)y0, 0.f), 1.f); wx1[mg] = fminf(fmaxf(fx - (float)x0, 0.f), 1.f);
         wy0[mg] = 1.f - wy1[mg]; wx0[mg] = 1.f - wx1[mg];
-        q00[mg] = s_src + ((y0 - sy0) * HT_SRC_W + (x0 - sx0)) * ld + kq;
-        q01[mg] = s_src + ((y0 - sy0) * HT_SRC_W + (x1 - sx0)) * ld + kq;
-        q10[mg] = s_src + ((y1 - sy0) * HT_SRC_W + (x0 - sx0)) * ld + kq;
-        q11[mg] = s_src + ((y1 - sy0) * HT_SRC_W + (x1 - sx0)) * ld + kq;
+        q00[mg] = s_src + ((y0 - sy0) * HT_SRC_W + (x0 - sx0)) * ld + 4 * kq;
+        q01[mg] = s_src + ((y0 - sy0) * HT_SRC_W + (x1 - sx0)) * ld + 4 * kq;
+        q10[mg] = s_src + ((y1 - sy0) * HT_SRC_W + (x0 - sx0)) * ld + 4 * kq;
+        q11[mg] = s_src + ((y1 - sy0) * HT_SRC_W + (x1 - sx0)) * ld + 4 * kq;
     }
     f32x4_mfma acc[HT_NG];
 #pragma unroll
     for (int mg = 0; mg < HT_NG; ++mg) acc[mg] = f32x4_mfma{0.f, 0.f, 0.f, 0.f};
-    // the four source values of every chain, two K steps at a time, one pair of steps ahead of their use (pinned: left to
-    // itself the scheduler consumed each LDS read right behind its issue and the wave sat through the LDS latency 32 times).
-    // Vectors over the step pair: a ds_read2_b32 delivers both steps' values in adjacent registers, and the interpolation is
-    // 6 packed instructions (+ 2 max) per chain and step pair instead of 11 scalar ones per step.
-    f32x2 sv[2][HT_NG][4];
-    auto fetch = [&](int s2, int par) {
+    // the four source quads of every chain, one 16-channel block ahead of their use (pinned: left to itself the scheduler consumed
+    // each LDS read right behind its issue and the wave sat through the LDS latency every block)
+    f32x4 sv[2][HT_NG][4];
+    auto fetch = [&](int j, int par) {
 #pragma unroll
-        for (int mg = 0; mg < HT_NG; ++mg)
-#pragma unroll
-            for (int z = 0; z < 2; ++z) {
-                sv[par][mg][0][z] = q00[mg][4 * (2 * s2 + z)];
-                sv[par][mg][1][z] = q01[mg][4 * (2 * s2 + z)];
-                sv[par][mg][2][z] = q10[mg][4 * (2 * s2 + z)];
-                sv[par][mg][3][z] = q11[mg][4 * (2 * s2 + z)];
-            }
+        for (int mg = 0; mg < HT_NG; ++mg) {
+            sv[par][mg][0] = *reinterpret_cast<const f32x4*>(q00[mg] + 16 * j);
+            sv[par][mg][1] = *reinterpret_cast<const f32x4*>(q01[mg] + 16 * j);
+            sv[par][mg][2] = *reinterpret_cast<const f32x4*>(q10[mg] + 16 * j);
+            sv[par][mg][3] = *reinterpret_cast<const f32x4*>(q11[mg] + 16 * j);
+        }
     };
-    const int kpairs = ksteps >> 1;          // (cin % 8 == 0 is checked by the host)
+    const int kblocks = ksteps >> 2;          // (cin % 16 == 0 is checked by the host)
     fetch(0, 0);
 #pragma unroll
-    for (int s2 = 0; s2 < HT_MAXCIN / 8; ++s2) {
-        if (s2 < kpairs) {
-            if (s2 + 1 < kpairs) fetch(s2 + 1, (s2 + 1) & 1);
+    for (int j = 0; j < HT_MAXCIN / 16; ++j) {
+        if (j < kblocks) {
+            if (j + 1 < kblocks) fetch(j + 1, (j + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
-            // (the two K steps of a chain are dependent MFMAs: issued chain by chain, the second waited out the first - 8 passes - every
-            // time; issued step by step, a chain's next MFMA is four instructions away: 122 -> 118 us)
-            f32x2 u[HT_NG];
+            f32x4 u[HT_NG];
 #pragma unroll
             for (int mg = 0; mg < HT_NG; ++mg) {
-                const f32x2* v = sv[s2 & 1][mg];
+                const f32x4* v = sv[j & 1][mg];
                 u[mg] = wy0[mg] * (wx0[mg] * v[0] + wx1[mg] * v[1]) + wy1[mg] * (wx0[mg] * v[2] + wx1[mg] * v[3]);
             }
-            // ReLU as one v_max (NaN -> 0, like the `t > 0 ? t : 0` of the conv epilogues)
+            // ReLU as one v_max (NaN -> 0, like the `t > 0 ? t : 0` of the conv epilogues); the four steps of a chain are dependent
+            // MFMAs: issued step by step over the chains, a chain's next MFMA is four instructions away
 #pragma unroll
-            for (int mg = 0; mg < HT_NG; ++mg) acc[mg] = __builtin_amdgcn_mfma_f32_16x16x4f32(fmaxf(u[mg][0], 0.f), bw[2 * s2], acc[mg], 0, 0, 0);
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int mg = 0; mg < HT_NG; ++mg) acc[mg] = __builtin_amdgcn_mfma_f32_16x16x4f32(fmaxf(u[mg][1], 0.f), bw[2 * s2 + 1], acc[mg], 0, 0, 0);
+                for (int mg = 0; mg < HT_NG; ++mg)
+                    acc[mg] = __builtin_amdgcn_mfma_f32_16x16x4f32(fmaxf(u[mg][r], 0.f), bw[4 * j + r], acc[mg], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -440,7 +440,7 @@ extern "C" int egr_up2_relu_head_f32(const float* lo, int32_t n, int32_t h, int3
                                      int32_t cout, float* planes, int32_t n_inner, int64_t stride_inner, int64_t stride_outer,
                                      int32_t groups, int64_t gy, void* stream) {
     if (!lo || !wgt || !planes) return EGR_ENULL;
-    if (n <= 0 || groups <= 0 || n % groups != 0 || h <= 0 || w <= 0 || cin <= 0 || cin % 8 != 0 || cin > HT_MAXCIN || cout <= 0 ||
+    if (n <= 0 || groups <= 0 || n % groups != 0 || h <= 0 || w <= 0 || cin <= 0 || cin % 16 != 0 || cin > HT_MAXCIN || cout <= 0 ||
         cout > HT_MAXCO || (2 * h) % HT_H != 0 || (2 * w) % HT_W != 0 || n_inner <= 0 || ((uintptr_t)planes & 15) ||
         ((stride_inner | stride_outer | gy) % 4 != 0))
         return EGR_EINVAL;

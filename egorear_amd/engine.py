@@ -336,7 +336,7 @@ def run_stack(st: State, seqs: Sequence[nn.Sequential], x: Img, out: Optional[Im
                 lo = conv(st, x, p, ACT_NONE)
                 fin = m0[i + 3] if i + 4 == len(m0) else None
                 if (isinstance(fin, nn.Conv2d) and fin.kernel_size == (1, 1) and fin.stride == (1, 1) and fin.out_channels <= 16
-                        and fin.in_channels <= 128 and last_kw is not None and "out_nchw" in last_kw and (2 * lo.h) % 8 == 0
+                        and fin.in_channels <= 128 and fin.in_channels % 16 == 0 and last_kw is not None and "out_nchw" in last_kw and (2 * lo.h) % 8 == 0
                         and (2 * lo.w) % 32 == 0):
                     # tail of a heat-map head: up x2 + ReLU + the final narrow 1x1 conv in one pass, straight into the
                     # (B, V, 15, H, W) planes; the 128-channel full-resolution tensor in between is never written

@@ -271,7 +271,7 @@ int egr_conv_set_persist(int slots, int max_ktiles);
  * (cin <= 128 -> cout <= 16, with bias) written as channel-major planes: lo (n, h, w, cin) NHWC, all groups' images back to back;
  * wgt (groups, cout, cin) plain row-major; image i of group g goes to planes + g*gy + nmap(i).  The cin-channel tensor at the
  * doubled resolution is never materialised.  Replaces `nn.Upsample -> ... -> ReLU -> Conv2d(128, 15, 1)` of
- * egoposeformer_heatmap_mvf_ex.py:101-126 (indices 6-9) and :570-584 (indices 4-7); 2h % 8 == 0, 2w % 32 == 0. */
+ * egoposeformer_heatmap_mvf_ex.py:101-126 (indices 6-9) and :570-584 (indices 4-7); 2h % 8 == 0, 2w % 32 == 0, cin % 16 == 0. */
 int egr_up2_relu_head_f32(const float* lo, int32_t n, int32_t h, int32_t w, int32_t cin, const float* wgt, const float* bias,
                           int32_t cout, float* planes, int32_t n_inner, int64_t stride_inner, int64_t stride_outer,
                           int32_t groups, int64_t gy, void* stream);
