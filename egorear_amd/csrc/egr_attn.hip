@@ -4,6 +4,12 @@
 
 namespace {
 
+// 1: the gather reads feature rows by half waves and positional slices by quarter waves (EGR_GATHER_WIDE=0: one corner per instruction)
+static const bool g_gather_wide_env = getenv("EGR_GATHER_WIDE") ? atoi(getenv("EGR_GATHER_WIDE")) != 0 : true;
+
+#ifndef GATHER_UNROLL
+#define GATHER_UNROLL 4    // (8 / 16 rows in flight measured no faster: the loop runs at ~60 % of the L1 rate, 21 TB/s of corner bytes at batch 64)
+#endif
 constexpr int NPTS = 16;  // n_points of MSDeformAttn (heatmap_mvf_ex.py:772, egoposeformer_mvf_ex.py:460)
 
 // ------------------------------------------------------------------ deformable sampling
@@ -15,7 +21,7 @@ constexpr int NPTS = 16;  // n_points of MSDeformAttn (heatmap_mvf_ex.py:772, eg
 // The value projection is linear, so sampling first and projecting the 960 sampled rows per frame
 // afterwards (egr_conv2d on g, with the per-row in-bounds mass sigma scaling the bias) gives the same
 // result as projecting all 4096 tokens per view and then sampling — at ~1/70 of the FLOPs.
-template <int CPL, bool POS>  // feature channels per lane = cf / 64; POS: the positional table is read as well
+template <int CPL, bool POS, bool WIDE>  // feature channels per lane = cf / 64; POS: the positional table is read as well
 __global__ __launch_bounds__(256) void msda_gather_kernel(const float* feat, const float* pos, int dh,
                                                           const float* offs_logits, const float* anchors,
                                                           const uint8_t* valid, int B, int V, int J, int heads, int hgt,
@@ -84,8 +90,82 @@ __global__ __launch_bounds__(256) void msda_gather_kernel(const float* feat, con
             sig = sp;
 #pragma unroll
             for (int c = 0; c < 4; ++c) cw[c] *= aw;
-            // ---- gather: (point, corner) list broadcast from the owning lane
+            // ---- gather.  WIDE form (round 5; the path's shapes: cf a multiple of 64, dh = 64 with the positional table): the loop was
+            // bound by the NUMBER of vector-memory instructions (64 + 64 per head, 8 / 4 bytes per lane), not by bytes - so a feature
+            // row is read by HALF a wave (16 bytes per lane at cf = 128) and every instruction fetches TWO corners, a positional slice by
+            // a QUARTER wave and every instruction fetches FOUR: 32 + 16 instructions per head.  The partial sums of the halves / quarters are added at the end (fixed order).
             const float* pbase = pos ? pos + (int64_t)v * hw * (heads * dh) + h * dh : nullptr;
+            if (WIDE && (!POS || dh == 64)) {
+                constexpr int VPL = 2 * CPL;                     // feature floats per lane: the half wave covers the row
+                const int half = lane >> 5, l32 = lane & 31, quarter = lane >> 4, l16 = lane & 15;
+                // the lane that broadcasts corner (point q, corner c) to a reader in half `hf` / quarter `qt` is lane q of the SAME half /
+                // quarter (every lane holds the corners of point lane & 15), with the corner picked by its own half / quarter
+                float selw[2], selq;
+                int seli[2], selqi;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) { selw[t] = half ? cw[2 * t + 1] : cw[2 * t]; seli[t] = half ? ci[2 * t + 1] : ci[2 * t]; }
+                selq = quarter == 0 ? cw[0] : (quarter == 1 ? cw[1] : (quarter == 2 ? cw[2] : cw[3]));
+                selqi = quarter == 0 ? ci[0] : (quarter == 1 ? ci[1] : (quarter == 2 ? ci[2] : ci[3]));
+                float af[VPL];
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) af[i] = 0.f;
+                // (zero-weight corners - outside the map - read pixel 0 instead of being skipped: without a branch in the loop several row
+                // reads stay in flight; with one every read waited for the read before it)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) seli[t] = (selw[t] == 0.f) ? 0 : seli[t];
+                selqi = (selq == 0.f) ? 0 : selqi;
+#pragma unroll GATHER_UNROLL
+                for (int st = 0; st < 2 * NPTS; ++st) {          // corner 2 st + half: point st / 2, corner 2 (st & 1) + half
+                    const int src = (st >> 1) + 32 * half;
+                    const float wgt = __shfl((st & 1) ? selw[1] : selw[0], src, 64);
+                    const int idx = __shfl((st & 1) ? seli[1] : seli[0], src, 64);
+                    {
+                        const float* fr = fbase + (int64_t)idx * cf + l32 * VPL;
+                        if constexpr (VPL == 4) {
+                            const f32x4 t = *reinterpret_cast<const f32x4*>(fr);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) af[i] = fmaf(wgt, t[i], af[i]);
+                        } else if constexpr (VPL == 8) {
+                            const f32x4 t0 = *reinterpret_cast<const f32x4*>(fr), t1 = *reinterpret_cast<const f32x4*>(fr + 4);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { af[i] = fmaf(wgt, t0[i], af[i]); af[4 + i] = fmaf(wgt, t1[i], af[4 + i]); }
+                        } else {
+                            const f32x2 t = *reinterpret_cast<const f32x2*>(fr);
+                            af[0] = fmaf(wgt, t[0], af[0]);
+                            af[1] = fmaf(wgt, t[1], af[1]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) af[i] += __shfl_xor(af[i], 32, 64);     // (both halves end with the row's sum)
+                f32x4 ae = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (POS) {
+#pragma unroll GATHER_UNROLL
+                    for (int st = 0; st < NPTS; ++st) {          // corner 4 st + quarter: point st, corner = quarter
+                        const int src = st + 16 * quarter;
+                        const float wgt = __shfl(selq, src, 64);
+                        const int idx = __shfl(selqi, src, 64);
+                        {
+                            const f32x4 t = *reinterpret_cast<const f32x4*>(pbase + (int64_t)idx * (heads * dh) + l16 * 4);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) ae[i] = fmaf(wgt, t[i], ae[i]);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        ae[i] += __shfl_xor(ae[i], 16, 64);
+                        ae[i] += __shfl_xor(ae[i], 32, 64);
+                    }
+                }
+                if (half == 0) {
+                    float* go = g + ((int64_t)row * heads + h) * cf + l32 * VPL;
+#pragma unroll
+                    for (int i = 0; i < VPL; ++i) go[i] = af[i];
+                }
+                if (POS && quarter == 0) *reinterpret_cast<f32x4*>(e + (int64_t)row * heads * dh + h * dh + l16 * 4) = ae;
+                if (lane == 0) sigma[(int64_t)h * gridDim.x + row] = sig;
+                continue;
+            }
             auto corner = [&](float wgt, int idx) {
                 const float* fr = fbase + (int64_t)idx * cf + lane * CPL;
                 if constexpr (CPL == 2) {
@@ -258,13 +338,21 @@ extern "C" int egr_msda_gather_f32(const float* feat, int32_t cf, const float* p
     if (rows >= (1LL << 31)) return EGR_EINVAL;
     dim3 grid((unsigned)rows, (unsigned)groups), block(64 * (heads < 4 ? heads : 4));
     hipStream_t s = (hipStream_t)stream;
+    // the wide form needs 16-byte aligned rows / slices
+    const bool wide = g_gather_wide_env && !(((uintptr_t)feat | (uintptr_t)pos | (uintptr_t)e) & 15) && (!pos || (dh == 64 && (heads * dh) % 4 == 0));
 #define EGR_GATHER(CPL_)                                                                                                            \
     do {                                                                                                                            \
-        if (pos)                                                                                                                    \
-            hipLaunchKernelGGL((msda_gather_kernel<CPL_, true>), grid, block, 0, s, feat, pos, dh, offs_logits, anchors, valid, b, views, \
+        if (pos && wide)                                                                                                            \
+            hipLaunchKernelGGL((msda_gather_kernel<CPL_, true, true>), grid, block, 0, s, feat, pos, dh, offs_logits, anchors, valid, b, views, \
+                               joints, heads, hgt, wid, g, e, sigma, rowmask);                                                      \
+        else if (pos)                                                                                                               \
+            hipLaunchKernelGGL((msda_gather_kernel<CPL_, true, false>), grid, block, 0, s, feat, pos, dh, offs_logits, anchors, valid, b, views, \
+                               joints, heads, hgt, wid, g, e, sigma, rowmask);                                                      \
+        else if (wide)                                                                                                              \
+            hipLaunchKernelGGL((msda_gather_kernel<CPL_, false, true>), grid, block, 0, s, feat, pos, dh, offs_logits, anchors, valid, b, views, \
                                joints, heads, hgt, wid, g, e, sigma, rowmask);                                                      \
         else                                                                                                                        \
-            hipLaunchKernelGGL((msda_gather_kernel<CPL_, false>), grid, block, 0, s, feat, pos, dh, offs_logits, anchors, valid, b, views, \
+            hipLaunchKernelGGL((msda_gather_kernel<CPL_, false, false>), grid, block, 0, s, feat, pos, dh, offs_logits, anchors, valid, b, views, \
                                joints, heads, hgt, wid, g, e, sigma, rowmask);                                                      \
     } while (0)
     if (cf == 128) EGR_GATHER(2);
