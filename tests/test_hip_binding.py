@@ -115,3 +115,75 @@ def test_grad_free_rule_names_real_parameters():
     assert all("heatmap_estimator_stereo_" in k for k in heads)
     assert len({k.split(".frame_feat_proj_layers.")[0] for k in proj}) == 4          # the four refiners
     assert len(names) - len(free) == 536                                             # the gradients the golden step holds
+
+
+def test_chain_entry_refuses_unsupported_shapes_before_any_launch():
+    """egr_conv1x1_chain_f32 (two 1x1 convs in one launch): every refusal of the C entry point comes back as a return code BEFORE a
+    kernel is launched - checked here without a GPU through the raw C ABI (fake, aligned pointers: none is dereferenced on these paths)."""
+    from egorear_amd import hip
+    lib = hip.lib
+
+    def desc(**kw):
+        d = hip.ConvDesc()
+        d.n, d.h, d.w, d.cin, d.cout = 2, 8, 8, 64, 128
+        d.kh = d.kw = d.stride = 1
+        d.pad, d.ho, d.wo = 0, 8, 8
+        d.ldx, d.ldy, d.ldr = 64, 128, 128
+        d.xmap = hip.NMap(2, 8 * 8 * 64, 0)
+        d.ymap = hip.NMap(2, 8 * 8 * 128, 0)
+        d.rmap = hip.NMap(1, 0, 0)
+        d.act, d.res_mode, d.split_k, d.groups, d.w_format = 1, 0, 1, 1, 4
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return d
+
+    P = 0x10000          # 16-byte aligned fake device pointer
+    aux = hip.ConvAux(P, P, None, None, None, 0)
+    ch = hip.ChainAux(P, P, None, 128, 1, 0, 0)
+
+    def call(d, x=P, w1=P, res=None, aux_=aux, ch_=ch):
+        return lib.egr_conv1x1_chain_f32(C.byref(d), x, w1, None, res, P, C.byref(aux_) if aux_ is not None else None,
+                                          C.byref(ch_) if ch_ is not None else None, None)
+
+    assert call(desc(), x=None) == hip.ENULL
+    assert call(desc(), aux_=None) == hip.ENULL
+    assert call(desc(), ch_=None) == hip.ENULL
+    assert call(desc(), aux_=hip.ConvAux(P, None, None, None, None, 0)) == hip.ENULL        # the input's abs-max record is required
+    assert call(desc(cin=96)) == hip.EINVAL                                                  # cin 64 / 128 only
+    assert call(desc(cout=132)) == hip.EINVAL and call(desc(cout=126)) == hip.EINVAL
+    assert call(desc(kh=3, kw=3, pad=1)) == hip.EINVAL and call(desc(stride=2, ho=4, wo=4)) == hip.EINVAL
+    assert call(desc(w_format=1)) == hip.EINVAL                                              # fp16 scheme only
+    assert call(desc(act=2)) == hip.EINVAL                                                   # GELU is not one of the chain's activations
+    assert call(desc(), ch_=hip.ChainAux(P, P, None, 64, 1, 0, 0)) == hip.EINVAL             # the intermediate has 128 channels
+    assert call(desc(res_mode=1), res=None) == hip.ENULL
+    assert call(desc(res_mode=3, ho=7, wo=7, h=7, w=7), res=P) == hip.EINVAL                 # up-sampled residual: even output size
+    assert call(desc(ldx=66)) == hip.EINVAL and call(desc(), x=P + 4) == hip.EINVAL          # 16-byte rows
+
+
+def test_chain_eligibility_rule():
+    from egorear_amd import hip
+
+    class W(hip.W6):
+        def __init__(self, npad, K, groups=1, h2=True):
+            super().__init__(None, npad, K, groups, 0)
+            self.h2 = object() if h2 else None
+
+    class X:
+        def __init__(self, n, h, w, c, amax=True):
+            self.n, self.h, self.w, self.c, self.amax = n, h, w, c, (object() if amax else None)
+
+    big = X(64, 64, 64, 64)
+    assert hip.chain_eligible(big, W(128, 64), W(128, 128), 128, 128, 1)
+    assert not hip.chain_eligible(X(64, 64, 64, 64, amax=False), W(128, 64), W(128, 128), 128, 128, 1)     # no record: no fp16 pre-scale
+    assert not hip.chain_eligible(big, W(128, 64, h2=False), W(128, 128), 128, 128, 1)
+    assert not hip.chain_eligible(big, W(128, 64), W(128, 128), 128, 128, 1, scale1=object())                # BatchNorm-scaled conv
+    assert not hip.chain_eligible(X(64, 64, 64, 256), W(128, 256), W(128, 128), 128, 128, 1)                 # cin 256: W1 does not fit LDS
+    assert not hip.chain_eligible(big, W(256, 64), W(128, 256), 256, 128, 1)                                 # 256-channel intermediate
+    assert not hip.chain_eligible(X(2, 8, 8, 64), W(128, 64), W(128, 128), 128, 128, 1)                      # too few pixels to stream
+    assert not hip.chain_eligible(X(63, 64, 64, 64), W(128, 64, groups=2), W(128, 128, groups=2), 128, 128, 2)   # images not divisible by groups
+    saved = hip.CHAIN
+    try:
+        hip.CHAIN = False
+        assert not hip.chain_eligible(big, W(128, 64), W(128, 128), 128, 128, 1)
+    finally:
+        hip.CHAIN = saved
