@@ -1,6 +1,7 @@
 // Joint-query attention kernels: deformable sampling (sample-then-project form), the 15/16-token
 // joint-to-joint attention core, and the fisheye anchor reprojection.
 #include "egr_common.h"
+#include "egr_fisheye.h"
 
 namespace {
 
@@ -264,28 +265,7 @@ __global__ __launch_bounds__(64) void joint_mha_kernel(const float* qkv, float* 
 }
 
 // ------------------------------------------------------------------ fisheye reprojection
-constexpr int CAM_REC = 17;  // [npoly, cx, cy, W, H, poly[12]]
-
-__device__ __forceinline__ void fisheye_one(const float* cam, float x, float y, float z, float* u_out, float* v_out,
-                                            uint8_t* ok_out) {
-    const int npoly = (int)cam[0];
-    const float cx = cam[1], cy = cam[2], W = cam[3], H = cam[4];
-    float norm = sqrtf(x * x + y * y);
-    float theta = atanf(-z / norm);
-    // rho = sum_i a_i * theta^i, left to right from 0 (utils/camera_models.py:85)
-    float rho = 0.f, pw = 1.f;
-    for (int i = 0; i < npoly; ++i) {
-        rho = rho + cam[5 + i] * pw;
-        pw *= theta;
-    }
-    float u = x / norm * rho + cx;
-    float v = y / norm * rho + cy;
-    u = u / W;
-    v = v / H;
-    *ok_out = (u > 0.f && v > 0.f && u < 1.f && v < 1.f) ? 1 : 0;
-    *u_out = fminf(fmaxf(u, 0.f), 1.f);
-    *v_out = fminf(fmaxf(v, 0.f), 1.f);
-}
+using egrf::CAM_REC;
 
 // pts_out receives the anchors the later layers add their offsets to: the mutated points in syn mode, a copy in rw mode (may be pts)
 __global__ __launch_bounds__(256) void fisheye_kernel(const float* pts, float* pts_out, const float* ctm, const float* cams, int B, int J,
@@ -294,30 +274,7 @@ __global__ __launch_bounds__(256) void fisheye_kernel(const float* pts, float* p
     if (idx >= B * J) return;
     const int b = idx / J, j = idx % J;
     float x = pts[idx * 3 + 0], y = pts[idx * 3 + 1], z = pts[idx * 3 + 2];
-    // ego4view_syn rigid offsets (cm): FL, FR, BL, BR; the back cameras flip x,y first (camera_models.py:29-40,59-63)
-    const float offx[4] = {6.f, -6.f, -6.f, 6.f};
-    const float offy[4] = {0.f, 0.f, 37.f, 37.f};
-    for (int c = 0; c < 4; ++c) {
-        float px, py, pz;
-        if (ctm) {  // rw: M . [p*0.01, 1] * 100, no mutation
-            const float* m = ctm + ((int64_t)b * 4 + c) * 16;
-            float sx = x * 0.01f, sy = y * 0.01f, sz = z * 0.01f;
-            px = (m[0] * sx + m[1] * sy + m[2] * sz + m[3]) * 100.f;
-            py = (m[4] * sx + m[5] * sy + m[6] * sz + m[7]) * 100.f;
-            pz = (m[8] * sx + m[9] * sy + m[10] * sz + m[11]) * 100.f;
-        } else {  // syn: the reference mutates its argument in place, so the four cameras chain (F7)
-            if (c >= 2) { x = x * -1.f; y = y * -1.f; }
-            x += offx[c]; y += offy[c]; z += 0.f;
-            px = x; py = y; pz = z;
-        }
-        float u, v;
-        uint8_t ok;
-        fisheye_one(cams + c * CAM_REC, px, py, pz, &u, &v, &ok);
-        int64_t o = ((int64_t)b * 4 + c) * J + j;
-        anchors[o * 2 + 0] = u;
-        anchors[o * 2 + 1] = v;
-        valid[o] = ok;
-    }
+    egrf::fisheye_joint(x, y, z, ctm, cams, b, j, J, anchors, valid);
     if (!ctm || pts_out != pts) { pts_out[idx * 3 + 0] = x; pts_out[idx * 3 + 1] = y; pts_out[idx * 3 + 2] = z; }
     q4[idx * 4 + 0] = (float)(j + 1) / (float)J;
     q4[idx * 4 + 1] = x; q4[idx * 4 + 2] = y; q4[idx * 4 + 3] = z;

@@ -30,6 +30,7 @@
 
 #include "egr_common.h"
 #include "egr_conv_shared.h"
+#include "egr_fisheye.h"
 
 namespace {
 
@@ -555,6 +556,63 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
                 const int r = idx / C, ch = idx - r * C;
                 d.xn_out[(xrow0 + r) * C + ch] = tile0[r * LC + ch];
             }
+        // ---- tail: the refiner's head offset (heatmap_mvf_ex.py:707-711 + TransformerHeadLayer.head[0..2]): the J x (s*s) token
+        // matrix IS an s x s image with the joints as channels (pixel p = channel p of xn); Conv2d(J, HN, 1) + ReLU on it (the fma chain of
+        // linear_smallk_kernel: k left to right, then the bias), then Upsample(x2, bilinear, align_corners) with upsample2x_kernel's
+        // arithmetic, straight to (2s, 2s, HN) NHWC - the launches egr_tokens_to_nhwc_f32, egr_linear_smallk_f32, egr_upsample2x_nhwc_f32
+        if constexpr (C == 256) {
+            if (d.w_h0) {
+                constexpr int S = 16, HN = 64;
+                float* const h0 = bufO;                       // [C pixels][HN]
+                float* const wT = bufG;                       // [J][HN] + bias [HN]
+                const float* const w_h0 = d.w_h0 + (int64_t)grp * HN * J;
+                for (int idx = tid; idx < HN * J; idx += NTH) {
+                    const int n = idx / J, jj = idx - n * J;
+                    wT[jj * HN + n] = w_h0[idx];
+                }
+                if (tid < HN) wT[J * HN + tid] = d.b_h0[grp * HN + tid];
+                __syncthreads();
+                float amx = 0.f;
+                {
+                    const int n = tid & (HN - 1);
+                    const float bb = wT[J * HN + n];
+                    for (int p = tid / HN; p < C; p += NTH / HN) {
+                        float s = 0.f;
+                        for (int jj = 0; jj < J; ++jj) s = fmaf(tile0[jj * LC + p], wT[jj * HN + n], s);
+                        s += bb;
+                        s = s > 0.f ? s : 0.f;
+                        h0[p * HN + n] = s;
+                        amx = fmaxf(amx, s);
+                    }
+                }
+                if (d.amax_h0) {        // an upper bound of |h0_out| (interpolation weights are non-negative and sum to 1): one atomic per wave
+                    amx = wave_max(amx);
+                    if (lane == 0 && amx > 0.f) atomicMax(d.amax_h0 + (blockIdx.x & 63), __float_as_uint(amx));
+                }
+                __syncthreads();
+                constexpr int SO = 2 * S;
+                const float sc = (float)(S - 1) / (float)(SO - 1);
+                const int cq = tid & (HN / 4 - 1), ox = tid / (HN / 4);          // 16 channel quads x 32 columns = 512 threads
+                static_assert(NTH == (HN / 4) * SO, "one thread per (column, channel quad)");
+                const float fx = sc * (float)ox;
+                const int x0 = (int)fx, x1 = min(x0 + 1, S - 1);
+                const float lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f), lx0 = 1.f - lx1;
+                float* const out = d.h0_out + ((int64_t)grp * B + fb) * SO * SO * HN;
+                for (int oy = 0; oy < SO; ++oy) {
+                    const float fy = sc * (float)oy;
+                    const int y0 = (int)fy, y1 = min(y0 + 1, S - 1);
+                    const float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), ly0 = 1.f - ly1;
+                    const f32x4_t v00 = *reinterpret_cast<const f32x4_t*>(h0 + (y0 * S + x0) * HN + cq * 4);
+                    const f32x4_t v01 = *reinterpret_cast<const f32x4_t*>(h0 + (y0 * S + x1) * HN + cq * 4);
+                    const f32x4_t v10 = *reinterpret_cast<const f32x4_t*>(h0 + (y1 * S + x0) * HN + cq * 4);
+                    const f32x4_t v11 = *reinterpret_cast<const f32x4_t*>(h0 + (y1 * S + x1) * HN + cq * 4);
+                    f32x4_t o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = ly0 * (lx0 * v00[i] + lx1 * v01[i]) + ly1 * (lx0 * v10[i] + lx1 * v11[i]);
+                    *reinterpret_cast<f32x4_t*>(out + ((int64_t)oy * SO + ox) * HN + cq * 4) = o;
+                }
+            }
+        }
         if (d.w_r0) {
             linear16(tile0, LC, d.w_r0 + grp * wsz(C, C), C, d.b_r0 + grp * C, C, bufG, LC, true, 12, -1);
             __syncthreads();
@@ -570,6 +628,287 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
         }
     }
     LSTAMP(9);
+}
+
+// ------------------------------------------------------------------ token chains in front of the layers (round 5)
+// The small launches between the big ones - the JQA query of a refiner and the decoder query of the lifting head - as ONE launch
+// each, built from the layer kernel's pieces: one workgroup per (query set, frame), the <= 16 tokens as one MFMA row block in LDS,
+// weights streamed in fragment order (w_packed as in egr_joint_layer_f32), intermediates never leave the CU.
+template <bool H2>
+struct TileGemm {
+    int lane, wave;
+    bool wpk;
+    unsigned* s_amax;
+    // epi(nb, acc) for the 16-column blocks nb = wave, wave + NW, ... of  A[16][K] . W^T (W: rows x K, its descales behind the image)
+    template <typename Epi>
+    __device__ __forceinline__ void run(const float* A, int lda, const float* W, int rows, int K, int slot, Epi&& epi) const {
+        if constexpr (H2) {
+            float sa, inv;
+            tile_prescale(s_amax[slot], sa, inv);
+            gemm_cols_h2<1, 1>(A, lda, 0, W, W + (int64_t)rows * K, K, wave, NW, rows / 16, lane, sa, inv, epi);
+        } else {
+            gemm_cols<1, 1>(A, lda, 0, W, K, 0, K, wave, NW, rows / 16, lane, wpk, epi);
+        }
+    }
+};
+
+// (query set, frame) of a workgroup: blocks b and b + 8 share an XCD - keep a query set's frames (same weights) on the same XCDs
+__device__ __forceinline__ void wg_group_frame(int bid, int G, int B, int& grp, int& fb) {
+    if (G > 1 && (8 % G) == 0 && ((G * B) % 8) == 0) {
+        const int per = 8 / G;
+        grp = (bid & 7) / per;
+        fb = (bid >> 3) * per + ((bid & 7) % per);
+    } else {
+        grp = bid / B;
+        fb = bid - grp * B;
+    }
+}
+
+struct JqaArgs {
+    egr_jqa_query_desc d;
+};
+
+// JQA query of HeatmapMVF.forward_feat_only (egoposeformer_heatmap_mvf_ex.py:655-665) behind heatmap_proj[0] + ReLU:
+//   hm_embed = heatmap_proj[2](t);  bfb = fc_bfb(adaptive_avg_pool2d(backbone_feat_bottom, 1));
+//   x = fc_query(ReLU)((joint_query_embed + bfb) + hm_embed);  and the layer's sampling_offsets / attention_weights Linear of x
+// = the launches egr_avgpool_nhwc_f32, 4 x egr_conv2d_nhwc_f32 (small), egr_jqa_sum_f32.
+template <int C, bool H2>
+__global__ __launch_bounds__(NTH) void jqa_query_kernel(const JqaArgs a) {
+    const egr_jqa_query_desc& d = a.d;
+    constexpr int LC = C + PAD, KB = 512;
+    __shared__ __attribute__((aligned(16))) float tA[16 * LC];
+    __shared__ __attribute__((aligned(16))) float tB[16 * LC];
+    __shared__ __attribute__((aligned(16))) float tC[16 * LC];
+    __shared__ __attribute__((aligned(16))) float tP[KB];
+    __shared__ unsigned s_amax[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, q4 = lane >> 4;
+    const int B = d.B, J = d.J, G = d.groups;
+    int grp, fb;
+    wg_group_frame(blockIdx.x, G, B, grp, fb);
+    const int64_t frame = (int64_t)grp * B + fb, xrow0 = frame * J;
+    auto wsz = [](int rows, int k) { return (int64_t)rows * k + (H2 ? rows : 0); };
+    const float* const w_hp2 = d.w_hp2 + grp * wsz(C, C);
+    const float* const w_bfb = d.w_bfb + grp * wsz(C, KB);
+    const float* const w_q = d.w_q + grp * wsz(C, C);
+    const float* const w_ol = d.w_ol + grp * wsz(d.ol_n, C);
+    const float* const b_hp2 = d.b_hp2 + grp * C;
+    const float* const b_bfb = d.b_bfb + grp * C;
+    const float* const b_q = d.b_q + grp * C;
+    const float* const b_ol = d.b_ol + grp * d.ol_n;
+    const float* const embed = d.embed + (int64_t)grp * J * C;
+    if (tid < 8) s_amax[tid] = 0u;
+    __syncthreads();
+    const TileGemm<H2> mm{lane, wave, d.w_packed != 0, s_amax};
+    // ---- the token rows behind heatmap_proj[0] (rows >= J: zeros) and the pooled stride-32 features (avgpool_kernel's chain)
+    {
+        float amx = 0.f;
+        for (int idx = tid; idx < 16 * (C / 4); idx += NTH) {
+            const int r = idx / (C / 4), c4 = idx - r * (C / 4);
+            f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+            if (r < J) v = *reinterpret_cast<const f32x4_t*>(d.t + (xrow0 + r) * C + c4 * 4);
+            *reinterpret_cast<f32x4_t*>(tA + r * LC + c4 * 4) = v;
+            amx = fmaxf(fmaxf(amx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
+        if constexpr (H2) tile_track(s_amax + 0, amx);
+        const int hw = d.pool_hw;
+        const float* const xp = d.s32 + frame * hw * KB;
+        float pmx = 0.f;
+        for (int ch = tid; ch < KB; ch += NTH) {
+            float sum = 0.f;
+            int p = 0;
+            for (; p + 8 <= hw; p += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = xp[(int64_t)(p + u) * KB + ch];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sum += v[u];
+            }
+            for (; p < hw; ++p) sum += xp[(int64_t)p * KB + ch];
+            sum = sum / (float)hw;
+            tP[ch] = sum;
+            pmx = fmaxf(pmx, fabsf(sum));
+        }
+        if constexpr (H2) tile_track(s_amax + 1, pmx);
+    }
+    __syncthreads();
+    // ---- hm_embed -> tB;  bfb -> tC (row stride 0: the one pooled row stands for all sixteen, every row of tC is fc_bfb's output)
+    mm.run(tA, LC, w_hp2, C, C, 0, [&](int nb, const f32x4_t (&acc)[1]) {
+        const int col = nb * 16 + i16;
+        const float bb = b_hp2[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tB[(4 * q4 + r) * LC + col] = acc[0][r] + bb;
+    });
+    mm.run(tP, 0, w_bfb, C, KB, 1, [&](int nb, const f32x4_t (&acc)[1]) {
+        const int col = nb * 16 + i16;
+        const float bb = b_bfb[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tC[(4 * q4 + r) * LC + col] = acc[0][r] + bb;
+    });
+    __syncthreads();
+    // ---- (joint_query_embed + bfb) + heatmap_embed, the reference's association order (jqa_sum_kernel)
+    {
+        float amx = 0.f;
+        for (int idx = tid; idx < 16 * C; idx += NTH) {
+            const int r = idx / C, ch = idx - r * C;
+            const float v = r < J ? (embed[r * C + ch] + tC[r * LC + ch]) + tB[r * LC + ch] : 0.f;
+            tA[r * LC + ch] = v;
+            amx = fmaxf(amx, fabsf(v));
+        }
+        if constexpr (H2) tile_track(s_amax + 2, amx);
+    }
+    __syncthreads();
+    // ---- fc_query + ReLU -> tB and x_out
+    {
+        float amx = 0.f;
+        mm.run(tA, LC, w_q, C, C, 2, [&](int nb, const f32x4_t (&acc)[1]) {
+            const int col = nb * 16 + i16;
+            const float bb = b_q[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * q4 + r;
+                float v = acc[0][r] + bb;
+                v = v > 0.f ? v : 0.f;
+                tB[row * LC + col] = v;
+                amx = fmaxf(amx, v);
+                if (row < J) d.x_out[(xrow0 + row) * C + col] = v;
+            }
+        });
+        if constexpr (H2) tile_track(s_amax + 3, amx);
+    }
+    __syncthreads();
+    // ---- the layer's sampling offsets / attention logits from the query
+    {
+        const int oln = d.ol_n;
+        mm.run(tB, LC, w_ol, oln, C, 3, [&](int nb, const f32x4_t (&acc)[1]) {
+            const int col = nb * 16 + i16;
+            const float bb = b_ol[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * q4 + r;
+                if (row < J) d.ol_out[(xrow0 + row) * oln + col] = acc[0][r] + bb;
+            }
+        });
+    }
+}
+
+struct PoseQArgs {
+    egr_pose_query_desc d;
+};
+
+// Lifting head between mlp_pred[1] and the first decoder layer (egoposeformer_mvf_ex.py:255-262, 317-322, 340-348, 400-410): one
+// workgroup per frame - mlp_pred[2] (the 3-D proposal), the fisheye reprojection of its joints into the four views, query_gen_mlp
+// (Linear(4, c) + ReLU, Linear + ReLU, Linear) and the first layer's sampling_offsets / attention_weights Linear
+// = the launches 4 x egr_conv2d_nhwc_f32 (small), egr_fisheye_project_f32, egr_linear_smallk_f32.
+template <int C, bool H2>
+__global__ __launch_bounds__(NTH) void pose_query_kernel(const PoseQArgs a) {
+    const egr_pose_query_desc& d = a.d;
+    constexpr int LC = C + PAD;
+    __shared__ __attribute__((aligned(16))) float tA[16 * LC];
+    __shared__ __attribute__((aligned(16))) float tB[16 * LC];
+    __shared__ __attribute__((aligned(16))) float tH[C];
+    __shared__ float s_pred[48], s_q4[16 * 4];
+    __shared__ unsigned s_amax[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, q4 = lane >> 4;
+    const int J = d.J, fb = blockIdx.x;
+    const int64_t xrow0 = (int64_t)fb * J;
+    if (tid < 8) s_amax[tid] = 0u;
+    __syncthreads();
+    const TileGemm<H2> mm{lane, wave, d.w_packed != 0, s_amax};
+    {
+        float amx = 0.f;
+        for (int ch = tid; ch < C; ch += NTH) {
+            const float v = d.h1[(int64_t)fb * C + ch];
+            tH[ch] = v;
+            amx = fmaxf(amx, fabsf(v));
+        }
+        if constexpr (H2) tile_track(s_amax + 0, amx);
+    }
+    __syncthreads();
+    // ---- mlp_pred[2]: C -> 3 J (every row of the product is the frame's one row; row 0 is kept)
+    mm.run(tH, 0, d.w_m2, 3 * J, C, 0, [&](int nb, const f32x4_t (&acc)[1]) {
+        const int col = nb * 16 + i16;
+        if (q4 == 0) s_pred[col] = acc[0][0] + d.b_m2[col];
+    });
+    __syncthreads();
+    // ---- proposal out, fisheye reprojection, decoder query input [ (j + 1) / J, mutated point ]
+    if (tid < J) {
+        const int j = tid;
+        float x = s_pred[3 * j], y = s_pred[3 * j + 1], z = s_pred[3 * j + 2];
+        float* const po = d.pred_out + (xrow0 + j) * 3;
+        po[0] = x; po[1] = y; po[2] = z;
+        egrf::fisheye_joint(x, y, z, d.ctm, d.cams, fb, j, J, d.anchors2d_out, d.valid_out);
+        float* const ao = d.anchors3d_out + (xrow0 + j) * 3;
+        ao[0] = x; ao[1] = y; ao[2] = z;
+        s_q4[j * 4 + 0] = (float)(j + 1) / (float)J;
+        s_q4[j * 4 + 1] = x; s_q4[j * 4 + 2] = y; s_q4[j * 4 + 3] = z;
+    }
+    __syncthreads();
+    // ---- query_gen_mlp[0]: Linear(4, C) + ReLU (linear_smallk_kernel's chain)
+    {
+        float amx = 0.f;
+        for (int idx = tid; idx < 16 * C; idx += NTH) {
+            const int r = idx / C, n = idx - r * C;
+            float v = 0.f;
+            if (r < J) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s = fmaf(s_q4[r * 4 + k], d.w_qg0[n * 4 + k], s);
+                s += d.b_qg0[n];
+                v = s > 0.f ? s : 0.f;
+            }
+            tA[r * LC + n] = v;
+            amx = fmaxf(amx, v);
+        }
+        if constexpr (H2) tile_track(s_amax + 1, amx);
+    }
+    __syncthreads();
+    {
+        float amx = 0.f;
+        mm.run(tA, LC, d.w_qg2, C, C, 1, [&](int nb, const f32x4_t (&acc)[1]) {
+            const int col = nb * 16 + i16;
+            const float bb = d.b_qg2[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[0][r] + bb;
+                v = v > 0.f ? v : 0.f;
+                tB[(4 * q4 + r) * LC + col] = v;
+                amx = fmaxf(amx, v);
+            }
+        });
+        if constexpr (H2) tile_track(s_amax + 2, amx);
+    }
+    __syncthreads();
+    {
+        float amx = 0.f;
+        mm.run(tB, LC, d.w_qg4, C, C, 2, [&](int nb, const f32x4_t (&acc)[1]) {
+            const int col = nb * 16 + i16;
+            const float bb = d.b_qg4[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * q4 + r;
+                const float v = acc[0][r] + bb;
+                tA[row * LC + col] = v;
+                amx = fmaxf(amx, fabsf(v));
+                if (row < J) d.x_out[(xrow0 + row) * C + col] = v;
+            }
+        });
+        if constexpr (H2) tile_track(s_amax + 3, amx);
+    }
+    __syncthreads();
+    {
+        const int oln = d.ol_n;
+        mm.run(tA, LC, d.w_ol, oln, C, 3, [&](int nb, const f32x4_t (&acc)[1]) {
+            const int col = nb * 16 + i16;
+            const float bb = d.b_ol[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * q4 + r;
+                if (row < J) d.ol_out[(xrow0 + row) * oln + col] = acc[0][r] + bb;
+            }
+        });
+    }
 }
 
 // (rows, k) row-major -> fragment order; one thread per 16 bytes of the output
@@ -669,7 +1008,9 @@ extern "C" int egr_joint_layer_f32(const egr_layer_desc* dd, void* stream) {
     if (d.C != 128 && d.C != 256) return EGR_EINVAL;
     if (d.w_ol && (!d.b_ol || !d.ol_out || d.ol_n <= 0 || d.ol_n % 16 != 0)) return EGR_EINVAL;
     if (d.lnp_g && !d.lnp_b) return EGR_ENULL;
-    if ((d.xn_out || d.w_r0) && !d.lnp_g) return EGR_EINVAL;
+    if ((d.xn_out || d.w_r0 || d.w_h0) && !d.lnp_g) return EGR_EINVAL;
+    if (d.w_h0 && (!d.b_h0 || !d.h0_out)) return EGR_ENULL;
+    if (d.w_h0 && (d.C != 256 || d.h0_n != 64 || d.w_r0 || ((uintptr_t)d.h0_out & 15))) return EGR_EINVAL;   // s * s == c tokens-as-image; 16-byte stores
     if (d.w_r0 && (!d.b_r0 || !d.w_r2 || !d.b_r2 || !d.anchors3d || !d.pred_out)) return EGR_ENULL;
     if ((int64_t)d.B * d.groups >= (1LL << 31) || (int64_t)d.B * d.J * d.V * d.heads * d.cf >= (1LL << 31)) return EGR_EINVAL;
     const uintptr_t al = (uintptr_t)d.g | (uintptr_t)d.w_fold | (uintptr_t)d.w_out | (uintptr_t)d.w_fuse | (uintptr_t)d.w_qkv | (uintptr_t)d.w_mo |
@@ -700,4 +1041,37 @@ extern "C" int egr_joint_layer_f32(const egr_layer_desc* dd, void* stream) {
     using C128 = std::integral_constant<int, 128>;
     if (d.C == 256) return d.w_packed == 2 ? run(C256{}, std::true_type{}, 0) : run(C256{}, std::false_type{}, 1);
     return d.w_packed == 2 ? run(C128{}, std::true_type{}, 2) : run(C128{}, std::false_type{}, 3);
+}
+
+extern "C" int egr_jqa_query_f32(const egr_jqa_query_desc* dd, void* stream) {
+    if (!dd) return EGR_ENULL;
+    const egr_jqa_query_desc& d = *dd;
+    if (!d.t || !d.s32 || !d.w_hp2 || !d.b_hp2 || !d.w_bfb || !d.b_bfb || !d.embed || !d.w_q || !d.b_q || !d.w_ol || !d.b_ol || !d.x_out || !d.ol_out)
+        return EGR_ENULL;
+    if (d.B <= 0 || d.groups <= 0 || d.J <= 0 || d.J > 16 || d.C != 256 || d.kb != 512 || d.pool_hw <= 0 || d.ol_n <= 0 || d.ol_n % 16 != 0) return EGR_EINVAL;
+    if (d.w_packed < 0 || d.w_packed > 2) return EGR_EINVAL;
+    if ((int64_t)d.B * d.groups >= (1LL << 31)) return EGR_EINVAL;
+    if (((uintptr_t)d.t | (uintptr_t)d.w_hp2 | (uintptr_t)d.w_bfb | (uintptr_t)d.w_q | (uintptr_t)d.w_ol) & 15) return EGR_EINVAL;
+    JqaArgs a;
+    a.d = d;
+    const dim3 grid((unsigned)(d.B * d.groups)), block(NTH);
+    if (d.w_packed == 2) hipLaunchKernelGGL((jqa_query_kernel<256, true>), grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((jqa_query_kernel<256, false>), grid, block, 0, (hipStream_t)stream, a);
+    return egr_launch_status();
+}
+
+extern "C" int egr_pose_query_f32(const egr_pose_query_desc* dd, void* stream) {
+    if (!dd) return EGR_ENULL;
+    const egr_pose_query_desc& d = *dd;
+    if (!d.h1 || !d.w_m2 || !d.b_m2 || !d.cams || !d.w_qg0 || !d.b_qg0 || !d.w_qg2 || !d.b_qg2 || !d.w_qg4 || !d.b_qg4 || !d.w_ol || !d.b_ol ||
+        !d.pred_out || !d.anchors3d_out || !d.anchors2d_out || !d.valid_out || !d.x_out || !d.ol_out)
+        return EGR_ENULL;
+    if (d.B <= 0 || d.J != 16 || d.C != 128 || d.ol_n <= 0 || d.ol_n % 16 != 0 || d.w_packed < 0 || d.w_packed > 2) return EGR_EINVAL;
+    if (((uintptr_t)d.w_m2 | (uintptr_t)d.w_qg2 | (uintptr_t)d.w_qg4 | (uintptr_t)d.w_ol) & 15) return EGR_EINVAL;
+    PoseQArgs a;
+    a.d = d;
+    const dim3 grid((unsigned)d.B), block(NTH);
+    if (d.w_packed == 2) hipLaunchKernelGGL((pose_query_kernel<128, true>), grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((pose_query_kernel<128, false>), grid, block, 0, (hipStream_t)stream, a);
+    return egr_launch_status();
 }

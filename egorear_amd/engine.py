@@ -506,6 +506,10 @@ class PLayer:
 # One launch per transformer layer behind the sampling (egr_joint_layer_f32) instead of ~14 small ones; EGR_FUSED_LAYER=0 keeps
 # the per-op launches (the training forward always uses those: it needs the intermediates).
 FUSED_LAYER = os.environ.get("EGR_FUSED_LAYER", "1") != "0"
+# The small launches in front of / behind the fused layers as one launch each (round 5): the refiners' JQA query
+# (egr_jqa_query_f32), the lifting head's proposal -> reprojection -> decoder query (egr_pose_query_f32), the refiners' head offset as
+# a tail of the layer launch; EGR_FUSED_QUERY=0 keeps the per-op launches.
+FUSED_QUERY = os.environ.get("EGR_FUSED_QUERY", "1") != "0"
 # the fused layer's contractions in the fp16 scheme (read when a module's layers are packed): follows EGR_W_FORMAT, EGR_LAYER_H2=0 keeps
 # the fp32 matrix cores
 LAYER_H2 = hip.H2 and os.environ.get("EGR_LAYER_H2", "1") != "0"
@@ -605,7 +609,7 @@ def pack_layers(layers, pres, poss) -> PLayer:
 
 def run_layer_fused(st: State, P: PLayer, x: torch.Tensor, memory: torch.Tensor, anchors: torch.Tensor, valid: torch.Tensor,
                     B: int, V: int, J: int, hgt: int, wid: int, ol: Optional[torch.Tensor] = None, next_P: Optional[PLayer] = None,
-                    post=None, reg=None, want_xn: bool = False):
+                    post=None, reg=None, want_xn: bool = False, head=None):
     """run_layer as TWO launches: the sampling (egr_msda_gather_f32) and everything behind it (egr_joint_layer_f32), optionally
     with the next layer's offsets / logits, post_norm and the regression head as tails.  `ol`: this layer's offsets / logits if a
     previous fused layer already produced them.  Returns (x, ol_next | None, xn | None, pred | None)."""
@@ -614,7 +618,7 @@ def run_layer_fused(st: State, P: PLayer, x: torch.Tensor, memory: torch.Tensor,
         ol = linear(st, x, P.offs_logits)
     g, e, sigma, rowmask = hip.msda_gather(memory, P.pos_proj, ol, anchors, valid, B, V, J, heads, dh, hgt, wid, groups=G)
     return hip.joint_layer(x, g, e, sigma, rowmask, P.fused, B, J, V, C, G, ol=next_P.ol_plain if next_P is not None else None,
-                           post=post, reg=reg, want_xn=want_xn)
+                           post=post, reg=reg, want_xn=want_xn, head=head)
 
 
 def run_layer(st: State, P: PLayer, x: torch.Tensor, memory: torch.Tensor, anchors: torch.Tensor, valid: torch.Tensor,
@@ -656,7 +660,7 @@ def run_layer(st: State, P: PLayer, x: torch.Tensor, memory: torch.Tensor, ancho
 # --------------------------------------------------------------------------- EgoPoseFormerHeatmapMVFEX (a5-a18)
 
 class PRefiners:
-    __slots__ = ("hp0", "hp2", "fc_bfb", "fc_query", "embed", "layer", "post_norm", "head0_w", "head0_b", "head3")
+    __slots__ = ("hp0", "hp2", "fc_bfb", "fc_query", "embed", "layer", "post_norm", "head0_w", "head0_b", "head3", "q")
 
 
 def _pack_refiners(rs) -> PRefiners:
@@ -675,6 +679,19 @@ def _pack_refiners(rs) -> PRefiners:
                              for r in rs]).contiguous()                                   # (G, 64, 15)
     P.head0_b = torch.stack([r.head_layers[0].head[0].bias.detach().float() for r in rs]).contiguous()
     P.head3 = pack_convs([r.head_layers[0].head[3] for r in rs])
+    # egr_jqa_query_f32's operands: the matrices in the fused layer's weight order (it shares the layer's offsets / logits image)
+    P.q = None
+    r0 = rs[0]
+    if (P.layer.fused is not None and r0.embed_dims == 256 and r0.fc_bfb.in_features == 512 and r0.num_heatmap <= 16):
+        pk = hip.pack_layer_wh2 if LAYER_H2 else hip.pack_layer_w
+
+        def stk(ts):
+            return torch.stack([t.detach().float() for t in ts]).contiguous()
+        P.q = {"w_hp2": pk(stk([r.heatmap_proj[2].weight for r in rs])), "b_hp2": stk([r.heatmap_proj[2].bias for r in rs]),
+               "w_bfb": pk(stk([r.fc_bfb.weight for r in rs])), "b_bfb": stk([r.fc_bfb.bias for r in rs]),
+               "embed": P.embed,
+               "w_q": pk(stk([r.fc_query[0].weight for r in rs])), "b_q": stk([r.fc_query[0].bias for r in rs]),
+               "w_ol": P.layer.ol_plain["w"], "b_ol": P.layer.ol_plain["b"], "packed": 2 if LAYER_H2 else True}
     return P
 
 
@@ -697,23 +714,36 @@ def _run_refiners(st: State, rs, B: int, V: int, hm_init: torch.Tensor, feat_all
     # --- joint queries (JQA): heatmap_proj(hm) + fc_bfb(avgpool s32) + embedding -> fc_query
     hm_rows = Img(hm_init.view(B * V, J, 1, hw)[0::V])                        # group 0 = view 0 rows; group stride = J*hw
     t = conv(st, hm_rows, P.hp0, ACT_RELU, gx=J * hw)                        # (G*B, J, 1, C)
-    hm_embed = linear(st, t.t.view(G * B * J, C), P.hp2)
-    bfb = linear(st, hip.avgpool(Img(s32_all)), P.fc_bfb)                    # s32_all is (V*B, 8, 8, 512) = (G, B, ...)
-    x = linear(st, hip.jqa_sum(hm_embed, P.embed, bfb, G * B, J, C, groups=G), P.fc_query, ACT_RELU)
+    fused = FUSED_LAYER and P.layer.fused is not None
+    ol = None
+    if fused and FUSED_QUERY and P.q is not None and s32_all.shape[-1] == 512:
+        # heatmap_proj[2], the pooled fc_bfb, the sum, fc_query and the layer's offsets / logits: one launch
+        x, ol = hip.jqa_query(t.t.view(G * B * J, C), s32_all, P.q, B, J, C, G)
+    else:
+        hm_embed = linear(st, t.t.view(G * B * J, C), P.hp2)
+        bfb = linear(st, hip.avgpool(Img(s32_all)), P.fc_bfb)                # s32_all is (V*B, 8, 8, 512) = (G, B, ...)
+        x = linear(st, hip.jqa_sum(hm_embed, P.embed, bfb, G * B, J, C, groups=G), P.fc_query, ACT_RELU)
     # --- own-view feature projection: group g reads feat_all[g*B:(g+1)*B]
     ff = run_stack(st, [r.frame_feat_proj_layers for r in rs], Img(feat_all))  # (G*B, 32, 32, 128)
     # --- transformer layer over the 4-view memory (sampled un-projected, see pack_layers)
     # --- head: LN -> (B, J, 16, 16) image with joints as channels -> 1x1 15->64, up x2, 1x1 64->128 (+ frame_feat)
-    if FUSED_LAYER and P.layer.fused is not None:
-        _, _, xn, _ = run_layer_fused(st, P.layer, x, feat_all.view(V, B, hw, feat_all.shape[-1]), anchors, valid, B, V, J, hgt, wid,
-                                      post={"g": P.post_norm[0], "b": P.post_norm[1]}, want_xn=True)
+    head = None
+    if fused:
+        # (the head offset rides on the layer launch when its shape is the kernel's: 16 x 16 tokens-as-image, 64 channels)
+        if FUSED_QUERY and C == 256 and P.head0_w.shape[1] == 64:
+            head = {"w": P.head0_w, "b": P.head0_b, "amax": st.new_amax()}
+        _, _, xn, _ = run_layer_fused(st, P.layer, x, feat_all.view(V, B, hw, feat_all.shape[-1]), anchors, valid, B, V, J, hgt, wid, ol=ol,
+                                      post={"g": P.post_norm[0], "b": P.post_norm[1]}, want_xn=head is None or CAPTURE is not None, head=head)
     else:
         x = run_layer(st, P.layer, x, feat_all.view(V, B, hw, feat_all.shape[-1]), anchors, valid, B, V, J, hgt, wid)
         xn = hip.layernorm(x, P.post_norm[0], P.post_norm[1], groups=G)
-    side = int(math.isqrt(C))
-    tok = hip.tokens_to_nhwc(xn, G * B, J, C)                                # (G*B, 256, J)
-    h0 = hip.linear_smallk(tok, J, 1, P.head0_w, P.head0_b, G * B * C, P.head0_w.shape[1], J, ACT_RELU, groups=G)
-    h0 = hip.upsample2x(Img(h0.view(G * B, side, side, -1)))
+    if head is not None:
+        h0 = Img(head["out"])
+    else:
+        side = int(math.isqrt(C))
+        tok = hip.tokens_to_nhwc(xn, G * B, J, C)                            # (G*B, 256, J)
+        h0 = hip.linear_smallk(tok, J, 1, P.head0_w, P.head0_b, G * B * C, P.head0_w.shape[1], J, ACT_RELU, groups=G)
+        h0 = hip.upsample2x(Img(h0.view(G * B, side, side, -1)))
     summed = conv(st, h0, P.head3, ACT_RELU, res=ff, res_mode=RES_AFTER_ACT)   # offset_pred + frame_feat
     if CAPTURE is not None:
         CAPTURE.update(query=x.view(G, B, J, C).clone(), post_norm=xn.view(G, B, J, C).clone(), head_sum=summed.t.clone())
@@ -776,7 +806,8 @@ def heatmap_mvfex_forward_api(mod, img, heatmap_for_anchor=None):
 # --------------------------------------------------------------------------- EgoPoseFormerPose3D (a20-a24)
 
 class PPose:
-    __slots__ = ("mlp0", "mlp0_ws", "mlp0_src", "mlp1", "mlp2", "qg0_w", "qg0_b", "qg2", "qg4", "layers", "post", "reg0", "reg2", "cams", "reg_plain")
+    __slots__ = ("mlp0", "mlp0_ws", "mlp0_src", "mlp1", "mlp2", "qg0_w", "qg0_b", "qg2", "qg4", "layers", "post", "reg0", "reg2", "cams", "reg_plain",
+                 "q")
 
 
 def _pack_pose3d(p3) -> PPose:
@@ -814,6 +845,14 @@ def _pack_pose3d(p3) -> PPose:
         P.reg_plain = [(pk(f32(r[0].weight).contiguous()), f32(r[0].bias), f32(r[2].weight), f32(r[2].bias)) for r in p3.reg_mlp]
     rec = np.stack([c.packed() for c in p3.cameras()])
     P.cams = torch.from_numpy(rec).to(w0.device)
+    # egr_pose_query_f32's operands (mlp_pred[2], query_gen_mlp, the first layer's offsets / logits) in the fused layers' weight order
+    P.q = None
+    if (P.reg_plain is not None and p3.embed_dims == 128 and p3.num_joints == 16 and p3.mlp_pred[2].in_features == 128
+            and qg[0].in_features == 4 and P.layers[0].ol_plain is not None):
+        pk = hip.pack_layer_wh2 if LAYER_H2 else hip.pack_layer_w
+        P.q = {"w_m2": pk(f32(p3.mlp_pred[2].weight)), "b_m2": f32(p3.mlp_pred[2].bias), "w_qg0": P.qg0_w, "b_qg0": P.qg0_b,
+               "w_qg2": pk(f32(qg[2].weight)), "b_qg2": f32(qg[2].bias), "w_qg4": pk(f32(qg[4].weight)), "b_qg4": f32(qg[4].bias),
+               "w_ol": P.layers[0].ol_plain["w"], "b_ol": P.layers[0].ol_plain["b"], "packed": 2 if LAYER_H2 else True}
     return P
 
 
@@ -856,23 +895,27 @@ def _pose3d_body(p3, st: State, feat_init: torch.Tensor, feat_final: torch.Tenso
                 P.mlp0 = pack_linears([P.mlp0_src])
         h = linear(st, flat, P.mlp0, ACT_GELU)
     h = linear(st, h, P.mlp1, ACT_GELU)
-    mlp_pred = linear(st, h, P.mlp2).view(B, J, 3)
-    anchors_3d = torch.empty_like(mlp_pred)                                  # init_anchors_3d = mlp_pred.clone().detach(): written by the projection kernel
     ctm32 = None
     if p3.camera_model.startswith("ego4view_rw"):
         if ctm is None:
             raise RuntimeError("egorear_amd: camera_model ego4view_rw needs coord_trans_mat (B,4,4,4)")
         ctm32 = ctm.to(device=dev, dtype=torch.float32).contiguous()         # any float dtype accepted
-    anchors_2d, valid, q4 = hip.fisheye_project(mlp_pred, ctm32, P.cams, out=anchors_3d)   # syn: anchors_3d = the points after the in-place chain (F7)
-    # --- decoder
     C = p3.embed_dims
-    x = hip.linear_smallk(q4, 4, 1, P.qg0_w, P.qg0_b, B * J, C, 4, ACT_RELU)
-    x = linear(st, x, P.qg2, ACT_RELU)
-    x = linear(st, x, P.qg4)
+    ol = None
+    if FUSED_LAYER and FUSED_QUERY and P.q is not None and all(L.fused is not None for L in P.layers):
+        # mlp_pred[2], the reprojection, query_gen_mlp and the first layer's offsets / logits: one launch
+        mlp_pred, anchors_3d, anchors_2d, valid, x, ol = hip.pose_query(h, ctm32, P.cams, P.q, B, J, C)
+    else:
+        mlp_pred = linear(st, h, P.mlp2).view(B, J, 3)
+        anchors_3d = torch.empty_like(mlp_pred)                              # init_anchors_3d = mlp_pred.clone().detach(): written by the projection kernel
+        anchors_2d, valid, q4 = hip.fisheye_project(mlp_pred, ctm32, P.cams, out=anchors_3d)   # syn: anchors_3d = the points after the in-place chain (F7)
+        # --- decoder
+        x = hip.linear_smallk(q4, 4, 1, P.qg0_w, P.qg0_b, B * J, C, 4, ACT_RELU)
+        x = linear(st, x, P.qg2, ACT_RELU)
+        x = linear(st, x, P.qg4)
     memory = src.view(V, B, hgt * wid, src.shape[-1])
     preds = [mlp_pred]
     a3 = anchors_3d.view(B * J, 3)
-    ol = None
     for i, L in enumerate(P.layers):
         if FUSED_LAYER and L.fused is not None and P.reg_plain is not None:
             nxt = P.layers[i + 1] if i + 1 < len(P.layers) else None

@@ -31,6 +31,7 @@ EXPORTS = [
     "egr_conv2d_nhwc_ex_f32", "egr_wh2_elems", "egr_pack_wh2_f32", "egr_absmax_f32", "egr_stem_conv7x7_x6_ex_f32", "egr_stem_wh2_bytes", "egr_pack_stem_wh2_f32", "egr_stem_conv7x7_h2_f32",
     "egr_pack_wh2_many_f32", "egr_conv2d_masked_ex_f32", "egr_conv2d_wgrad_ex_f32", "egr_wgrad_last_h2",
     "egr_wstream_image_bytes", "egr_pack_wstream_f32", "egr_linear_wstream_workspace_bytes", "egr_linear_wstream_f32", "egr_conv1x1_chain_f32",
+    "egr_jqa_query_f32", "egr_pose_query_f32",
 ]
 
 
@@ -74,7 +75,23 @@ class LayerDesc(C.Structure):
                                            "w_qkv", "b_qkv", "w_mo", "b_mo", "ln2_g", "ln2_b", "w_f0", "b_f0", "w_f1", "b_f1", "ln3_g", "ln3_b",
                                            "x_out", "w_ol", "b_ol", "ol_out")] +
                 [("ol_n", C.c_int32), ("w_packed", C.c_int32)] +
-                [(n, C.c_void_p) for n in ("lnp_g", "lnp_b", "xn_out", "w_r0", "b_r0", "w_r2", "b_r2", "anchors3d", "pred_out")])
+                [(n, C.c_void_p) for n in ("lnp_g", "lnp_b", "xn_out", "w_r0", "b_r0", "w_r2", "b_r2", "anchors3d", "pred_out",
+                                           "w_h0", "b_h0", "h0_out", "amax_h0")] +
+                [("h0_n", C.c_int32)])
+
+
+class JqaQueryDesc(C.Structure):
+    """egr_jqa_query_desc of include/egorear_hip.h (field for field)."""
+    _fields_ = ([(n, C.c_int32) for n in ("B", "J", "C", "groups", "kb", "pool_hw", "ol_n", "w_packed")] +
+                [(n, C.c_void_p) for n in ("t", "s32", "w_hp2", "b_hp2", "w_bfb", "b_bfb", "embed", "w_q", "b_q", "w_ol", "b_ol",
+                                           "x_out", "ol_out")])
+
+
+class PoseQueryDesc(C.Structure):
+    """egr_pose_query_desc of include/egorear_hip.h (field for field)."""
+    _fields_ = ([(n, C.c_int32) for n in ("B", "J", "C", "ol_n", "w_packed")] +
+                [(n, C.c_void_p) for n in ("h1", "w_m2", "b_m2", "ctm", "cams", "w_qg0", "b_qg0", "w_qg2", "b_qg2", "w_qg4", "b_qg4",
+                                           "w_ol", "b_ol", "pred_out", "anchors3d_out", "anchors2d_out", "valid_out", "x_out", "ol_out")])
 
 
 def _load() -> C.CDLL:
@@ -146,6 +163,8 @@ def _load() -> C.CDLL:
     lib.egr_msda_fwd_f32.argtypes = [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp, vp]
     lib.egr_msda_bwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.egr_joint_layer_f32.argtypes = [C.POINTER(LayerDesc), vp]
+    lib.egr_jqa_query_f32.argtypes = [C.POINTER(JqaQueryDesc), vp]
+    lib.egr_pose_query_f32.argtypes = [C.POINTER(PoseQueryDesc), vp]
     lib.egr_pack_layer_w_f32.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.egr_pack_layer_wh2_f32.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.egr_preprocess_fused_u8_f32.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]
@@ -1129,10 +1148,12 @@ def pack_layer_wh2(w: torch.Tensor) -> torch.Tensor:
 
 def joint_layer(x: torch.Tensor, g: torch.Tensor, e: Optional[torch.Tensor], sigma: torch.Tensor, rowmask: torch.Tensor, W: dict,
                 B: int, J: int, V: int, Cdim: int, groups: int, *, ol: Optional[dict] = None, post: Optional[dict] = None,
-                reg: Optional[dict] = None, want_xn: bool = False):
+                reg: Optional[dict] = None, want_xn: bool = False, head: Optional[dict] = None):
     """One transformer layer behind egr_msda_gather_f32 as one launch (egr_joint_layer_f32).  W: the layer's plain weight stacks
     (engine.pack_layer_fused).  ol = {"w", "b"}: also the next layer's offsets / logits; post = {"g", "b"}: also post_norm
-    (want_xn: return it); reg = {"w0", "b0", "w2", "b2", "anchors"}: also the 3-D regression head.
+    (want_xn: return it); reg = {"w0", "b0", "w2", "b2", "anchors"}: also the 3-D regression head; head = {"w" (groups, 64, J),
+    "b" (groups, 64), "amax": record | None}: also the refiner's head offset (tokens as a 16 x 16 image -> 1x1 conv + ReLU -> up x2),
+    returned as head["out"] (groups*B, 32, 32, 64).
     Returns (x_out, ol_out | None, xn | None, pred | None)."""
     rows = groups * B * J
     if x.shape != (rows, Cdim) or not x.is_contiguous():
@@ -1185,9 +1206,91 @@ def joint_layer(x: torch.Tensor, g: torch.Tensor, e: Optional[torch.Tensor], sig
         pred = torch.empty((rows, 3), device=x.device, dtype=torch.float32)
         d.w_r0, d.b_r0, d.w_r2, d.b_r2 = _p(_cont(reg["w0"], "w_r0")), _p(reg["b0"]), _p(_cont(reg["w2"], "w_r2")), _p(reg["b2"])
         d.anchors3d, d.pred_out = _p(_cont(reg["anchors"], "anchors")), _p(pred)
+    if head is not None:
+        if post is None or reg is not None or Cdim != 256:
+            raise RuntimeError("egorear_amd.joint_layer: the head offset sits behind post_norm of a 256-channel layer, without the regression head")
+        hn = head["b"].shape[-1]
+        if hn != 64 or head["w"].numel() != groups * hn * J or head["b"].numel() != groups * hn:
+            raise RuntimeError("egorear_amd.joint_layer: head offset weights do not match")
+        h0 = torch.empty((groups * B, 32, 32, hn), device=x.device, dtype=torch.float32)
+        d.w_h0, d.b_h0, d.h0_out, d.h0_n = _p(_cont(head["w"], "w_h0")), _p(_cont(head["b"], "b_h0")), _p(h0), hn
+        rec = head.get("amax")
+        if rec is not None:
+            d.amax_h0 = _p(rec, torch.int32)
+            h0._egr_amax = rec
+        head["out"] = h0
     flops = 2.0 * groups * B * (J * V * (Cdim * 128 + Cdim * Cdim) + J * (V * Cdim * Cdim + 3 * Cdim * Cdim + Cdim * Cdim + 2 * 512 * Cdim))
     _launch("egr_joint_layer_f32", lib.egr_joint_layer_f32, C.byref(d), _stream(), flops=flops)
     return x_out, ol_out, xn, pred
+
+
+def jqa_query(t: torch.Tensor, s32: torch.Tensor, W: dict, B: int, J: int, Cdim: int, groups: int):
+    """The JQA query of the refiners as one launch (egr_jqa_query_f32): t (groups*B*J, C) = ReLU(heatmap_proj[0](hm)), s32
+    (groups*B, h, w, 512) NHWC.  W: {"w_hp2", "b_hp2", "w_bfb", "b_bfb", "embed", "w_q", "b_q", "w_ol", "b_ol", "packed"} - matrices in
+    pack_layer_w / pack_layer_wh2 order.  Returns (x (groups*B*J, C), ol (groups*B*J, ol_n))."""
+    rows = groups * B * J
+    if t.shape != (rows, Cdim) or not t.is_contiguous() or Cdim != 256:
+        raise RuntimeError("egorear_amd.jqa_query: t must be (groups*B*J, 256) contiguous")
+    if s32.dim() != 4 or s32.shape[0] != groups * B or s32.shape[3] != 512 or not s32.is_contiguous():
+        raise RuntimeError("egorear_amd.jqa_query: s32 must be (groups*B, h, w, 512) contiguous NHWC")
+    packed = W.get("packed")
+    packed = 2 if packed == 2 else (1 if packed else 0)
+
+    def msz(r, k):
+        return r * k + (r if packed == 2 else 0)
+    n = W["b_ol"].shape[-1]
+    need = {"w_hp2": groups * msz(Cdim, Cdim), "b_hp2": groups * Cdim, "w_bfb": groups * msz(Cdim, 512), "b_bfb": groups * Cdim,
+            "embed": groups * J * Cdim, "w_q": groups * msz(Cdim, Cdim), "b_q": groups * Cdim, "w_ol": groups * msz(n, Cdim), "b_ol": groups * n}
+    d = JqaQueryDesc()
+    d.B, d.J, d.C, d.groups, d.kb, d.pool_hw, d.ol_n, d.w_packed = B, J, Cdim, groups, 512, s32.shape[1] * s32.shape[2], n, packed
+    d.t, d.s32 = _p(t), _p(s32)
+    for k, ne in need.items():
+        w = W[k]
+        if w.numel() != ne or not w.is_contiguous():
+            raise RuntimeError(f"egorear_amd.jqa_query: weight {k} has {w.numel()} elements, expected {ne}")
+        setattr(d, k, _p(w))
+    x = torch.empty((rows, Cdim), device=t.device, dtype=torch.float32)
+    ol = torch.empty((rows, n), device=t.device, dtype=torch.float32)
+    d.x_out, d.ol_out = _p(x), _p(ol)
+    _launch("egr_jqa_query_f32", lib.egr_jqa_query_f32, C.byref(d), _stream(),
+            flops=2.0 * groups * B * (J * Cdim * (2 * Cdim + n) + Cdim * 512))
+    return x, ol
+
+
+def pose_query(h1: torch.Tensor, ctm: Optional[torch.Tensor], cams: torch.Tensor, W: dict, B: int, J: int, Cdim: int):
+    """The lifting head between mlp_pred[1] and its first decoder layer as one launch (egr_pose_query_f32).  h1 (B, C).  W: {"w_m2",
+    "b_m2", "w_qg0", "b_qg0", "w_qg2", "b_qg2", "w_qg4", "b_qg4", "w_ol", "b_ol", "packed"}.
+    Returns (pred (B, J, 3), anchors_3d (B, J, 3), anchors_2d (B, 4, J, 2), valid (B, 4, J) uint8, x (B*J, C), ol (B*J, ol_n))."""
+    if h1.shape != (B, Cdim) or not h1.is_contiguous() or Cdim != 128 or J != 16:
+        raise RuntimeError("egorear_amd.pose_query: h1 must be (B, 128) contiguous, 16 joints")
+    if ctm is not None and (ctm.shape != (B, 4, 4, 4) or not ctm.is_contiguous()):
+        raise RuntimeError("egorear_amd.pose_query: coord_trans_mat must be (B, 4, 4, 4) contiguous")
+    packed = W.get("packed")
+    packed = 2 if packed == 2 else (1 if packed else 0)
+
+    def msz(r, k):
+        return r * k + (r if packed == 2 else 0)
+    n = W["b_ol"].shape[-1]
+    need = {"w_m2": msz(3 * J, Cdim), "b_m2": 3 * J, "w_qg0": Cdim * 4, "b_qg0": Cdim, "w_qg2": msz(Cdim, Cdim), "b_qg2": Cdim,
+            "w_qg4": msz(Cdim, Cdim), "b_qg4": Cdim, "w_ol": msz(n, Cdim), "b_ol": n}
+    d = PoseQueryDesc()
+    d.B, d.J, d.C, d.ol_n, d.w_packed = B, J, Cdim, n, packed
+    d.h1, d.ctm, d.cams = _p(h1), _p(ctm), _p(cams)
+    for k, ne in need.items():
+        w = W[k]
+        if w.numel() != ne or not w.is_contiguous():
+            raise RuntimeError(f"egorear_amd.pose_query: weight {k} has {w.numel()} elements, expected {ne}")
+        setattr(d, k, _p(w))
+    dev = h1.device
+    pred = torch.empty((B, J, 3), device=dev, dtype=torch.float32)
+    a3 = torch.empty((B, J, 3), device=dev, dtype=torch.float32)
+    a2 = torch.empty((B, 4, J, 2), device=dev, dtype=torch.float32)
+    valid = torch.empty((B, 4, J), device=dev, dtype=torch.uint8)
+    x = torch.empty((B * J, Cdim), device=dev, dtype=torch.float32)
+    ol = torch.empty((B * J, n), device=dev, dtype=torch.float32)
+    d.pred_out, d.anchors3d_out, d.anchors2d_out, d.valid_out, d.x_out, d.ol_out = _p(pred), _p(a3), _p(a2), _p(valid, torch.uint8), _p(x), _p(ol)
+    _launch("egr_pose_query_f32", lib.egr_pose_query_f32, C.byref(d), _stream(), flops=2.0 * B * (Cdim * 3 * J + J * Cdim * (2 * Cdim + n + 4)))
+    return pred, a3, a2, valid, x, ol
 
 
 

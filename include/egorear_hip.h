@@ -432,8 +432,51 @@ typedef struct egr_layer_desc {
     float* xn_out;
     const float *w_r0, *b_r0, *w_r2, *b_r2, *anchors3d;
     float* pred_out;
+    /* tail (round 5): the refiner's head offset behind post_norm (heatmap_mvf_ex.py:707-711; TransformerHeadLayer.head[0..2]): the
+     * (joints, c) tokens read as an s x s image (s * s == c; c = 256) with the joints as channels -> Conv2d(joints, h0_n, 1) + ReLU ->
+     * Upsample(x2, bilinear, align_corners=True) -> h0_out (groups*b, 2s, 2s, h0_n) NHWC.  w_h0 (groups, h0_n, joints) plain
+     * row-major, b_h0 (groups, h0_n); h0_n == 64; excludes the regression head.  amax_h0: NULL or the 64-slot abs-max record of
+     * h0_out (receives an upper bound).  Replaces egr_tokens_to_nhwc_f32 + egr_linear_smallk_f32 + egr_upsample2x_nhwc_f32. */
+    const float *w_h0, *b_h0;
+    float* h0_out;
+    uint32_t* amax_h0;
+    int32_t h0_n;
 } egr_layer_desc;
 int egr_joint_layer_f32(const egr_layer_desc* d, void* stream);
+/* The JQA query of a refiner as ONE launch (round 5; HeatmapMVF.forward_feat_only, egoposeformer_heatmap_mvf_ex.py:655-665, behind
+ * heatmap_proj[0] + ReLU):  hm_embed = heatmap_proj[2](t);  bfb = fc_bfb(adaptive_avg_pool2d(backbone_feat_bottom, (1, 1)));
+ * x = ReLU(fc_query((joint_query_embed + bfb) + hm_embed));  ol = [sampling_offsets | attention_weights](x) of the refiner's
+ * transformer layer (models/utils/deform_attn.py:122-135).  One workgroup per (query set, frame).
+ * t (groups*b*joints, c); s32 (groups*b, pool_hw, kb) NHWC; embed (groups, joints, c); matrices w_hp2 (c, c), w_bfb (c, kb),
+ * w_q (c, c), w_ol (ol_n, c) per group in the order w_packed names (egr_layer_desc.w_packed), vectors plain.
+ * Limits: c = 256, kb = 512, joints <= 16, ol_n % 16 == 0.  Replaces egr_avgpool_nhwc_f32, egr_jqa_sum_f32 and four small
+ * egr_conv2d_nhwc_f32 launches. */
+typedef struct egr_jqa_query_desc {
+    int32_t B, J, C, groups, kb, pool_hw, ol_n, w_packed;
+    const float *t, *s32;
+    const float *w_hp2, *b_hp2, *w_bfb, *b_bfb, *embed, *w_q, *b_q, *w_ol, *b_ol;
+    float *x_out /* (groups*b*joints, c) */, *ol_out /* (groups*b*joints, ol_n) */;
+} egr_jqa_query_desc;
+int egr_jqa_query_f32(const egr_jqa_query_desc* d, void* stream);
+
+/* The lifting head between mlp_pred[1] and its first decoder layer as ONE launch (round 5; egoposeformer_mvf_ex.py:255-262,
+ * 317-322, 340-348, 400-410): pred = mlp_pred[2](h1) (b, joints, 3); the fisheye reprojection of egr_fisheye_project2_f32
+ * (anchors3d_out = the points behind it: mutated in syn mode (ctm NULL), a copy in rw mode); x = query_gen_mlp([(j+1)/joints,
+ * point]) (Linear(4, c) + ReLU, Linear + ReLU, Linear); ol = the first layer's [sampling_offsets | attention_weights](x).
+ * One workgroup per frame.  h1 (b, c) = GELU(mlp_pred[1](..)); w_m2 (3*joints, c), w_qg2 / w_qg4 (c, c), w_ol (ol_n, c) in the
+ * order w_packed names; w_qg0 (c, 4) and all vectors plain; cams / ctm as in egr_fisheye_project_f32.
+ * Limits: c = 128, joints = 16, ol_n % 16 == 0.  Replaces egr_fisheye_project_f32, egr_linear_smallk_f32 and four small
+ * egr_conv2d_nhwc_f32 launches. */
+typedef struct egr_pose_query_desc {
+    int32_t B, J, C, ol_n, w_packed;
+    const float *h1, *w_m2, *b_m2, *ctm /* or NULL */, *cams;
+    const float *w_qg0, *b_qg0, *w_qg2, *b_qg2, *w_qg4, *b_qg4, *w_ol, *b_ol;
+    float *pred_out /* (b, joints, 3) */, *anchors3d_out /* (b, joints, 3) */, *anchors2d_out /* (b, 4, joints, 2) */;
+    uint8_t* valid_out /* (b, 4, joints) */;
+    float *x_out /* (b*joints, c) */, *ol_out /* (b*joints, ol_n) */;
+} egr_pose_query_desc;
+int egr_pose_query_f32(const egr_pose_query_desc* d, void* stream);
+
 /* `matrices` row-major (rows, k) fp32 matrices (rows % 16 == 0, k % 128 == 0) -> the fragment order egr_joint_layer_f32 reads with
  * w_packed: [matrix][16-row block][128-deep chunk][16-deep k block u][lane = 16 q + i][4 floats] = w[16 block + i][128 chunk + 16 u + 4 q ..+3].
  * Same number of elements; out must not alias w. */

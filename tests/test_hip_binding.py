@@ -187,3 +187,67 @@ def test_chain_eligibility_rule():
         assert not hip.chain_eligible(big, W(128, 64), W(128, 128), 128, 128, 1)
     finally:
         hip.CHAIN = saved
+
+
+def test_token_chain_entries_refuse_before_any_launch():
+    """egr_jqa_query_f32 / egr_pose_query_f32 / the head-offset tail of egr_joint_layer_f32 (round 5): every refusal is a return code
+    BEFORE a launch - raw C ABI, fake aligned pointers, no GPU."""
+    from egorear_amd import hip
+    lib = hip.lib
+    P = 0x10000
+    ptrs_q = ("t", "s32", "w_hp2", "b_hp2", "w_bfb", "b_bfb", "embed", "w_q", "b_q", "w_ol", "b_ol", "x_out", "ol_out")
+
+    def q(**kw):
+        d = hip.JqaQueryDesc()
+        d.B, d.J, d.C, d.groups, d.kb, d.pool_hw, d.ol_n, d.w_packed = 2, 15, 256, 4, 512, 64, 192, 2
+        for n in ptrs_q:
+            setattr(d, n, P)
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return lib.egr_jqa_query_f32(C.byref(d), None)
+
+    assert lib.egr_jqa_query_f32(None, None) == hip.ENULL
+    for n in ptrs_q:
+        assert q(**{n: None}) == hip.ENULL, n
+    assert q(C=128) == hip.EINVAL and q(kb=256) == hip.EINVAL                # the shipped refiner: 256 channels, 512-wide stride-32 features
+    assert q(J=17) == hip.EINVAL and q(J=0) == hip.EINVAL and q(B=0) == hip.EINVAL and q(groups=0) == hip.EINVAL
+    assert q(ol_n=190) == hip.EINVAL and q(w_packed=3) == hip.EINVAL and q(pool_hw=0) == hip.EINVAL
+    assert q(w_q=P + 4) == hip.EINVAL                                        # 16-byte weight loads
+
+    ptrs_p = ("h1", "w_m2", "b_m2", "cams", "w_qg0", "b_qg0", "w_qg2", "b_qg2", "w_qg4", "b_qg4", "w_ol", "b_ol", "pred_out", "anchors3d_out",
+              "anchors2d_out", "valid_out", "x_out", "ol_out")
+
+    def p(**kw):
+        d = hip.PoseQueryDesc()
+        d.B, d.J, d.C, d.ol_n, d.w_packed = 2, 16, 128, 192, 2
+        for n in ptrs_p:
+            setattr(d, n, P)
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return lib.egr_pose_query_f32(C.byref(d), None)
+
+    assert lib.egr_pose_query_f32(None, None) == hip.ENULL
+    for n in ptrs_p:
+        assert p(**{n: None}) == hip.ENULL, n
+    assert p(J=15) == hip.EINVAL and p(C=256) == hip.EINVAL and p(B=0) == hip.EINVAL and p(ol_n=8) == hip.EINVAL and p(w_packed=-1) == hip.EINVAL
+    assert p(w_m2=P + 8) == hip.EINVAL
+
+    # the layer launch with the head-offset tail: needs post_norm, 256 channels, 64 head channels, no regression head
+    need = ("x", "g", "sigma", "rowmask", "w_fold", "c_fold", "w_out", "b_out", "w_fuse", "b_fuse", "ln1_g", "ln1_b", "w_qkv", "b_qkv", "w_mo", "b_mo",
+            "ln2_g", "ln2_b", "w_f0", "b_f0", "w_f1", "b_f1", "ln3_g", "ln3_b", "x_out")
+
+    def layer(**kw):
+        d = hip.LayerDesc()
+        d.B, d.J, d.V, d.C, d.heads, d.cf, d.groups, d.ffn_dim = 2, 15, 4, 256, 4, 128, 4, 512
+        d.w_packed = 2
+        for n in need + ("lnp_g", "lnp_b", "w_h0", "b_h0", "h0_out"):
+            setattr(d, n, P)
+        d.h0_n = 64
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return lib.egr_joint_layer_f32(C.byref(d), None)
+
+    assert layer(lnp_g=None) == hip.EINVAL                                   # the tail reads post_norm's output
+    assert layer(b_h0=None) == hip.ENULL and layer(h0_out=None) == hip.ENULL
+    assert layer(C=128) == hip.EINVAL and layer(h0_n=32) == hip.EINVAL and layer(h0_out=P + 4) == hip.EINVAL
+    assert layer(w_r0=P, b_r0=P, w_r2=P, b_r2=P, anchors3d=P, pred_out=P) == hip.EINVAL
