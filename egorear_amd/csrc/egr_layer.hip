@@ -52,9 +52,33 @@ __device__ __forceinline__ float gelu_erf(float t) { return 0.5f * t * (1.0f + e
 // packed: W is in fragment order (egr_pack_layer_w_f32: [16-column block][128-deep chunk][16-deep k block][lane][4 floats]) - a
 // wave's weight load is then 1 KiB contiguous instead of 16 rows x 64 bytes (the layer kernel streams 0.9 - 3.4 MB of weights per
 // workgroup: -14 % time); the segments of a multi-segment call must be adjacent in K (w_seg == K), which they are.
+// A first weight chunk requested AHEAD of its product (gemm_first_*): the request goes out before the barrier / staging that precedes
+// the product, so its latency runs under them instead of behind them.
+struct WPre {
+    f32x4_t b[8];
+};
+__device__ __forceinline__ void gemm_first_f32(const float* __restrict__ W, int ldw, int K, int nb0, int lane, bool packed, WPre& pre) {
+    const int i = lane & 15, q = lane >> 4;
+    if (packed) {
+        const float* p = W + (int64_t)nb0 * (K / 128) * 8 * 256 + lane * 4;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pre.b[u] = *reinterpret_cast<const f32x4_t*>(p + 256 * u);
+    } else {
+        const float* p = W + (int64_t)(nb0 * 16 + i) * ldw + 4 * q;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pre.b[u] = *reinterpret_cast<const f32x4_t*>(p + 16 * u);
+    }
+}
+// (fp16 scheme: the image's first chunk of column block nb0; K = the matrix' whole depth)
+__device__ __forceinline__ void gemm_first_h2(const float* __restrict__ W, int K, int nb0, int lane, WPre& pre) {
+    const float* p = W + (int64_t)nb0 * (K / 128) * 8 * 256 + lane * 4;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) pre.b[u] = *reinterpret_cast<const f32x4_t*>(p + 256 * u);
+}
+
 template <int RB, int NSEG, typename Epi>
 __device__ __forceinline__ void gemm_cols(const float* __restrict__ A, int lda, int a_seg, const float* __restrict__ W, int ldw, int w_seg, int K,
-                                          int nb0, int nstep, int nb1, int lane, bool packed, Epi&& epi) {
+                                          int nb0, int nstep, int nb1, int lane, bool packed, Epi&& epi, const WPre* pre = nullptr) {
     const int i = lane & 15, q = lane >> 4;
     constexpr int CH = 8;      // 16-deep k blocks per chunk (128 k)
     const int cps = K / (16 * CH);          // chunks per segment
@@ -104,7 +128,13 @@ __device__ __forceinline__ void gemm_cols(const float* __restrict__ A, int lda, 
             ++c_blk;
         }
     };
-    load(b0);
+    if (pre) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) b0[u] = pre->b[u];
+        if (++l_c == cpb) { l_c = 0; ++l_blk; }
+    } else {
+        load(b0);
+    }
     for (int s = 0; s < steps; s += 2) {
         if (s + 1 < steps) load(b1);
         compute(b0);
@@ -119,7 +149,7 @@ __device__ __forceinline__ void gemm_cols(const float* __restrict__ A, int lda, 
 // W[column i][the same k]; products (l,h) (h,l) (h,h) as in the conv kernels.  The accumulators reach epi() descaled.
 template <int RB, int NSEG, typename Epi>
 __device__ __forceinline__ void gemm_cols_h2(const float* __restrict__ A, int lda, int a_seg, const float* __restrict__ W, const float* __restrict__ wds,
-                                             int K, int nb0, int nstep, int nb1, int lane, float sa, float inv, Epi&& epi) {
+                                             int K, int nb0, int nstep, int nb1, int lane, float sa, float inv, Epi&& epi, const WPre* pre = nullptr) {
     using namespace egrc;
     const int i = lane & 15, q = lane >> 4;
     constexpr int CH = 8;
@@ -170,7 +200,13 @@ __device__ __forceinline__ void gemm_cols_h2(const float* __restrict__ A, int ld
             ++c_blk;
         }
     };
-    load(b0);
+    if (pre) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) b0[u] = __builtin_bit_cast(u32x4, pre->b[u]);
+        if (++l_c == cpb) { l_c = 0; ++l_blk; }
+    } else {
+        load(b0);
+    }
     for (int s = 0; s < steps; s += 2) {
         if (s + 1 < steps) load(b1);
         compute(b0);
@@ -329,15 +365,20 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
     // one contraction in either arithmetic: `rows` x `ktot` is the whole weight matrix (its descales sit behind the image), `slot` the
     // abs-max slot of the A tile
     auto gemm = [&](auto rb_tag, auto nseg_tag, const float* A, int lda, int a_seg, const float* W, int rows, int ktot, int ldw, int w_seg, int K,
-                    int nb0, int nstep, int nb1, int slot, auto&& epi) __attribute__((always_inline)) {
+                    int nb0, int nstep, int nb1, int slot, auto&& epi, const WPre* pre = nullptr) __attribute__((always_inline)) {
         constexpr int RB = decltype(rb_tag)::value, NSEG = decltype(nseg_tag)::value;
         if constexpr (H2) {
             float sa, inv;
             tile_prescale(s_amax[slot], sa, inv);
-            gemm_cols_h2<RB, NSEG>(A, lda, a_seg, W, W + (int64_t)rows * ktot, K, nb0, nstep, nb1, lane, sa, inv, epi);
+            gemm_cols_h2<RB, NSEG>(A, lda, a_seg, W, W + (int64_t)rows * ktot, K, nb0, nstep, nb1, lane, sa, inv, epi, pre);
         } else {
-            gemm_cols<RB, NSEG>(A, lda, a_seg, W, ldw, w_seg, K, nb0, nstep, nb1, lane, wpk, epi);
+            gemm_cols<RB, NSEG>(A, lda, a_seg, W, ldw, w_seg, K, nb0, nstep, nb1, lane, wpk, epi, pre);
         }
+    };
+    // the first weight chunk of column block nb0 of a (rows x ktot) matrix, requested ahead (WPre)
+    auto first = [&](const float* W, int ktot, int nb0, WPre& pre) __attribute__((always_inline)) {
+        if constexpr (H2) gemm_first_h2(W, ktot, nb0, lane, pre);
+        else gemm_first_f32(W, ktot, ktot, nb0, lane, wpk, pre);
     };
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
@@ -360,14 +401,17 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
         if (H2 && slot_out >= 0) tile_track(s_amax + slot_out, amx);
     };
 
-    // ---- value projection of the sampled rows (sample-then-project) + output_proj, in two 32-row halves
-    for (int hf = 0; hf < 2; ++hf) {
-        for (int ps = 0; ps < C / PW; ++ps) {          // PW output columns per pass: one 16-column block per wave
-            // stage the sampled features of the heads behind these columns: bufG[hp][32][LG]
-            // (all of a thread's loads first, then the LDS writes: a load -> store loop waits for every load in turn)
-            constexpr int NST = HPP * 32 * (CF / 4) / NTH;
-            static_assert(HPP * 32 * (CF / 4) % NTH == 0, "staging units per thread");
-            f32x4_t stg[NST];
+    // ---- value projection of the sampled rows (sample-then-project) + output_proj, in two 32-row halves.
+    // Round 5: software-pipelined over the (half, pass) sequence - every global request of a pass (its weight chunk, its positional
+    // terms, the NEXT pass's sampled features) is on its way before the barrier in front of the product instead of being waited for
+    // one after the other behind it (per pass: three exposed round trips -> one).
+    {
+        constexpr int NPS = C / PW;                    // passes per half: PW output columns each, one 16-column block per wave
+        constexpr int NST = HPP * 32 * (CF / 4) / NTH;
+        static_assert(HPP * 32 * (CF / 4) % NTH == 0, "staging units per thread");
+        f32x4_t stg[NST];
+        // the sampled features of the heads behind a pass' columns: bufG[hp][32][LG] (all of a thread's loads first, then the LDS writes)
+        auto stage_load = [&](int hf, int ps) __attribute__((always_inline)) {
 #pragma unroll
             for (int it = 0; it < NST; ++it) {
                 const int idx = tid + it * NTH;
@@ -376,61 +420,88 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
                 stg[it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
                 if (rl < nrow) stg[it] = *reinterpret_cast<const f32x4_t*>(gq + ((int64_t)(row0 + rl) * HEADS + h) * CF + cq * 4);
             }
-            float samx = 0.f;
+        };
+        stage_load(0, 0);
+        for (int hf = 0; hf < 2; ++hf) {
+            WPre pre_out;
+            for (int ps = 0; ps < NPS; ++ps) {
+                float samx = 0.f;
 #pragma unroll
-            for (int it = 0; it < NST; ++it) {
-                const int idx = tid + it * NTH;
-                const int cq = idx % (CF / 4), r = (idx / (CF / 4)) % 32, hp = idx / (32 * (CF / 4));
-                *reinterpret_cast<f32x4_t*>(bufG + (hp * 32 + r) * LG + cq * 4) = stg[it];
-                samx = fmaxf(fmaxf(samx, fmaxf(fabsf(stg[it][0]), fabsf(stg[it][1]))), fmaxf(fabsf(stg[it][2]), fabsf(stg[it][3])));
-            }
-            if constexpr (H2) tile_track(s_amax + hf * 2 + ps, samx);
-            __syncthreads();
-            if (wave * 16 < PW) {
+                for (int it = 0; it < NST; ++it) {
+                    const int idx = tid + it * NTH;
+                    const int cq = idx % (CF / 4), r = (idx / (CF / 4)) % 32, hp = idx / (32 * (CF / 4));
+                    *reinterpret_cast<f32x4_t*>(bufG + (hp * 32 + r) * LG + cq * 4) = stg[it];
+                    samx = fmaxf(fmaxf(samx, fmaxf(fabsf(stg[it][0]), fabsf(stg[it][1]))), fmaxf(fabsf(stg[it][2]), fabsf(stg[it][3])));
+                }
+                if constexpr (H2) tile_track(s_amax + hf * 2 + ps, samx);
+                const bool mine = wave * 16 < PW;
                 const int n0 = ps * PW + wave * 16;    // this wave's output columns [n0, n0 + 16)
                 const int h = n0 / DH, hp = h - ps * HPP;
+                WPre pre;
+                float ev[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                if (mine) {
+                    first(w_fold, CF, n0 / 16, pre);
+                    if (eq) {
+#pragma unroll
+                        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int rl = hf * 32 + rb * 16 + 4 * q4 + r;
+                                if (rl < nrow) ev[rb][r] = eq[(int64_t)(row0 + rl) * C + n0 + i16];
+                            }
+                    }
+                }
+                __syncthreads();
+                // the next pass's sampled features travel under this pass's product (the next HALF's first pass is requested behind
+                // output_proj instead: in flight across it they cost registers the fp16 variant does not have)
+                if (ps + 1 < NPS) stage_load(hf, ps + 1);
+                if (mine) {
+                    float amx = 0.f;
+                    gemm(I2{}, I1{}, bufG + hp * 32 * LG, LG, 0, w_fold, C, CF, CF, 0, CF, n0 / 16, 1, n0 / 16 + 1, hf * 2 + ps, [&](int nb, const f32x4_t (&acc)[2]) {
+                        const int col = nb * 16 + i16;
+                        const float cf_ = c_fold[col];
+#pragma unroll
+                        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int rl32 = rb * 16 + 4 * q4 + r, rl = hf * 32 + rl32;
+                                float v = 0.f;
+                                if (rl < nrow) {
+                                    v = acc[rb][r] + cf_ * s_sig[h * 64 + rl];
+                                    if (eq) v += ev[rb][r];
+                                }
+                                bufA[rl32 * LC + col] = v;
+                                amx = fmaxf(amx, fabsf(v));
+                            }
+                    }, &pre);
+                    if constexpr (H2) tile_track(s_amax + 4 + hf, amx);
+                }
+                if (ps == NPS - 1) first(w_out, C, wave, pre_out);     // output_proj's first chunk under the barrier
+                __syncthreads();
+            }
+            // output_proj on the 32 rows of this half; masked_fill(~valid) AFTER it (the bias is zeroed too)
+            {
                 float amx = 0.f;
-                gemm(I2{}, I1{}, bufG + hp * 32 * LG, LG, 0, w_fold, C, CF, CF, 0, CF, n0 / 16, 1, n0 / 16 + 1, hf * 2 + ps, [&](int nb, const f32x4_t (&acc)[2]) {
+                gemm(I2{}, I1{}, bufA, LC, 0, w_out, C, C, C, 0, C, wave, NW, C / 16, 4 + hf, [&](int nb, const f32x4_t (&acc)[2]) {
                     const int col = nb * 16 + i16;
-                    const float cf_ = c_fold[col];
+                    const float bo = b_out[col];
 #pragma unroll
                     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int rl32 = rb * 16 + 4 * q4 + r, rl = hf * 32 + rl32;
-                            float v = 0.f;
-                            if (rl < nrow) {
-                                v = acc[rb][r] + cf_ * s_sig[h * 64 + rl];
-                                if (eq) v += eq[(int64_t)(row0 + rl) * C + col];
-                            }
-                            bufA[rl32 * LC + col] = v;
+                            const int rl = hf * 32 + rb * 16 + 4 * q4 + r;
+                            const bool keep = s_keep[rl] != 0.f;
+                            const float v = keep ? acc[rb][r] + bo : 0.f;
+                            bufO[rl * LC + col] = v;
                             amx = fmaxf(amx, fabsf(v));
                         }
-                });
-                if constexpr (H2) tile_track(s_amax + 4 + hf, amx);
+                }, &pre_out);
+                if constexpr (H2) tile_track(s_amax + 6, amx);
             }
+            if (hf == 0) stage_load(1, 0);
             __syncthreads();
+            LSTAMP(16 + hf);
         }
-        // output_proj on the 32 rows of this half; masked_fill(~valid) AFTER it (the bias is zeroed too)
-        {
-            float amx = 0.f;
-            gemm(I2{}, I1{}, bufA, LC, 0, w_out, C, C, C, 0, C, wave, NW, C / 16, 4 + hf, [&](int nb, const f32x4_t (&acc)[2]) {
-                const int col = nb * 16 + i16;
-                const float bo = b_out[col];
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int rl = hf * 32 + rb * 16 + 4 * q4 + r;
-                        const bool keep = s_keep[rl] != 0.f;
-                        const float v = keep ? acc[rb][r] + bo : 0.f;
-                        bufO[rl * LC + col] = v;
-                        amx = fmaxf(amx, fabsf(v));
-                    }
-            });
-            if constexpr (H2) tile_track(s_amax + 6, amx);
-        }
-        __syncthreads();
     }
     LSTAMP(1);
     // ---- cat over views -> fuse_mlp: token j = rows 4j .. 4j+3 of bufO side by side (V segments of K = C)
@@ -574,15 +645,29 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
                 __syncthreads();
                 float amx = 0.f;
                 {
+                    // lane = output channel (its filter row in registers), a wave walks pixel quads: one broadcast 16-byte LDS read per
+                    // (joint, quad) instead of two 4-byte reads per multiply-add
                     const int n = tid & (HN - 1);
                     const float bb = wT[J * HN + n];
-                    for (int p = tid / HN; p < C; p += NTH / HN) {
-                        float s = 0.f;
-                        for (int jj = 0; jj < J; ++jj) s = fmaf(tile0[jj * LC + p], wT[jj * HN + n], s);
-                        s += bb;
-                        s = s > 0.f ? s : 0.f;
-                        h0[p * HN + n] = s;
-                        amx = fmaxf(amx, s);
+                    float wr[16];
+#pragma unroll
+                    for (int jj = 0; jj < 16; ++jj) wr[jj] = jj < J ? wT[jj * HN + n] : 0.f;
+                    for (int p0 = 4 * (tid / HN); p0 < C; p0 += 4 * (NTH / HN)) {
+                        float sacc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int jj = 0; jj < 16; ++jj)
+                            if (jj < J) {
+                                const f32x4_t t = *reinterpret_cast<const f32x4_t*>(tile0 + jj * LC + p0);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) sacc[i] = fmaf(t[i], wr[jj], sacc[i]);
+                            }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float v = sacc[i] + bb;
+                            v = v > 0.f ? v : 0.f;
+                            h0[(p0 + i) * HN + n] = v;
+                            amx = fmaxf(amx, v);
+                        }
                     }
                 }
                 if (d.amax_h0) {        // an upper bound of |h0_out| (interpolation weights are non-negative and sum to 1): one atomic per wave
