@@ -26,6 +26,7 @@
 // scale, two fp16 planes in fragment order, the descales behind the image).  Activations: every tile that feeds a contraction is
 // produced inside this kernel, its producers fold max |v| into an LDS slot (one atomic per wave), the consumer scales by the
 // power of two that puts that maximum into [2^14, 2^15) and splits its A fragments on the fly (8 floats of a row -> 2 x 8 fp16).
+#include <cstdlib>
 #include <type_traits>
 
 #include "egr_common.h"
@@ -41,6 +42,8 @@ struct LayerArgs {
 };
 
 constexpr int PAD = 4;   // LDS row padding (floats)
+constexpr int NW = 8;    // waves per workgroup (two per SIMD: one's weight fetches hide under the other's MFMAs)
+constexpr int NTH = NW * 64;
 
 __device__ __forceinline__ float gelu_erf(float t) { return 0.5f * t * (1.0f + erff(t * 0.70710678118654752440f)); }
 
@@ -265,6 +268,79 @@ __device__ __forceinline__ void ln_rows(const float* t, int ldt, const float* re
     if (slot) tile_track(slot, amx);
 }
 
+// ---- tail: the refiner's head offset (heatmap_mvf_ex.py:707-711 + TransformerHeadLayer.head[0..2]): the J x (s*s) token
+// matrix IS an s x s image with the joints as channels (pixel p = channel p of xn); Conv2d(J, HN, 1) + ReLU on it (the fma chain of
+// linear_smallk_kernel: k left to right, then the bias), then Upsample(x2, bilinear, align_corners) with upsample2x_kernel's
+// arithmetic, straight to (2s, 2s, HN) NHWC - the launches egr_tokens_to_nhwc_f32, egr_linear_smallk_f32, egr_upsample2x_nhwc_f32
+template <int LC>
+__device__ __forceinline__ void head_offset_tail(const egr_layer_desc& d, int grp, int fb, int B, int J, const float* tile0, float* bufO, float* bufG,
+                                                 int tid, int lane) {
+    constexpr int C = 256;
+    constexpr int S = 16, HN = 64;
+    float* const h0 = bufO;                       // [C pixels][HN]
+    float* const wT = bufG;                       // [J][HN] + bias [HN]
+    const float* const w_h0 = d.w_h0 + (int64_t)grp * HN * J;
+    for (int idx = tid; idx < HN * J; idx += NTH) {
+        const int n = idx / J, jj = idx - n * J;
+        wT[jj * HN + n] = w_h0[idx];
+    }
+    if (tid < HN) wT[J * HN + tid] = d.b_h0[grp * HN + tid];
+    __syncthreads();
+    float amx = 0.f;
+    {
+        // lane = output channel (its filter row in registers), a wave walks pixel quads: one broadcast 16-byte LDS read per
+        // (joint, quad) instead of two 4-byte reads per multiply-add
+        const int n = tid & (HN - 1);
+        const float bb = wT[J * HN + n];
+        float wr[16];
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) wr[jj] = jj < J ? wT[jj * HN + n] : 0.f;
+        for (int p0 = 4 * (tid / HN); p0 < C; p0 += 4 * (NTH / HN)) {
+            float sacc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj)
+                if (jj < J) {
+                    const f32x4_t t = *reinterpret_cast<const f32x4_t*>(tile0 + jj * LC + p0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sacc[i] = fmaf(t[i], wr[jj], sacc[i]);
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = sacc[i] + bb;
+                v = v > 0.f ? v : 0.f;
+                h0[(p0 + i) * HN + n] = v;
+                amx = fmaxf(amx, v);
+            }
+        }
+    }
+    if (d.amax_h0) {        // an upper bound of |h0_out| (interpolation weights are non-negative and sum to 1): one atomic per wave
+        amx = wave_max(amx);
+        if (lane == 0 && amx > 0.f) atomicMax(d.amax_h0 + (blockIdx.x & 63), __float_as_uint(amx));
+    }
+    __syncthreads();
+    constexpr int SO = 2 * S;
+    const float sc = (float)(S - 1) / (float)(SO - 1);
+    const int cq = tid & (HN / 4 - 1), ox = tid / (HN / 4);          // 16 channel quads x 32 columns = 512 threads
+    static_assert(NTH == (HN / 4) * SO, "one thread per (column, channel quad)");
+    const float fx = sc * (float)ox;
+    const int x0 = (int)fx, x1 = min(x0 + 1, S - 1);
+    const float lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f), lx0 = 1.f - lx1;
+    float* const out = d.h0_out + ((int64_t)grp * B + fb) * SO * SO * HN;
+    for (int oy = 0; oy < SO; ++oy) {
+        const float fy = sc * (float)oy;
+        const int y0 = (int)fy, y1 = min(y0 + 1, S - 1);
+        const float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), ly0 = 1.f - ly1;
+        const f32x4_t v00 = *reinterpret_cast<const f32x4_t*>(h0 + (y0 * S + x0) * HN + cq * 4);
+        const f32x4_t v01 = *reinterpret_cast<const f32x4_t*>(h0 + (y0 * S + x1) * HN + cq * 4);
+        const f32x4_t v10 = *reinterpret_cast<const f32x4_t*>(h0 + (y1 * S + x0) * HN + cq * 4);
+        const f32x4_t v11 = *reinterpret_cast<const f32x4_t*>(h0 + (y1 * S + x1) * HN + cq * 4);
+        f32x4_t o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = ly0 * (lx0 * v00[i] + lx1 * v01[i]) + ly1 * (lx0 * v10[i] + lx1 * v11[i]);
+        *reinterpret_cast<f32x4_t*>(out + ((int64_t)oy * SO + ox) * HN + cq * 4) = o;
+    }
+}
+
 #ifdef LAYER_STAMPS      // diagnostic build (tools/probes/layer_stamps.py): s_memtime of workgroup 0 at the phase boundaries
 __device__ unsigned long long g_layer_stamps[64];
 #define LSTAMP(n) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_layer_stamps[n] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -272,8 +348,18 @@ __device__ unsigned long long g_layer_stamps[64];
 #define LSTAMP(n) do { } while (0)
 #endif
 
-constexpr int NW = 8;            // waves per workgroup (two per SIMD: one's weight fetches hide under the other's MFMAs)
-constexpr int NTH = NW * 64;
+// (query set, frame) of a workgroup: blocks b and b + 8 share an XCD - keep a query set's frames (same weights) on the same XCDs
+__device__ __forceinline__ void wg_group_frame(int bid, int G, int B, int& grp, int& fb) {
+    if (G > 1 && (8 % G) == 0 && ((G * B) % 8) == 0) {
+        const int per = 8 / G;
+        grp = (bid & 7) / per;
+        fb = (bid >> 3) * per + ((bid & 7) % per);
+    } else {
+        grp = bid / B;
+        fb = bid - grp * B;
+    }
+}
+
 
 template <int C>
 struct LayerLds {
@@ -627,76 +713,8 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
                 const int r = idx / C, ch = idx - r * C;
                 d.xn_out[(xrow0 + r) * C + ch] = tile0[r * LC + ch];
             }
-        // ---- tail: the refiner's head offset (heatmap_mvf_ex.py:707-711 + TransformerHeadLayer.head[0..2]): the J x (s*s) token
-        // matrix IS an s x s image with the joints as channels (pixel p = channel p of xn); Conv2d(J, HN, 1) + ReLU on it (the fma chain of
-        // linear_smallk_kernel: k left to right, then the bias), then Upsample(x2, bilinear, align_corners) with upsample2x_kernel's
-        // arithmetic, straight to (2s, 2s, HN) NHWC - the launches egr_tokens_to_nhwc_f32, egr_linear_smallk_f32, egr_upsample2x_nhwc_f32
         if constexpr (C == 256) {
-            if (d.w_h0) {
-                constexpr int S = 16, HN = 64;
-                float* const h0 = bufO;                       // [C pixels][HN]
-                float* const wT = bufG;                       // [J][HN] + bias [HN]
-                const float* const w_h0 = d.w_h0 + (int64_t)grp * HN * J;
-                for (int idx = tid; idx < HN * J; idx += NTH) {
-                    const int n = idx / J, jj = idx - n * J;
-                    wT[jj * HN + n] = w_h0[idx];
-                }
-                if (tid < HN) wT[J * HN + tid] = d.b_h0[grp * HN + tid];
-                __syncthreads();
-                float amx = 0.f;
-                {
-                    // lane = output channel (its filter row in registers), a wave walks pixel quads: one broadcast 16-byte LDS read per
-                    // (joint, quad) instead of two 4-byte reads per multiply-add
-                    const int n = tid & (HN - 1);
-                    const float bb = wT[J * HN + n];
-                    float wr[16];
-#pragma unroll
-                    for (int jj = 0; jj < 16; ++jj) wr[jj] = jj < J ? wT[jj * HN + n] : 0.f;
-                    for (int p0 = 4 * (tid / HN); p0 < C; p0 += 4 * (NTH / HN)) {
-                        float sacc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int jj = 0; jj < 16; ++jj)
-                            if (jj < J) {
-                                const f32x4_t t = *reinterpret_cast<const f32x4_t*>(tile0 + jj * LC + p0);
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) sacc[i] = fmaf(t[i], wr[jj], sacc[i]);
-                            }
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            float v = sacc[i] + bb;
-                            v = v > 0.f ? v : 0.f;
-                            h0[(p0 + i) * HN + n] = v;
-                            amx = fmaxf(amx, v);
-                        }
-                    }
-                }
-                if (d.amax_h0) {        // an upper bound of |h0_out| (interpolation weights are non-negative and sum to 1): one atomic per wave
-                    amx = wave_max(amx);
-                    if (lane == 0 && amx > 0.f) atomicMax(d.amax_h0 + (blockIdx.x & 63), __float_as_uint(amx));
-                }
-                __syncthreads();
-                constexpr int SO = 2 * S;
-                const float sc = (float)(S - 1) / (float)(SO - 1);
-                const int cq = tid & (HN / 4 - 1), ox = tid / (HN / 4);          // 16 channel quads x 32 columns = 512 threads
-                static_assert(NTH == (HN / 4) * SO, "one thread per (column, channel quad)");
-                const float fx = sc * (float)ox;
-                const int x0 = (int)fx, x1 = min(x0 + 1, S - 1);
-                const float lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f), lx0 = 1.f - lx1;
-                float* const out = d.h0_out + ((int64_t)grp * B + fb) * SO * SO * HN;
-                for (int oy = 0; oy < SO; ++oy) {
-                    const float fy = sc * (float)oy;
-                    const int y0 = (int)fy, y1 = min(y0 + 1, S - 1);
-                    const float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), ly0 = 1.f - ly1;
-                    const f32x4_t v00 = *reinterpret_cast<const f32x4_t*>(h0 + (y0 * S + x0) * HN + cq * 4);
-                    const f32x4_t v01 = *reinterpret_cast<const f32x4_t*>(h0 + (y0 * S + x1) * HN + cq * 4);
-                    const f32x4_t v10 = *reinterpret_cast<const f32x4_t*>(h0 + (y1 * S + x0) * HN + cq * 4);
-                    const f32x4_t v11 = *reinterpret_cast<const f32x4_t*>(h0 + (y1 * S + x1) * HN + cq * 4);
-                    f32x4_t o;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = ly0 * (lx0 * v00[i] + lx1 * v01[i]) + ly1 * (lx0 * v10[i] + lx1 * v11[i]);
-                    *reinterpret_cast<f32x4_t*>(out + ((int64_t)oy * SO + ox) * HN + cq * 4) = o;
-                }
-            }
+            if (d.w_h0) head_offset_tail<LC>(d, grp, fb, B, J, tile0, bufO, bufG, tid, lane);
         }
         if (d.w_r0) {
             linear16(tile0, LC, d.w_r0 + grp * wsz(C, C), C, d.b_r0 + grp * C, C, bufG, LC, true, 12, -1);
@@ -709,6 +727,491 @@ __global__ __launch_bounds__(NTH) void joint_layer_kernel(const LayerArgs a) {
                 for (int k = 0; k < C; ++k) s = fmaf(bufG[r * LC + k], w[k], s);
                 s += d.b_r2[grp * 3 + o];
                 d.pred_out[(xrow0 + r) * 3 + o] = s + d.anchors3d[(xrow0 + r) * 3 + o];
+            }
+        }
+    }
+    LSTAMP(9);
+}
+
+// ------------------------------------------------------------------ the layer with its A tiles split ONCE (round 5)
+// joint_layer_kernel<C, true> splits a row's 8 floats into their fp16 planes inside the product loop - every one of the eight waves
+// does that for the SAME 16 (or 32) rows, and the conversion (2 x 10 vector instructions per 3 matrix instructions) is what a
+// product step costs.  Here a tile that feeds a contraction is split once, by all threads, into fragment-ordered planes in a
+// dedicated LDS region ([128-deep chunk][32-deep block][row block][plane h | l][lane][8 fp16]); the product loop is two 16-byte
+// LDS reads and three MFMAs per block.  Same scales, same products in the same order: bit-identical to joint_layer_kernel<C, true>
+// (tested).  The first weight chunk of every product is requested before the barriers in front of it.
+template <int C>
+struct PlaneLds {
+    static constexpr int HEADS = 4, DH = C / HEADS, CF = 128, FF = 512;
+    static constexpr int LC = C + PAD, LQ = 3 * C + PAD, LF = FF + PAD;
+    static constexpr int T = 16 * LC;
+    static constexpr int PW = (NW * 16 < C) ? NW * 16 : C;
+    static constexpr int HPP = PW / DH;
+    static constexpr int BUFA = 2 * T;
+    static constexpr int M1 = 64 * LC, M2 = 16 * LQ, M3 = 16 * LF;
+    static constexpr int BUFO = (M1 > M2 ? (M1 > M3 ? M1 : M3) : (M2 > M3 ? M2 : M3));
+    static constexpr int BUFG = T > 2048 ? T : 2048;           // x residual / small products / attention probabilities / head filter
+    // plane region (bytes): the sampled rows of a pass (HPP heads x 32 rows x 128), output_proj's 32 x C, the FFN's 16 x 512; fuse_mlp's
+    // 16 x 4C takes the region and, where that is too small (C = 256), the idle bufA behind it
+    static constexpr int PV = HPP * 16384, PO = 32 * C * 4, PF = 16 * FF * 4;
+    static constexpr int PBYTES = (PV > PO ? (PV > PF ? PV : PF) : (PO > PF ? PO : PF));
+    static constexpr int FUSE_CH = 4 * C / 128;                // chunks of fuse_mlp's A
+    static constexpr int FUSE_IN_P = (PBYTES / 8192 < FUSE_CH) ? PBYTES / 8192 : FUSE_CH;
+    static_assert((FUSE_CH - FUSE_IN_P) * 8192 <= BUFA * 4, "fuse_mlp planes: region + bufA");
+    static constexpr int SIDE = 64 * HEADS + 64 + 16;
+    static constexpr size_t BYTES = sizeof(float) * (size_t)(BUFA + BUFO + BUFG + SIDE) + PBYTES;
+};
+
+// 16 RB rows x K of fp32 (element (row, k) at src(row, k), 8 consecutive k contiguous) -> planes: chunk c < nsplit in P0, the rest in P1
+template <int RB, typename Src>
+__device__ __forceinline__ void split_tile(Src&& src, int K, char* P0, char* P1, int nsplit, float sa, int tid) {
+    const int oct = K >> 3, units = RB * 16 * oct;
+    constexpr int CHB = 8192 * RB;
+    for (int u = tid; u < units; u += NTH) {
+        const int i = u & 15, t = u >> 4, o = t % oct, rb = t / oct;
+        const float* p = src(rb * 16 + i, o * 8);
+        const f32x4_t x0 = *reinterpret_cast<const f32x4_t*>(p), x1 = *reinterpret_cast<const f32x4_t*>(p + 4);
+        unsigned h0, l0, h1, l1, h2, l2, h3, l3;
+        egrc::split4_f16(x0[0], x0[1], x0[2], x0[3], sa, h0, l0, h1, l1);
+        egrc::split4_f16(x1[0], x1[1], x1[2], x1[3], sa, h2, l2, h3, l3);
+        const int c = o >> 4, kb = (o >> 2) & 3, q = o & 3;
+        char* d = (c < nsplit ? P0 + c * CHB : P1 + (c - nsplit) * CHB) + ((kb * RB + rb) * 2) * 1024 + (16 * q + i) * 16;
+        *reinterpret_cast<egrc::u32x4*>(d) = egrc::u32x4{h0, h1, h2, h3};
+        *reinterpret_cast<egrc::u32x4*>(d + 1024) = egrc::u32x4{l0, l1, l2, l3};
+    }
+}
+
+// gemm_cols_h2's pipeline with the A fragments read from planes (chunk c of a column block: P0 + c CHB for c < nsplit, else P1)
+template <int RB, typename Epi>
+__device__ __forceinline__ void gemm_planes(const char* P0, const char* P1, int nsplit, const float* __restrict__ W, const float* __restrict__ wds,
+                                            int cpb, int nb0, int nstep, int nb1, int lane, float inv, Epi&& epi, const WPre* pre = nullptr) {
+    using namespace egrc;
+    constexpr int CH = 8, CHB = 8192 * RB;
+    const int i = lane & 15;
+    const int nblk = (nb1 - nb0 + nstep - 1) / nstep;
+    if (nblk <= 0) return;
+    const int steps = nblk * cpb;
+    u32x4 b0[CH], b1[CH];
+    f32x4_t acc[RB];
+    int l_blk = 0, l_c = 0;
+    auto load = [&](u32x4 (&b)[CH]) {
+        const float* p = W + ((int64_t)((nb0 + l_blk * nstep) * cpb + l_c) * CH) * 256 + lane * 4;
+#pragma unroll
+        for (int u = 0; u < CH; ++u) b[u] = *reinterpret_cast<const u32x4*>(p + 256 * u);
+        if (++l_c == cpb) { l_c = 0; ++l_blk; }
+    };
+    int c_blk = 0, c_c = 0;
+    auto compute = [&](const u32x4 (&b)[CH]) {
+        if (c_c == 0) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+        const char* p = (c_c < nsplit ? P0 + c_c * CHB : P1 + (c_c - nsplit) * CHB) + lane * 16;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const u32x4 ah = *reinterpret_cast<const u32x4*>(p + ((kb * RB + rb) * 2) * 1024);
+                const u32x4 al = *reinterpret_cast<const u32x4*>(p + ((kb * RB + rb) * 2 + 1) * 1024);
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al), __builtin_bit_cast(f16x8, b[2 * kb]), acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, b[2 * kb + 1]), acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, b[2 * kb]), acc[rb], 0, 0, 0);
+            }
+        }
+        if (++c_c == cpb) {
+            const int nb = nb0 + c_blk * nstep;
+            const float dsc = wds[nb * 16 + i] * inv;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[rb] *= dsc;
+            epi(nb, acc);
+            c_c = 0;
+            ++c_blk;
+        }
+    };
+    if (pre) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) b0[u] = __builtin_bit_cast(u32x4, pre->b[u]);
+        if (++l_c == cpb) { l_c = 0; ++l_blk; }
+    } else {
+        load(b0);
+    }
+    for (int s = 0; s < steps; s += 2) {
+        if (s + 1 < steps) load(b1);
+        compute(b0);
+        if (s + 2 < steps) load(b0);
+        if (s + 1 < steps) compute(b1);
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(NTH) void joint_layer_p_kernel(const LayerArgs a) {
+    const egr_layer_desc& d = a.d;
+    using L = PlaneLds<C>;
+    constexpr int HEADS = L::HEADS, DH = L::DH, CF = L::CF, FF = L::FF, VPL = C / 64;
+    constexpr int LC = L::LC, LQ = L::LQ, LF = L::LF, T = L::T, PW = L::PW, HPP = L::HPP;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const bufA = lds;
+    float* const bufO = bufA + L::BUFA;
+    float* const bufG = bufO + L::BUFO;
+    char* const P = reinterpret_cast<char*>(bufG + L::BUFG);
+    float* const s_sig = reinterpret_cast<float*>(P + L::PBYTES);      // [HEADS][64]
+    float* const s_keep = s_sig + 64 * HEADS;                          // [64]
+    unsigned* const s_amax = reinterpret_cast<unsigned*>(s_keep + 64); // slots as in joint_layer_kernel
+    float* const tile0 = bufA;
+    float* const tile1 = bufA + T;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, q4 = lane >> 4;
+    const int B = d.B, J = d.J, V = d.V, G = d.groups;
+    int grp, fb;
+    wg_group_frame(blockIdx.x, G, B, grp, fb);
+    const int rows_all = B * J * V, row0 = fb * J * V, nrow = J * V;
+    const int64_t xrow0 = ((int64_t)grp * B + fb) * J;
+    const float* const gq = d.g + (int64_t)grp * rows_all * HEADS * CF;
+    const float* const eq = d.e ? d.e + (int64_t)grp * rows_all * C : nullptr;
+    const float* const sg = d.sigma + (int64_t)grp * HEADS * rows_all;
+    auto wsz = [](int rows, int k) { return (int64_t)rows * k + rows; };
+    const float* const w_fold = d.w_fold + grp * wsz(C, CF);
+    const float* const c_fold = d.c_fold + grp * C;
+    const float* const w_out = d.w_out + grp * wsz(C, C);
+    const float* const b_out = d.b_out + grp * C;
+    const float* const w_fuse = d.w_fuse + grp * wsz(C, 4 * C);
+    const float* const b_fuse = d.b_fuse + grp * C;
+    const float* const w_qkv = d.w_qkv + grp * wsz(3 * C, C);
+    const float* const b_qkv = d.b_qkv + grp * 3 * C;
+    const float* const w_mo = d.w_mo + grp * wsz(C, C);
+    const float* const b_mo = d.b_mo + grp * C;
+    const float* const w_f0 = d.w_f0 + grp * wsz(FF, C);
+    const float* const b_f0 = d.b_f0 + grp * FF;
+    const float* const w_f1 = d.w_f1 + grp * wsz(C, FF);
+    const float* const b_f1 = d.b_f1 + grp * C;
+
+    LSTAMP(0);
+    if (tid < 64 * HEADS) {
+        const int h = tid >> 6, rl = tid & 63;
+        s_sig[tid] = rl < nrow ? sg[(int64_t)h * rows_all + row0 + rl] : 0.f;
+    }
+    if (tid < 64) s_keep[tid] = (tid < nrow && d.rowmask[row0 + tid] != 0) ? 1.f : 0.f;
+    if (tid < 16) s_amax[tid] = 0u;
+    __syncthreads();
+
+    // a 16-row fp32 tile -> planes (behind the barrier that completed its abs-max slot); returns the inverse scale
+    auto split16 = [&](const float* src, int lda, int K, int slot) __attribute__((always_inline)) {
+        float sa, inv;
+        tile_prescale(s_amax[slot], sa, inv);
+        split_tile<1>([&](int row, int k) { return src + row * lda + k; }, K, P, P, 1 << 20, sa, tid);
+        return inv;
+    };
+    // out[16][ldo] = act(planes . W^T + bias) for the wave's column blocks
+    auto linear_p = [&](const float* W, int K, const float* bias, int N, float inv, float* out, int ldo, bool gelu, int slot_out, const WPre* pre)
+                        __attribute__((always_inline)) {
+        float amx = 0.f;
+        gemm_planes<1>(P, P, 1 << 20, W, W + (int64_t)N * K, K / 128, wave, NW, N / 16, lane, inv, [&](int nb, const f32x4_t (&acc)[1]) {
+            const int col = nb * 16 + i16;
+            const float bb = bias[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[0][r] + bb;
+                v = gelu ? gelu_erf(v) : v;
+                out[(4 * q4 + r) * ldo + col] = v;
+                amx = fmaxf(amx, fabsf(v));
+            }
+        }, pre);
+        if (slot_out >= 0) tile_track(s_amax + slot_out, amx);
+    };
+
+    // ---- value projection of the sampled rows + output_proj, in two 32-row halves
+    {
+        constexpr int NPS = C / PW;
+        constexpr int NU = HPP * 32 * (CF / 8) / NTH;          // octets of sampled features per thread and pass
+        static_assert(HPP * 32 * (CF / 8) % NTH == 0, "staging units per thread");
+        f32x4_t stg[NU][2];
+        // unit u = tid + it NTH: row i = u & 15, octet o = (u >> 4) & 15, row block rb = (u >> 8) & 1, head hp = u >> 9
+        auto stage_load = [&](int hf, int ps) __attribute__((always_inline)) {
+#pragma unroll
+            for (int it = 0; it < NU; ++it) {
+                const int u = tid + it * NTH;
+                const int i = u & 15, o = (u >> 4) & 15, rb = (u >> 8) & 1, hp = u >> 9;
+                const int rl = hf * 32 + rb * 16 + i, h = ps * HPP + hp;
+                stg[it][0] = stg[it][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                if (rl < nrow) {
+                    const float* p = gq + ((int64_t)(row0 + rl) * HEADS + h) * CF + o * 8;
+                    stg[it][0] = *reinterpret_cast<const f32x4_t*>(p);
+                    stg[it][1] = *reinterpret_cast<const f32x4_t*>(p + 4);
+                }
+            }
+        };
+        stage_load(0, 0);
+        for (int hf = 0; hf < 2; ++hf) {
+            WPre pre_out;
+            for (int ps = 0; ps < NPS; ++ps) {
+                float samx = 0.f;
+#pragma unroll
+                for (int it = 0; it < NU; ++it)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh)
+                        samx = fmaxf(fmaxf(samx, fmaxf(fabsf(stg[it][hh][0]), fabsf(stg[it][hh][1]))), fmaxf(fabsf(stg[it][hh][2]), fabsf(stg[it][hh][3])));
+                tile_track(s_amax + hf * 2 + ps, samx);
+                const bool mine = wave * 16 < PW;
+                const int n0 = ps * PW + wave * 16;
+                const int h = n0 / DH, hp = h - ps * HPP;
+                WPre pre;
+                float ev[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                if (mine) {
+                    gemm_first_h2(w_fold, CF, n0 / 16, lane, pre);
+                    if (eq) {
+#pragma unroll
+                        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int rl = hf * 32 + rb * 16 + 4 * q4 + r;
+                                if (rl < nrow) ev[rb][r] = eq[(int64_t)(row0 + rl) * C + n0 + i16];
+                            }
+                    }
+                }
+                __syncthreads();                                   // the pass' abs-max slot is complete
+                float sa, inv;
+                tile_prescale(s_amax[hf * 2 + ps], sa, inv);
+#pragma unroll
+                for (int it = 0; it < NU; ++it) {                  // the features go from the registers straight into their planes
+                    const int u = tid + it * NTH;
+                    const int i = u & 15, o = (u >> 4) & 15, rb = (u >> 8) & 1, hp2 = u >> 9;
+                    unsigned h0, l0, h1, l1, h2, l2, h3, l3;
+                    egrc::split4_f16(stg[it][0][0], stg[it][0][1], stg[it][0][2], stg[it][0][3], sa, h0, l0, h1, l1);
+                    egrc::split4_f16(stg[it][1][0], stg[it][1][1], stg[it][1][2], stg[it][1][3], sa, h2, l2, h3, l3);
+                    char* dst = P + hp2 * 16384 + ((((o >> 2) & 3) * 2 + rb) * 2) * 1024 + (16 * (o & 3) + i) * 16;
+                    *reinterpret_cast<egrc::u32x4*>(dst) = egrc::u32x4{h0, h1, h2, h3};
+                    *reinterpret_cast<egrc::u32x4*>(dst + 1024) = egrc::u32x4{l0, l1, l2, l3};
+                }
+                __syncthreads();
+                if (ps + 1 < NPS) stage_load(hf, ps + 1);          // the next pass's features travel under this pass's product
+                if (mine) {
+                    float amx = 0.f;
+                    gemm_planes<2>(P + hp * 16384, P, 1 << 20, w_fold, w_fold + (int64_t)C * CF, 1, n0 / 16, 1, n0 / 16 + 1, lane, inv,
+                                   [&](int nb, const f32x4_t (&acc)[2]) {
+                        const int col = nb * 16 + i16;
+                        const float cf_ = c_fold[col];
+#pragma unroll
+                        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int rl32 = rb * 16 + 4 * q4 + r, rl = hf * 32 + rl32;
+                                float v = 0.f;
+                                if (rl < nrow) {
+                                    v = acc[rb][r] + cf_ * s_sig[h * 64 + rl];
+                                    if (eq) v += ev[rb][r];
+                                }
+                                bufA[rl32 * LC + col] = v;
+                                amx = fmaxf(amx, fabsf(v));
+                            }
+                    }, &pre);
+                    tile_track(s_amax + 4 + hf, amx);
+                }
+                if (ps == NPS - 1) gemm_first_h2(w_out, C, wave, lane, pre_out);
+                __syncthreads();
+            }
+            // output_proj on the 32 rows of this half; masked_fill(~valid) AFTER it (the bias is zeroed too)
+            {
+                float sa, inv;
+                tile_prescale(s_amax[4 + hf], sa, inv);
+                split_tile<2>([&](int row, int k) { return bufA + row * LC + k; }, C, P, P, 1 << 20, sa, tid);
+                __syncthreads();
+                float amx = 0.f;
+                gemm_planes<2>(P, P, 1 << 20, w_out, w_out + (int64_t)C * C, C / 128, wave, NW, C / 16, lane, inv, [&](int nb, const f32x4_t (&acc)[2]) {
+                    const int col = nb * 16 + i16;
+                    const float bo = b_out[col];
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int rl = hf * 32 + rb * 16 + 4 * q4 + r;
+                            const bool keep = s_keep[rl] != 0.f;
+                            const float v = keep ? acc[rb][r] + bo : 0.f;
+                            bufO[rl * LC + col] = v;
+                            amx = fmaxf(amx, fabsf(v));
+                        }
+                }, &pre_out);
+                tile_track(s_amax + 6, amx);
+            }
+            if (hf == 0) stage_load(1, 0);
+            __syncthreads();
+            LSTAMP(16 + hf);
+        }
+    }
+    LSTAMP(1);
+    // ---- cat over views -> fuse_mlp: token j = rows 4j .. 4j+3 of bufO side by side (k = view * C + channel)
+    constexpr int NX4 = 16 * C / 4 / NTH;
+    static_assert(16 * C / 4 % NTH == 0, "residual tile");
+    f32x4_t xr[NX4];
+    {
+        WPre pre;
+        gemm_first_h2(w_fuse, 4 * C, wave, lane, pre);
+        // the layer input (residual of norm_cross) is requested here and parked in tile0 behind the product
+#pragma unroll
+        for (int it = 0; it < NX4; ++it) {
+            const int idx = tid + it * NTH, r = idx / (C / 4), c4 = idx - r * (C / 4);
+            xr[it] = *reinterpret_cast<const f32x4_t*>(d.x + (xrow0 + (r < J ? r : 0)) * C + c4 * 4);
+        }
+        float sa, inv;
+        tile_prescale(s_amax[6], sa, inv);
+        split_tile<1>([&](int row, int k) { return bufO + row * (V * LC) + (k / C) * LC + (k % C); }, 4 * C, P, reinterpret_cast<char*>(bufA), L::FUSE_IN_P, sa, tid);
+        __syncthreads();
+        gemm_planes<1>(P, reinterpret_cast<const char*>(bufA), L::FUSE_IN_P, w_fuse, w_fuse + (int64_t)C * 4 * C, 4 * C / 128, wave, NW, C / 16, lane, inv,
+                       [&](int nb, const f32x4_t (&acc)[1]) {
+            const int col = nb * 16 + i16;
+            const float bb = b_fuse[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bufG[(4 * q4 + r) * LC + col] = acc[0][r] + bb;
+        }, &pre);
+    }
+    WPre pre_qkv;
+    gemm_first_h2(w_qkv, C, wave, lane, pre_qkv);
+    __syncthreads();
+    LSTAMP(2);
+    // ---- + residual -> norm_cross -> tile1
+#pragma unroll
+    for (int it = 0; it < NX4; ++it) {
+        const int idx = tid + it * NTH, r = idx / (C / 4), c4 = idx - r * (C / 4);
+        *reinterpret_cast<f32x4_t*>(tile0 + r * LC + c4 * 4) = xr[it];
+    }
+    __syncthreads();
+    ln_rows<VPL, NW>(bufG, LC, tile0, LC, d.ln1_g + grp * C, d.ln1_b + grp * C, d.eps, tile1, LC, wave, lane, s_amax + 7);
+    __syncthreads();
+    LSTAMP(3);
+    // ---- q/k/v projections -> bufO [16][3C]
+    {
+        const float inv = split16(tile1, LC, C, 7);
+        __syncthreads();
+        linear_p(w_qkv, C, b_qkv, 3 * C, inv, bufO, LQ, false, -1, &pre_qkv);
+    }
+    WPre pre_mo;
+    gemm_first_h2(w_mo, C, wave, lane, pre_mo);
+    __syncthreads();
+    LSTAMP(4);
+    // ---- joint-to-joint attention (joint_mha_kernel's arithmetic)
+    if (wave < HEADS) {
+        const int h = wave;
+        float* const sp = bufG + h * 256;
+        const float scale = d.mha_scale;
+        const int i = lane >> 2, gq_ = lane & 3;
+        float sc[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int jj = gq_ + 4 * t;
+            float dot = 0.f;
+            if (i < J && jj < J)
+                for (int dd = 0; dd < DH; ++dd) dot = fmaf(bufO[i * LQ + h * DH + dd], bufO[jj * LQ + C + h * DH + dd], dot);
+            sc[t] = (i < J && jj < J) ? dot * scale : -INFINITY;
+            mx = fmaxf(mx, sc[t]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            sc[t] = (sc[t] == -INFINITY) ? 0.f : expf(sc[t] - mx);
+            sum += sc[t];
+        }
+        sum += __shfl_xor(sum, 1, 64);
+        sum += __shfl_xor(sum, 2, 64);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sp[i * 16 + gq_ + 4 * t] = (i < J) ? sc[t] / sum : 0.f;
+    }
+    __syncthreads();
+    {
+        const int h = wave & (HEADS - 1), part = wave / HEADS;
+        const float* const sp = bufG + h * 256;
+        float amx = 0.f;
+        for (int idx = part * 64 + lane; idx < 16 * DH; idx += 64 * (NW / HEADS)) {
+            const int t = idx / DH, dd = idx - t * DH;
+            float o = 0.f;
+            for (int jj = 0; jj < J; ++jj) o = fmaf(sp[t * 16 + jj], bufO[jj * LQ + 2 * C + h * DH + dd], o);
+            tile0[t * LC + h * DH + dd] = o;
+            amx = fmaxf(amx, fabsf(o));
+        }
+        tile_track(s_amax + 8, amx);
+    }
+    __syncthreads();
+    LSTAMP(5);
+    // ---- out_proj -> bufG, + residual (tile1) -> norm_spatial -> tile0
+    {
+        const float inv = split16(tile0, LC, C, 8);
+        __syncthreads();
+        linear_p(w_mo, C, b_mo, C, inv, bufG, LC, false, -1, &pre_mo);
+    }
+    WPre pre_f0;
+    gemm_first_h2(w_f0, C, wave, lane, pre_f0);
+    __syncthreads();
+    ln_rows<VPL, NW>(bufG, LC, tile1, LC, d.ln2_g + grp * C, d.ln2_b + grp * C, d.eps, tile0, LC, wave, lane, s_amax + 9);
+    __syncthreads();
+    LSTAMP(6);
+    // ---- FFN: Linear + GELU -> bufO [16][512]; Linear -> bufG; + residual (tile0) -> norm_ffn -> tile1
+    {
+        const float inv = split16(tile0, LC, C, 9);
+        __syncthreads();
+        linear_p(w_f0, C, b_f0, FF, inv, bufO, LF, true, 10, &pre_f0);
+    }
+    {
+        WPre pre_f1;
+        gemm_first_h2(w_f1, FF, wave, lane, pre_f1);
+        __syncthreads();
+        const float inv = split16(bufO, LF, FF, 10);
+        __syncthreads();
+        linear_p(w_f1, FF, b_f1, C, inv, bufG, LC, false, -1, &pre_f1);
+    }
+    __syncthreads();
+    ln_rows<VPL, NW>(bufG, LC, tile0, LC, d.ln3_g + grp * C, d.ln3_b + grp * C, d.eps, tile1, LC, wave, lane, s_amax + 11);
+    __syncthreads();
+    LSTAMP(7);
+    // ---- the layer's output tokens
+    for (int idx = tid; idx < J * C; idx += NTH) {
+        const int r = idx / C, ch = idx - r * C;
+        d.x_out[(xrow0 + r) * C + ch] = tile1[r * LC + ch];
+    }
+    // ---- tail: the next layer's sampling offsets / attention logits from these tokens (straight to global memory)
+    if (d.w_ol) {
+        const float* const w_ol = d.w_ol + grp * wsz(d.ol_n, C);
+        const float* const b_ol = d.b_ol + grp * d.ol_n;
+        const int oln = d.ol_n;
+        const float inv = split16(tile1, LC, C, 11);
+        __syncthreads();
+        gemm_planes<1>(P, P, 1 << 20, w_ol, w_ol + (int64_t)oln * C, C / 128, wave, NW, oln / 16, lane, inv, [&](int nb, const f32x4_t (&acc)[1]) {
+            const int col = nb * 16 + i16;
+            const float bb = b_ol[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * q4 + r;
+                if (row < J) d.ol_out[(xrow0 + row) * oln + col] = acc[0][r] + bb;
+            }
+        });
+    }
+    LSTAMP(8);
+    // ---- tail: post_norm [+ head offset | regression MLP + anchor]
+    if (d.lnp_g) {
+        ln_rows<VPL, NW>(tile1, LC, nullptr, 0, d.lnp_g + grp * C, d.lnp_b + grp * C, d.eps, tile0, LC, wave, lane, s_amax + 12);
+        __syncthreads();
+        if (d.xn_out)
+            for (int idx = tid; idx < J * C; idx += NTH) {
+                const int r = idx / C, ch = idx - r * C;
+                d.xn_out[(xrow0 + r) * C + ch] = tile0[r * LC + ch];
+            }
+        if constexpr (C == 256) {
+            if (d.w_h0) head_offset_tail<LC>(d, grp, fb, B, J, tile0, bufO, bufG, tid, lane);
+        }
+        if (d.w_r0) {
+            const float* const w_r0 = d.w_r0 + grp * wsz(C, C);
+            const float inv = split16(tile0, LC, C, 12);     // (the planes' last readers - the offsets tail - are behind post_norm's barrier)
+            __syncthreads();
+            linear_p(w_r0, C, d.b_r0 + grp * C, C, inv, bufG, LC, true, -1, nullptr);
+            __syncthreads();
+            if (tid < J * 3) {
+                const int r = tid / 3, o = tid - r * 3;
+                const float* w = d.w_r2 + ((int64_t)grp * 3 + o) * C;
+                float sum = 0.f;
+                for (int k = 0; k < C; ++k) sum = fmaf(bufG[r * LC + k], w[k], sum);
+                sum += d.b_r2[grp * 3 + o];
+                d.pred_out[(xrow0 + r) * 3 + o] = sum + d.anchors3d[(xrow0 + r) * 3 + o];
             }
         }
     }
@@ -736,18 +1239,6 @@ struct TileGemm {
         }
     }
 };
-
-// (query set, frame) of a workgroup: blocks b and b + 8 share an XCD - keep a query set's frames (same weights) on the same XCDs
-__device__ __forceinline__ void wg_group_frame(int bid, int G, int B, int& grp, int& fb) {
-    if (G > 1 && (8 % G) == 0 && ((G * B) % 8) == 0) {
-        const int per = 8 / G;
-        grp = (bid & 7) / per;
-        fb = (bid >> 3) * per + ((bid & 7) % per);
-    } else {
-        grp = bid / B;
-        fb = bid - grp * B;
-    }
-}
 
 struct JqaArgs {
     egr_jqa_query_desc d;
@@ -1082,6 +1573,14 @@ extern "C" int egr_pack_layer_w_f32(const float* w, int32_t matrices, int32_t ro
     return egr_launch_status();
 }
 
+// fp16 scheme: 1 = joint_layer_p_kernel (A tiles split once), 0 = joint_layer_kernel<C, true> (split inside the product loop)
+static int g_layer_planes = getenv("EGR_LAYER_PLANES") ? atoi(getenv("EGR_LAYER_PLANES")) != 0 : 1;
+extern "C" int egr_layer_set_planes(int on) {
+    const int old = g_layer_planes;
+    if (on >= 0) g_layer_planes = on != 0;
+    return old;
+}
+
 extern "C" int egr_joint_layer_f32(const egr_layer_desc* dd, void* stream) {
     if (!dd) return EGR_ENULL;
     const egr_layer_desc& d = *dd;
@@ -1124,6 +1623,22 @@ extern "C" int egr_joint_layer_f32(const egr_layer_desc* dd, void* stream) {
     };
     using C256 = std::integral_constant<int, 256>;
     using C128 = std::integral_constant<int, 128>;
+    // fp16 scheme: the kernel that splits its A tiles once (EGR_LAYER_PLANES=0: the round-4 kernel that splits inside the product loop)
+    if (d.w_packed == 2 && g_layer_planes) {
+        static bool allowed_p[2][64] = {};
+        auto run_p = [&](auto c_tag, int slot) {
+            constexpr int CC = decltype(c_tag)::value;
+            if (!allowed_p[slot][dev]) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(joint_layer_p_kernel<CC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)PlaneLds<CC>::BYTES) != hipSuccess)
+                    return EGR_EINVAL;
+                allowed_p[slot][dev] = true;
+            }
+            hipLaunchKernelGGL((joint_layer_p_kernel<CC>), grid, block, PlaneLds<CC>::BYTES, s, a);
+            return egr_launch_status();
+        };
+        return d.C == 256 ? run_p(C256{}, 0) : run_p(C128{}, 1);
+    }
     if (d.C == 256) return d.w_packed == 2 ? run(C256{}, std::true_type{}, 0) : run(C256{}, std::false_type{}, 1);
     return d.w_packed == 2 ? run(C128{}, std::true_type{}, 2) : run(C128{}, std::false_type{}, 3);
 }

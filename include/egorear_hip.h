@@ -443,6 +443,10 @@ typedef struct egr_layer_desc {
     int32_t h0_n;
 } egr_layer_desc;
 int egr_joint_layer_f32(const egr_layer_desc* d, void* stream);
+/* Which kernel egr_joint_layer_f32 launches under w_packed = 2 (round 5): 1 (default; EGR_LAYER_PLANES) = every tile that feeds a
+ * contraction is split ONCE into fragment-ordered fp16 planes in LDS, 0 = the round-4 kernel that splits inside the product loop;
+ * bit-identical results.  on < 0 only queries.  Returns the previous setting. */
+int egr_layer_set_planes(int on);
 /* The JQA query of a refiner as ONE launch (round 5; HeatmapMVF.forward_feat_only, egoposeformer_heatmap_mvf_ex.py:655-665, behind
  * heatmap_proj[0] + ReLU):  hm_embed = heatmap_proj[2](t);  bfb = fc_bfb(adaptive_avg_pool2d(backbone_feat_bottom, (1, 1)));
  * x = ReLU(fc_query((joint_query_embed + bfb) + hm_embed));  ol = [sampling_offsets | attention_weights](x) of the refiner's

@@ -112,3 +112,52 @@ def test_head_offset_tail_is_the_three_launches():
     np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-6)   # (fma contraction differs between the two builds of the interpolation)
     bound = rec.view(torch.float32).max().item()
     assert bound >= out.abs().max().item() and bound == h0.abs().max().item()
+
+
+@pytest.mark.parametrize("kind", ["refiner", "lifting"])
+@pytest.mark.parametrize("B", [1, 3])
+def test_split_once_layer_kernel_is_bit_identical_to_the_in_loop_split(kind, B):
+    """joint_layer_p_kernel (A tiles split once into LDS planes, weight chunks requested ahead) against joint_layer_kernel<C, true>:
+    same scales, same products in the same order - every output bit for bit, all tails."""
+    from egorear_amd import engine, hip, synth
+    net = _net("syn")
+    with torch.no_grad():
+        net(synth.synth_images(2, 4, seed=3).to(DEV))
+    dev = torch.device(DEV)
+    he = net.heatmap_estimator
+    gen = torch.Generator().manual_seed(17)
+    V = 4
+    if kind == "refiner":
+        P = engine._state(he, dev).get(he.refiners()[0], lambda: None)
+        G, J, C, W = 4, 15, 256, P.layer.fused
+        post = {"g": P.post_norm[0], "b": P.post_norm[1]}
+        kw = lambda: dict(post=post, want_xn=True, head={"w": P.head0_w, "b": P.head0_b, "amax": torch.zeros(64, dtype=torch.int32, device=DEV)})
+        e = torch.randn(G * B * J * V, C, generator=gen).to(DEV)
+    else:
+        p3 = net.pose3d_estimator
+        P = engine._state(p3, dev).get(p3, lambda: None)
+        G, J, C, W = 1, 16, 128, P.layers[0].fused
+        a3 = torch.randn(B * J, 3, generator=gen).to(DEV)
+        kw = lambda: dict(ol=P.layers[1].ol_plain, post={"g": P.post[0][0], "b": P.post[0][1]}, want_xn=True,
+                          reg={"w0": P.reg_plain[0][0], "b0": P.reg_plain[0][1], "w2": P.reg_plain[0][2], "b2": P.reg_plain[0][3], "anchors": a3})
+        e = None
+    assert W["packed"] == 2
+    x = torch.randn(G * B * J, C, generator=gen).to(DEV)
+    g = (torch.randn(G * B * J * V, 4 * 128, generator=gen) * 3.0).to(DEV)
+    sigma = torch.rand(G * 4 * B * J * V, generator=gen).to(DEV)
+    rowmask = (torch.rand(B * J * V, generator=gen) > 0.2).to(torch.uint8).to(DEV)
+    outs = []
+    for planes in (1, 0):
+        old = hip.lib.egr_layer_set_planes(planes)
+        try:
+            k = kw()
+            r = hip.joint_layer(x, g, e, sigma, rowmask, W, B, J, V, C, G, **k)
+            extra = [k["head"]["out"], k["head"]["amax"]] if "head" in k else []
+            outs.append([t for t in r if t is not None] + extra)
+        finally:
+            hip.lib.egr_layer_set_planes(old)
+    torch.cuda.synchronize()
+    assert len(outs[0]) == len(outs[1]) >= 3
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert torch.isfinite(outs[0][0]).all()
