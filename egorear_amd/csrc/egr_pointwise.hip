@@ -401,6 +401,134 @@ __global__ __launch_bounds__(256) void up2_relu_head_kernel(const float* lo, int
     }
 }
 
+// Round 5: the same pass as a PERSISTENT workgroup of eight waves (one output row each) over the same 8 x 32 output pixels.  The tile kernel above spends most of a workgroup's life waiting for its source pixels (a workgroup lives
+// ~15 us of which ~3 are arithmetic: two per CU cannot cover that); here the NEXT tile's source pixels are requested into registers
+// before the current tile's arithmetic and parked in LDS behind it - the load latency runs under the matrix instructions.
+// Same arithmetic per output (same interpolation expression, same K order, same MFMA chain): bit-identical to the tile kernel.
+constexpr int PT_H = 8, PT_W = 32, PT_SRC_H = PT_H / 2 + 2, PT_SRC_W = 18, PT_NG = 2;   // a wave: one row = 2 groups of 16 columns
+__global__ __launch_bounds__(512) void up2_relu_head_p_kernel(const float* lo, int h, int w, const float* wgt, const float* bias, int cout,
+                                                              float* planes, egr_nmap map, int npg, int64_t gy, int ntiles) {
+    constexpr int CIN = 128, LD = CIN + 4, C4N = CIN / 4;
+    extern __shared__ __attribute__((aligned(16))) float s_src[];   // [PT_SRC_H * PT_SRC_W][LD]
+    const int ho = 2 * h, wo = 2 * w;
+    const int tiles_x = wo / PT_W, tiles_y = ho / PT_H;
+    const float sh = (ho > 1) ? (float)(h - 1) / (float)(ho - 1) : 0.f;
+    const float sw = (wo > 1) ? (float)(w - 1) / (float)(wo - 1) : 0.f;
+    constexpr int NSRC = PT_SRC_H * PT_SRC_W * C4N;
+    constexpr int NLD = (NSRC + 511) / 512;
+    f32x4 stg[NLD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pj = lane & 15, kq = lane >> 4;
+    auto decode = [&](int t, int& img, int& oy0, int& ox0) {
+        img = t / (tiles_x * tiles_y);
+        t -= img * tiles_x * tiles_y;
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        oy0 = ty * PT_H;
+        ox0 = tx * PT_W;
+    };
+    auto request = [&](int t) {
+        int img, oy0, ox0;
+        decode(t, img, oy0, ox0);
+        const int sy0 = (int)(sh * (float)oy0), sx0 = (int)(sw * (float)ox0);
+        const float* src = lo + (int64_t)img * h * w * CIN;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int i = threadIdx.x + 512 * u;
+            const int ii = i < NSRC ? i : 0;
+            const int cq = ii % C4N, p = ii / C4N;
+            const int py = p / PT_SRC_W, px = p - py * PT_SRC_W;
+            const int iy = min(sy0 + py, h - 1), ix = min(sx0 + px, w - 1);
+            stg[u] = *reinterpret_cast<const f32x4*>(src + ((int64_t)iy * w + ix) * CIN + cq * 4);
+        }
+    };
+    float bw[CIN / 4];
+    float bco = 0.f;
+    int cur_grp = -1;
+    int tile = blockIdx.x;
+    if (tile < ntiles) request(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int i = threadIdx.x + 512 * u;
+            if (i < NSRC) {
+                const int cq = i % C4N, p = i / C4N;
+                *reinterpret_cast<f32x4*>(&s_src[p * LD + cq * 4]) = stg[u];
+            }
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) request(tile + gridDim.x);      // in flight under this tile's arithmetic
+        int img, oy0, ox0;
+        decode(tile, img, oy0, ox0);
+        const int grp = img / npg;
+        if (grp != cur_grp) {          // (workgroup-uniform) the group's filter: b[s] = W[co = pj][channel 16 (s / 4) + 4 kq + s % 4]
+            cur_grp = grp;
+            const float* wg = wgt + (int64_t)grp * cout * CIN;
+#pragma unroll
+            for (int s_ = 0; s_ < CIN / 4; ++s_) bw[s_] = pj < cout ? wg[pj * CIN + 16 * (s_ >> 2) + 4 * kq + (s_ & 3)] : 0.f;
+            bco = (bias && pj < cout) ? bias[grp * cout + pj] : 0.f;
+        }
+        const int sy0 = (int)(sh * (float)oy0), sx0 = (int)(sw * (float)ox0);
+        float* outg = planes + grp * gy + egr_map(map, img - grp * npg);
+        const float* q00[PT_NG]; const float* q01[PT_NG]; const float* q10[PT_NG]; const float* q11[PT_NG];
+        float wy0[PT_NG], wy1[PT_NG], wx0[PT_NG], wx1[PT_NG];
+#pragma unroll
+        for (int mg = 0; mg < PT_NG; ++mg) {
+            const int oy = oy0 + wave;
+            const int ox = ox0 + mg * 16 + pj;
+            const float fy = sh * (float)oy, fx = sw * (float)ox;
+            const int y0 = (int)fy, x0 = (int)fx;
+            const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+            wy1[mg] = fminf(fmaxf(fy - (float)y0, 0.f), 1.f); wx1[mg] = fminf(fmaxf(fx - (float)x0, 0.f), 1.f);
+            wy0[mg] = 1.f - wy1[mg]; wx0[mg] = 1.f - wx1[mg];
+            q00[mg] = s_src + ((y0 - sy0) * PT_SRC_W + (x0 - sx0)) * LD + 4 * kq;
+            q01[mg] = s_src + ((y0 - sy0) * PT_SRC_W + (x1 - sx0)) * LD + 4 * kq;
+            q10[mg] = s_src + ((y1 - sy0) * PT_SRC_W + (x0 - sx0)) * LD + 4 * kq;
+            q11[mg] = s_src + ((y1 - sy0) * PT_SRC_W + (x1 - sx0)) * LD + 4 * kq;
+        }
+        f32x4_mfma acc[PT_NG];
+#pragma unroll
+        for (int mg = 0; mg < PT_NG; ++mg) acc[mg] = f32x4_mfma{0.f, 0.f, 0.f, 0.f};
+        f32x4 sv[2][PT_NG][4];
+        auto fetch = [&](int j, int par) {
+#pragma unroll
+            for (int mg = 0; mg < PT_NG; ++mg) {
+                sv[par][mg][0] = *reinterpret_cast<const f32x4*>(q00[mg] + 16 * j);
+                sv[par][mg][1] = *reinterpret_cast<const f32x4*>(q01[mg] + 16 * j);
+                sv[par][mg][2] = *reinterpret_cast<const f32x4*>(q10[mg] + 16 * j);
+                sv[par][mg][3] = *reinterpret_cast<const f32x4*>(q11[mg] + 16 * j);
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int j = 0; j < CIN / 16; ++j) {
+            if (j + 1 < CIN / 16) fetch(j + 1, (j + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 u[PT_NG];
+#pragma unroll
+            for (int mg = 0; mg < PT_NG; ++mg) {
+                const f32x4* v = sv[j & 1][mg];
+                u[mg] = wy0[mg] * (wx0[mg] * v[0] + wx1[mg] * v[1]) + wy1[mg] * (wx0[mg] * v[2] + wx1[mg] * v[3]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int mg = 0; mg < PT_NG; ++mg)
+                    acc[mg] = __builtin_amdgcn_mfma_f32_16x16x4f32(fmaxf(u[mg][r], 0.f), bw[4 * j + r], acc[mg], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (pj < cout) {
+#pragma unroll
+            for (int mg = 0; mg < PT_NG; ++mg) {
+                const int oy = oy0 + wave;
+                const int oxg = ox0 + mg * 16;
+                f32x4 v = {acc[mg][0] + bco, acc[mg][1] + bco, acc[mg][2] + bco, acc[mg][3] + bco};
+                *reinterpret_cast<f32x4*>(outg + (int64_t)pj * ho * wo + (int64_t)oy * wo + oxg + 4 * kq) = v;
+            }
+        }
+        __syncthreads();               // every wave is done with the tile's source pixels before the next ones are parked
+    }
+}
+
 inline unsigned nblocks(int64_t total) { return (unsigned)((total + 255) / 256); }
 
 }  // namespace
@@ -436,6 +564,13 @@ extern "C" int egr_upsample2x_nhwc_f32(const float* x, int32_t ldx, float* y, in
     return egr_launch_status();
 }
 
+static int g_head_persist = getenv("EGR_HEAD_PERSIST") ? atoi(getenv("EGR_HEAD_PERSIST")) != 0 : 1;
+extern "C" int egr_head_set_persist(int on) {
+    const int old = g_head_persist;
+    if (on >= 0) g_head_persist = on != 0;
+    return old;
+}
+
 extern "C" int egr_up2_relu_head_f32(const float* lo, int32_t n, int32_t h, int32_t w, int32_t cin, const float* wgt, const float* bias,
                                      int32_t cout, float* planes, int32_t n_inner, int64_t stride_inner, int64_t stride_outer,
                                      int32_t groups, int64_t gy, void* stream) {
@@ -448,6 +583,26 @@ extern "C" int egr_up2_relu_head_f32(const float* lo, int32_t n, int32_t h, int3
     const size_t lds = (size_t)(HT_SRC_H * HT_SRC_W * (cin + 4)) * sizeof(float);
     const int64_t blocks = (int64_t)n * ((2 * h) / HT_H) * ((2 * w) / HT_W);
     if (blocks >= (1LL << 31) || lds > 64 * 1024) return EGR_EINVAL;
+    // the persistent form (EGR_HEAD_PERSIST=0: the tile kernel): 128 channels, 16-row tiles, enough tiles to give every CU several
+    if (g_head_persist && cin == 128 && (2 * h) % PT_H == 0 && (2 * w) % PT_W == 0) {
+        const int64_t nt = (int64_t)n * ((2 * h) / PT_H) * ((2 * w) / PT_W);
+        int dev = 0, cus = 0;
+        if (nt >= 1024 && nt < (1LL << 31) && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
+            const size_t lds_p = (size_t)(PT_SRC_H * PT_SRC_W * (128 + 4)) * sizeof(float);
+            static bool allowed[64] = {};
+            if (!allowed[dev]) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(up2_relu_head_p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p) !=
+                    hipSuccess)
+                    return EGR_EINVAL;
+                allowed[dev] = true;
+            }
+            const unsigned grid = (unsigned)(nt < cus ? nt : cus);
+            hipLaunchKernelGGL(up2_relu_head_p_kernel, dim3(grid), dim3(512), lds_p, (hipStream_t)stream, lo, h, w, wgt, bias, cout, planes, map,
+                               n / groups, gy, (int)nt);
+            return egr_launch_status();
+        }
+    }
     if (cin == 128)
         hipLaunchKernelGGL(up2_relu_head_kernel<128>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, lo, h, w, cin, wgt, bias, cout,
                            planes, map, n / groups, gy);

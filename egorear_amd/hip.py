@@ -31,7 +31,7 @@ EXPORTS = [
     "egr_conv2d_nhwc_ex_f32", "egr_wh2_elems", "egr_pack_wh2_f32", "egr_absmax_f32", "egr_stem_conv7x7_x6_ex_f32", "egr_stem_wh2_bytes", "egr_pack_stem_wh2_f32", "egr_stem_conv7x7_h2_f32",
     "egr_pack_wh2_many_f32", "egr_conv2d_masked_ex_f32", "egr_conv2d_wgrad_ex_f32", "egr_wgrad_last_h2",
     "egr_wstream_image_bytes", "egr_pack_wstream_f32", "egr_linear_wstream_workspace_bytes", "egr_linear_wstream_f32", "egr_conv1x1_chain_f32",
-    "egr_jqa_query_f32", "egr_pose_query_f32", "egr_layer_set_planes",
+    "egr_jqa_query_f32", "egr_pose_query_f32", "egr_layer_set_planes", "egr_head_set_persist",
 ]
 
 

@@ -275,6 +275,10 @@ int egr_conv_set_persist(int slots, int max_ktiles);
 int egr_up2_relu_head_f32(const float* lo, int32_t n, int32_t h, int32_t w, int32_t cin, const float* wgt, const float* bias,
                           int32_t cout, float* planes, int32_t n_inner, int64_t stride_inner, int64_t stride_outer,
                           int32_t groups, int64_t gy, void* stream);
+/* Which kernel egr_up2_relu_head_f32 launches for 128 input channels and >= 1024 tiles (round 5): 1 (default; EGR_HEAD_PERSIST) =
+ * persistent eight-wave workgroups that request the next tile's source pixels under the current tile's arithmetic, 0 = one
+ * workgroup per tile; bit-identical results.  on < 0 only queries.  Returns the previous setting. */
+int egr_head_set_persist(int on);
 
 /* Diagnostic only (tools/conv_stamps.py): when `buf` is non-NULL every conv workgroup writes 8 x uint64 — s_memtime at
  * [0] start, [1] row decode done, [2] first chunk landed, [3] K loop done, [4] accumulators staged, [5] stores issued, and

@@ -750,6 +750,32 @@ def test_up2_relu_head_matches_torch(groups, cout, h, w):
         assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (v, err)
 
 
+@pytest.mark.parametrize("groups,cout,B", [(2, 15, 48), (4, 15, 16), (1, 16, 64)])
+def test_up2_relu_head_persistent_kernel_is_bit_identical_to_the_tile_kernel(groups, cout, B):
+    """From 1024 tiles the launch takes the persistent kernel (next tile's source pixels requested under the current tile's
+    arithmetic): same bits as the one-workgroup-per-tile kernel, also where a workgroup's tiles cross images and groups."""
+    from egorear_amd import hip
+    from egorear_amd.hip import NMap
+    h = w = 32
+    cin, V = 128, groups
+    g = torch.Generator().manual_seed(23)
+    lo = torch.randn(V * B, h, w, cin, generator=g).to(DEV)
+    wt = (torch.randn(groups, cout, cin, generator=g) / 11.0).to(DEV)
+    bias = torch.randn(groups, cout, generator=g).to(DEV)
+    plane = cout * 4 * h * w
+    outs = []
+    for persist in (1, 0):
+        old = hip.lib.egr_head_set_persist(persist)
+        try:
+            planes = torch.zeros(B, V, cout, 2 * h, 2 * w, device=DEV)
+            hip.up2_relu_head(hip.Img(lo), wt, bias, planes, NMap(B, V * plane, 0), plane, groups=groups)
+            outs.append(planes)
+        finally:
+            hip.lib.egr_head_set_persist(old)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and float(outs[0].abs().max()) > 0
+
+
 @pytest.mark.parametrize("groups,k", [(1, 1), (2, 3)])
 def test_conv_with_residual_upsampled_in_the_epilogue(groups, k):
     """EGR_RES_UP2_BEFORE_ACT: y = relu(conv(x) + bias + up2_bilinear_ac(lo)) with lo at half resolution (the FPN top-down add)."""
