@@ -196,14 +196,16 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const StemWgradArgs 
     const float* xg = a.x + grp * a.gx;
     const float* dyg = a.dy + (int64_t)grp * a.n * a.ho * a.wo * 64;
 
-    int p_lds[PLOADS], p_ci[PLOADS], p_py[PLOADS], p_px[PLOADS];
+    // per-thread patch slots, one packed word each: (ci << 16) | (py << 8) | px, -1 past the patch (four separate arrays cost 120 registers
+    // beside the 160 accumulators: the kernel spilled)
+    int p_geo[PLOADS];
 #pragma unroll
     for (int u = 0; u < PLOADS; ++u) {
         const int i = tid + 256 * u;
         const int ci = i / (PH * PW);
         const int r = i - ci * PH * PW;
-        p_ci[u] = ci; p_py[u] = r / PW; p_px[u] = r - p_py[u] * PW;
-        p_lds[u] = (i < 3 * PH * PW) ? ci * PH * PWS + p_py[u] * PWS + p_px[u] : -1;
+        const int py = r / PW;
+        p_geo[u] = (i < 3 * PH * PW) ? ((ci << 16) | (py << 8) | (r - py * PW)) : -1;
     }
     auto fetch = [&](int tile, float (&v)[PLOADS]) {
         const int n = tile / tpi;
@@ -213,15 +215,21 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const StemWgradArgs 
         const float* img = xg + egr_map(a.xmap, n);
 #pragma unroll
         for (int u = 0; u < PLOADS; ++u) {
-            const int iy = iy0 + p_py[u], ix = ix0 + p_px[u];
-            const bool ok = p_lds[u] >= 0 && iy >= 0 && iy < a.h && ix >= 0 && ix < a.w;
-            v[u] = ok ? img[((int64_t)p_ci[u] * a.h + iy) * a.w + ix] : 0.f;
+            int g = p_geo[u];
+            asm volatile("" : "+v"(g));          // (unpacked per use: hoisted out of the tile loop the fields are the 120 registers again)
+            const int ci = g >> 16, py = (g >> 8) & 255, px = g & 255;
+            const int iy = iy0 + py, ix = ix0 + px;
+            const bool ok = g >= 0 && iy >= 0 && iy < a.h && ix >= 0 && ix < a.w;
+            v[u] = ok ? img[((int64_t)ci * a.h + iy) * a.w + ix] : 0.f;
         }
     };
     auto park = [&](int buf, const float (&v)[PLOADS]) {
 #pragma unroll
-        for (int u = 0; u < PLOADS; ++u)
-            if (p_lds[u] >= 0) s_patch[buf][p_lds[u]] = v[u];
+        for (int u = 0; u < PLOADS; ++u) {
+            int g = p_geo[u];
+            asm volatile("" : "+v"(g));
+            if (g >= 0) s_patch[buf][(g >> 16) * PH * PWS + ((g >> 8) & 255) * PWS + (g & 255)] = v[u];
+        }
     };
     // K offsets of this lane's five B columns (columns >= 147 point at a valid slot and are dropped at the end)
     int koff[5];
@@ -253,20 +261,43 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const StemWgradArgs 
         const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
         // wave w owns tile rows 2w, 2w+1: 64 pixels = 32 k-steps of two horizontally adjacent pixels (lane half = which one)
         const float* dyt = dyg + (((int64_t)n * a.ho + ty * TH) * a.wo + tx * TW) * 64;
-#pragma unroll 4
-        for (int s = 0; s < 32; ++s) {
-            const int prow = 2 * wave + (s >> 4), pcol = 2 * (s & 15) + half;
-            const float* dp = dyt + ((int64_t)prow * a.wo + pcol) * 64;
-            const float a0 = dp[l31], a1 = dp[32 + l31];
-            const int pb = (2 * prow) * PWS + 2 * pcol;
-            float b[5];
+        // (round 5: the output gradients of a group of four steps are requested one group ahead of their MFMAs - the loop used to issue a
+        // group's eight loads and wait for them in front of its forty matrix instructions)
+        constexpr int SG = 4;
+        float av0[SG][2], av1[SG][2];
+        auto dy_load = [&](int g, float (&av)[SG][2]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int kb = 0; kb < 5; ++kb) b[kb] = sp[pb + koff[kb]];
-#pragma unroll
-            for (int kb = 0; kb < 5; ++kb) {
-                acc[0][kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[kb], acc[0][kb], 0, 0, 0);
-                acc[1][kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[kb], acc[1][kb], 0, 0, 0);
+            for (int u = 0; u < SG; ++u) {
+                const int s = g * SG + u;
+                const int prow = 2 * wave + (s >> 4), pcol = 2 * (s & 15) + half;
+                const float* dp = dyt + ((int64_t)prow * a.wo + pcol) * 64;
+                av[u][0] = dp[l31];
+                av[u][1] = dp[32 + l31];
             }
+        };
+        auto group = [&](int g, const float (&av)[SG][2]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < SG; ++u) {
+                const int s = g * SG + u;
+                const int prow = 2 * wave + (s >> 4), pcol = 2 * (s & 15) + half;
+                const int pb = (2 * prow) * PWS + 2 * pcol;
+                float b[5];
+#pragma unroll
+                for (int kb = 0; kb < 5; ++kb) b[kb] = sp[pb + koff[kb]];
+#pragma unroll
+                for (int kb = 0; kb < 5; ++kb) {
+                    acc[0][kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][0], b[kb], acc[0][kb], 0, 0, 0);
+                    acc[1][kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][1], b[kb], acc[1][kb], 0, 0, 0);
+                }
+            }
+        };
+        dy_load(0, av0);
+#pragma unroll 1
+        for (int g = 0; g < 32 / SG; g += 2) {
+            dy_load(g + 1, av1);
+            group(g, av0);
+            if (g + 2 < 32 / SG) dy_load(g + 2, av0);
+            group(g + 1, av1);
         }
         if (next < total) park(buf ^ 1, pv);
         __syncthreads();
