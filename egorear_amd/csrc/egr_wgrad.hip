@@ -1019,8 +1019,11 @@ extern "C" int egr_conv2d_wgrad_ex_f32(const egr_conv_desc* dd, const float* x, 
                     ((d.w_format & EGR_W_FORCE) || (a.M >= 1024 && 2.0 * (double)a.M * d.cout * a.K * G >= 4e9));
     // small 1x1 problems on the fp32 path: one launch of wgrad_small_kernel (weights and bias gradient, no slabs)
     static const int g_small = getenv("EGR_WGRAD_SMALL") ? atoi(getenv("EGR_WGRAD_SMALL")) : 1;
+    // (a workgroup of the small kernel walks ALL rows of its group: ~14 us per 1000 rows - beyond EGR_WGRAD_SMALL_ROWS per group the split kernel
+    // with its slab reduction is faster: the FPN's top-level 1x1 convs at batch 32, 4096 rows, took 120 us each)
+    static const int g_small_rows = getenv("EGR_WGRAD_SMALL_ROWS") ? atoi(getenv("EGR_WGRAD_SMALL_ROWS")) : 2048;
     if (g_small && !x6 && d.kh == 1 && d.kw == 1 && d.stride == 1 && d.pad == 0 && d.h == d.ho && d.w == d.wo && (int64_t)a.M * G <= 8192 &&
-        d.gw >= (int64_t)d.cout * a.K) {
+        a.M <= g_small_rows && d.gw >= (int64_t)d.cout * a.K) {
         const int64_t tiles32 = (int64_t)((d.cout + 31) / 32) * (a.K / 32);
         if (tiles32 * G <= 256 &&      // (1024 tiles of M 480 x K 4096: 65 us against 38 on the tiled kernel, measured)
              !(db && (d.ymap.n_inner < d.n || d.ymap.stride_inner != (int64_t)d.ho * d.wo * d.ldy))) {

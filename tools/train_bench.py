@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph")
+    ap.add_argument("--dump", default="", help="write every launch of the instrumented step (order, us, name, tag) to this file")
     a = ap.parse_args()
     dev = "cuda:0"
     net = EgoPoseFormerMVFEX(**copy.deepcopy(configs.pose3d_cfg("ego4view_rw")))
@@ -52,6 +53,11 @@ def main():
     tr._run(img, ctm, gt_pose, gt_hm, update=True)      # eager and instrumented even when the timed steps were graph replays
     torch.cuda.synchronize()
     prof, hip.PROFILE = hip.PROFILE, None
+    if a.dump:
+        with open(a.dump, "w") as f:
+            for i, (name, s, e, fl, nb, tag) in enumerate(prof):
+                us = s.elapsed_time(e) * 1e3
+                f.write(f"{i:4d} {us:9.1f} us  {fl / us / 1e6 if fl > 0 else 0:7.1f} TF  {nb / us / 1e3 if nb > 0 else 0:7.0f} GB/s  {name:30s} {tag}\n")
     agg = collections.OrderedDict()
     for name, s, e, fl, nb, tag in prof:
         key = name
