@@ -72,7 +72,7 @@ def test_forced_policy_really_takes_the_fp16_scheme(nets):
     try:
         with torch.no_grad():
             net(synth.synth_images(2, 4, seed=0).to(DEV))
-        tags = [t for name, *_, t in hip.PROFILE if name == "egr_conv2d_nhwc_f32"]
+        tags = [t for name, *_, t in hip.PROFILE if name in ("egr_conv2d_nhwc_f32", "egr_conv1x1_chain_f32")]   # (a chained pair: one fp16-scheme launch)
     finally:
         hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS, hip.PROFILE = saved
     h2 = sum(1 for t in tags if t.startswith("h2 "))
