@@ -202,6 +202,13 @@ class State:
         if self.amax is not None:
             self.amax.begin()
 
+    def fork(self, images: int):
+        """A side branch for launches that do not depend on what the main stream does next (round 5): `with st.fork(n) as f: ...; f.join(t)`.
+        Only small forwards under graph capture take it (FORK_MAX_IMAGES: their launches leave most of the chip idle, so independent
+        branches - the down-sample conv of a residual block, the refiners' own-view projection stack - run side by side as parallel
+        branches of the captured graph).  Otherwise the block runs inline."""
+        return _Fork(self, images <= FORK_MAX_IMAGES)
+
     def new_amax(self):
         return self.amax.new() if self.amax is not None else None
 
@@ -213,6 +220,52 @@ class State:
                 v = builder()
             self.packs[k] = v
         return v
+
+
+# Independent branches on a side stream, while a hipGraph is being captured, for forwards of at most this many images (views x
+# frames); 0 = never (EGR_FORK_MAX_IMAGES).  Measured as single-lane graph replays: batch 2 1.75 -> 1.71 ms, batch 8 2.72 -> 2.56,
+# batch 16 3.53 -> 3.39, batch 32 5.65 -> 5.50; batch 1 unchanged (1.43); batch 64 with two lanes in flight 6890 -> 6600 frames/s -
+# there the other lane already fills what the branch would.
+FORK_MAX_IMAGES = int(os.environ.get("EGR_FORK_MAX_IMAGES", "64"))
+
+
+class _Fork:
+    """Context of State.fork: inside it the current stream is the state's side stream (which first waits for the main stream) and the
+    split-K workspace is the side branch's own; join(tensors...) makes the main stream wait for the branch and hands its results over."""
+
+    def __init__(self, st: "State", on: bool):
+        # (graph capture only: eagerly the stream switches cost the host more than the overlap returns - batch 1: 2.07 -> 2.40 ms)
+        self.st, self.on = st, on and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+        self.ctx = None
+
+    def __enter__(self):
+        if not self.on:
+            return self
+        st = self.st
+        if getattr(st, "side", None) is None:
+            st.side = torch.cuda.Stream(device=st.device)
+            st.ws_side = torch.empty(_WORKSPACE_FLOATS, device=st.device, dtype=torch.float32)
+        self.main = torch.cuda.current_stream(st.device)
+        st.side.wait_stream(self.main)
+        self.ws_main, st.workspace = st.workspace, st.ws_side
+        self.ctx = torch.cuda.stream(st.side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+            self.st.workspace = self.ws_main
+        return False
+
+    def join(self, *tensors):
+        """Call on the main stream, before the first launch there that reads the branch's results."""
+        if not self.on:
+            return
+        self.main.wait_stream(self.st.side)
+        for t in tensors:
+            if isinstance(t, torch.Tensor):
+                t.record_stream(self.main)      # allocated on the side stream, read (and later freed) under the main one
 
 
 # Bumped whenever packed weights are created or dropped: a captured hipGraph holds raw pointers into the packs it was recorded
@@ -381,12 +434,17 @@ def _pack_stems(trunks) -> tuple:
 def _basic_block(st: State, blks, x: Img, out: Optional[Img] = None) -> Img:
     b0 = blks[0]
     identity = x
+    f = None
     if b0.downsample is not None:
         pd = st.get(b0.downsample, lambda: pack_convs([b.downsample[0] for b in blks], [b.downsample[1] for b in blks]))
-        identity = conv(st, x, pd, ACT_NONE)
+        f = st.fork(x.n)                 # (small forwards: the 1x1 / stride-2 conv of the shortcut runs beside conv1)
+        with f:
+            identity = conv(st, x, pd, ACT_NONE)
     p1 = st.get(b0.conv1, lambda: pack_convs([b.conv1 for b in blks], [b.bn1 for b in blks]))
     p2 = st.get(b0.conv2, lambda: pack_convs([b.conv2 for b in blks], [b.bn2 for b in blks]))
     y = conv(st, x, p1, ACT_RELU)
+    if f is not None:
+        f.join(identity.t)
     return conv(st, y, p2, ACT_RELU, res=identity, res_mode=RES_BEFORE_ACT, out=out)
 
 
@@ -711,6 +769,11 @@ def _run_refiners(st: State, rs, B: int, V: int, hm_init: torch.Tensor, feat_all
     J, C = r0.num_heatmap, r0.embed_dims
     hgt, wid = r0.feat_shape
     hw = hgt * wid
+    # --- own-view feature projection: group g reads feat_all[g*B:(g+1)*B].  It depends on the features only and is first read behind the
+    # transformer layer: small forwards run it on the side branch, next to the query / sampling / layer launches
+    fk = st.fork(G * B)
+    with fk:
+        ff = run_stack(st, [r.frame_feat_proj_layers for r in rs], Img(feat_all))  # (G*B, 32, 32, 128)
     # --- joint queries (JQA): heatmap_proj(hm) + fc_bfb(avgpool s32) + embedding -> fc_query
     hm_rows = Img(hm_init.view(B * V, J, 1, hw)[0::V])                        # group 0 = view 0 rows; group stride = J*hw
     t = conv(st, hm_rows, P.hp0, ACT_RELU, gx=J * hw)                        # (G*B, J, 1, C)
@@ -723,8 +786,6 @@ def _run_refiners(st: State, rs, B: int, V: int, hm_init: torch.Tensor, feat_all
         hm_embed = linear(st, t.t.view(G * B * J, C), P.hp2)
         bfb = linear(st, hip.avgpool(Img(s32_all)), P.fc_bfb)                # s32_all is (V*B, 8, 8, 512) = (G, B, ...)
         x = linear(st, hip.jqa_sum(hm_embed, P.embed, bfb, G * B, J, C, groups=G), P.fc_query, ACT_RELU)
-    # --- own-view feature projection: group g reads feat_all[g*B:(g+1)*B]
-    ff = run_stack(st, [r.frame_feat_proj_layers for r in rs], Img(feat_all))  # (G*B, 32, 32, 128)
     # --- transformer layer over the 4-view memory (sampled un-projected, see pack_layers)
     # --- head: LN -> (B, J, 16, 16) image with joints as channels -> 1x1 15->64, up x2, 1x1 64->128 (+ frame_feat)
     head = None
@@ -744,6 +805,7 @@ def _run_refiners(st: State, rs, B: int, V: int, hm_init: torch.Tensor, feat_all
         tok = hip.tokens_to_nhwc(xn, G * B, J, C)                            # (G*B, 256, J)
         h0 = hip.linear_smallk(tok, J, 1, P.head0_w, P.head0_b, G * B * C, P.head0_w.shape[1], J, ACT_RELU, groups=G)
         h0 = hip.upsample2x(Img(h0.view(G * B, side, side, -1)))
+    fk.join(ff.t)
     summed = conv(st, h0, P.head3, ACT_RELU, res=ff, res_mode=RES_AFTER_ACT)   # offset_pred + frame_feat
     if CAPTURE is not None:
         CAPTURE.update(query=x.view(G, B, J, C).clone(), post_norm=xn.view(G, B, J, C).clone(), head_sum=summed.t.clone())

@@ -161,3 +161,25 @@ def test_split_once_layer_kernel_is_bit_identical_to_the_in_loop_split(kind, B):
     for a, b in zip(*outs):
         assert torch.equal(a, b)
     assert torch.isfinite(outs[0][0]).all()
+
+
+@pytest.mark.parametrize("batch", [1, 4])
+def test_forked_branches_of_a_captured_forward_give_the_same_bits(batch):
+    """Small forwards captured as a hipGraph run the shortcut convs and the refiners' own-view projection stack as parallel branches
+    (engine.State.fork): outputs equal the inline forward's bit for bit, replay after replay."""
+    from egorear_amd import engine, synth
+    from egorear_amd.runner import GraphedForward
+    net = _net("syn")
+    img = synth.synth_images(batch, 4, seed=9).to(DEV)
+    with torch.no_grad():
+        ref_p, ref_h = net(img)
+        ref_p, ref_h = [t.clone() for t in ref_p], [t.clone() for t in ref_h]
+    assert engine.FORK_MAX_IMAGES >= 4 * batch
+    g = GraphedForward(net)
+    for _ in range(3):
+        p, h = g(img)
+        torch.cuda.synchronize()
+        for a, b in zip(list(p) + list(h), ref_p + ref_h):
+            assert torch.equal(a, b)
+    st = engine._state(net.heatmap_estimator, torch.device(DEV))
+    assert getattr(st, "side", None) is not None          # the branch was really taken during the capture
