@@ -207,7 +207,13 @@ class State:
         Only small forwards under graph capture take it (FORK_MAX_IMAGES: their launches leave most of the chip idle, so independent
         branches - the down-sample conv of a residual block, the refiners' own-view projection stack - run side by side as parallel
         branches of the captured graph).  Otherwise the block runs inline."""
-        return _Fork(self, images <= FORK_MAX_IMAGES)
+        small = images <= FORK_MAX_IMAGES
+        if small and getattr(self, "side", None) is None and torch.cuda.is_available():
+            # made at the first small forward - the warm-up in front of a capture - so that the stream and the 64-MB workspace do not
+            # come out of a graph's private pool
+            self.side = torch.cuda.Stream(device=self.device)
+            self.ws_side = torch.empty(_WORKSPACE_FLOATS, device=self.device, dtype=torch.float32)
+        return _Fork(self, small)
 
     def new_amax(self):
         return self.amax.new() if self.amax is not None else None
@@ -242,9 +248,6 @@ class _Fork:
         if not self.on:
             return self
         st = self.st
-        if getattr(st, "side", None) is None:
-            st.side = torch.cuda.Stream(device=st.device)
-            st.ws_side = torch.empty(_WORKSPACE_FLOATS, device=st.device, dtype=torch.float32)
         self.main = torch.cuda.current_stream(st.device)
         st.side.wait_stream(self.main)
         self.ws_main, st.workspace = st.workspace, st.ws_side

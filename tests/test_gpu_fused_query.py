@@ -182,4 +182,19 @@ def test_forked_branches_of_a_captured_forward_give_the_same_bits(batch):
         for a, b in zip(list(p) + list(h), ref_p + ref_h):
             assert torch.equal(a, b)
     st = engine._state(net.heatmap_estimator, torch.device(DEV))
-    assert getattr(st, "side", None) is not None          # the branch was really taken during the capture
+    assert getattr(st, "side", None) is not None          # small forward: the side branch exists (taken while capturing only)
+    names = []
+    real = engine._Fork.__enter__
+
+    def spy(self):
+        names.append(self.on)
+        return real(self)
+    engine._Fork.__enter__ = spy
+    try:
+        with torch.no_grad():
+            net(img)                                       # eager: inline
+        g2 = GraphedForward(net, warmup=1)
+        g2(img)                                            # warm-up (inline) + capture (forked)
+    finally:
+        engine._Fork.__enter__ = real
+    assert names and not names[0] and any(names)
