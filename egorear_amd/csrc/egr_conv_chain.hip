@@ -382,6 +382,337 @@ __global__ __launch_bounds__(512) void conv_pw_chain_kernel(const ChainArgs ca) 
     if (a.amax_out) amax_flush(a.amax_out, amx, (int)blockIdx.x * 8 + wave);
 }
 
+// ------------------------------------------------------------------ 256 -> 256 -> <= 128 (round 5): both weight matrices STREAMED
+// The heat-map heads' Conv2d(256, 256, 1) + ReLU -> [Upsample ->] Conv2d(256, 128, 1) (egoposeformer_heatmap_mvf_ex.py:101-126, 570-584):
+// W1 alone is 256 KB as two fp16 planes - nothing stays in LDS.  Same lane-owns-a-pixel structure and register hand-over between the
+// products as conv_pw_chain_kernel, but
+//   * the eight waves of a workgroup walk their 32-pixel tiles in LOCKSTEP through one sequence of 48 weight chunks per tile round
+//     (8 KB each: four 32-row fragments x two planes of one k16 step), every thread fetches 16 bytes of a chunk four steps ahead
+//     (L2-resident: 384 KB per group), parks it in a four-slot LDS ring one step ahead, one barrier per step;
+//   * the 256-channel intermediate is produced and consumed in two halves of 128 channels (mh): first product W1[128 mh ..] . x over
+//     all 256 input channels (the pixel's row is streamed from L1 / L2 a second time for mh = 1), then the second product's K range
+//     128 mh .. 128 mh + 127 on the registers - 64 + 64 accumulators as in the resident kernel;
+//   * each half scales its own pixel maximum into [2^14, 2^15); between the halves the second product's accumulators move to the new
+//     scale by an exact power of two (clamped to 2^+-40 of the first: the other half is then below 2^-40 of the sum).
+// NWV waves per workgroup: 8 (one workgroup per CU) or 4 (two per CU, each with its own ring and barriers: while one waits for its
+// pixel rows the other multiplies - eight waves in lockstep stall together)
+template <int RESK, int NWV>
+__global__ __launch_bounds__(64 * NWV, 8 / NWV) void conv_pw2_kernel(const ChainArgs ca) {
+    static_assert(RESK == 0 && (NWV == 4 || NWV == 8), "the heads' chains carry no residual");
+    constexpr int NTHR = 64 * NWV, PPT = 512 / NTHR;          // 16-byte pieces of a chunk per thread
+    constexpr int NCF = 4, NPL = 2, KS1 = 16, KS2H = 8, CH = NCF * NPL * 1024;      // a chunk: 8 KB
+    constexpr int NCH = 2 * (KS1 + KS2H);                                           // 48 chunks per tile round
+    constexpr int R = 4, D = NWV == 8 ? 4 : 3;                                                     // ring slots; global requests this many steps ahead
+    constexpr int PR = 16, PATCH = PR * 144;
+    constexpr int VEC = (256 + 256 + 128 + 128) * 4;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[R * CH + VEC + NWV * PATCH];
+    float* const s_sc1 = reinterpret_cast<float*>(lds + R * CH);
+    float* const s_sh1 = s_sc1 + 256;
+    float* const s_sc2 = s_sh1 + 256;
+    float* const s_sh2 = s_sc2 + 128;
+    const ConvArgs& a = ca.a;
+    const egr_conv_desc& d = a.d;
+    const int grp = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 31, h = lane >> 5;
+    float sa, ads;
+    act_prescale(a.amax_in, lane, sa, ads);
+    float amx = 0.f;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.x + grp * d.gx), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.y + grp * d.gy), 0, 0x80000000u, 0x00020000);
+    const int HoWo = d.ho * d.wo;
+    const int T = (a.M + 31) >> 5, NW = gridDim.x * NWV;
+    const int rounds = (T + NW - 1) / NW;                 // workgroup-uniform: every wave passes every barrier
+
+    auto x_off = [&](int tile) {      // byte offset of the lane's pixel in x (OOB past the last pixel: the loads return zeros)
+        const int m = tile * 32 + p;
+        int n, pix;
+        if (a.howo_shift >= 0) { n = m >> a.howo_shift; pix = m & (HoWo - 1); }
+        else { n = fdiv(m, a.dHoWo); pix = m - n * HoWo; }
+        const int xb = a.x_plain ? n * (int)d.xmap.stride_inner : (int)fmap(d.xmap, a.dXin, n);
+        // (the first product takes its operands in the image's own k order - lane half h: k 8h .. 8h+7 of a k16 step - so a lane reads 32
+        // CONTIGUOUS bytes of its pixel's row per step and the two lanes of a pixel share a 64-byte line: half the address work of the
+        // {4h..4h+3} u {8+4h..} order that the register hand-over imposes on the second product only)
+        return (tile < T && m < a.M) ? (xb + pix * d.ldx) * 4 + h * 32 : OOB;
+    };
+    // this thread's 16 bytes of chunk c (c: a literal): W1 image [cf 8][ks 16][pl][lane][16 B], W2 image [cf 4][ks 16][pl][lane][16 B]
+    // (through buffer descriptors: ONE per-thread offset register - fragment cfl, plane pl_, lane - and the chunk's position as the
+    // instruction's scalar offset; as 48 flat pointers the addresses took ~100 registers and the kernel spilled)
+    const __amdgpu_buffer_rsrc_t rw1 = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(reinterpret_cast<const uint8_t*>(a.w) + (int64_t)grp * d.gw * 2), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw2 = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(reinterpret_cast<const uint8_t*>(ca.w2) + (int64_t)grp * ca.gw2 * 2), 0, 0x80000000u, 0x00020000);
+    struct Piece { u32x4 v[PPT]; };
+    const int cfl = tid >> 7, pl_ = (tid >> 6) & 1;          // piece j of this thread: fragment cfl + (4 / PPT) j
+    const int woff = (cfl * 16 * NPL + pl_) * 1024 + lane * 16;
+    auto chunk_load = [&](const int c) __attribute__((always_inline)) {
+        const int mh = c / (KS1 + KS2H), r = c % (KS1 + KS2H);
+        Piece q;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int fo = j * (NCF / PPT) * 16 * NPL * 1024;          // the fragment step between a thread's pieces
+            q.v[j] = r < KS1 ? __builtin_amdgcn_raw_buffer_load_b128(rw1, woff, (mh * NCF * 16 + r) * NPL * 1024 + fo, 0)
+                             : __builtin_amdgcn_raw_buffer_load_b128(rw2, woff, (mh * KS2H + (r - KS1)) * NPL * 1024 + fo, 0);
+        }
+        return q;
+    };
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    // a 16-byte piece of the image (lane (p, q): k 8q .. 8q+7) goes as two 8-byte halves to the lanes (p, 0) and (p, 1), slot q (the
+    // resident kernel's permutation: a lane's k order is {4h .. 4h+3} u {8+4h .. 8+4h+3})
+    uint8_t* const park_dst = lds + (cfl * NPL + pl_) * 1024 + (lane & 31) * 16 + (lane >> 5) * 8;
+    uint8_t* const park_nat = lds + (cfl * NPL + pl_) * 1024 + lane * 16;
+    // (chunk c, a literal, is parked in slot c % R: first-product chunks as they come, second-product chunks permuted)
+    auto park = [&](const int c, const Piece& q) __attribute__((always_inline)) {
+        const int slot = c % R;
+        const bool nat = (c % (KS1 + KS2H)) < KS1;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int fo = j * (NCF / PPT) * NPL * 1024;
+            if (nat) {
+                *reinterpret_cast<u32x4*>(park_nat + slot * CH + fo) = q.v[j];
+            } else {
+                *reinterpret_cast<u32x2*>(park_dst + slot * CH + fo) = u32x2{q.v[j][0], q.v[j][1]};
+                *reinterpret_cast<u32x2*>(park_dst + slot * CH + fo + 512) = u32x2{q.v[j][2], q.v[j][3]};
+            }
+        }
+    };
+    for (int i = tid; i < 256; i += NTHR) {
+        s_sc1[i] = ads * a.wds[grp * ca.gp1 + i];
+        s_sh1[i] = ca.shift1 ? ca.shift1[grp * ca.gp1 + i] : 0.f;
+    }
+    if (tid < 128) {
+        s_sc2[tid] = (tid < d.cout) ? ca.wds2[grp * d.gp + tid] * ((a.scale && tid < d.cout) ? a.scale[grp * d.gp + tid] : 1.f) : 1.f;
+        s_sh2[tid] = (a.shift && tid < d.cout) ? a.shift[grp * d.gp + tid] : 0.f;
+    }
+    // Pipeline of a step c: request chunk c + 4, park chunk c + 2 (visible from step c + 1 on: one barrier per step), multiply fragments
+    // 0-1 of chunk c while fragments 2-3 are read from LDS, then multiply 2-3 while fragments 0-1 of chunk c + 1 are read - the LDS
+    // reads of the eight waves (64 KB per step: 512 cycles of the LDS pipe) run under the matrix instructions instead of in front of them
+    Piece wst[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) wst[c] = chunk_load(c);
+    park(0, wst[0]);
+    park(1, wst[1]);
+    wst[0] = chunk_load(D);                                // (step c requests chunk c + 2 + D into the register set it has just parked)
+    wst[1] = chunk_load(D + 1);
+    __syncthreads();
+    u32x4 wfa[2][NPL], wfb[2][NPL];                       // fragments 0-1 / 2-3 of the current chunk
+    auto read_half = [&](const int c, const int hf, u32x4 (&w)[2][NPL]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int cf = 0; cf < 2; ++cf)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl)
+                w[cf][pl] = *reinterpret_cast<const u32x4*>(lds + (c % R) * CH + ((2 * hf + cf) * NPL + pl) * 1024 + lane * 16);
+    };
+    read_half(0, 0, wfa);
+
+    const float floor1 = (ca.act1 == EGR_ACT_RELU) ? 0.f : -__builtin_inff();
+    const float floor_ = (d.act == EGR_ACT_RELU) ? 0.f : -__builtin_inff();
+    constexpr int PW[3] = {1, 0, 0}, PX[3] = {0, 1, 0};      // (l,h) (h,l) (h,h): smallest products first
+    constexpr int PF = 2;                                     // k16 steps of the pixel's row in flight (3: no faster, and the kernel spills)
+    u32x4 raw[PF][2];
+    {
+        const int xo0 = x_off((int)blockIdx.x * NWV + wave);
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            raw[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo0 + i * 64, 0, 0);
+            raw[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo0 + i * 64 + 16, 0, 0);
+        }
+    }
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int t = (rd * (int)gridDim.x + (int)blockIdx.x) * NWV + wave;
+        const int xo = x_off(t);
+        f32x16 acc2[NCF];
+#pragma unroll
+        for (int cf = 0; cf < NCF; ++cf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[cf][r] = 0.f;
+        float inv2 = 1.f;
+        int k2_prev = 0;
+        // the memory side of step c (see above)
+        auto step_io = [&](const int c) __attribute__((always_inline)) {
+#ifndef PW2_EXP_NOW          // (PW2_EXP_*: elimination builds for tools/probes/chain_big_micro.py - timing only, the results are wrong)
+            park((c + 2) % NCH, wst[(c + 2) % D]);            // (requested D steps ago)
+            wst[(c + 2) % D] = chunk_load((c + 2 + D) % NCH);
+#endif
+            read_half(c, 1, wfb);
+        };
+        auto step_mm = [&](const int c, f32x16 (&acc)[NCF], const u32x4 (&xb)[NPL]) __attribute__((always_inline)) {
+            SB_G();
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+                for (int cf = 0; cf < 2; ++cf)
+#ifdef PW2_EXP_NOMFMA
+                    if (t3 == 0 && c % 8 == 0)
+#endif
+                    acc[cf] = mfma_split<NPL>(wfa[cf][PW[t3]], xb[PX[t3]], acc[cf]);
+            SB_G();
+            read_half(c + 1, 0, wfa);                     // (chunk c + 1: parked during step c - 1)
+            SB_G();
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+                for (int cf = 0; cf < 2; ++cf)
+#ifdef PW2_EXP_NOMFMA
+                    if (t3 == 0 && c % 8 == 0)
+#endif
+                    acc[2 + cf] = mfma_split<NPL>(wfb[cf][PW[t3]], xb[PX[t3]], acc[2 + cf]);
+            SB_G();
+#ifndef PW2_EXP_NOBAR
+            // (LDS traffic only: __syncthreads() also waits for every outstanding global load - the chunk requested four steps ahead and the
+            // pixel rows would be waited for at every step)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+        };
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh) {
+            // ------------------------------------------------------------ first product, this half of the intermediate: acc1 = W1[128 mh ..] . x
+            f32x16 acc1[NCF];
+#pragma unroll
+            for (int cf = 0; cf < NCF; ++cf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[cf][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                const int c = mh * (KS1 + KS2H) + ks;
+                step_io(c);
+                unsigned xh[4], xl[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const u32x4& src = raw[ks % PF][e >> 1];
+                    split2_f16(__uint_as_float(src[2 * (e & 1)]), __uint_as_float(src[2 * (e & 1) + 1]), sa, xh[e], xl[e]);
+                }
+                u32x4 xb[NPL];
+                xb[0] = u32x4{xh[0], xh[1], xh[2], xh[3]};
+                xb[1] = u32x4{xl[0], xl[1], xl[2], xl[3]};
+                // the row's step ks + PF (the same pixel's next pass when this one is done) takes the registers just consumed
+                {
+                    const int kn = ks + PF;
+#ifdef PW2_EXP_NOX
+                    if (false) {
+#else
+                    if (kn < KS1) {
+#endif
+                        raw[ks % PF][0] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo + kn * 64, 0, 0);
+                        raw[ks % PF][1] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo + kn * 64 + 16, 0, 0);
+                    }
+                }
+                step_mm(c, acc1, xb);
+            }
+            // the row's first PF steps again: the second half's pass (mh = 0) or the next round's tile (mh = 1) - in flight under the second product
+            {
+                const int xn = mh == 0 ? xo : x_off(((rd + 1) * (int)gridDim.x + (int)blockIdx.x) * NWV + wave);
+                if (mh == 0 || rd + 1 < rounds) {
+#pragma unroll
+                    for (int i = 0; i < PF; ++i) {
+                        raw[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rx, xn + i * 64, 0, 0);
+                        raw[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rx, xn + i * 64 + 16, 0, 0);
+                    }
+                }
+            }
+            // ------------------------------------------------------------ bias + activation on the accumulators, the pixel's maximum over this half
+            float pmax = 0.f;
+#pragma unroll
+            for (int cf = 0; cf < NCF; ++cf)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(s_sc1 + mh * 128 + cf * 32 + 8 * g + 4 * h);
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(s_sh1 + mh * 128 + cf * 32 + 8 * g + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc1[cf][4 * g + e] * sc[e] + sh[e];
+                        v = v > floor1 ? v : floor1;
+                        acc1[cf][4 * g + e] = v;
+                        pmax = fmaxf(pmax, fabsf(v));
+                    }
+                }
+            pmax = fmaxf(pmax, __shfl_xor(pmax, 32, 64));
+            int k2 = 141 - (int)(__float_as_uint(pmax) >> 23);
+            k2 = k2 > 60 ? 60 : (k2 < -60 ? -60 : k2);
+            if (mh == 1) {
+                // the accumulators of the first half move to this half's scale (an exact power of two, at most 2^+-40: beyond that
+                // the smaller half is below 2^-40 of the sum and keeps the other's scale)
+                k2 = k2 > k2_prev + 40 ? k2_prev + 40 : (k2 < k2_prev - 40 ? k2_prev - 40 : k2);
+                const float mv = __uint_as_float((unsigned)(127 + k2 - k2_prev) << 23);
+#pragma unroll
+                for (int cf = 0; cf < NCF; ++cf)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[cf][r] *= mv;
+            }
+            k2_prev = k2;
+            const float sa2 = __uint_as_float((unsigned)(127 + k2) << 23);
+            inv2 = __uint_as_float((unsigned)(127 - k2) << 23);
+            // ------------------------------------------------------------ second product over this half's 128 channels: acc2 += W2[:, 128 mh ..] . y1
+#pragma unroll
+            for (int ks = 0; ks < KS2H; ++ks) {
+                const int c = mh * (KS1 + KS2H) + KS1 + ks;
+                step_io(c);
+                const int cf1 = ks >> 1, g0 = 2 * (ks & 1);
+                unsigned xh[4], xl[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r0 = 4 * (g0 + (e >> 1)) + 2 * (e & 1);
+                    split2_f16(acc1[cf1][r0], acc1[cf1][r0 + 1], sa2, xh[e], xl[e]);
+                }
+                u32x4 xb[NPL];
+                xb[0] = u32x4{xh[0], xh[1], xh[2], xh[3]};
+                xb[1] = u32x4{xl[0], xl[1], xl[2], xl[3]};
+                step_mm(c, acc2, xb);
+            }
+        }
+        // ---------------------------------------------------------------- epilogue (conv_pw_chain_kernel's, without a residual)
+        const int m = t * 32 + p;
+        int n, pix;
+        if (a.howo_shift >= 0) { n = m >> a.howo_shift; pix = m & (HoWo - 1); }
+        else { n = fdiv(m, a.dHoWo); pix = m - n * HoWo; }
+        const bool live = t < T && m < a.M;
+        const int yo_p = live ? ((a.y_plain ? n * (int)d.ymap.stride_inner : (int)fmap(d.ymap, a.dYin, n)) + pix * d.ldy) * 4 : OOB;
+        const int qd = lane & 7, rsub = lane >> 3;
+        uint8_t* const patch = lds + R * CH + VEC + wave * PATCH;
+        int yo[2][2];
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) yo[hp][i] = __shfl(yo_p, hp * 16 + i * 8 + rsub) + qd * 16;
+        auto patch_write = [&](const int u) __attribute__((always_inline)) {
+            const int hp = u >> 2, cf = u & 3;
+            if ((p >> 4) == hp) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(patch + (p & 15) * 144 + g * 32 + h * 16) =
+                        f32x4{acc2[cf][4 * g] * inv2, acc2[cf][4 * g + 1] * inv2, acc2[cf][4 * g + 2] * inv2, acc2[cf][4 * g + 3] * inv2};
+            }
+        };
+        patch_write(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int hp = u >> 2, cf = u & 3;
+            __builtin_amdgcn_wave_barrier();
+            f32x4 vv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) vv[i] = *reinterpret_cast<const f32x4*>(patch + (i * 8 + rsub) * 144 + qd * 16);
+            const int c = cf * 32 + 4 * qd;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(s_sc2 + c), sh = *reinterpret_cast<const f32x4*>(s_sh2 + c);
+            const bool cok = c < d.cout;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (u + 1 < 8) patch_write(u + 1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x4 v = vv[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float tt = v[e] * sc[e] + sh[e];
+                    tt = tt > floor_ ? tt : floor_;
+                    v[e] = tt;
+                }
+                if (cok && yo[hp][i] >= 0) amx = fmaxf(fmaxf(amx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, cok ? yo[hp][i] + cf * 128 : OOB, 0, 0);
+            }
+        }
+    }
+    if (a.amax_out) amax_flush(a.amax_out, amx, (int)blockIdx.x * NWV + wave);
+}
+
 int g_chain_blocks = getenv("EGR_CONV_CHAIN_BLOCKS") ? atoi(getenv("EGR_CONV_CHAIN_BLOCKS")) : 256;    // resident workgroups (one per CU)
 
 }  // namespace
@@ -396,7 +727,10 @@ extern "C" int egr_conv1x1_chain_f32(const egr_conv_desc* dd, const float* x, co
     egr_conv_desc& d = a.d;
     if (d.groups <= 0) d.groups = 1;
     if (d.kh != 1 || d.kw != 1 || d.stride != 1 || d.pad != 0 || d.h != d.ho || d.w != d.wo || d.transposed || d.out_nchw || d.split_k > 1) return EGR_EINVAL;
-    if ((d.cin != 64 && d.cin != 128) || chain->cmid != 128 || d.cout <= 0 || d.cout > 128 || d.cout % 4 != 0) return EGR_EINVAL;
+    const bool big = d.cin == 256 && chain->cmid == 256;      // both matrices streamed (conv_pw2_kernel): no residual
+    if (!big && ((d.cin != 64 && d.cin != 128) || chain->cmid != 128)) return EGR_EINVAL;
+    if (d.cout <= 0 || d.cout > 128 || d.cout % 4 != 0) return EGR_EINVAL;
+    if (big && d.res_mode != EGR_RES_NONE) return EGR_EINVAL;
     if (d.w_format != EGR_W_F16X2 || d.n <= 0 || d.ho <= 0 || d.wo <= 0 || d.groups > 65535) return EGR_EINVAL;
     if ((d.act != EGR_ACT_NONE && d.act != EGR_ACT_RELU) || (chain->act1 != EGR_ACT_NONE && chain->act1 != EGR_ACT_RELU)) return EGR_EINVAL;
     if (d.res_mode != EGR_RES_NONE && !res) return EGR_ENULL;
@@ -445,6 +779,18 @@ extern "C" int egr_conv1x1_chain_f32(const egr_conv_desc* dd, const float* x, co
     const dim3 grid((unsigned)nblk, 1, (unsigned)d.groups);
     const int resk = d.res_mode == EGR_RES_NONE ? 0 : (d.res_mode == EGR_RES_UP2_BEFORE_ACT ? 2 : 1);
     hipStream_t s = (hipStream_t)stream;
+    if (big) {
+        static const int nwv = getenv("EGR_CONV_CHAIN_BIG_WAVES") ? atoi(getenv("EGR_CONV_CHAIN_BIG_WAVES")) : 8;   // (4: two workgroups per CU - measured the same)
+        if (nwv == 8) {
+            hipLaunchKernelGGL((conv_pw2_kernel<0, 8>), grid, dim3(512), 0, s, ca);
+        } else {
+            int nb4 = 2 * g_chain_blocks / d.groups;          // two four-wave workgroups per CU
+            if (nb4 < 1) nb4 = 1;
+            if (nb4 * 4 > t32) nb4 = (t32 + 3) / 4;
+            hipLaunchKernelGGL((conv_pw2_kernel<0, 4>), dim3((unsigned)nb4, 1, (unsigned)d.groups), dim3(256), 0, s, ca);
+        }
+        return egr_launch_status();
+    }
     if (d.cin == 64) {
         if (resk == 0) hipLaunchKernelGGL((conv_pw_chain_kernel<4, 0>), grid, dim3(512), 0, s, ca);
         else if (resk == 1) hipLaunchKernelGGL((conv_pw_chain_kernel<4, 1>), grid, dim3(512), 0, s, ca);

@@ -347,6 +347,7 @@ def run_stack(st: State, seqs: Sequence[nn.Sequential], x: Img, out: Optional[Im
     mods = [list(s) for s in seqs]
     m0 = mods[0]
     i = 0
+    pre_lo = None          # the conv in front of an Upsample, already evaluated by a chained launch
     while i < len(m0):
         m = m0[i]
         if isinstance(m, nn.Conv2d):
@@ -367,6 +368,14 @@ def run_stack(st: State, seqs: Sequence[nn.Sequential], x: Img, out: Optional[Im
                 ok = (not up) or relu2                                         # ReLU(conv(up(x))) = ReLU(up(conv(x))) needs the ReLU
                 if up and end + 1 == len(m0) and last_kw and "out_nchw" in last_kw:
                     ok = False                                                 # tail of a heat-map head: egr_up2_relu_head_f32's pattern below
+                    # ... whose first two convs (256 -> 256 + ReLU, then 256 -> 128 commuted in front of the up-sampling) are one
+                    # launch where the streamed chain covers them; the Upsample branch below then starts from its result
+                    ph = st.get(nxt, lambda k=k: pack_convs([g[k] for g in mods]))
+                    if relu2 and hip.chain_eligible(x, p.w, ph.w, p.cout, ph.cout, p.groups, p.scale, ph.scale):
+                        pre_lo = hip.conv1x1_chain(x, p.w, ph.w, p.cout, ph.cout, shift1=p.shift, shift2=ph.shift, act1=act, act2=ACT_NONE,
+                                                   groups=p.groups, amax_out=st.new_amax())
+                        i = j
+                        continue
                 if fin and last_kw:
                     ok = False                                                 # (a placed / channel-major final output stays on the single launches)
                 p2 = st.get(nxt, lambda k=k: pack_convs([g[k] for g in mods])) if ok else None
@@ -389,7 +398,7 @@ def run_stack(st: State, seqs: Sequence[nn.Sequential], x: Img, out: Optional[Im
             if (isinstance(nxt, nn.Conv2d) and nxt.kernel_size == (1, 1) and nxt.stride == (1, 1) and i + 2 < len(m0)
                     and isinstance(m0[i + 2], nn.ReLU)):
                 p = st.get(nxt, lambda i=i: pack_convs([g[i + 1] for g in mods]))
-                lo = conv(st, x, p, ACT_NONE)
+                lo, pre_lo = (pre_lo, None) if pre_lo is not None else (conv(st, x, p, ACT_NONE), None)
                 fin = m0[i + 3] if i + 4 == len(m0) else None
                 if (isinstance(fin, nn.Conv2d) and fin.kernel_size == (1, 1) and fin.stride == (1, 1) and fin.out_channels <= 16
                         and fin.in_channels <= 128 and fin.in_channels % 16 == 0 and last_kw is not None and "out_nchw" in last_kw and (2 * lo.h) % 8 == 0

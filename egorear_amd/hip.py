@@ -659,16 +659,25 @@ CHAIN = os.environ.get("EGR_CONV_CHAIN", "1") != "0"
 CHAIN_MIN_ROWS = int(os.environ.get("EGR_CONV_CHAIN_MIN_ROWS", "8192"))      # (measured: batch 1 1.46 -> 1.41 ms with the FPN level-1 chain; smaller chains lose)
 
 
-def chain_eligible(x: Img, w1, w2, cmid: int, cout: int, groups: int, scale1=None, scale2=None) -> bool:
+CHAIN_BIG = os.environ.get("EGR_CONV_CHAIN_BIG", "1") != "0"
+CHAIN_BIG_MIN_ROWS = int(os.environ.get("EGR_CONV_CHAIN_BIG_MIN_ROWS", "65536"))
+
+
+def chain_eligible(x: Img, w1, w2, cmid: int, cout: int, groups: int, scale1=None, scale2=None, res_mode: int = 0) -> bool:
     """Whether conv1x1_chain covers this pair: fp16 scheme on both operands, x carries its abs-max record, cin 64 / 128 -> 128 -> <= 128,
     bias-only convs, enough pixels for the streaming structure (the rule of the single streaming launches)."""
     if not (CHAIN and H2 and isinstance(w1, W6) and isinstance(w2, W6) and w1.h2 is not None and w2.h2 is not None):
         return False
-    if x.amax is None or scale1 is not None or scale2 is not None or x.c not in (64, 128) or cmid != 128 or cout > 128 or cout % 4:
+    if x.amax is None or scale1 is not None or scale2 is not None or cout > 128 or cout % 4:
         return False
-    if x.n % groups or w1.groups != groups or w2.groups != groups or w1.npad != 128 or w2.npad != 128 or w1.K != x.c or w2.K != cmid:
+    big = x.c == 256 and cmid == 256        # both matrices streamed through LDS (conv_pw2_kernel: the heat-map heads' 256 -> 256 -> 128)
+    if not big and (x.c not in (64, 128) or cmid != 128):
         return False
-    return x.n * x.h * x.w >= CHAIN_MIN_ROWS
+    if big and (not CHAIN_BIG or res_mode != RES_NONE):
+        return False
+    if x.n % groups or w1.groups != groups or w2.groups != groups or w1.npad != cmid or w2.npad != 128 or w1.K != x.c or w2.K != cmid:
+        return False
+    return x.n * x.h * x.w >= (CHAIN_BIG_MIN_ROWS if big else CHAIN_MIN_ROWS)
 
 
 def conv1x1_chain(x: Img, w1, w2, cmid: int, cout: int, *, shift1=None, shift2=None, act1: int = ACT_RELU, act2: int = ACT_NONE,
@@ -676,7 +685,7 @@ def conv1x1_chain(x: Img, w1, w2, cmid: int, cout: int, *, shift1=None, shift2=N
                   amax_out: Optional[torch.Tensor] = None) -> Img:
     """y = act2(W2 . act1(W1 . x + shift1) + shift2 [+ res]) in one launch; the cmid-channel intermediate never reaches memory.
     x / out / res hold the images of all groups back to back (as hip.conv2d).  Call chain_eligible first."""
-    if not chain_eligible(x, w1, w2, cmid, cout, groups):
+    if not chain_eligible(x, w1, w2, cmid, cout, groups, res_mode=res_mode):
         raise LaunchError("egr_conv1x1_chain_f32", EINVAL)
     ng = x.n // groups
     gx = ng * x.nstride if groups > 1 else 0
@@ -713,14 +722,14 @@ def conv1x1_chain(x: Img, w1, w2, cmid: int, cout: int, *, shift1=None, shift2=N
     else:
         d.rmap = NMap(1, 0, 0)
     d.groups, d.gx, d.gw, d.gp, d.gy, d.gr = groups, gx, (w1.h2_gstride if groups > 1 else 0), (128 if groups > 1 else 0), gy, gr
-    for t, nm, need in ((shift1, "shift1", cmid), (shift2, "shift2", cout)):
-        if t is not None and t.numel() < ((groups - 1) * 128 + need):
+    for t, nm, need, gs in ((shift1, "shift1", cmid, w1.npad), (shift2, "shift2", cout, 128)):
+        if t is not None and t.numel() < ((groups - 1) * gs + need):
             raise RuntimeError(f"egorear_amd.conv1x1_chain: {nm} shorter than expected")
     if amax_out is not None and (amax_out.numel() != 64 or amax_out.dtype != torch.int32 or not amax_out.is_contiguous()):
         raise RuntimeError("egorear_amd.conv1x1_chain: amax_out must be 64 contiguous int32 slots")
     aux = ConvAux(_p(w1.h2_ds).value, _p(x.amax, torch.int32).value, _p(amax_out, torch.int32).value if amax_out is not None else None, None, None, 0)
     ch = ChainAux(_p(w2.h2, torch.float16).value, _p(w2.h2_ds).value, _p(shift1).value if shift1 is not None else None, cmid, act1,
-                  (w2.h2_gstride if groups > 1 else 0), (128 if groups > 1 else 0))
+                  (w2.h2_gstride if groups > 1 else 0), (w1.npad if groups > 1 else 0))
     M = ng * x.h * x.w
     _launch("egr_conv1x1_chain_f32", lib.egr_conv1x1_chain_f32, C.byref(d), _p(xg.t), _p(w1.h2, torch.float16), _p(shift2),
             _p(res.t) if res is not None else None, _p(og.t), C.byref(aux), C.byref(ch), _stream(),

@@ -181,7 +181,11 @@ int egr_conv2d_nhwc_ex_f32(const egr_conv_desc* d, const float* x, const void* w
  * (models/estimator/egoposeformer_heatmap_mvf_ex.py:553-563, 715).
  * d: the chain described as ONE 1x1 conv cin -> cout (n, h = ho, w = wo, ldx / ldy / ldr, the three maps, act = act2, res_mode,
  *    groups with gx / gy / gr / gp, gw = 16-bit elements between the groups' W1 images; kh = kw = stride = 1, pad = 0,
- *    w_format = EGR_W_F16X2); cin 64 or 128, chain->cmid 128, cout <= 128 (cout % 4 == 0).
+ *    w_format = EGR_W_F16X2); cin 64 or 128 with chain->cmid 128 (both weight images stay in LDS), or cin 256 with chain->cmid 256 and
+ *    no residual (the heat-map heads' Conv2d(256, 256, 1) + ReLU -> [Upsample ->] Conv2d(256, 128, 1),
+ *    egoposeformer_heatmap_mvf_ex.py:101-126, 570-584: both images are STREAMED through a four-slot LDS ring, one 8-KB chunk per k16
+ *    step, and the intermediate is produced / consumed in two halves of 128 channels, each under its own per-pixel scale);
+ *    cout <= 128 (cout % 4 == 0).
  * w1 / aux->w_descale: egr_pack_wh2_f32 image and descale of the first conv (cmid x cin; descale group stride chain->gp1);
  * aux->amax_in: abs-max record of x; aux->amax_out: record of y (may be NULL); shift2 / chain->w2_descale: (groups,) 128 floats,
  * group stride d->gp.  EGR_EINVAL for any other shape - the caller then runs the two launches of egr_conv2d_nhwc_ex_f32. */
@@ -189,7 +193,7 @@ typedef struct {
     const void* w2;            /* egr_pack_wh2_f32 image of the second conv (round_up(cout, 32) padded to 128 rows x cmid) */
     const float* w2_descale;
     const float* shift1;       /* bias of the first conv, (groups,) cmid floats, group stride gp1; NULL = 0 */
-    int32_t cmid, act1;        /* 128; EGR_ACT_NONE | EGR_ACT_RELU */
+    int32_t cmid, act1;        /* 128 (256 with cin 256); EGR_ACT_NONE | EGR_ACT_RELU */
     int64_t gw2, gp1;          /* group strides: 16-bit elements of w2; floats of shift1 and of aux->w_descale */
 } egr_chain_aux;
 int egr_conv1x1_chain_f32(const egr_conv_desc* d, const float* x, const void* w1, const float* shift2, const float* res, float* y,

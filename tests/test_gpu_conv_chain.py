@@ -147,3 +147,56 @@ def test_refusals():
         hip.conv1x1_chain(xin, p1, p2, 128, 128)
     x3 = rnd(1, 8, 8, 96, seed=1).to(DEV)
     assert not hip.chain_eligible(hip.Img(x3, amax=record_of(x3)), p1, p2, 128, 128, 1)
+
+
+BIG = [
+    # n (per group), h, w, cout, G, act1, act2, scale of the second half of the intermediate's channels
+    (2, 32, 32, 128, 2, 1, 0, 1.0),          # the stereo heads' 256 -> 256 (+ReLU) -> 128 (the ReLU sits behind the up-sampling)
+    (2, 16, 16, 128, 4, 1, 1, 1.0),          # four groups (the refiners' heads), ReLU behind the second conv
+    (1, 20, 12, 124, 1, 1, 1, 1.0),          # ragged: 240 pixels (7.5 tiles of 32), 124 output channels
+    (3, 8, 8, 128, 3, 0, 0, 1.0),            # no activations, three groups of 192 pixels (most waves idle in the last round)
+    (1, 16, 16, 128, 1, 1, 0, 1e-5),         # the second half of the intermediate far below the first: its own (clamped) scale
+    (1, 16, 16, 128, 1, 1, 0, 3e4),          # ... and far above
+]
+
+
+@pytest.mark.parametrize("case", BIG, ids=[f"n{c[0]}x{c[1]}x{c[2]}-{c[3]}G{c[4]}a{c[5]}{c[6]}s{c[7]:g}" for c in BIG])
+def test_streamed_chain_256_256_128_matches_fp64_and_the_two_launches(case):
+    """conv_pw2_kernel (round 5): 256 -> 256 -> <= 128 with both weight matrices streamed through an LDS ring and the intermediate
+    produced / consumed in two halves of 128 channels, each under its own per-pixel scale."""
+    from egorear_amd import hip
+    n, h, w, cout, G, act1, act2, half2 = case
+    cin = cmid = 256
+    x = F.relu(rnd(G * n, h, w, cin, seed=17)) * 2.0
+    w1, w2, b1, b2, _, _ = _ops(hip, cin, cmid, cout, G, 140)
+    if half2 != 1.0:
+        w1 = [torch.cat([wg[:128], wg[128:] * half2]) for wg in w1]
+        b1 = torch.cat([b1[:, :128], b1[:, 128:] * half2], 1)
+    st1 = torch.stack([pack_w(wg) for wg in w1]) if G > 1 else pack_w(w1[0])
+    st2 = torch.stack([pack_w(wg) for wg in w2]) if G > 1 else pack_w(w2[0])
+    p1, p2 = hip.add_wh2(hip.pack_w6(st1.to(DEV))), hip.add_wh2(hip.pack_w6(st2.to(DEV)))
+    ref = _reference(x, w1, w2, b1, b2, G, act1, act2, None, 0, cout)
+    saved = hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS, hip.CHAIN_BIG_MIN_ROWS
+    hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS, hip.CHAIN_BIG_MIN_ROWS = 0, 0.0, 0
+    try:
+        xd = x.to(DEV)
+        xin = hip.Img(xd, amax=record_of(xd))
+        b1d, b2d = b1.to(DEV).contiguous(), b2.to(DEV).contiguous()
+        assert hip.chain_eligible(xin, p1, p2, cmid, cout, G)
+        assert not hip.chain_eligible(xin, p1, p2, cmid, cout, G, res_mode=1)            # no residual in the streamed form
+        rec = torch.zeros(64, dtype=torch.int32, device=DEV)
+        y = hip.conv1x1_chain(xin, p1, p2, cmid, cout, shift1=b1d, shift2=b2d, act1=act1, act2=act2, groups=G, amax_out=rec)
+        y2 = hip.conv1x1_chain(xin, p1, p2, cmid, cout, shift1=b1d, shift2=b2d, act1=act1, act2=act2, groups=G)
+        r1 = torch.zeros(64, dtype=torch.int32, device=DEV)
+        mid = hip.conv2d(xin, p1, cmid, 1, 1, 1, 0, shift=b1d, act=act1, groups=G, amax_out=r1)
+        two = hip.conv2d(mid, p2, cout, 1, 1, 1, 0, shift=b2d, act=act2, groups=G)
+    finally:
+        hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS, hip.CHAIN_BIG_MIN_ROWS = saved
+    torch.cuda.synchronize()
+    assert torch.equal(y.t, y2.t), "deterministic"
+    scale = max(float(ref.abs().max()), 1e-6)
+    e_chain = float((y.t.cpu().double() - ref).abs().max()) / scale
+    e_two = float((two.t.cpu().double() - ref).abs().max()) / scale
+    assert e_chain <= 2e-5 and e_two <= 2e-5, (e_chain, e_two)
+    assert e_chain <= 1.5 * e_two + 4e-7, ("the chain is less accurate than the two launches", e_chain, e_two)
+    assert record_value(rec) == float(y.t.abs().max()), "the record is the maximum over exactly what the launch stored"

@@ -34,7 +34,7 @@ def _am(t):
 
 
 def _h2_launches(prof):
-    tags = [t for name, *_, t in prof if name == "egr_conv2d_nhwc_f32"]
+    tags = [t for name, *_, t in prof if name in ("egr_conv2d_nhwc_f32", "egr_conv1x1_chain_f32")]      # (a chained pair: one fp16-scheme launch)
     return sum(t.startswith("h2 ") for t in tags), len(tags)
 
 

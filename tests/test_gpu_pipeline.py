@@ -54,30 +54,34 @@ def launch_policy(request):
     wherever the input carries an abs-max record, i.e. the shipped choice at the benchmarked batch sizes - and the same with the
     fp16 scheme switched off (split-bf16 everywhere), so that the reference's golden vectors pin both kernels end to end."""
     from egorear_amd import hip
-    saved = (hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS, hip.H2)
+    saved = (hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS, hip.H2, hip.CHAIN_MIN_ROWS, hip.CHAIN_BIG_MIN_ROWS)
     if request.param != "by-size":
         hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS = 0, 0.0
+        hip.CHAIN_MIN_ROWS = hip.CHAIN_BIG_MIN_ROWS = 0       # ... and every chained pair as one launch (also the heads' streamed 256 -> 256 -> 128)
     if request.param == "bf16-everywhere":
         hip.H2 = False
     yield request.param
-    hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS, hip.H2 = saved
+    hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS, hip.H2, hip.CHAIN_MIN_ROWS, hip.CHAIN_BIG_MIN_ROWS = saved
 
 
 def test_forced_policy_really_takes_the_fp16_scheme(nets):
     """Under 'split-everywhere' the forward's convolutions run the fp16 scheme (all but the few whose input has no record)."""
     from egorear_amd import hip, synth
     net = nets("syn")
-    saved = (hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS, hip.PROFILE)
+    saved = (hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS, hip.PROFILE, hip.CHAIN_MIN_ROWS, hip.CHAIN_BIG_MIN_ROWS)
     hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS, hip.PROFILE = 0, 0.0, []
+    hip.CHAIN_MIN_ROWS = hip.CHAIN_BIG_MIN_ROWS = 0
     try:
         with torch.no_grad():
             net(synth.synth_images(2, 4, seed=0).to(DEV))
-        tags = [t for name, *_, t in hip.PROFILE if name in ("egr_conv2d_nhwc_f32", "egr_conv1x1_chain_f32")]   # (a chained pair: one fp16-scheme launch)
+        tags = [t for name, *_, t in hip.PROFILE if name in ("egr_conv2d_nhwc_f32", "egr_conv1x1_chain_f32")]
     finally:
-        hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS, hip.PROFILE = saved
+        hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS, hip.PROFILE, hip.CHAIN_MIN_ROWS, hip.CHAIN_BIG_MIN_ROWS = saved
     h2 = sum(1 for t in tags if t.startswith("h2 "))
     x6 = sum(1 for t in tags if t.startswith("x6 "))
-    assert h2 >= 45 and x6 <= 12, (h2, x6, len(tags))
+    chains = [t for t in tags if " chain " in t]
+    # (a chained pair is one fp16-scheme launch: three resident chains + the two streamed 256 -> 256 -> 128 of the heads)
+    assert h2 + len(chains) >= 45 and x6 <= 12 and len(chains) == 5 and sum("mid256" in t for t in chains) == 2, (h2, x6, len(tags), chains)
 
 
 def test_library_is_the_native_one():
@@ -366,7 +370,7 @@ def test_benchmarked_batch_sizes_default_launch_policy_vs_oracle(batch, nets):
         preds, hms = net(img.to(DEV))
         prof, hip.PROFILE = hip.PROFILE, None
         preds2, hms2 = net(img.to(DEV))
-    tags = [t for name, _, _, _, _, t in prof if name == "egr_conv2d_nhwc_f32"]
+    tags = [t for name, _, _, _, _, t in prof if name in ("egr_conv2d_nhwc_f32", "egr_conv1x1_chain_f32")]
     assert sum(t.startswith("h2 ") for t in tags) >= 35, "the large launches must have gone to the fp16-scheme kernel by size"
     assert sum(t.startswith("x6 ") for t in tags) <= 3, "only launches whose input has no abs-max record stay on the split-bf16 kernel"
     assert all(torch.equal(a, b) for a, b in zip(preds, preds2)) and all(torch.equal(a, b) for a, b in zip(hms, hms2))
@@ -395,11 +399,11 @@ def test_a_frame_does_not_depend_on_the_batch_it_arrives_in(nets):
     with torch.no_grad():
         hip.PROFILE = []
         p64, h64 = net(img64)
-        tags64, hip.PROFILE = [t for name, *_, t in hip.PROFILE if name == "egr_conv2d_nhwc_f32"], None
+        tags64, hip.PROFILE = [t for name, *_, t in hip.PROFILE if name in ("egr_conv2d_nhwc_f32", "egr_conv1x1_chain_f32")], None
         idx64 = net.__dict__["_egr_last_aux"]["heatmap"]["argmax_idx"][lo:lo + 2].clone()
         hip.PROFILE = []
         p2, h2 = net(img64[lo:lo + 2].contiguous())
-        tags2, hip.PROFILE = [t for name, *_, t in hip.PROFILE if name == "egr_conv2d_nhwc_f32"], None
+        tags2, hip.PROFILE = [t for name, *_, t in hip.PROFILE if name in ("egr_conv2d_nhwc_f32", "egr_conv1x1_chain_f32")], None
         idx2 = net.__dict__["_egr_last_aux"]["heatmap"]["argmax_idx"]
     assert sum(t.startswith("h2 ") for t in tags64) >= 40 and sum(t.startswith("h2 ") for t in tags2) <= 30   # different kernels did the work
     assert torch.equal(idx64, idx2)

@@ -158,6 +158,12 @@ def test_chain_entry_refuses_unsupported_shapes_before_any_launch():
     assert call(desc(res_mode=1), res=None) == hip.ENULL
     assert call(desc(res_mode=3, ho=7, wo=7, h=7, w=7), res=P) == hip.EINVAL                 # up-sampled residual: even output size
     assert call(desc(ldx=66)) == hip.EINVAL and call(desc(), x=P + 4) == hip.EINVAL          # 16-byte rows
+    # the streamed form: 256 -> 256 -> <= 128 only, without a residual
+    big = hip.ChainAux(P, P, None, 256, 1, 0, 0)
+    assert call(desc(cin=256, ldx=256), ch_=hip.ChainAux(P, P, None, 128, 1, 0, 0)) == hip.EINVAL      # 256 -> 128 -> ..: no such kernel
+    assert call(desc(cin=128, ldx=128), ch_=big) == hip.EINVAL
+    assert call(desc(cin=256, ldx=256, res_mode=1), res=P, ch_=big) == hip.EINVAL
+    assert call(desc(cin=256, ldx=256, cout=132), ch_=big) == hip.EINVAL
 
 
 def test_chain_eligibility_rule():
@@ -177,7 +183,10 @@ def test_chain_eligibility_rule():
     assert not hip.chain_eligible(X(64, 64, 64, 64, amax=False), W(128, 64), W(128, 128), 128, 128, 1)     # no record: no fp16 pre-scale
     assert not hip.chain_eligible(big, W(128, 64, h2=False), W(128, 128), 128, 128, 1)
     assert not hip.chain_eligible(big, W(128, 64), W(128, 128), 128, 128, 1, scale1=object())                # BatchNorm-scaled conv
-    assert not hip.chain_eligible(X(64, 64, 64, 256), W(128, 256), W(128, 128), 128, 128, 1)                 # cin 256: W1 does not fit LDS
+    assert not hip.chain_eligible(X(64, 64, 64, 256), W(128, 256), W(128, 128), 128, 128, 1)                 # cin 256 -> 128: W1 does not fit LDS
+    assert hip.chain_eligible(X(64, 64, 64, 256), W(256, 256), W(128, 256), 256, 128, 1)                     # 256 -> 256 -> 128: streamed
+    assert not hip.chain_eligible(X(64, 64, 64, 256), W(256, 256), W(128, 256), 256, 128, 1, res_mode=1)     # ... without a residual only
+    assert not hip.chain_eligible(X(8, 32, 32, 256), W(256, 256), W(128, 256), 256, 128, 1)                  # ... from 65536 pixels
     assert not hip.chain_eligible(big, W(256, 64), W(128, 256), 256, 128, 1)                                 # 256-channel intermediate
     assert not hip.chain_eligible(X(2, 8, 8, 64), W(128, 64), W(128, 128), 128, 128, 1)                      # too few pixels to stream
     assert not hip.chain_eligible(X(63, 64, 64, 64), W(128, 64, groups=2), W(128, 128, groups=2), 128, 128, 2)   # images not divisible by groups
