@@ -23,7 +23,7 @@ for r in csv.DictReader(open(f)):
         per[kk][r["Counter_Name"]] += float(r["Counter_Value"])
         if ("t", r["Dispatch_Id"]) not in seen:
             seen.add(("t", r["Dispatch_Id"])); dur[kk] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-    chain = "conv_pw_chain_kernel" in n          # chained 1x1 pairs (fp16 scheme only): booked with the streaming / tiled kernels
+    chain = "conv_pw_chain_kernel" in n or "conv_pw2_kernel" in n          # chained 1x1 pairs (fp16 scheme only): booked with the streaming / tiled kernels
     if "conv_tapx_kernel" not in n and ((("conv_igemm_tap" in n or "conv_pw_x6" in n or "conv_igemm_x6" in n) and h2) or chain):
         kk = "conv_other_split_f16x2"      # what is left on the tap-sharing / streaming / tiled kernels
         per[kk][r["Counter_Name"]] += float(r["Counter_Value"])

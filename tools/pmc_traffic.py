@@ -15,7 +15,7 @@ def load(d, counter):
         nm = r["Kernel_Name"]
         # conv_igemm_x6 / x6p / tap / tap2 / conv_pw_x6 kernels = the split launches (last template argument: 3 = bf16 x 3 planes,
         # 2 = fp16 x 2 planes), conv_igemm_kernel the fp32 ones
-        tapx = "conv_tapx_kernel" in nm or "conv_pw_chain_kernel" in nm    # role-split persistent workgroups / chained 1x1 pairs: fp16 scheme only
+        tapx = "conv_tapx_kernel" in nm or "conv_pw_chain_kernel" in nm or "conv_pw2_kernel" in nm    # role-split persistent workgroups / chained 1x1 pairs: fp16 scheme only
         split = "conv_igemm_x6" in nm or "conv_igemm_tap" in nm or "conv_pw_x6" in nm or tapx
         h2 = tapx or (split and re.search(r",\s*2>\(", nm.replace(") ", ")")) is not None)
         k = (("conv_h2" if h2 else "conv_x6") if split else "conv") if ("conv_igemm" in nm or "conv_pw_x6" in nm or tapx) else "other"

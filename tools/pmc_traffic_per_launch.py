@@ -11,7 +11,7 @@ def per_dispatch(d, counter):
     val = collections.OrderedDict()
     for r in csv.DictReader(open(f)):
         nm = r["Kernel_Name"]
-        if r["Counter_Name"] != counter or not ("conv_igemm" in nm or "conv_pw_x6" in nm or "conv_tapx_kernel" in nm or "conv_pw_chain_kernel" in nm or "linear_small_kernel" in nm):
+        if r["Counter_Name"] != counter or not ("conv_igemm" in nm or "conv_pw_x6" in nm or "conv_tapx_kernel" in nm or "conv_pw_chain_kernel" in nm or "conv_pw2_kernel" in nm or "linear_small_kernel" in nm):
             continue
         k = int(r["Dispatch_Id"])
         val[k] = val.get(k, 0.0) + float(r["Counter_Value"])
