@@ -313,7 +313,10 @@ __global__ __launch_bounds__(512) void conv_pw_chain_kernel(const ChainArgs ca) 
 #ifdef CHAIN_EXP_NORES
                 if (st > 0) return;
 #endif
-                rq[par][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ro[hp][i] + cf * 128, 0, 0));
+                // RESK == 1: the residual has the OUTPUT's shape - a fragment past cout (cout < 128) lies outside its row (and, at the
+                // last pixel, outside the tensor): not requested, like the stores of those channels
+                const int r0 = (RESK == 1 && cf * 32 + 4 * qd >= d.cout) ? OOB : ro[hp][i] + cf * 128;
+                rq[par][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, r0, 0, 0));
                 if constexpr (RESK == 2) {
                     rq[par][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ro[hp][i] + ox[hp][i] + cf * 128, 0, 0));
                     rq[par][2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ro[hp][i] + oy[hp][i] + cf * 128, 0, 0));
@@ -629,9 +632,12 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void conv_pw2_kernel(const Chain
             int k2 = 141 - (int)(__float_as_uint(pmax) >> 23);
             k2 = k2 > 60 ? 60 : (k2 < -60 ? -60 : k2);
             if (mh == 1) {
-                // the accumulators of the first half move to this half's scale (an exact power of two, at most 2^+-40: beyond that
-                // the smaller half is below 2^-40 of the sum and keeps the other's scale)
-                k2 = k2 > k2_prev + 40 ? k2_prev + 40 : (k2 < k2_prev - 40 ? k2_prev - 40 : k2);
+                // the accumulators of the first half move to this half's scale by an exact power of two.  Only the UPPER side is
+                // clamped (a second half below 2^-40 of the first keeps k2_prev + 40: acc2 * 2^40 stays far inside fp32).  A second
+                // half that is LARGER keeps its natural scale - forcing it up towards the first half's (an all-zero first half has
+                // k2_prev = 60) would push y1 * 2^k2 past 65504 and split2_f16 would return +inf / -inf planes; mv then goes down to
+                // 2^-120 (biased exponent 7: a valid float) and a negligible first half underflows harmlessly.
+                k2 = k2 > k2_prev + 40 ? k2_prev + 40 : k2;
                 const float mv = __uint_as_float((unsigned)(127 + k2 - k2_prev) << 23);
 #pragma unroll
                 for (int cf = 0; cf < NCF; ++cf)

@@ -339,6 +339,11 @@ def linear(st: State, x: torch.Tensor, p: PConv, act=ACT_NONE, **kw) -> torch.Te
     return out.t.view(x.shape[0], p.cout)
 
 
+def _unpadded(m: nn.Conv2d) -> bool:
+    """A padded 1x1 conv grows the image: conv1x1_chain evaluates pad 0 only, such a pair stays on the single launches."""
+    return tuple(m.padding) == (0, 0) if not isinstance(m.padding, (str, int)) else m.padding in (0, "valid")
+
+
 def run_stack(st: State, seqs: Sequence[nn.Sequential], x: Img, out: Optional[Img] = None,
               last_kw: Optional[dict] = None) -> Optional[Img]:
     """Execute tree.stack()s (one per group, identical structure): Conv2d(+ReLU) fuse into one launch; Upsample /
@@ -360,8 +365,8 @@ def run_stack(st: State, seqs: Sequence[nn.Sequential], x: Img, out: Optional[Im
             up = j < len(m0) and isinstance(m0[j], nn.Upsample)
             k = j + 1 if up else j
             nxt = m0[k] if k < len(m0) else None
-            if (m.kernel_size == (1, 1) and m.stride == (1, 1) and isinstance(nxt, nn.Conv2d) and nxt.kernel_size == (1, 1)
-                    and nxt.stride == (1, 1)):
+            if (m.kernel_size == (1, 1) and m.stride == (1, 1) and _unpadded(m) and isinstance(nxt, nn.Conv2d)
+                    and nxt.kernel_size == (1, 1) and nxt.stride == (1, 1) and _unpadded(nxt)):
                 relu2 = k + 1 < len(m0) and isinstance(m0[k + 1], nn.ReLU)
                 end = k + (2 if relu2 else 1)
                 fin = end >= len(m0)

@@ -677,6 +677,10 @@ def chain_eligible(x: Img, w1, w2, cmid: int, cout: int, groups: int, scale1=Non
         return False
     if x.n % groups or w1.groups != groups or w2.groups != groups or w1.npad != cmid or w2.npad != 128 or w1.K != x.c or w2.K != cmid:
         return False
+    # the entry's own layout checks (egr_conv1x1_chain_f32 returns EINVAL on them): 16-byte pixel rows and image strides, a 16-byte
+    # aligned base - a channel slice at an odd offset stays on the single launches instead of aborting the forward
+    if x.ld % 4 or x.nstride % 4 or x.t.data_ptr() % 16:
+        return False
     return x.n * x.h * x.w >= (CHAIN_BIG_MIN_ROWS if big else CHAIN_MIN_ROWS)
 
 

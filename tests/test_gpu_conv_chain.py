@@ -200,3 +200,52 @@ def test_streamed_chain_256_256_128_matches_fp64_and_the_two_launches(case):
     assert e_chain <= 2e-5 and e_two <= 2e-5, (e_chain, e_two)
     assert e_chain <= 1.5 * e_two + 4e-7, ("the chain is less accurate than the two launches", e_chain, e_two)
     assert record_value(rec) == float(y.t.abs().max()), "the record is the maximum over exactly what the launch stored"
+
+
+@pytest.mark.parametrize("dead", ["first-all", "first-some", "second-all", "second-some"])
+def test_streamed_chain_with_a_dead_half_of_the_intermediate(dead):
+    """a pixel whose first 128 post-ReLU intermediate channels are all zero has k2_prev = 60; the second half's scale
+    used to be clamped UP to k2_prev - 40 = 20, y1 * 2^20 overflowed fp16 and the pixel's outputs were NaN.  Whole tensors and single
+    pixels with a dead first / second half: finite, and at the two launches' accuracy."""
+    from egorear_amd import hip
+    n, h, w, cout, G = 2, 16, 16, 128, 2
+    cin = cmid = 256
+    x = F.relu(rnd(G * n, h, w, cin, seed=27)) * 2.0
+    w1, w2, b1, b2, _, _ = _ops(hip, cin, cmid, cout, G, 240)
+    lo, hi = (0, 128) if dead.startswith("first") else (128, 256)
+    b1 = b1.clone()
+    b1[:, lo:hi] = -b1[:, lo:hi].abs()                          # the dead half's bias <= 0
+    if dead.endswith("all"):
+        w1 = [wg.clone() for wg in w1]
+        for wg in w1:
+            wg[lo:hi] = 0                                         # ... and no input reaches it: dead for every pixel
+    else:
+        x = x.clone()
+        x.view(-1, cin)[::7] = 0                                  # every seventh pixel has no input: its dead half is exactly zero,
+        b1[:, hi % 256:(hi % 256) + 128] = b1[:, hi % 256:(hi % 256) + 128].abs() + 0.1      # the other half is its bias (> 0)
+    st1, st2 = torch.stack([pack_w(wg) for wg in w1]), torch.stack([pack_w(wg) for wg in w2])
+    p1, p2 = hip.add_wh2(hip.pack_w6(st1.to(DEV))), hip.add_wh2(hip.pack_w6(st2.to(DEV)))
+    ref = _reference(x, w1, w2, b1, b2, G, 1, 0, None, 0, cout)
+    saved = hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS, hip.CHAIN_BIG_MIN_ROWS
+    hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS, hip.CHAIN_BIG_MIN_ROWS = 0, 0.0, 0
+    try:
+        xd = x.to(DEV)
+        xin = hip.Img(xd, amax=record_of(xd))
+        b1d, b2d = b1.to(DEV).contiguous(), b2.to(DEV).contiguous()
+        assert hip.chain_eligible(xin, p1, p2, cmid, cout, G)
+        y = hip.conv1x1_chain(xin, p1, p2, cmid, cout, shift1=b1d, shift2=b2d, act1=1, act2=0, groups=G)
+        r1 = torch.zeros(64, dtype=torch.int32, device=DEV)
+        mid = hip.conv2d(xin, p1, cmid, 1, 1, 1, 0, shift=b1d, act=1, groups=G, amax_out=r1)
+        two = hip.conv2d(mid, p2, cout, 1, 1, 1, 0, shift=b2d, act=0, groups=G)
+    finally:
+        hip.X6_MIN_ROWS, hip.X6_MIN_FLOPS, hip.CHAIN_BIG_MIN_ROWS = saved
+    torch.cuda.synchronize()
+    assert float(mid.t[..., lo:hi].abs().max()) == 0.0 or dead.endswith("some")
+    if dead.endswith("some"):
+        assert float(mid.t.view(-1, cmid)[::7, lo:hi].abs().max()) == 0.0 and float(mid.t.view(-1, cmid)[::7].abs().max()) > 0.0
+    assert bool(torch.isfinite(y.t).all()), "a dead half of the intermediate produced Inf / NaN"
+    scale = max(float(ref.abs().max()), 1e-6)
+    e_chain = float((y.t.cpu().double() - ref).abs().max()) / scale
+    e_two = float((two.t.cpu().double() - ref).abs().max()) / scale
+    assert e_chain <= 2e-5 and e_two <= 2e-5, (e_chain, e_two)
+    assert e_chain <= 1.5 * e_two + 4e-7, (e_chain, e_two)
