@@ -124,12 +124,10 @@ def exact_leg(net, img, B: int, lanes: int, steps: int = 50):
     import torch
     from egorear_amd import engine, hip
     from egorear_amd.runner import PipelinedForward
-    saved = (hip.H2, engine.LAYER_H2, engine.W_FORMAT)
-    mods = (net, net.heatmap_estimator, net.pose3d_estimator)
+    # a second LaunchPolicy held by the module for the duration of this leg (engine.set_policy): nothing process-global is flipped,
+    # the packs of this module alone are rebuilt for the other weight format
     try:
-        hip.H2, engine.LAYER_H2, engine.W_FORMAT = False, False, "bf16x3"
-        for m in mods:
-            engine.invalidate(m)               # packs and scratch are rebuilt for the other format
+        engine.set_policy(net, hip.policy().exact())
         with torch.no_grad():
             net(img)
             torch.cuda.synchronize()
@@ -147,9 +145,7 @@ def exact_leg(net, img, B: int, lanes: int, steps: int = 50):
                 "what": "same forward, weights, batch and launch mode as `value` with EGR_W_FORMAT=bf16x3 arithmetic: what the fp16 scheme's "
                         "22-bit operands buy (parity of this leg: tests/test_gpu_bf16x3_leg.py)"}
     finally:
-        hip.H2, engine.LAYER_H2, engine.W_FORMAT = saved
-        for m in mods:
-            engine.invalidate(m)
+        engine.set_policy(net, None)
 
 
 def parse():
@@ -166,7 +162,7 @@ def parse():
                     help="captured forwards in flight (runner.PipelinedForward): consecutive steps overlap on that many streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
-    ap.add_argument("--cpu-iters", type=int, default=28)      # ~12 s of CPU work on the GPU box's 16 host threads
+    ap.add_argument("--cpu-iters", type=int, default=30)      # + 2 warm-ups = 32 forwards of 8 = 256 frames = four GPU batches of 64; ~15 s on the GPU box's 16 host threads
     ap.add_argument("--no-train", action="store_true", help="skip the training-step leg (config 5)")
     ap.add_argument("--no-configs", action="store_true", help="skip the config 1-3 legs")
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-arithmetic (bf16x3) leg")
@@ -203,61 +199,62 @@ def _natural(path: str):
     return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(path))]
 
 
-_TRAFFIC_SOURCE = {}
-
-
 def _pmc_traffic(batch: int, fmt: str = "", launches_per_step: int = 0):
     """HBM bytes per launch of the conv kernel from the committed rocprofv3 PMC passes (profiles/*pmc_traffic.json,
     produced by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command, with the
     gfx950 x2 correction on FETCH_SIZE).  Counters cannot be collected from inside the timed run; null if the file
     is absent, was measured at another batch size, or counted another number of launches of this kernel per forward than
-    this run makes (a stale file: the launch rule or the kernels changed since the passes were collected)."""
+    this run makes (a stale file: the launch rule or the kernels changed since the passes were collected).
+    Returns (bytes per launch, provenance) - the provenance names the file and commit the figure is replayed from."""
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "*pmc_traffic.json")), key=_natural)
     if not files:
-        return None
+        return None, None
     try:
         with open(files[-1]) as f:
             t = json.load(f)
         if t.get("batch") != batch:
-            return None
+            return None, None
         e = t
         if fmt and t.get("by_format"):      # per weight format of the implicit-GEMM kernel ("f16x2" / "bf16x3" / "f32")
             e = t["by_format"].get(fmt)
         if not e:
-            return None
+            return None, None
         if launches_per_step and e.get("launches_per_forward") not in (None, launches_per_step):
-            return None
+            return None, None
         # provenance: PMC counters cannot be read inside the timed run - the value is REPLAYED from the committed passes of this command
-        _TRAFFIC_SOURCE["file"] = {"replayed_from": os.path.relpath(files[-1], REPO), "commit": t.get("commit"),
-                                   "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH x 2 on gfx950); null when the launch count of this run differs"}
-        return e["hbm_bytes_per_launch"]
+        return e["hbm_bytes_per_launch"], {"replayed_from": os.path.relpath(files[-1], REPO), "commit": t.get("commit"),
+                                           "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH x 2 on gfx950); null when the launch count of this run differs"}
     except Exception:
-        return None
+        return None, None
 
 
 def _pmc_traffic_train(batch: int, key: str):
     """HBM bytes per launch of a training-step kernel from the committed PMC passes (profiles/*pmc_traffic_train.json, produced by
-    tools/pmc_traffic_train.py from separate FETCH_SIZE / WRITE_SIZE runs of tools/train_bench.py); null if absent / other batch."""
+    tools/pmc_traffic_train.py from separate FETCH_SIZE / WRITE_SIZE runs of tools/train_bench.py); null if absent / other batch.
+    Returns (bytes per launch, provenance)."""
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "*pmc_traffic_train.json")), key=_natural)
     if not files:
-        return None
+        return None, None
     try:
         with open(files[-1]) as f:
             t = json.load(f)
         if t.get("batch") != batch:
-            return None
+            return None, None
         name = {"egr_conv2d_nhwc_f32[f16x2]": "conv_igemm_f16x2", "egr_conv2d_nhwc_f32[bf16x3]": "conv_igemm_bf16x3",
                 "egr_conv2d_nhwc_f32": "conv_igemm_f32", "egr_conv2d_wgrad_f32[f16x2]": "conv_wgrad_f16x2",
                 "egr_conv2d_wgrad_f32": "conv_wgrad_bf16x3"}.get(key)
         e = t["kernels"].get(name) if name else None
-        return e["hbm_bytes_per_launch"] if e else None
+        if not e:
+            return None, None
+        return e["hbm_bytes_per_launch"], {"replayed_from": os.path.relpath(files[-1], REPO), "commit": t.get("commit"),
+                                           "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/train_bench.py (FETCH x 2 on gfx950)"}
     except Exception:
-        return None
+        return None, None
 
 
-def _roofline(key: str, k: dict, traffic):
+def _roofline(key: str, k: dict, traffic, traffic_source=None):
     """Roofline object of one profiled kernel.  Split launches execute X6_TERMS bf16 (H2_TERMS fp16) MFMA products per algorithmic
     fp32 product: `achieved` is the executed 16-bit matrix-core rate against the bf16 / fp16 dense peak; the algorithmic
     (fp32-equivalent) rate and the fp32-matrix-core peak it would otherwise be priced against are given beside it."""
@@ -270,7 +267,7 @@ def _roofline(key: str, k: dict, traffic):
          "flops_per_launch": round(k["flops"] / k["launches"], 1), "algorithmic_bytes_per_launch": round(k["bytes"] / k["launches"], 1),
          "kernel_ms_per_step": round(k["ms"], 3), "algorithmic_tflops": round(alg, 2),
          "frac_algorithmic": round(alg / (PEAK_BF16_MFMA_TFLOPS if (x6 or h2) else PEAK_F32_MFMA_TFLOPS), 4),
-         "traffic_source": _TRAFFIC_SOURCE.get("file") if traffic is not None else None,
+         "traffic_source": traffic_source if traffic is not None else None,
          # the same computation priced against the roof it faced before (and still faces with EGR_W_FORMAT=f32)
          "algorithmic_frac_of_f32_mfma_peak": round(alg / PEAK_F32_MFMA_TFLOPS, 4)}
     if x6:
@@ -291,39 +288,60 @@ def _log(msg: str):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(state_dict, batch: int, iters: int, gpu_out=None):
-    """Time the CPU oracle (kind 'port') on a bounded sample: `iters` forwards of `batch` frames.  `gpu_out` = the HIP path's
-    (poses, heat maps) on the same frames: the oracle's warm-up forward doubles as the checker for the metric's
-    "MPJPE vs ref" half (returned as the second value)."""
+def cpu_baseline(state_dict, net, dev, batch: int, iters: int, gpu_batch: int = 64):
+    """The CPU oracle (kind 'port') timed on a bounded sample AND used as the checker of the metric's "MPJPE vs ref" half, in one
+    pass: `iters` + 2 forwards of `batch` DISTINCT seeded frames each (the first two are warm-ups: compared, not timed).  The same
+    frames go through the HIP path in batches of `gpu_batch` (the benchmarked batch size and launch policy) and every oracle forward
+    is compared with its slice (oracle/census.py: arg-max of both heat-map sets, valid masks, all four pose sets, top-2 gap census).
+    `value` = batch / MEDIAN per-forward time (a wall-clock total moved 2x between boxes: one slow forward of a noisy neighbour)."""
+    import statistics
+
     import torch
     from egorear_amd import synth
+    from oracle import census
     from oracle import egorear_oracle as O
     cores = _host_cores()
     torch.set_num_threads(cores)
     cams = O.make_cameras("ego4view_syn", os.path.join(REPO, "egorear_amd", "calib", "ego4view"))
-    img = synth.synth_images(batch, 4, seed=1234)
+    n_fwd = iters + 2
+    frames = n_fwd * batch
+    n_gpu = -(-frames // gpu_batch)
+    # alternating image scales 1.0 / 0.35 (the reference goldens' two settings: maxima on both sides of the 0.5 threshold)
+    batches = [synth.synth_images(gpu_batch, 4, seed=1234 + i, scale=(1.0 if i % 2 == 0 else 0.35)) for i in range(n_gpu)]
+    flat = torch.cat(batches)[:frames]
+    left = frames - (n_gpu - 1) * gpu_batch
+    batches[-1] = batches[-1][:left] if left < gpu_batch else batches[-1]
+    gt = synth.synth_gt_pose(frames, seed=1235)
+    times, acc = [], None
+    mp_hip = mp_cpu = 0.0
+    _log(f"cpu baseline + parity census: {n_fwd} oracle forwards of batch {batch} ({frames} frames), {cores} threads (torch.get_num_threads() = {torch.get_num_threads()})")
     with torch.no_grad():
-        _log(f"cpu baseline: warm-up forward, batch {batch}, {cores} threads")
-        ref_pose, ref_hm, _ = O.mvfex_forward(state_dict, cams, img)  # warm-up
-        parity = None
-        if gpu_out is not None:
-            gt = synth.synth_gt_pose(batch, seed=1235)
-            pose, hm = gpu_out
-            am_g = hm.flatten(-2).argmax(-1)
-            am_c = ref_hm[-1].flatten(-2).argmax(-1)
-            parity = {"frames": batch, "argmax_equal": bool((am_g == am_c).all()), "argmax_compared": int(am_c.numel()),
-                      "max_joint_err_cm": float((pose - ref_pose[-1]).abs().max()),
-                      "mpjpe_mm_hip": float(O.compute_mpjpe_batch(pose, gt).mean() * 10),
-                      "mpjpe_mm_cpu_oracle": float(O.compute_mpjpe_batch(ref_pose[-1], gt).mean() * 10),
-                      "tolerance_cm": 1e-3}
-        _log("cpu baseline: timing")
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            O.mvfex_forward(state_dict, cams, img)
-        dt = time.perf_counter() - t0
-    return {"value": round(batch * iters / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
-            "sample": f"{iters} forwards of batch {batch} (config ego4view_syn_pose3d, eval/no_grad, torch-CPU fp32, "
-                      f"{cores} threads), {dt:.1f} s"}, parity
+        pos = 0
+        for bi, imgb in enumerate(batches):
+            g = census.gpu_outputs(net, imgb.to(dev))
+            for lo in range(0, imgb.shape[0], batch):
+                hi = min(lo + batch, imgb.shape[0])
+                t0 = time.perf_counter()
+                o = census.oracle_outputs(state_dict, cams, imgb[lo:hi], O)
+                times.append(time.perf_counter() - t0)
+                gs = census._slice(g, lo, hi)
+                acc = census.merge(acc, census.compare(gs, o))
+                mp_hip += float(O.compute_mpjpe_batch(gs["preds"][-1], gt[pos:pos + hi - lo]).sum())
+                mp_cpu += float(O.compute_mpjpe_batch(o["preds"][-1], gt[pos:pos + hi - lo]).sum())
+                pos += hi - lo
+            _log(f"  batch {bi + 1}/{n_gpu}: {acc['frames']} frames, {acc['argmax_mismatches']} arg-max mismatches, max joint err {acc['max_joint_err_cm']:.2e} cm")
+    timed = times[2:]
+    med = statistics.median(timed)
+    parity = {"frames": acc["frames"], "gpu_batch": gpu_batch, "argmax_equal": acc["argmax_mismatches"] == 0 and acc["anchor_index_mismatches"] == 0,
+              **{k: v for k, v in acc.items() if k != "frames"},
+              "mpjpe_mm_hip": mp_hip / frames * 10, "mpjpe_mm_cpu_oracle": mp_cpu / frames * 10, "tolerance_cm": 1e-3,
+              "what": "HIP path at the benchmarked batch size / launch policy vs the CPU oracle on the same frames (oracle/census.py); "
+                      "argmax_compared = both heat-map sets x 4 views x 15 joints per frame; image scales 1.0 and 0.35 alternate per GPU batch"}
+    return {"value": round(batch / med, 3), "unit": "frames/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
+            "torch_num_threads": torch.get_num_threads(), "forward_s_median": round(med, 4), "forward_s_min": round(min(timed), 4),
+            "forward_s_max": round(max(timed), 4),
+            "sample": f"{len(timed)} forwards of batch {batch}, distinct frames (config ego4view_syn_pose3d, eval/no_grad, torch-CPU fp32, "
+                      f"{cores} threads) after 2 warm-up forwards; value = batch / median forward time; {sum(timed):.1f} s timed"}, parity
 
 
 def cpu_train_baseline(batch: int = 4, iters: int = 7):
@@ -373,10 +391,10 @@ def roofline_hbm(kernels: dict, pre_leg) -> list:
                 # no HBM peak.  k["unique_bytes"] is filled in from the launch tags by the caller.
                 ub = k.get("unique_bytes", 0.0)
                 e["l2_gather_GBps"] = e.pop("algorithmic_GBps")
-                e["algorithmic_GBps"] = round(ub / k["ms"] / 1e6, 1)
-                e["frac"] = round(ub / k["ms"] / 1e6 / PEAK_HBM_GBS, 4)
+                e["unique_bytes_GBps_upper_bound"] = round(ub / k["ms"] / 1e6, 1)
+                e["frac"] = None                 # not an HBM-bound kernel: no fraction of the HBM roof is claimed for it
                 e["bound"] = "l2 gather"
-                e["note"] = ("frac / algorithmic_GBps: an UPPER bound of the unique bytes (every feature map and positional table once + offsets / logits / "
+                e["note"] = ("unique_bytes_GBps_upper_bound: an UPPER bound of the unique bytes (every feature map and positional table once + offsets / logits / "
                              "anchors + sampled rows out; the samples touch only part of each map, and the maps were written by the launches just before - "
                              "the 256-MB infinity cache serves most of them) against the HBM peak - the kernel is not HBM-bound; l2_gather_GBps: sampled-corner bytes (a 64x64x128 map, 2 MB per view, is re-read 60-64 "
                              "times per frame out of L2) - an L2 gather rate, priced against no HBM roof")
@@ -560,6 +578,61 @@ def _exchange_leg(tr, world: int, backend: str, dev):
             "bytes_per_step": sum(x["bytes"] for x in stages), "standalone_ms_per_step": round(sum(x["allreduce_ms"] for x in stages), 3)}
 
 
+def frames_per_rank(batch: int, global_batch: int, world: int) -> int:
+    """Frames per rank and step: weak scaling = `batch` on every rank; strong scaling (--global-batch G) = G / world, refused when the
+    ranks would get unequal shares (value = world x B x steps / time assumes equal ones)."""
+    if global_batch > 0:
+        if global_batch % world:
+            raise SystemExit(f"bench.py: --global-batch {global_batch} is not divisible by {world} ranks")
+        return global_batch // world        # strong scaling: the total work is fixed, every rank takes an equal share of the frames
+    return batch
+
+
+def init_distributed(world: int, rank: int, backend: str, dev):
+    """The process group of an N > 1 run -> (backend in use, backend note for the line, rccl_ok).  "nccl" (= RCCL on ROCm) is tried
+    first with one eager collective; if it fails the run falls back to gloo for the barrier / max-over-ranks - and the fallback must
+    be UNANIMOUS: every rank publishes its outcome and a mixed outcome is refused (tests/test_dist_gloo.py rehearses this with eight
+    ranks on the CPU, where the RCCL attempt fails on every rank)."""
+    import torch
+    import torch.distributed as dist
+    backend_note, rccl_ok = "", None
+    if world <= 1:
+        return backend, backend_note, rccl_ok
+    if backend == "nccl":
+        try:
+            dist.init_process_group("nccl", device_id=dev)  # inference: only the barrier and the max-over-ranks; training: the gradient all-reduce
+            probe = torch.zeros(1, device=dev)
+            dist.all_reduce(probe)                             # the communicator's first collective, before anything is timed
+            torch.cuda.synchronize()
+            rccl_ok = True
+        except Exception as exc:
+            rccl_ok = False
+            # RCCL unusable on this node (every rank fails the same way: the eager connect is collective).  The inference line needs
+            # no data-path collective, so it is still measured, with gloo for the barrier / timing; the JSON says so and the
+            # training leg is then skipped instead of measuring a host-staged exchange.
+            backend_note = f"gloo (RCCL failed: {type(exc).__name__}: {str(exc)[:200]})"
+            if os.environ.get("EGR_REQUIRE_RCCL") == "1":
+                raise SystemExit(f"bench.py: RCCL was required (EGR_REQUIRE_RCCL=1) and failed on rank {rank}: {exc}")
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            dist.init_process_group("gloo")
+            backend = "gloo"
+        # The fallback must be unanimous: a rank that fell back while its peers run RCCL would sit in a different rendezvous.  Every
+        # rank publishes its outcome in the launcher's store-backed gloo group / the RCCL group it ended up in; a mixed outcome
+        # cannot complete this all-gather and ends in the process group's timeout with the reason on stderr instead of a silent hang.
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(rccl_ok))
+        check_unanimous(flags)
+    else:
+        dist.init_process_group(backend)
+    return backend, backend_note, rccl_ok
+
+
+def check_unanimous(flags) -> None:
+    if any(flags) != all(flags):
+        raise SystemExit(f"bench.py: RCCL came up on some ranks only ({list(flags)}); refusing to mix backends")
+
+
 def train_leg(args, dev, rank: int, world: int, backend: str):
     """SURVEY.md §8(f) rank 2 / BASELINE.json config 5, timed separately (never part of `value`): one optimisation step =
     training-mode forward + wrapper losses + backward + gradient all-reduce (RCCL, world > 1) + clip + AdamW, all on the
@@ -621,11 +694,12 @@ def train_leg(args, dev, rank: int, world: int, backend: str):
     if world == 1 and not args.no_cpu_baseline:
         leg["cpu_baseline"] = cpu_train_baseline()
     if kernels:
+        leg["launches_per_step"] = sum(v["launches"] for v in kernels.values())      # launches through the C ABI in one step (torch's own few copies not counted)
         leg["kernel_ms"] = {n: round(v["ms"], 3) for n, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])[:12]}
         dom = max(kernels, key=lambda n: kernels[n]["ms"])
         k = kernels[dom]
         if k["flops"] > 0:
-            leg["roofline"] = _roofline(dom, k, _pmc_traffic_train(B, dom))
+            leg["roofline"] = _roofline(dom, k, *_pmc_traffic_train(B, dom))
     return leg
 
 
@@ -649,47 +723,13 @@ def main():
     backend = os.environ.get("EGR_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; "gloo" only for rehearsals on one GPU
     backend_note = ""
     rccl_log = _rccl_debug_setup(world) if backend == "nccl" else None
-    rccl_ok = None
-    if world > 1:
-        if backend == "nccl":
-            try:
-                dist.init_process_group("nccl", device_id=dev)  # inference: only the barrier and the max-over-ranks; training: the gradient all-reduce
-                probe = torch.zeros(1, device=dev)
-                dist.all_reduce(probe)                             # the communicator's first collective, before anything is timed
-                torch.cuda.synchronize()
-                rccl_ok = True
-            except Exception as exc:
-                rccl_ok = False
-                # RCCL unusable on this node (every rank fails the same way: the eager connect is collective).  The inference line needs
-                # no data-path collective, so it is still measured, with gloo for the barrier / timing; the JSON says so and the
-                # training leg's all-reduce then goes through the host.
-                backend_note = f"gloo (RCCL failed: {type(exc).__name__}: {str(exc)[:200]})"
-                if os.environ.get("EGR_REQUIRE_RCCL") == "1":
-                    raise SystemExit(f"bench.py: RCCL was required (EGR_REQUIRE_RCCL=1) and failed on rank {rank}: {exc}")
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                dist.init_process_group("gloo")
-                backend = "gloo"
-            # The fallback must be unanimous: a rank that fell back while its peers run RCCL would sit in a different rendezvous.  Every
-            # rank publishes its outcome in the launcher's store-backed gloo group / the RCCL group it ended up in; a mixed outcome
-            # cannot complete this all-gather and ends in the process group's timeout with the reason on stderr instead of a silent hang.
-            flags = [None] * world
-            dist.all_gather_object(flags, bool(rccl_ok))
-            if any(flags) != all(flags):
-                raise SystemExit(f"bench.py: RCCL came up on some ranks only ({flags}); refusing to mix backends")
-        else:
-            dist.init_process_group(backend)
+    backend, backend_note, rccl_ok = init_distributed(world, rank, backend, dev)
 
     from egorear_amd import configs, hip, synth
     from egorear_amd.estimator import EgoPoseFormerMVFEX
 
     strong = args.global_batch > 0
-    if strong:
-        if args.global_batch % world:
-            raise SystemExit(f"bench.py: --global-batch {args.global_batch} is not divisible by {world} ranks")
-        B = args.global_batch // world        # strong scaling: the total work is fixed, every rank takes an equal share of the frames
-    else:
-        B = args.batch
+    B = frames_per_rank(args.batch, args.global_batch, world)
     net = EgoPoseFormerMVFEX(**copy.deepcopy(configs.pose3d_cfg("ego4view_syn"))).eval()
     synth.load_synth(net, 42)
     cpu_sd = {k: v.clone() for k, v in net.state_dict().items()} if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
@@ -746,6 +786,18 @@ def main():
             el2 = timed_steps(run, args.steady_steps, 0, torch.cuda.synchronize, dev if backend == "nccl" else None)
             steady = {"steps": args.steady_steps, "value": round(world * B * args.steady_steps / el2, 2), "unit": "frames/s",
                       "ms_per_step": round(1e3 * el2 / args.steady_steps, 3)}
+        # one lane: the same forward as ONE captured graph replayed back to back (what the second lane's overlap is worth; never `value`)
+        one_lane = None
+        if rank == 0 and world == 1 and pipe is not None and args.steady_steps > 0:
+            try:
+                g1 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1):
+                    step()
+                ms1 = _gpu_time_ms(g1.replay, 5, 60)
+                one_lane = {"value": round(B / ms1 * 1e3, 2), "unit": "frames/s", "ms_per_step": round(ms1, 3), "steps": 60}
+                del g1
+            except Exception as exc:
+                one_lane = {"error": f"{type(exc).__name__}: {exc}"}
         import socket
         rec = {"rank": rank, "local_rank": local_rank, "host": socket.gethostname(), **device_record(dev_index),
                "frames_per_s": round(B * args.steps / own["own_s"], 2)}
@@ -779,8 +831,8 @@ def main():
                     if tag.startswith("unique") and tag[6:].isdigit():
                         k["unique_bytes"] = k.get("unique_bytes", 0.0) + float(tag[6:])
             dom = max(kernels, key=lambda n: kernels[n]["ms"])
-            roof = _roofline(dom, kernels[dom], _pmc_traffic(B, "f16x2" if dom.endswith("[f16x2]") else ("bf16x3" if dom.endswith("[bf16x3]") else "f32"),
-                                                             kernels[dom]["launches"]))
+            roof = _roofline(dom, kernels[dom], *_pmc_traffic(B, "f16x2" if dom.endswith("[f16x2]") else ("bf16x3" if dom.endswith("[bf16x3]") else "f32"),
+                                                              kernels[dom]["launches"]))
             roof["families"] = _family_roofs(fams)
             # the same per-family figures as SCALAR keys (a parser that keeps scalars only loses `families`)
             f3, f1 = roof["families"].get("conv3x3[f16x2]"), roof["families"].get("conv1x1[f16x2]")
@@ -801,11 +853,12 @@ def main():
                             + (f" and, with {args.lanes} lanes, overlaps the low-occupancy tail of one step with the convolutions of the next "
                                "(measured on one box in round 4: 6168 frames/s with one lane, 6511-6516 with two, 6391 with three, 6506 with four)" if (use_graph and args.lanes > 1) else ""))
 
-    parity_out = None
-    if cpu_sd is not None:  # the HIP path on the frames the CPU oracle will see (checked inside the cpu_baseline leg)
-        with torch.no_grad():
-            poses, hms = net(synth.synth_images(args.cpu_batch, 4, seed=1234).to(dev))
-        parity_out = (poses[-1].cpu(), hms[-1].cpu())
+    cpu_line = parity_line = None
+    if cpu_sd is not None:   # BEFORE the other legs mutate the launch policy / release the network: the checker sees the benchmarked state
+        try:
+            cpu_line, parity_line = cpu_baseline(cpu_sd, net, dev, args.cpu_batch, args.cpu_iters, B)
+        except Exception as exc:
+            cpu_line = {"error": f"{type(exc).__name__}: {exc}"}
     pre_leg = None
     if rank == 0:
         # §8(f) rank 1, timed separately (never part of `value`): raw uint8 872x872 frames -> model input, on the GPU
@@ -908,10 +961,31 @@ def main():
         }
         if kernels:
             line["kernel_ms"] = {n: round(v["ms"], 3) for n, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])}
-        if cpu_sd is not None:
-            line["cpu_baseline"], line["parity_vs_cpu_oracle"] = cpu_baseline(cpu_sd, args.cpu_batch, args.cpu_iters, parity_out)
-        elif world == 1:
-            line["cpu_baseline"] = None
+        line["one_lane"] = one_lane
+        line["cpu_baseline"], line["parity_vs_cpu_oracle"] = cpu_line, parity_line
+        # ---- everything a scalar-only parser must see, as SCALAR keys: at the top level (last, so that the tail of the line shows them)
+        # and - because the driver's record keeps `roofline` / `cpu_baseline` / `config` only - once more at the front of `roofline`
+        def _get(d, *path):
+            for k in path:
+                d = d.get(k) if isinstance(d, dict) else None
+            return d
+        tr_roof = _get(train, "roofline") or {}
+        scal = {
+            "exact_fps": _get(exact, "value"), "steady_fps": _get(steady, "value"), "one_lane_fps": _get(one_lane, "value"),
+            "cfg2_fps": _get(cfg_legs, "config2_heatmap_4view", "value"), "cfg3_fps": _get(cfg_legs, "config3_heatmap_mvfex", "value"),
+            "train_ms_per_step": _get(train, "ms_per_step"), "train_fps": _get(train, "value"), "train_frac": tr_roof.get("frac"),
+            "train_dominant_kernel": tr_roof.get("kernel"), "train_launches_per_step": _get(train, "launches_per_step"),
+            "parity_frames": _get(parity_line, "frames"), "argmax_compared": _get(parity_line, "argmax_compared"),
+            "argmax_mismatches": _get(parity_line, "argmax_mismatches"), "valid_mask_mismatches": _get(parity_line, "valid_mask_mismatches"),
+            "max_joint_err_cm": _get(parity_line, "max_joint_err_cm"), "top2_gap_below_1e-5": _get(parity_line, "top2_gap_below_1e-5"),
+            "frac_conv3x3": _get(roof, "frac_conv3x3"), "conv3x3_ms": _get(roof, "conv3x3_ms"),
+            "frac_conv1x1_hbm": _get(roof, "frac_conv1x1_hbm"), "conv1x1_ms": _get(roof, "conv1x1_ms"),
+            "all_kernels_ms_per_step": _get(roof, "all_kernels_ms_per_step"), "launches_per_forward": len(prof) if rank == 0 else None,
+        }
+        if roof is not None:
+            head = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic")
+            line["roofline"] = {**{k: roof[k] for k in head if k in roof}, **scal, **{k: v for k, v in roof.items() if k not in head and k not in scal}}
+        line.update(scal)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -51,17 +51,19 @@ class PConv:
 # the others on the bf16 matrix cores; "bf16x3" = the bf16 image only (three planes, six products, fp32-exact, §5b);
 # "f32" = the packed fp32 matrix (fp32 matrix cores).  Matrices above W6_MAX_ELEMS are streamed once per step from HBM
 # (mlp_pred.0: 67 M weights) and stay in the 4-byte format.
-W_FORMAT = os.environ.get("EGR_W_FORMAT", "f16x2")
+# (W_FORMAT, LAYER_H2, FUSED_LAYER, FUSED_QUERY are fields of hip.LaunchPolicy; the module attributes of those names are properties
+# onto it - installed at the end of this file.)
 W6_MAX_ELEMS = 1 << 24
 
 
 def _w_operand(w: Optional[torch.Tensor], h2: bool = True):
     """h2=False: no fp16 companion image (the training step: its launches carry no abs-max records, and its images are re-split
     after every update)."""
-    if w is None or W_FORMAT not in ("bf16x3", "f16x2") or not w.is_cuda or w.shape[-1] % 32 != 0 or w.shape[-2] * w.shape[-1] > W6_MAX_ELEMS:
+    fmt = hip.policy().w_format
+    if w is None or fmt not in ("bf16x3", "f16x2") or not w.is_cuda or w.shape[-1] % 32 != 0 or w.shape[-2] * w.shape[-1] > W6_MAX_ELEMS:
         return w
     w6 = hip.pack_w6(w)
-    return hip.add_wh2(w6) if (h2 and W_FORMAT == "f16x2") else w6
+    return hip.add_wh2(w6) if (h2 and fmt == "f16x2") else w6
 
 
 def _npad(cout: int) -> int:
@@ -196,7 +198,7 @@ class State:
         self.packs: Dict[object, object] = share.packs if share is not None else {}
         self.workspace = torch.empty(_WORKSPACE_FLOATS, device=device, dtype=torch.float32)
         # abs-max records of the forward's activations (hip.AmaxArena): the pre-scales of the fp16-scheme launches come from them
-        self.amax = hip.AmaxArena(device) if W_FORMAT == "f16x2" else None
+        self.amax = hip.AmaxArena(device) if hip.policy().w_format == "f16x2" else None
 
     def begin_forward(self):
         if self.amax is not None:
@@ -301,6 +303,32 @@ def invalidate(mod: nn.Module):
     mod.__dict__.pop("_egr_state_lanes", None)
     if mod.__dict__.pop("_egr_state", None) is not None:
         GENERATION[0] += 1
+
+
+def set_policy(mod: nn.Module, pol: Optional["hip.LaunchPolicy"]) -> None:
+    """Give `mod` (and everything below it) its own launch policy - None: follow the process default again.  Packs are dropped (they
+    are made under a policy: weight format, fused-layer images); two modules with different policies coexist in one process, and
+    a forward activates its module's policy for the calling thread only (hip.use_policy)."""
+    for m in mod.modules():
+        if pol is None:
+            m.__dict__.pop("_egr_policy", None)
+        else:
+            m.__dict__["_egr_policy"] = pol
+        invalidate(m)
+
+
+def _under_module_policy(fn):
+    """Entry points run under their module's own policy when it has one (set_policy); nested engine calls inherit it."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(mod, *a, **k):
+        pol = mod.__dict__.get("_egr_policy")
+        if pol is None:
+            return fn(mod, *a, **k)
+        with hip.use_policy(pol):
+            return fn(mod, *a, **k)
+    return wrapped
 
 
 def as_rgb(img: torch.Tensor) -> torch.Tensor:
@@ -481,7 +509,7 @@ def run_backbone(st: State, encs, img: torch.Tensor, view0: int, nviews: int, fe
     t0, n0 = trunks[0], necks[0]
     wp, sc, sh = st.get(t0.layer_s2, lambda: _pack_stems(trunks))
     if STEM_X6 and img.shape[3] % 32 == 0 and img.shape[4] % 64 == 0:     # the split kernel's tile is 16 x 32 output pixels (fp32 kernel: 8 x 32)
-        if W_FORMAT == "f16x2":       # the fp16 scheme (per-tile pre-scale of the input patch)
+        if hip.policy().w_format == "f16x2":       # the fp16 scheme (per-tile pre-scale of the input patch)
             wh2, wds = st.get((id(t0.layer_s2), "wh2"), lambda: hip.pack_stem_wh2(wp))
             x = hip.stem_x6(img, view0, nviews, wh2, sc, sh, groups=G, pool=STEM_POOL, w_descale=wds,
                             amax_out=st.new_amax() if STEM_POOL else None)
@@ -547,6 +575,7 @@ def _heatmap_core(mod, img):
     return st, feat, pyr
 
 
+@_under_module_policy
 def heatmap_backbone_api(mod, img):
     _check_input(img, mod)
     img = as_rgb(img)
@@ -555,6 +584,7 @@ def heatmap_backbone_api(mod, img):
     return _vb_view(feat, V, B), [_vb_view(p.t, V, B) for p in pyr]
 
 
+@_under_module_policy
 def heatmap_forward_api(mod, img, return_feat=False):
     """EgoPoseFormerHeatmap.forward (egoposeformer_heatmap.py:29-44)."""
     _check_input(img, mod)
@@ -580,14 +610,14 @@ class PLayer:
 
 # One launch per transformer layer behind the sampling (egr_joint_layer_f32) instead of ~14 small ones; EGR_FUSED_LAYER=0 keeps
 # the per-op launches (the training forward always uses those: it needs the intermediates).
-FUSED_LAYER = os.environ.get("EGR_FUSED_LAYER", "1") != "0"
+# (hip.LaunchPolicy.fused_layer)
 # The small launches in front of / behind the fused layers as one launch each (round 5): the refiners' JQA query
 # (egr_jqa_query_f32), the lifting head's proposal -> reprojection -> decoder query (egr_pose_query_f32), the refiners' head offset as
 # a tail of the layer launch; EGR_FUSED_QUERY=0 keeps the per-op launches.
-FUSED_QUERY = os.environ.get("EGR_FUSED_QUERY", "1") != "0"
+# (hip.LaunchPolicy.fused_query)
 # the fused layer's contractions in the fp16 scheme (read when a module's layers are packed): follows EGR_W_FORMAT, EGR_LAYER_H2=0 keeps
 # the fp32 matrix cores
-LAYER_H2 = hip.H2 and os.environ.get("EGR_LAYER_H2", "1") != "0"
+# (hip.LaunchPolicy.layer_h2)
 
 
 def pack_layers(layers, pres, poss) -> PLayer:
@@ -674,10 +704,10 @@ def pack_layers(layers, pres, poss) -> PLayer:
     # the kernel streams its weight matrices as 1-KiB contiguous wave loads: fragment order, flagged in the dict - the fp16 scheme's
     # images (hip.pack_layer_wh2: the layer's contractions then run like the conv launches') or, with
     # EGR_W_FORMAT=bf16x3 / EGR_LAYER_H2=0, the fp32 matrices (hip.pack_layer_w: fp32 matrix cores, the reference's arithmetic class)
-    pk = hip.pack_layer_wh2 if LAYER_H2 else hip.pack_layer_w
+    pk = hip.pack_layer_wh2 if hip.policy().layer_h2 else hip.pack_layer_w
     for k in ("w_fold", "w_out", "w_fuse", "w_qkv", "w_mo", "w_f0", "w_f1"):
         P.fused[k] = pk(P.fused[k])
-    P.fused["packed"] = 2 if LAYER_H2 else True
+    P.fused["packed"] = 2 if hip.policy().layer_h2 else True
     P.ol_plain["w"] = pk(P.ol_plain["w"])
     return P
 
@@ -758,7 +788,7 @@ def _pack_refiners(rs) -> PRefiners:
     P.q = None
     r0 = rs[0]
     if (P.layer.fused is not None and r0.embed_dims == 256 and r0.fc_bfb.in_features == 512 and r0.num_heatmap <= 16):
-        pk = hip.pack_layer_wh2 if LAYER_H2 else hip.pack_layer_w
+        pk = hip.pack_layer_wh2 if hip.policy().layer_h2 else hip.pack_layer_w
 
         def stk(ts):
             return torch.stack([t.detach().float() for t in ts]).contiguous()
@@ -766,7 +796,7 @@ def _pack_refiners(rs) -> PRefiners:
                "w_bfb": pk(stk([r.fc_bfb.weight for r in rs])), "b_bfb": stk([r.fc_bfb.bias for r in rs]),
                "embed": P.embed,
                "w_q": pk(stk([r.fc_query[0].weight for r in rs])), "b_q": stk([r.fc_query[0].bias for r in rs]),
-               "w_ol": P.layer.ol_plain["w"], "b_ol": P.layer.ol_plain["b"], "packed": 2 if LAYER_H2 else True}
+               "w_ol": P.layer.ol_plain["w"], "b_ol": P.layer.ol_plain["b"], "packed": 2 if hip.policy().layer_h2 else True}
     return P
 
 
@@ -794,9 +824,10 @@ def _run_refiners(st: State, rs, B: int, V: int, hm_init: torch.Tensor, feat_all
     # --- joint queries (JQA): heatmap_proj(hm) + fc_bfb(avgpool s32) + embedding -> fc_query
     hm_rows = Img(hm_init.view(B * V, J, 1, hw)[0::V])                        # group 0 = view 0 rows; group stride = J*hw
     t = conv(st, hm_rows, P.hp0, ACT_RELU, gx=J * hw)                        # (G*B, J, 1, C)
-    fused = FUSED_LAYER and P.layer.fused is not None
+    pol = hip.policy()
+    fused = pol.fused_layer and P.layer.fused is not None
     ol = None
-    if fused and FUSED_QUERY and P.q is not None and s32_all.shape[-1] == 512:
+    if fused and pol.fused_query and P.q is not None and s32_all.shape[-1] == 512:
         # heatmap_proj[2], the pooled fc_bfb, the sum, fc_query and the layer's offsets / logits: one launch
         x, ol = hip.jqa_query(t.t.view(G * B * J, C), s32_all, P.q, B, J, C, G)
     else:
@@ -808,7 +839,7 @@ def _run_refiners(st: State, rs, B: int, V: int, hm_init: torch.Tensor, feat_all
     head = None
     if fused:
         # (the head offset rides on the layer launch when its shape is the kernel's: 16 x 16 tokens-as-image, 64 channels)
-        if FUSED_QUERY and C == 256 and P.head0_w.shape[1] == 64:
+        if pol.fused_query and C == 256 and P.head0_w.shape[1] == 64:
             head = {"w": P.head0_w, "b": P.head0_b, "amax": st.new_amax()}
         _, _, xn, _ = run_layer_fused(st, P.layer, x, feat_all.view(V, B, hw, feat_all.shape[-1]), anchors, valid, B, V, J, hgt, wid, ol=ol,
                                       post={"g": P.post_norm[0], "b": P.post_norm[1]}, want_xn=head is None or CAPTURE is not None, head=head)
@@ -839,6 +870,7 @@ def _anchors(hm: torch.Tensor, thr: float):
     return anchors.view(B, V, J, 2), maxvals.view(B, V, J), valid.view(B, V, J), index.view(B, V, J)
 
 
+@_under_module_policy
 def anchors_from_heatmap_api(mod, heatmap):
     """get_anchors_2d_from_hm (heatmap_mvf_ex.py:128-143) -> (pts2d, maxvals, mask_valid[bool])."""
     a, m, v, _ = _anchors(heatmap.contiguous(), mod.heatmap_threshold)
@@ -872,6 +904,7 @@ def _mvfex(mod, img: torch.Tensor, heatmap_for_anchor=None):
     return hm_init, hm_ref, feat_all, feat_ref, aux
 
 
+@_under_module_policy
 def heatmap_mvfex_forward_api(mod, img, heatmap_for_anchor=None):
     """EgoPoseFormerHeatmapMVFEX.forward -> ([hm_init, hm_refined], [feat_init, feat_refined])."""
     _check_input(img, mod)
@@ -898,7 +931,7 @@ def _pack_pose3d(p3) -> PPose:
     w0p = w0.view(n_out, V, 128, 8, 8).permute(0, 1, 3, 4, 2).reshape(n_out, -1)
     P.mlp0 = P.mlp0_ws = None
     P.mlp0_src = (w0p, p3.mlp_pred[0][0].bias)
-    if W_FORMAT == "f16x2" and n_out % 64 == 0 and w0p.shape[1] % 256 == 0:
+    if hip.policy().w_format == "f16x2" and n_out % 64 == 0 and w0p.shape[1] % 256 == 0:
         # the weight-stream launch (egr_linear_wstream_f32): two fp16 planes at the same 4 bytes per weight
         img, ds = hip.pack_wstream(w0p.float().contiguous())
         P.mlp0_ws = (img, ds, p3.mlp_pred[0][0].bias.detach().float().contiguous())
@@ -920,7 +953,7 @@ def _pack_pose3d(p3) -> PPose:
     # the fused layer's regression tail (w0 in fragment order); None when a layer is outside the fused kernel's shapes (pack_layers)
     P.reg_plain = None
     if all(L.fused is not None for L in P.layers):
-        pk = hip.pack_layer_wh2 if LAYER_H2 else hip.pack_layer_w
+        pk = hip.pack_layer_wh2 if hip.policy().layer_h2 else hip.pack_layer_w
         P.reg_plain = [(pk(f32(r[0].weight).contiguous()), f32(r[0].bias), f32(r[2].weight), f32(r[2].bias)) for r in p3.reg_mlp]
     rec = np.stack([c.packed() for c in p3.cameras()])
     P.cams = torch.from_numpy(rec).to(w0.device)
@@ -928,10 +961,10 @@ def _pack_pose3d(p3) -> PPose:
     P.q = None
     if (P.reg_plain is not None and p3.embed_dims == 128 and p3.num_joints == 16 and p3.mlp_pred[2].in_features == 128
             and qg[0].in_features == 4 and P.layers[0].ol_plain is not None):
-        pk = hip.pack_layer_wh2 if LAYER_H2 else hip.pack_layer_w
+        pk = hip.pack_layer_wh2 if hip.policy().layer_h2 else hip.pack_layer_w
         P.q = {"w_m2": pk(f32(p3.mlp_pred[2].weight)), "b_m2": f32(p3.mlp_pred[2].bias), "w_qg0": P.qg0_w, "b_qg0": P.qg0_b,
                "w_qg2": pk(f32(qg[2].weight)), "b_qg2": f32(qg[2].bias), "w_qg4": pk(f32(qg[4].weight)), "b_qg4": f32(qg[4].bias),
-               "w_ol": P.layers[0].ol_plain["w"], "b_ol": P.layers[0].ol_plain["b"], "packed": 2 if LAYER_H2 else True}
+               "w_ol": P.layers[0].ol_plain["w"], "b_ol": P.layers[0].ol_plain["b"], "packed": 2 if hip.policy().layer_h2 else True}
     return P
 
 
@@ -981,7 +1014,8 @@ def _pose3d_body(p3, st: State, feat_init: torch.Tensor, feat_final: torch.Tenso
         ctm32 = ctm.to(device=dev, dtype=torch.float32).contiguous()         # any float dtype accepted
     C = p3.embed_dims
     ol = None
-    if FUSED_LAYER and FUSED_QUERY and P.q is not None and all(L.fused is not None for L in P.layers):
+    pol = hip.policy()
+    if pol.fused_layer and pol.fused_query and P.q is not None and all(L.fused is not None for L in P.layers):
         # mlp_pred[2], the reprojection, query_gen_mlp and the first layer's offsets / logits: one launch
         mlp_pred, anchors_3d, anchors_2d, valid, x, ol = hip.pose_query(h, ctm32, P.cams, P.q, B, J, C)
     else:
@@ -996,7 +1030,7 @@ def _pose3d_body(p3, st: State, feat_init: torch.Tensor, feat_final: torch.Tenso
     preds = [mlp_pred]
     a3 = anchors_3d.view(B * J, 3)
     for i, L in enumerate(P.layers):
-        if FUSED_LAYER and L.fused is not None and P.reg_plain is not None:
+        if pol.fused_layer and L.fused is not None and P.reg_plain is not None:
             nxt = P.layers[i + 1] if i + 1 < len(P.layers) else None
             x, ol, _, pred = run_layer_fused(st, L, x, memory, anchors_2d, valid, B, V, J, hgt, wid, ol=ol, next_P=nxt,
                                              post={"g": P.post[i][0], "b": P.post[i][1]},
@@ -1021,6 +1055,7 @@ def _to_view_major(t: torch.Tensor) -> torch.Tensor:
     return p.reshape(V * B, H, W, C)
 
 
+@_under_module_policy
 def pose3d_forward_api(p3, feat_init, feat_final, ctm=None):
     _check_input(feat_init, p3)
     st = _state(p3, feat_init.device)
@@ -1030,6 +1065,7 @@ def pose3d_forward_api(p3, feat_init, feat_final, ctm=None):
     return preds
 
 
+@_under_module_policy
 def mvfex_forward_api(mod, img, ctm=None):
     """EgoPoseFormerMVFEX.forward (egoposeformer_mvf_ex.py:50-59) -> (list_pred_pose3d, list_pred_heatmap)."""
     _check_input(img, mod)
@@ -1041,3 +1077,6 @@ def mvfex_forward_api(mod, img, ctm=None):
     preds, aux_p = _pose3d(mod.pose3d_estimator, st, feat_all, feat_ref, B, V, ctm, behind=_state(he, img.device))
     mod.__dict__["_egr_last_aux"] = {"heatmap": aux_h, "pose3d": aux_p}
     return preds, [hm_init, hm_ref]
+
+
+hip.install_policy_properties(__name__, {"W_FORMAT": "w_format", "LAYER_H2": "layer_h2", "FUSED_LAYER": "fused_layer", "FUSED_QUERY": "fused_query"})

@@ -20,6 +20,106 @@ LIB_PATH = os.environ.get("EGR_LIB") or os.path.join(_HERE, "csrc", "libegorear_
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 RES_NONE, RES_BEFORE_ACT, RES_AFTER_ACT, RES_UP2_BEFORE_ACT = 0, 1, 2, 3
 
+
+# --------------------------------------------------------------------------- launch policy
+
+import contextlib
+import dataclasses
+import sys
+import types
+
+
+@dataclasses.dataclass
+class LaunchPolicy:
+    """Which kernel family a launch goes to - ONE object instead of module globals (round 6).  A module (engine.set_policy) or a
+    caller (`with hip.use_policy(p):`, thread-local) can hold its own; everything else follows the process default `hip.POLICY`,
+    which is made from the environment at import.  The historical module attributes (hip.H2, hip.X6_MIN_ROWS, hip.CHAIN_*,
+    engine.W_FORMAT, engine.LAYER_H2, engine.FUSED_*) are properties onto it: reading one returns the ACTIVE policy's value,
+    assigning one changes the process default (what the parity tests that sweep launch rules do)."""
+    # weight operand of the implicit-GEMM launches: "f16x2" = bf16x3 image + fp16 companion, "bf16x3", "f32" (engine._w_operand)
+    w_format: str = "f16x2"
+    # the fp16 scheme for the launches whose input carries an abs-max record (EGR_W_FORMAT=bf16x3 / f32 switch it off)
+    h2: bool = True
+    # Below these sizes (all groups together) a launch is bound by latency or by streaming the weights once, not by the matrix
+    # cores: it keeps the 4-byte weight format (measured: 3840 rows x K 4096 slower with the split, 8192 rows x N 512 x K 4608
+    # faster).  Re-swept with the tap-sharing / streaming kernels in place (tools/x6_small_sweep.sh: 8192 rows / 4e9 flops ->
+    # 4096 / 5e8: batch 2-16 latency -2 .. -7 %, batch 32 +1.9 % frames/s, batch 1 and 64 unchanged)
+    x6_min_rows: int = 4096
+    x6_min_flops: float = 5e8
+    # the training step keeps the rule its gradient goldens were recorded under (tests/test_gpu_train_step.py; train.py passes x6_min)
+    x6_train_min_rows: int = 8192
+    x6_train_min_flops: float = 4e9
+    # two 1x1 convolutions back to back as one launch (egr_conv1x1_chain_f32): EGR_CONV_CHAIN=0 keeps the pair of launches
+    chain: bool = True
+    chain_min_rows: int = 8192       # (measured: batch 1 1.46 -> 1.41 ms with the FPN level-1 chain; smaller chains lose)
+    chain_big: bool = True           # the streamed 256 -> 256 -> 128 form (conv_pw2_kernel)
+    chain_big_min_rows: int = 65536
+    # weight gradients of large layers on the 16-bit matrix cores with operand splits (the kernel keeps small ones on fp32 MFMA)
+    wgrad_x6: bool = True
+    wgrad_force: bool = False        # tests: every weight-gradient launch on the split kernel, whatever its size
+    # engine: the fused transformer layer's contractions in the fp16 scheme; one launch per layer / per token chain
+    layer_h2: bool = True
+    fused_layer: bool = True
+    fused_query: bool = True
+
+    @classmethod
+    def from_env(cls, env=None) -> "LaunchPolicy":
+        e = os.environ if env is None else env
+        fmt = e.get("EGR_W_FORMAT", "f16x2")
+        return cls(w_format=fmt, h2=fmt == "f16x2",
+                   x6_min_rows=int(e.get("EGR_X6_MIN_ROWS", "4096")), x6_min_flops=float(e.get("EGR_X6_MIN_FLOPS", "5e8")),
+                   x6_train_min_rows=int(e.get("EGR_X6_TRAIN_MIN_ROWS", "8192")), x6_train_min_flops=float(e.get("EGR_X6_TRAIN_MIN_FLOPS", "4e9")),
+                   chain=e.get("EGR_CONV_CHAIN", "1") != "0", chain_min_rows=int(e.get("EGR_CONV_CHAIN_MIN_ROWS", "8192")),
+                   chain_big=e.get("EGR_CONV_CHAIN_BIG", "1") != "0", chain_big_min_rows=int(e.get("EGR_CONV_CHAIN_BIG_MIN_ROWS", "65536")),
+                   wgrad_x6=fmt != "f32", layer_h2=fmt == "f16x2" and e.get("EGR_LAYER_H2", "1") != "0",
+                   fused_layer=e.get("EGR_FUSED_LAYER", "1") != "0", fused_query=e.get("EGR_FUSED_QUERY", "1") != "0")
+
+    def replace(self, **kw) -> "LaunchPolicy":
+        return dataclasses.replace(self, **kw)
+
+    def exact(self) -> "LaunchPolicy":
+        """The exact-operand arithmetic (EGR_W_FORMAT=bf16x3): three bf16 planes, six products, fused layers on the fp32 matrix cores."""
+        return self.replace(w_format="bf16x3", h2=False, layer_h2=False)
+
+
+POLICY = LaunchPolicy.from_env()       # the process default
+_POLICY_TLS = threading.local()
+
+
+def policy() -> LaunchPolicy:
+    """The policy in force for the calling thread: the innermost `use_policy`, else the process default."""
+    cur = getattr(_POLICY_TLS, "cur", None)
+    return cur if cur is not None else POLICY
+
+
+@contextlib.contextmanager
+def use_policy(p: Optional[LaunchPolicy]):
+    """Launches issued by this thread inside the block follow `p` (None: no change)."""
+    if p is None:
+        yield
+        return
+    old = getattr(_POLICY_TLS, "cur", None)
+    _POLICY_TLS.cur = p
+    try:
+        yield
+    finally:
+        _POLICY_TLS.cur = old
+
+
+def install_policy_properties(module_name: str, mapping: dict) -> None:
+    """{MODULE_ATTRIBUTE: LaunchPolicy field}: the module's historical knobs become properties - read = the active policy, write =
+    the process default."""
+    def make(field):
+        return property(lambda self: getattr(policy(), field), lambda self, v: setattr(POLICY, field, v))
+    mod = sys.modules[module_name]
+    mod.__class__ = type("_PolicyModule", (types.ModuleType,), {name: make(field) for name, field in mapping.items()})
+
+
+install_policy_properties(__name__, {
+    "H2": "h2", "X6_MIN_ROWS": "x6_min_rows", "X6_MIN_FLOPS": "x6_min_flops", "X6_TRAIN_MIN_ROWS": "x6_train_min_rows",
+    "X6_TRAIN_MIN_FLOPS": "x6_train_min_flops", "CHAIN": "chain", "CHAIN_MIN_ROWS": "chain_min_rows", "CHAIN_BIG": "chain_big",
+    "CHAIN_BIG_MIN_ROWS": "chain_big_min_rows", "WGRAD_X6": "wgrad_x6", "WGRAD_FORCE": "wgrad_force"})
+
 EXPORTS = [
     "egr_conv2d_nhwc_f32", "egr_stem_conv7x7_f32", "egr_maxpool_nhwc_f32", "egr_upsample2x_nhwc_f32",
     "egr_avgpool_nhwc_f32", "egr_argmax_rows_f32", "egr_layernorm_f32", "egr_joint_mha_f32", "egr_msda_gather_f32",
@@ -380,10 +480,6 @@ def add_wh2(w6: W6) -> W6:
     return w6
 
 
-# The fp16 scheme for the forward launches whose input carries an abs-max record (EGR_W_FORMAT=bf16x3 / f32 switch it off)
-H2 = os.environ.get("EGR_W_FORMAT", "f16x2") == "f16x2"
-
-
 ARENA_EXHAUSTED = 0      # over every AmaxArena of the process (bench.py reports it: a non-zero count means silent fallbacks)
 
 
@@ -481,17 +577,6 @@ def pack_wh2_into(w6: W6) -> None:
     _launch("egr_pack_wh2_f32", lib.egr_pack_wh2_f32, _p(w6.f32), w6.npad, w6.K, w6.groups, _p(w6.h2, torch.float16), _p(w6.h2_ds), _stream())
 
 
-# Launches below these sizes (all groups together) are bound by launch latency or by streaming the weights once, not by the
-# matrix cores: they keep the 4-byte weight format (measured: 3840 rows x K 4096 slower with the split, 8192 rows x N 512 x K 4608
-# faster).  Thresholds re-swept with the tap-sharing / streaming kernels in place (tools/x6_small_sweep.sh: 8192 rows / 4e9 flops ->
-# 4096 / 5e8: batch 2-16 latency -2 .. -7 %, batch 32 +1.9 % frames/s, batch 1 and 64 unchanged)
-X6_MIN_ROWS = int(os.environ.get("EGR_X6_MIN_ROWS", "4096"))
-X6_MIN_FLOPS = float(os.environ.get("EGR_X6_MIN_FLOPS", "5e8"))
-# the training step keeps the rule its gradient goldens were recorded under (tests/test_gpu_train_step.py; train.py passes x6_min)
-X6_TRAIN_MIN_ROWS = int(os.environ.get("EGR_X6_TRAIN_MIN_ROWS", "8192"))
-X6_TRAIN_MIN_FLOPS = float(os.environ.get("EGR_X6_TRAIN_MIN_FLOPS", "4e9"))
-
-
 def conv2d(x: Img, w, cout: int, kh: int, kw: int, stride: int, pad: int, *, scale=None, shift=None,
            act: int = ACT_NONE, res: Optional[Img] = None, res_mode: int = RES_NONE, rowscale=None, rowmask=None,
            out: Optional[Img] = None, out_nchw: Optional[torch.Tensor] = None, ymap: Optional[NMap] = None,
@@ -506,6 +591,7 @@ def conv2d(x: Img, w, cout: int, kh: int, kw: int, stride: int, pad: int, *, sca
     groups > 1: `groups` same-shape problems in one launch.  w is (groups, cout_pad, K), scale/shift
     (groups, cout_pad).  x / out / res hold the images of all groups back to back (group stride = images per group x
     image stride) unless an explicit element stride gx / gy / gr is given, in which case they describe group 0."""
+    pol = policy()
     x_full = x.t
     if groups > 1:
         if gx is None:
@@ -531,18 +617,18 @@ def conv2d(x: Img, w, cout: int, kh: int, kw: int, stride: int, pad: int, *, sca
         rows_all = x.n * groups * ho * wo
         # (the split kernel addresses one group's activations through a 2-GiB buffer window)
         x_bytes = 4 * ((x.n - 1) * x.nstride + (x.h * x.w + 2 * (kh * x.w + kw + 1)) * x.ld) + 64
-        min_rows, min_flops = x6_min if x6_min is not None else (X6_MIN_ROWS, X6_MIN_FLOPS)
+        min_rows, min_flops = x6_min if x6_min is not None else (pol.x6_min_rows, pol.x6_min_flops)
         if rows_all < min_rows or 2.0 * rows_all * cout * K < min_flops or x_bytes >= (1 << 31):
             w = w.f32
     x6 = isinstance(w, W6)
-    if x6 and H2 and w.h2 is not None and x.amax is None and amax_arena is not None and x_full.is_contiguous():
+    if x6 and pol.h2 and w.h2 is not None and x.amax is None and amax_arena is not None and x_full.is_contiguous():
         # an input without a record (it comes out of a launch that keeps none): one read of it makes one (the training step)
         rec = amax_arena.new()
         if rec is not None:
             absmax_record(x_full, rec)
             x.amax = rec
     # the fp16 scheme: launches whose input carries its abs-max record (the launch's pre-scale comes from it)
-    h2 = x6 and H2 and w.h2 is not None and x.amax is not None
+    h2 = x6 and pol.h2 and w.h2 is not None and x.amax is not None
     if x6 and not h2 and not w.used:
         if w.f32 is not None:
             pack_w6_into(w)     # an owner that only re-splits the images in use (the training step) may have left this one stale
@@ -654,26 +740,18 @@ def conv2d(x: Img, w, cout: int, kh: int, kw: int, stride: int, pad: int, *, sca
     return ret
 
 
-# Two 1x1 convolutions back to back in one launch (egr_conv1x1_chain_f32): EGR_CONV_CHAIN=0 keeps the two launches
-CHAIN = os.environ.get("EGR_CONV_CHAIN", "1") != "0"
-CHAIN_MIN_ROWS = int(os.environ.get("EGR_CONV_CHAIN_MIN_ROWS", "8192"))      # (measured: batch 1 1.46 -> 1.41 ms with the FPN level-1 chain; smaller chains lose)
-
-
-CHAIN_BIG = os.environ.get("EGR_CONV_CHAIN_BIG", "1") != "0"
-CHAIN_BIG_MIN_ROWS = int(os.environ.get("EGR_CONV_CHAIN_BIG_MIN_ROWS", "65536"))
-
-
 def chain_eligible(x: Img, w1, w2, cmid: int, cout: int, groups: int, scale1=None, scale2=None, res_mode: int = 0) -> bool:
     """Whether conv1x1_chain covers this pair: fp16 scheme on both operands, x carries its abs-max record, cin 64 / 128 -> 128 -> <= 128,
     bias-only convs, enough pixels for the streaming structure (the rule of the single streaming launches)."""
-    if not (CHAIN and H2 and isinstance(w1, W6) and isinstance(w2, W6) and w1.h2 is not None and w2.h2 is not None):
+    pol = policy()
+    if not (pol.chain and pol.h2 and isinstance(w1, W6) and isinstance(w2, W6) and w1.h2 is not None and w2.h2 is not None):
         return False
     if x.amax is None or scale1 is not None or scale2 is not None or cout > 128 or cout % 4:
         return False
     big = x.c == 256 and cmid == 256        # both matrices streamed through LDS (conv_pw2_kernel: the heat-map heads' 256 -> 256 -> 128)
     if not big and (x.c not in (64, 128) or cmid != 128):
         return False
-    if big and (not CHAIN_BIG or res_mode != RES_NONE):
+    if big and (not pol.chain_big or res_mode != RES_NONE):
         return False
     if x.n % groups or w1.groups != groups or w2.groups != groups or w1.npad != cmid or w2.npad != 128 or w1.K != x.c or w2.K != cmid:
         return False
@@ -681,7 +759,7 @@ def chain_eligible(x: Img, w1, w2, cmid: int, cout: int, groups: int, scale1=Non
     # aligned base - a channel slice at an odd offset stays on the single launches instead of aborting the forward
     if x.ld % 4 or x.nstride % 4 or x.t.data_ptr() % 16:
         return False
-    return x.n * x.h * x.w >= (CHAIN_BIG_MIN_ROWS if big else CHAIN_MIN_ROWS)
+    return x.n * x.h * x.w >= (pol.chain_big_min_rows if big else pol.chain_min_rows)
 
 
 def conv1x1_chain(x: Img, w1, w2, cmid: int, cout: int, *, shift1=None, shift2=None, act1: int = ACT_RELU, act2: int = ACT_NONE,
@@ -743,16 +821,11 @@ def conv1x1_chain(x: Img, w1, w2, cmid: int, cout: int, *, shift1=None, shift2=N
     return full
 
 
-# weight gradients of large layers on the bf16 matrix cores with exact operand splits (the kernel keeps small ones on fp32 MFMA)
-WGRAD_X6 = os.environ.get("EGR_W_FORMAT", "f16x2") != "f32"
-WGRAD_FORCE = False    # tests: every weight-gradient launch on the split kernel, whatever its size (EGR_W_FORCE)
-
-
 def wgrad_is_split(x: Img, dy: Img, kh: int, kw: int, groups: int = 1) -> bool:
     """Whether conv2d_wgrad would run this problem on the split kernels (the size rule of egr_conv2d_wgrad_f32, or the forced mode)."""
-    if not WGRAD_X6:
+    if not policy().wgrad_x6:
         return False
-    if WGRAD_FORCE:
+    if policy().wgrad_force:
         return True
     M = (x.n // groups) * dy.h * dy.w
     return M >= 1024 and 2.0 * M * dy.c * kh * kw * x.c * groups >= 4e9
@@ -760,7 +833,7 @@ def wgrad_is_split(x: Img, dy: Img, kh: int, kw: int, groups: int = 1) -> bool:
 
 def wgrad_records(x: Img, dy: Img, amax_arena: Optional["AmaxArena"]) -> None:
     """Abs-max records for the operands of a split weight-gradient launch that carry none (one read each), on the current stream."""
-    if not H2 or amax_arena is None:
+    if not policy().h2 or amax_arena is None:
         return
     for im in (x, dy):
         if im.amax is None and im.t.is_contiguous():
@@ -792,15 +865,15 @@ def conv2d_wgrad(x: Img, dy: Img, kh: int, kw: int, stride: int, pad: int, works
     d.xmap, d.ymap = NMap(ng, x.nstride, 0), NMap(ng, dy.nstride, 0)
     K = kh * kw * cin
     d.groups, d.gx, d.gy, d.gw, d.gp = groups, (gx if interleaved else ng * x.nstride), (gy if interleaved else ng * dy.nstride), cout * K, cout
-    if x6 is None and WGRAD_FORCE and WGRAD_X6:
+    if x6 is None and policy().wgrad_force and policy().wgrad_x6:
         x6 = "force"
-    d.w_format = 3 if x6 == "force" else (1 if (WGRAD_X6 if x6 is None else x6) else 0)   # "force": the split kernel at any size
+    d.w_format = 3 if x6 == "force" else (1 if (policy().wgrad_x6 if x6 is None else x6) else 0)   # "force": the split kernel at any size
     # the fp16 scheme: split launches whose two operands carry abs-max records (made here with one read each when an arena is given)
     M = ng * dy.h * dy.w
     split = d.w_format == 3 or (d.w_format == 1 and M >= 1024 and 2.0 * M * cout * K * groups >= 4e9)
     if split:
         wgrad_records(x, dy, amax_arena)
-    h2 = split and H2 and x.amax is not None and dy.amax is not None
+    h2 = split and policy().h2 and x.amax is not None and dy.amax is not None
     if h2:
         d.w_format |= 4
     shape_w, shape_b = ((groups, cout, K), (groups, cout)) if groups > 1 else ((cout, K), (cout,))

@@ -63,7 +63,7 @@ SIDE_WGRAD = SIDE_WGRAD if SIDE_WGRAD in ("small", "1") else ""
 
 def _conv2d(*a, **k):
     """hip.conv2d under the training step's split-launch rule (hip.X6_TRAIN_MIN_*)."""
-    return hip.conv2d(*a, x6_min=(hip.X6_TRAIN_MIN_ROWS, hip.X6_TRAIN_MIN_FLOPS), **k)
+    return hip.conv2d(*a, x6_min=(hip.policy().x6_train_min_rows, hip.policy().x6_train_min_flops), **k)
 
 
 def _ceil32(n: int) -> int:
@@ -103,7 +103,7 @@ class PackCache:
         self._w6_table, self._w6_key = None, None
         self._h2_table, self._h2_key = None, None
         # abs-max records of one step's activations and gradients (the graph of a captured step holds pointers into it)
-        self.amax = hip.AmaxArena(device, records=1024) if (TRAIN_H2 and hip.H2 and engine.W_FORMAT == "f16x2") else None
+        self.amax = hip.AmaxArena(device, records=1024) if (TRAIN_H2 and hip.policy().h2 and hip.policy().w_format == "f16x2") else None
         self.sources: Dict[int, tuple] = {}  # id(param) -> (param, data_ptr)
         self.ready = False
 
@@ -763,7 +763,7 @@ def backbone_train(S: Step, encs, img: torch.Tensor, view0: int, nviews: int):
     # (split-bf16 launch like the other convolutions; the bank is re-split from the refreshed fp32 pack every step: one tiny launch)
     # (with TRAIN_H2 in the fp16 scheme like the inference stem: per-tile pre-scale from the patch itself, no record needed)
     if engine.STEM_X6 and H % 32 == 0 and W % 64 == 0:
-        if TRAIN_H2 and hip.H2 and engine.W_FORMAT == "f16x2":
+        if TRAIN_H2 and hip.policy().h2 and hip.policy().w_format == "f16x2":
             bank, wds = hip.pack_stem_wh2(wp)
             x = hip.stem_x6(img, view0, nviews, bank, None, None, groups=G, w_descale=wds).t
         else:

@@ -337,3 +337,90 @@ def test_bench_exchange_leg_walks_the_stage_buckets():
     assert [st["stage"] for st in rec["stages"]] == ["lifting head", "refiners", "initial heat-map heads", "encoders"]
     assert rec["bytes_per_step"] == 4000 and rec["communicator_size"] == 2
     assert all(st["allreduce_ms"] > 0 for st in rec["stages"])
+
+
+# --------------------------------------------------------------------------- eight-rank rehearsal of bench.py's N > 1 plumbing
+
+def _eight_rank_worker(rank, world, port, out):
+    """Everything bench.py does around the timed region when the driver launches it on an 8-GPU node, on stand-in work and host
+    tensors: process-group bring-up with the RCCL attempt (fails on every rank here: no GPU) and the unanimous gloo fallback, the
+    strong-scaling share of --global-batch 512, barrier-fenced timing with max over ranks, the per-rank device records and the
+    distinct-device refusal, the stage-bucket gradient exchange (pl_wrappers/egoposeformer/pose_3d_mvf_ex.py:208, 253-256)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import time
+    import types
+    import bench
+    from egorear_amd import dist as D
+    res = {}
+    try:
+        backend, note, rccl_ok = bench.init_distributed(world, rank, "nccl", None)
+        res["backend"], res["rccl_ok"], res["note_has_reason"] = backend, rccl_ok, note.startswith("gloo (RCCL failed:")
+        B = bench.frames_per_rank(64, 512, world)
+        res["B"] = B
+        b, e = shard_range(512, rank, world)
+        res["span"] = (b, e)
+        own = {}
+        elapsed = timed_steps(lambda: time.sleep(0.005 * (1 + (rank == 5) * 4)), 4, 1, lambda: None, None, detail=own)
+        res["elapsed"], res["own_s"] = elapsed, own["own_s"]
+        rec = {"rank": rank, "local_rank": rank, "host": "node0", "device_index": rank, "pci_domain_id": 0, "pci_bus_id": 0x10 + rank, "pci_device_id": 0,
+               "frames_per_s": B * 4 / own["own_s"]}
+        records = D.gather_rank_records(rec)
+        res["n_records"], res["distinct"] = len(records), D.check_distinct_devices(records)
+        try:
+            D.check_distinct_devices(records[:7] + [dict(records[2], rank=7)])
+            res["refused"] = False
+        except RuntimeError:
+            res["refused"] = True
+        flat = torch.full((1000,), float(rank + 1))
+        tr = types.SimpleNamespace(opt=types.SimpleNamespace(stage_range={2: [600, 1000], 0: [0, 100], 1: [100, 600], 3: [1000, 1000]}, flat_g=flat, pg=None))
+        ex = bench._exchange_leg(tr, world, backend, torch.device("cpu"))
+        res["exchange_bytes"], res["comm"] = ex["bytes_per_step"], ex["communicator_size"]
+        # 7 warm-up/timed all-reduces per bucket: every element went through SUM 7 times -> value x world^7 is out of range; check one fresh reduce instead
+        g = torch.full((16,), float(rank + 1))
+        D.allreduce_gradients_(g, None)
+        res["sum"] = float(g[0])
+        gathered = [None] * world
+        dist.all_gather_object(gathered, res)
+        if rank == 0:
+            out.put(gathered)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_eight_rank_rehearsal_of_the_bench_plumbing():
+    import pytest
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 8
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_eight_rank_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = out.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert len(got) == world
+    for r, g in enumerate(got):
+        assert g["backend"] == "gloo" and g["rccl_ok"] is False and g["note_has_reason"]          # unanimous fallback, reason in the line
+        assert g["B"] == 64 and g["span"] == (64 * r, 64 * (r + 1))                               # strong scaling: 512 / 8 frames each
+        assert g["n_records"] == world and g["distinct"] is True and g["refused"] is True
+        assert g["exchange_bytes"] == 4000 and g["comm"] == world
+        assert g["sum"] == float(sum(range(1, world + 1)))
+    assert len({g["elapsed"] for g in got}) == 1                                                   # max over ranks: the same figure everywhere
+    assert got[0]["elapsed"] >= got[5]["own_s"] - 1e-3 and got[5]["own_s"] > 3 * got[0]["own_s"]   # ... and it is the slow rank's
+    # a mixed RCCL outcome is refused, and an uneven strong-scaling share too
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    with pytest.raises(SystemExit, match="refusing to mix backends"):
+        bench.check_unanimous([True] * 7 + [False])
+    bench.check_unanimous([False] * 8)
+    bench.check_unanimous([True] * 8)
+    with pytest.raises(SystemExit, match="not divisible"):
+        bench.frames_per_rank(64, 500, 8)
+    assert bench.frames_per_rank(64, 0, 8) == 64

@@ -1,0 +1,47 @@
+"""Parity census at the benchmarked arithmetic: 512 synthetic frames - eight seeds, both image scales of the
+reference goldens (1.0 and 0.35: maxima on both sides of the 0.5 `valid` threshold) - through the drop-in EgoPoseFormerMVFEX at
+batch 64 under the SHIPPED launch policy (fp16 scheme on every large contraction), against the CPU oracle on the same frames:
+every arg-max of both heat-map sets (4 views x 15 joints x 2 per frame = 61 440), the anchors' flat indices, the `valid` masks of
+the refiners and of the lifting head, all four pose sets, and the tie exposure (top-2 gaps below 1e-5) as numbers.
+Bar: 0 mismatches, 3-D joints within 1e-3 cm (BASELINE.json north_star; utils/loss.py:122-142,
+egoposeformer_heatmap_mvf_ex.py:128-143)."""
+import copy
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BATCH = 64
+PLAN = [(0, 1.0), (1, 0.35), (2, 1.0), (3, 0.35), (4, 1.0), (5, 0.35), (6, 1.0), (7, 0.35)]      # (seed, image scale): 8 x 64 = 512 frames
+
+
+def test_512_frames_at_the_benchmarked_arithmetic_vs_the_cpu_oracle(calib_dir):
+    from egorear_amd import configs, hip, synth
+    from egorear_amd.estimator import EgoPoseFormerMVFEX
+    from oracle import census
+    from oracle import egorear_oracle as O
+    assert hip.H2 and hip.X6_MIN_ROWS > 0 and hip.X6_MIN_FLOPS > 0, "the census is a statement about the shipped launch policy"
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    net = EgoPoseFormerMVFEX(**copy.deepcopy(configs.pose3d_cfg("ego4view_syn"))).eval()
+    synth.load_synth(net, 42)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(DEV)
+    cams = O.make_cameras("ego4view_syn", calib_dir)
+    # the launches of a 64-frame forward really are the fp16-scheme ones
+    hip.PROFILE = []
+    with torch.no_grad():
+        net(synth.synth_images(BATCH, 4, seed=0).to(DEV))
+    tags, hip.PROFILE = [t for name, *_, t in hip.PROFILE if name in ("egr_conv2d_nhwc_f32", "egr_conv1x1_chain_f32")], None
+    assert sum(t.startswith("h2 ") for t in tags) >= 35 and sum(t.startswith("x6 ") for t in tags) <= 3
+    batches = [synth.synth_images(BATCH, 4, seed=s, scale=sc) for s, sc in PLAN]
+    acc = census.run(net, sd, cams, O, batches, DEV, oracle_batch=8, log=print)
+    print("census:", json.dumps(acc))
+    assert acc["frames"] == 512 and acc["argmax_compared"] == 512 * 4 * 15 * 2
+    assert acc["valid_true"] > 0 and acc["valid_false"] > 0, "the sample must put maxima on both sides of the 0.5 threshold"
+    assert acc["argmax_mismatches"] == 0 and acc["anchor_index_mismatches"] == 0, acc
+    assert acc["valid_mask_mismatches"] == 0, acc
+    assert acc["max_joint_err_cm"] < 1e-3, acc
+    assert acc["max_heatmap_err"] < 1e-4, acc

@@ -506,3 +506,37 @@ def test_two_forwards_in_flight_give_the_frames_of_one(nets):
     with engine.use_lane(1):
         st1 = engine._state(net, torch.device(DEV))
     assert st1 is not st0 and st1.packs is st0.packs and st1.workspace.data_ptr() != st0.workspace.data_ptr()
+
+
+def test_two_modules_with_their_own_launch_policies_coexist(nets):
+    """Round 6: the launch policy is an object a module can hold (engine.set_policy), not process-global state.
+    One module on the shipped fp16 scheme and a second on the exact bf16x3 arithmetic run alternately in one process: each keeps
+    its own kernel family and packs, neither disturbs the other or the process default."""
+    from egorear_amd import configs, engine, hip, synth
+    from egorear_amd.estimator import EgoPoseFormerMVFEX
+    net_a = nets("syn")
+    net_b = _build(EgoPoseFormerMVFEX, configs.pose3d_cfg("ego4view_syn"))
+    img = synth.synth_images(16, 4, seed=5).to(DEV)
+    default = copy.deepcopy(hip.POLICY)
+
+    def run(net):
+        hip.PROFILE = []
+        with torch.no_grad():
+            p, h = net(img)
+        tags, hip.PROFILE = [t for name, *_, t in hip.PROFILE if name in ("egr_conv2d_nhwc_f32", "egr_conv1x1_chain_f32")], None
+        return p, h, sum(t.startswith("h2 ") for t in tags), sum(t.startswith("x6 ") for t in tags)
+    try:
+        engine.set_policy(net_b, hip.POLICY.exact())
+        pa, ha, a_h2, a_x6 = run(net_a)
+        pb, hb, b_h2, b_x6 = run(net_b)
+        pa2, ha2, a2_h2, a2_x6 = run(net_a)
+        assert a_h2 >= 30 and a_x6 <= 3 and (a2_h2, a2_x6) == (a_h2, a_x6)
+        assert b_h2 == 0 and b_x6 >= 30
+        assert hip.POLICY == default and hip.H2 is True
+        assert all(torch.equal(x, y) for x, y in zip(pa, pa2)) and all(torch.equal(x, y) for x, y in zip(ha, ha2))
+        for x, y in zip(ha, hb):
+            assert torch.equal(x.flatten(-2).argmax(-1), y.flatten(-2).argmax(-1)) and float((x - y).abs().max()) < TOL_HM
+        for x, y in zip(pa, pb):
+            assert float((x - y).abs().max()) < TOL_POSE_CM
+    finally:
+        engine.set_policy(net_b, None)

@@ -175,8 +175,11 @@ def test_chain_eligibility_rule():
             self.h2 = object() if h2 else None
 
     class X:
-        def __init__(self, n, h, w, c, amax=True):
+        def __init__(self, n, h, w, c, amax=True, ld=None, ptr=0x10000):
             self.n, self.h, self.w, self.c, self.amax = n, h, w, c, (object() if amax else None)
+            self.ld = c if ld is None else ld
+            self.nstride = h * w * self.ld
+            self.t = type("T", (), {"data_ptr": staticmethod(lambda: ptr)})()
 
     big = X(64, 64, 64, 64)
     assert hip.chain_eligible(big, W(128, 64), W(128, 128), 128, 128, 1)
@@ -190,6 +193,14 @@ def test_chain_eligibility_rule():
     assert not hip.chain_eligible(big, W(256, 64), W(128, 256), 256, 128, 1)                                 # 256-channel intermediate
     assert not hip.chain_eligible(X(2, 8, 8, 64), W(128, 64), W(128, 128), 128, 128, 1)                      # too few pixels to stream
     assert not hip.chain_eligible(X(63, 64, 64, 64), W(128, 64, groups=2), W(128, 128, groups=2), 128, 128, 2)   # images not divisible by groups
+    # the entry's layout checks, mirrored: a channel slice at an odd offset / with odd strides stays on the single launches
+    assert not hip.chain_eligible(X(64, 64, 64, 64, ptr=0x10004), W(128, 64), W(128, 128), 128, 128, 1)
+    assert not hip.chain_eligible(X(64, 64, 64, 64, ld=66), W(128, 64), W(128, 128), 128, 128, 1)
+    assert hip.chain_eligible(X(64, 64, 64, 64, ld=192), W(128, 64), W(128, 128), 128, 128, 1)               # an aligned slice of a wider buffer
+    # a policy of its own (round 6): the thread's active LaunchPolicy decides, the process default is untouched
+    with hip.use_policy(hip.POLICY.replace(chain=False)):
+        assert not hip.chain_eligible(big, W(128, 64), W(128, 128), 128, 128, 1) and hip.CHAIN is False
+    assert hip.CHAIN is True and hip.chain_eligible(big, W(128, 64), W(128, 128), 128, 128, 1)
     saved = hip.CHAIN
     try:
         hip.CHAIN = False

@@ -26,7 +26,7 @@ python3 tools/train_bench.py --batch 32 --graph > $out/train_step_breakdown.txt 
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/tfetch -- $TR > $out/tfetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/twrite -- $TR > $out/twrite.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/tmfma -- $TR > $out/tmfma.log 2>&1
-python3 tools/pmc_traffic_train.py $out/tfetch $out/twrite $out/pmc_traffic_train.json 32 > /dev/null
+python3 tools/pmc_traffic_train.py $out/tfetch $out/twrite $out/pmc_traffic_train.json 32 $commit > /dev/null
 python3 tools/pmc_mfma_util.py $out/tmfma $out/pmc_train_mfma_util.json > /dev/null
 rm -rf $out/stats/*/*kernel_trace.csv $out/fetch $out/write $out/mfma $out/tfetch $out/twrite $out/tmfma
 echo done-train $tag

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HBM bytes per launch of the training step's kernels from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs, as
 MI355X_MICROARCH.md prescribes; FETCH_SIZE x2 on gfx950) of `python3 tools/train_bench.py --batch 32 --steps 2 --warmup 1` (eager).
-    python tools/pmc_traffic_train.py <fetch_dir> <write_dir> <out.json> [batch]"""
+    python tools/pmc_traffic_train.py <fetch_dir> <write_dir> <out.json> [batch] [commit]"""
 import collections, csv, glob, json, re, sys
 
 
@@ -13,6 +13,7 @@ def _planes(nm: str) -> str:
 
 
 def classify(nm: str) -> str:
+    if "conv_tapx" in nm or "conv_pw_chain" in nm or "conv_pw2" in nm: return "conv_igemm_f16x2"      # role-split / chained kernels: fp16 scheme only
     if "conv_igemm_x6" in nm or "conv_igemm_tap" in nm or "conv_pw_x6" in nm: return "conv_igemm_" + _planes(nm)
     if "conv_igemm" in nm: return "conv_igemm_f32"
     if "conv_wgrad_x6" in nm or "conv_wgrad3_x6" in nm: return "conv_wgrad_" + _planes(nm)
@@ -34,7 +35,7 @@ def load(d, counter):
 
 fetch, lf = load(sys.argv[1], "FETCH_SIZE")
 write, lw = load(sys.argv[2], "WRITE_SIZE")
-out = {"batch": int(sys.argv[4]) if len(sys.argv) > 4 else 32, "fetch_correction": 2.0, "kernels": {},
+out = {"batch": int(sys.argv[4]) if len(sys.argv) > 4 else 32, "commit": sys.argv[5] if len(sys.argv) > 5 else None, "fetch_correction": 2.0, "kernels": {},
        "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 tools/train_bench.py --batch 32 --steps 2 --warmup 1"}
 for k in sorted(lf, key=lambda k: -(2 * fetch[k] + write.get(k, 0))):
     n, nw = lf[k], lw.get(k, 0)
