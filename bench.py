@@ -325,7 +325,7 @@ def cpu_baseline(state_dict, net, dev, batch: int, iters: int, gpu_batch: int = 
                 o = census.oracle_outputs(state_dict, cams, imgb[lo:hi], O)
                 times.append(time.perf_counter() - t0)
                 gs = census._slice(g, lo, hi)
-                acc = census.merge(acc, census.compare(gs, o))
+                acc = census.merge(acc, census.compare_chunk(gs, o, state_dict, imgb[lo:hi], O, first_frame=pos))
                 mp_hip += float(O.compute_mpjpe_batch(gs["preds"][-1], gt[pos:pos + hi - lo]).sum())
                 mp_cpu += float(O.compute_mpjpe_batch(o["preds"][-1], gt[pos:pos + hi - lo]).sum())
                 pos += hi - lo
@@ -977,6 +977,8 @@ def main():
             "train_dominant_kernel": tr_roof.get("kernel"), "train_launches_per_step": _get(train, "launches_per_step"),
             "parity_frames": _get(parity_line, "frames"), "argmax_compared": _get(parity_line, "argmax_compared"),
             "argmax_mismatches": _get(parity_line, "argmax_mismatches"), "valid_mask_mismatches": _get(parity_line, "valid_mask_mismatches"),
+            "argmax_mismatches_outside_rounding": _get(parity_line, "argmax_mismatches_outside_rounding"),
+            "argmax_mismatches_fp64_sides_with_hip": _get(parity_line, "argmax_mismatches_fp64_sides_with_hip"),
             "max_joint_err_cm": _get(parity_line, "max_joint_err_cm"), "top2_gap_below_1e-5": _get(parity_line, "top2_gap_below_1e-5"),
             "frac_conv3x3": _get(roof, "frac_conv3x3"), "conv3x3_ms": _get(roof, "conv3x3_ms"),
             "frac_conv1x1_hbm": _get(roof, "frac_conv1x1_hbm"), "conv1x1_ms": _get(roof, "conv1x1_ms"),

@@ -18,6 +18,11 @@ from typing import Callable, Dict, List, Optional
 import torch
 
 
+# two candidates of one map closer than this in the ORACLE's values are a tie within fp32 rounding of the reference's own conv stack
+# (heat-map values are O(0.1-1): 1e-6 is ~8-16 ulp; the HIP path's largest heat-map deviation from the oracle is 3e-6)
+ROUNDING_GAP = 1e-6
+
+
 def _gaps(hm: torch.Tensor) -> torch.Tensor:
     """(B, V, J, H, W) -> (B, V, J): largest minus second-largest value of every map."""
     top = hm.flatten(-2).topk(2, dim=-1).values
@@ -30,12 +35,28 @@ def compare(gpu: Dict[str, object], ora: Dict[str, object]) -> Dict[str, float]:
     out: Dict[str, float] = {"frames": int(ora["hms"][0].shape[0])}
     mism = 0
     compared = 0
-    for g, o in zip(gpu["hms"], ora["hms"]):
-        ag, ao = g.flatten(-2).argmax(-1), o.flatten(-2).argmax(-1)
-        mism += int((ag != ao).sum())
+    worst_gap, outside, detail = 0.0, 0, []
+    for si, (g, o) in enumerate(zip(gpu["hms"], ora["hms"])):
+        gf, of = g.flatten(-2), o.flatten(-2)
+        ag, ao = gf.argmax(-1), of.argmax(-1)
+        bad = (ag != ao).nonzero()
+        mism += int(bad.shape[0])
         compared += ao.numel()
+        for b, v, j in bad.tolist():
+            # what separates the two candidates IN THE ORACLE'S OWN MAP: a gap at rounding level means the reference's arg-max itself
+            # depends on the summation order of its convolutions (another BLAS / thread count would move it too)
+            gap = float(of[b, v, j, ao[b, v, j]] - of[b, v, j, ag[b, v, j]])
+            gap_hip = float(gf[b, v, j, ag[b, v, j]] - gf[b, v, j, ao[b, v, j]])
+            worst_gap = max(worst_gap, gap)
+            outside += int(gap > ROUNDING_GAP)
+            detail.append({"frame": b, "set": si, "view": v, "joint": j, "oracle_gap": gap, "hip_gap": gap_hip, "oracle_max": float(of[b, v, j, ao[b, v, j]]),
+                           "idx_oracle": int(ao[b, v, j]), "idx_hip": int(ag[b, v, j])})
     out["argmax_compared"] = compared
     out["argmax_mismatches"] = mism
+    out["argmax_mismatches_outside_rounding"] = outside       # oracle-side gap above ROUNDING_GAP: a real disagreement
+    out["max_mismatch_oracle_gap"] = worst_gap
+    out["mismatch_detail"] = detail
+    out["argmax_mismatches_fp64_sides_with_hip"] = 0          # filled in by _referee for chunks that have mismatches
     out["anchor_index_mismatches"] = int((gpu["argmax_idx"].long() != ora["argmax_idx"].long()).sum())
     out["valid_mask_mismatches"] = int((gpu["valid_h"].bool() != ora["valid_h"].bool()).sum())
     if gpu.get("valid_p") is not None and ora.get("valid_p") is not None:
@@ -57,13 +78,45 @@ def merge(acc: Optional[Dict[str, float]], c: Dict[str, float]) -> Dict[str, flo
     if acc is None:
         return dict(c)
     for k, v in c.items():
-        if k.startswith("max_"):
+        if isinstance(v, list):
+            acc[k] = acc[k] + v
+        elif k.startswith("max_"):
             acc[k] = max(acc[k], v)
         elif k.endswith("_min"):
             acc[k] = min(acc[k], v)
         else:
             acc[k] += v
     return acc
+
+
+def _referee(c: Dict[str, object], sd, img: torch.Tensor, O, ora) -> None:
+    """A mismatch is put before the SAME oracle evaluated in float64 (weights and input are float32 numbers, every operation behind
+    them in double): which of the two candidate positions does exact-ish arithmetic pick?  If float64 sides with the HIP path, the
+    float32 reference's own rounding moved its arg-max."""
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    frames = sorted({d["frame"] for d in c["mismatch_detail"]})
+    with torch.no_grad():
+        for b in frames:
+            hms64, _, _ = O.heatmap_mvfex_forward(sd64, "heatmap_estimator", img[b:b + 1].double(), 0.5)
+            for d in c["mismatch_detail"]:
+                if d["frame"] != b:
+                    continue
+                m = hms64[d["set"]][0, d["view"], d["joint"]].flatten()
+                i64 = int(m.argmax())
+                d["idx_fp64"] = i64
+                d["fp64_gap_oracle_minus_hip"] = float(m[d["idx_oracle"]] - m[d["idx_hip"]])
+                d["fp64_sides_with"] = "hip" if i64 == d["idx_hip"] else ("oracle" if i64 == d["idx_oracle"] else "neither")
+    c["argmax_mismatches_fp64_sides_with_hip"] = sum(d.get("fp64_sides_with") == "hip" for d in c["mismatch_detail"])
+
+
+def compare_chunk(g, o, sd, img: torch.Tensor, O, first_frame: int = 0) -> Dict[str, object]:
+    """compare() + the float64 referee for whatever disagrees; `first_frame` = index of the chunk's first frame in the whole sample."""
+    c = compare(g, o)
+    if c["mismatch_detail"]:
+        _referee(c, sd, img, O, ora=o)
+        for d in c["mismatch_detail"]:
+            d["frame_in_sample"] = first_frame + d["frame"]
+    return c
 
 
 def gpu_outputs(net, img_dev: torch.Tensor) -> Dict[str, object]:
@@ -102,7 +155,7 @@ def run(net, sd, cams, O, batches: List[torch.Tensor], dev, oracle_batch: int = 
             o = oracle_outputs(sd, cams, img[lo:hi], O)
             if times is not None:
                 times.append(time.perf_counter() - t0)
-            acc = merge(acc, compare(_slice(g, lo, hi), o))
+            acc = merge(acc, compare_chunk(_slice(g, lo, hi), o, sd, img[lo:hi], O, first_frame=bi * img.shape[0] + lo))
         if log:
             log(f"census: batch {bi + 1}/{len(batches)} done, {acc['frames']} frames, {acc['argmax_mismatches']} arg-max mismatches, "
                 f"max joint err {acc['max_joint_err_cm']:.2e} cm")

@@ -225,7 +225,8 @@ def ms_deform_attn(sd: SD, p: str, query, ref_pts, memory, H: int, W: int, n_hea
     aw = F.softmax(aw, -1).view(N, Lq, n_heads, 1, n_points)
     normalizer = torch.tensor([[W, H]], dtype=torch.long)  # (W, H) order: deform_attn.py:131-133
     loc = ref_pts[:, :, None, :, None, :] + off / normalizer[None, None, None, :, None, :]
-    out = msda_core(value.float(), H, W, loc[:, :, :, 0], aw[:, :, :, 0])
+    # (deform_attn.py:155 casts to float for the mmcv op; a float64 run of this oracle - the referee of oracle/census.py - stays float64)
+    out = msda_core(value if value.dtype == torch.float64 else value.float(), H, W, loc[:, :, :, 0], aw[:, :, :, 0])
     return _lin(sd, p + ".output_proj", out)
 
 
