@@ -21,6 +21,7 @@ a torch operator.
 """
 from __future__ import annotations
 
+import contextlib
 import math
 import os
 from typing import Dict, List, Optional, Sequence
@@ -57,6 +58,9 @@ BN_IN_CONV = os.environ.get("EGR_TRAIN_BN_IN_CONV", "1") != "0"
 # kernel time), and the small latency-bound launches of the heads sit in a different phase of the reverse pass than the large ones.
 # Forking only the small launches ("small") is no better (33.7 ms): the replay of a graph with ~100 cross-stream edges costs the host
 # 21 ms per step and the device follows it.
+OVERLAP = os.environ.get("EGR_TRAIN_OVERLAP", "1") != "0"       # the leaves of the reverse pass on a second stream (Step.backward)
+# which parts (bits): 1 = forward branches (own-view projection, refined heads), 2 = the detached heads' reverse pass, 4 = the refiners' reverse pass
+OVERLAP_PARTS = int(os.environ.get("EGR_TRAIN_OVERLAP_PARTS", "7"))
 SIDE_WGRAD = os.environ.get("EGR_TRAIN_SIDE_STREAM", "0")          # "0" | "small" (only launches below the split threshold) | "1" (all)
 SIDE_WGRAD = SIDE_WGRAD if SIDE_WGRAD in ("small", "1") else ""
 
@@ -274,27 +278,68 @@ class _Grads:
     def __init__(self):
         self.g: Dict[int, torch.Tensor] = {}
         self.gm: Dict[int, torch.Tensor] = {}   # contributions to post-ReLU tensors that already carry the [y > 0] mask
+        # Round 6: parts of the reverse pass run on a second stream (Step.backward).  When `track` is on, every stored gradient carries
+        # the stream of the launch that produced it; a closure that takes it on ANOTHER stream first makes its stream wait for what
+        # the producer's stream has been given so far (and tells the allocator about the second user) - gradient flow across streams
+        # is ordered by construction.  (One event per stored gradient would be the finer tool; ending a hipGraph capture that holds
+        # a few hundred recorded-and-dropped events crashed inside hipStreamEndCapture, Stream.wait_stream is the proven path.)
+        self.track = False
+        self.src: Dict[int, object] = {}        # id(gradient tensor) -> producing stream
+        self.hold: List = []
+
+    def _produced(self, g: torch.Tensor):
+        if self.track:
+            self.src[id(g)] = torch.cuda.current_stream(g.device)
+
+    def _taken(self, g: Optional[torch.Tensor], drop: bool):
+        if self.track and g is not None:
+            st = self.src.pop(id(g), None) if drop else self.src.get(id(g))
+            if st is not None:
+                cur = torch.cuda.current_stream(g.device)
+                if st != cur:
+                    cur.wait_stream(st)
+                    # the allocator must not hand the block back to the producer's stream while this stream still reads it: the
+                    # tensor lives to the end of the step (every stream is joined by then) - Tensor.record_stream inside a hipGraph
+                    # capture crashed hipStreamEndCapture on this stack
+                    self.hold.append(g)
+        return g
 
     def add_masked(self, t: torch.Tensor, g: torch.Tensor):
         k = id(t)
-        old = self.gm.get(k)
+        old = self._taken(self.gm.get(k), True)
         self.gm[k] = g if old is None else T.add(old, g)
+        self._produced(self.gm[k])
 
     def pop_masked(self, t: torch.Tensor) -> Optional[torch.Tensor]:
-        return self.gm.pop(id(t), None)
+        return self._taken(self.gm.pop(id(t), None), True)
 
     def add(self, t: torch.Tensor, g: torch.Tensor):
         if g.shape != t.shape:
             g = g.view(t.shape)
         k = id(t)
-        old = self.g.get(k)
+        old = self._taken(self.g.get(k), True)
         self.g[k] = g if old is None else T.add(old, g)
+        self._produced(self.g[k])
+
+    def put(self, t: torch.Tensor, g: torch.Tensor):
+        """Store g as THE gradient of t (the caller has folded the previous value in)."""
+        self.g[id(t)] = g
+        self._produced(g)
 
     def pop(self, t: torch.Tensor) -> Optional[torch.Tensor]:
-        return self.g.pop(id(t), None)
+        return self._taken(self.g.pop(id(t), None), True)
 
     def peek(self, t: torch.Tensor) -> Optional[torch.Tensor]:
-        return self.g.get(id(t))
+        return self._taken(self.g.get(id(t)), False)
+
+
+class _OnSide:
+    """A reverse-pass closure that runs on the step's second stream (Step.backward).  early: it depends on the loss seeds only and
+    feeds nothing but parameter gradients (a detached heat-map head) - enqueued first, under the lifting head's chain of small launches."""
+    __slots__ = ("fn", "early")
+
+    def __init__(self, fn, early: bool):
+        self.fn, self.early = fn, early
 
 
 class Step:
@@ -313,7 +358,7 @@ class Step:
         if st is None or st[0].device != device:
             st = (torch.empty(_WS_FLOATS, device=device, dtype=torch.float32), T.bn_workspace(device))
             net.__dict__["_egr_train_ws"] = st
-        self.ws, self.bnws = st
+        self._ws_main, self.bnws = st
         self.keep: List = []   # forward tensors whose identity keys the gradient store
         self.stage_hook = None                                  # callable(stage) run when a gradient stage is complete (multi-process)
         self.gviews: Optional[Dict[str, torch.Tensor]] = None   # flat-buffer views to write parameter gradients into (Trainer)
@@ -328,7 +373,15 @@ class Step:
             self.amax.begin()      # (one fill launch: every record of the step starts from zero)
         T.set_arena(self.amax)     # element-wise launches bound their outputs by their inputs' records
         self.side, self.ws_side, self._forked = None, None, False
-        if SIDE_WGRAD:
+        # ---- two-stream step (round 6, EGR_TRAIN_OVERLAP): forward_train switches it on for the config-5 graph, whose detached heat-map
+        # heads and refiners are LEAVES of the reverse pass (they feed parameter gradients only): they run on the side stream under the
+        # lifting head's / the encoders' launches.  One process only: the staged multi-process capture cuts the tape at stage markers.
+        self.allow_overlap = False
+        self._on_side = False      # launches issued now go to the side stream (its split-K workspace is ws_side)
+        self.bwd_side = False      # closures recorded now run on the side stream in the reverse pass ...
+        self.bwd_early = False     # ... and ahead of everything else (seed-only leaves)
+        self._side_dirty = False   # the side stream holds work the main stream has not waited for
+        if SIDE_WGRAD or OVERLAP:
             ss = net.__dict__.get("_egr_side")
             if ss is None or ss[1].device != device:
                 ss = (torch.cuda.Stream(device=device), torch.empty(_WS_FLOATS, device=device, dtype=torch.float32))
@@ -349,6 +402,42 @@ class Step:
             self.bn_mods = []
             self.bn_dirty = False
 
+    # ---- streams
+    @property
+    def ws(self) -> torch.Tensor:
+        """Split-K workspace of the stream the launches currently go to."""
+        return self.ws_side if self._on_side else self._ws_main
+
+    def overlap(self) -> bool:
+        return bool(OVERLAP and not SIDE_WGRAD and self.allow_overlap and self.stage_hook is None and self.side is not None)
+
+    def _rec(self, fn):
+        """Record a reverse-pass closure (on the side stream when the forward marked this section as a leaf: bwd_side)."""
+        side = self.bwd_side and self.overlap() and (OVERLAP_PARTS & (2 if self.bwd_early else 4))
+        self.tape.append(_OnSide(fn, self.bwd_early) if side else fn)
+
+    @contextlib.contextmanager
+    def side_branch(self):
+        """Forward: the block's launches go to the side stream, behind everything the main stream has been given so far; whoever
+        reads the results on the main stream calls join_side() first."""
+        if not (self.overlap() and OVERLAP_PARTS & 1):
+            yield
+            return
+        main = torch.cuda.current_stream(self.dev)
+        self.side.wait_stream(main)
+        self._on_side = True
+        try:
+            with torch.cuda.stream(self.side):
+                yield
+        finally:
+            self._on_side = False
+            self._side_dirty = True
+
+    def join_side(self):
+        if self._side_dirty:
+            torch.cuda.current_stream(self.dev).wait_stream(self.side)
+            self._side_dirty = False
+
     # ---- bookkeeping
     def name(self, p: torch.Tensor) -> str:
         return self.names[id(p)]
@@ -368,6 +457,7 @@ class Step:
         return t
 
     def finish_param_grads(self):
+        self.join_side()          # the leaves of the reverse pass on the side stream: their slabs feed the table below
         if self._forked:          # the weight gradients forked onto the side stream: their slabs feed the table below
             torch.cuda.current_stream().wait_stream(self.side)
             self._forked = False
@@ -390,11 +480,40 @@ class Step:
                 self.finish_param_grads()
                 self.stage_hook(stage)
         if self.record:
-            self.tape.append(bwd)
+            self.tape.append(bwd)      # (a marker, never a leaf: plain entry - tests drive mark_stage / backward on a stand-in object)
 
     def backward(self):
+        side = getattr(self, "side", None)
+
+        budget = [int(os.environ.get("EGR_TRAIN_OVERLAP_MAXSIDE", "1000000"))]      # (diagnostic: only the first n leaves go to the side stream)
+
+        def on_side(fn):
+            budget[0] -= 1
+            if budget[0] < 0:
+                if os.environ.get("EGR_TRAIN_OVERLAP_TRACE"):
+                    pass
+                return fn()
+            if os.environ.get("EGR_TRAIN_OVERLAP_TRACE"):
+                import sys
+                print("side:", getattr(fn, "__qualname__", fn), file=sys.stderr)
+            self._on_side = True
+            try:
+                with torch.cuda.stream(side):
+                    fn()
+            finally:
+                self._on_side = False
+                self._side_dirty = True
+        # seed-only leaves first: every one of them starts by taking a loss seed out of the gradient store, which orders the side
+        # stream behind the seed's launch (and through it behind the whole forward)
         for fn in reversed(self.tape):
-            fn()
+            if isinstance(fn, _OnSide) and fn.early:
+                on_side(fn.fn)
+        for fn in reversed(self.tape):
+            if isinstance(fn, _OnSide):
+                if not fn.early:
+                    on_side(fn.fn)
+            else:
+                fn()
         self.tape = []
 
     def grad_behind_relu(self, y: torch.Tensor) -> Optional[torch.Tensor]:
@@ -417,7 +536,7 @@ class Step:
             dx = _conv2d(Img(dz), p.wtop, p.cin_pad, p.kh, p.kw, p.stride, p.pad, mask=Img(x), **kw).t
             self.G.add_masked(x, dx)
         else:
-            self.G.g[id(x)] = _conv2d(Img(dz), p.wtop, p.cin_pad, p.kh, p.kw, p.stride, p.pad, **kw).t
+            self.G.put(x, _conv2d(Img(dz), p.wtop, p.cin_pad, p.kh, p.kw, p.stride, p.pad, **kw).t)
 
     # ---- conv / linear ------------------------------------------------------------------------------------------
     def pack(self, mods: Sequence[nn.Module], need_dx=True) -> TPack:
@@ -434,7 +553,7 @@ class Step:
         """Weight / bias gradients of every group.  x4 (G*n, h, w, cin_pad), dz4 (G*n, ho, wo, cout_pad) dense."""
         xi, di = Img(x4), Img(dz4)
         big = hip.wgrad_is_split(xi, di, p.kh, p.kw, p.groups)
-        if self.side is None or (big and SIDE_WGRAD == "small"):
+        if not SIDE_WGRAD or self.side is None or (big and SIDE_WGRAD == "small"):
             dws, dbs = hip.conv2d_wgrad(xi, di, p.kh, p.kw, p.stride, p.pad, self.ws, want_bias=p.bmeta is not None, groups=p.groups,
                                         amax_arena=self.amax)
         else:
@@ -516,7 +635,7 @@ class Step:
             if need_dx:
                 self._dgrad(p, x, dz, h, w)
         if self.record:
-            self.tape.append(bwd)
+            self._rec(bwd)
         self.keep.append((x, y))
         return y
 
@@ -537,7 +656,7 @@ class Step:
             if g is not None:
                 self.G.add(base, g.view(base.shape))
         if self.record:
-            self.tape.append(bwd)
+            self._rec(bwd)
         self.keep.append((base, view))
 
     # ---- BatchNorm (training mode), grouped ----------------------------------------------------------------------
@@ -582,7 +701,7 @@ class Step:
                 self.G.add(res, dz)
             self.G.add(x, dx)
         if self.record:
-            self.tape.append(bwd)
+            self._rec(bwd)
         self.keep.append((x, y))
         return y
 
@@ -596,7 +715,7 @@ class Step:
             if dy is not None:
                 self.G.add(x, T.maxpool_bwd(dy, slot, (x.shape[1], x.shape[2]), k, s, pd))
         if self.record:
-            self.tape.append(bwd)
+            self._rec(bwd)
         self.keep.append((x, y))
         return y
 
@@ -616,7 +735,7 @@ class Step:
                 dzm = T.add(dzm, T.relu_bwd(dy, y))
             self.G.add(x, T.upsample2x_bwd(dzm, None))
         if self.record:
-            self.tape.append(bwd)
+            self._rec(bwd)
         self.keep.append((x, y))
         return y
 
@@ -633,7 +752,7 @@ class Step:
             if b is not None:
                 self.G.add(b, dy)
         if self.record:
-            self.tape.append(bwd)
+            self._rec(bwd)
         self.keep.append((a, other, y))
         return y
 
@@ -645,7 +764,7 @@ class Step:
             if dh is not None:
                 self.G.add(z, T.gelu_bwd(dh, z))
         if self.record:
-            self.tape.append(bwd)
+            self._rec(bwd)
         self.keep.append((z, h))
         return h
 
@@ -670,7 +789,7 @@ class Step:
             if res is not None:
                 self.G.add(res, ds)
         if self.record:
-            self.tape.append(bwd)
+            self._rec(bwd)
         self.keep.append((x, res, pre, y))
         return y
 
@@ -682,7 +801,7 @@ class Step:
             if da is not None:
                 self.G.add(qkv, T.joint_mha_bwd(qkv, da, b, j, heads, d, d ** -0.5))
         if self.record:
-            self.tape.append(bwd)
+            self._rec(bwd)
         self.keep.append((qkv, att))
         return att
 
@@ -780,7 +899,7 @@ def backbone_train(S: Step, encs, img: torch.Tensor, view0: int, nviews: int):
         for g, nme in enumerate(wnames):
             S.gtable.add(repack.COPYPAD, dw, S.gdst(nme), 0, rows=64 * 147, total=64 * 147, src_off=g * 64 * 147)
     if S.record:
-        S.tape.append(bwd_stem)
+        S._rec(bwd_stem)
     S.keep.append((x,))
     x = S.bn(x, [t.layer_s2[1] for t in trunks], relu=True)
     x = S.maxpool(x, 3, 2, 1)
@@ -944,7 +1063,7 @@ def layer_train(S: Step, L: _LayerPack, x: torch.Tensor, memory: torch.Tensor, a
                 S.pacc(S.name(ca.value_proj.bias), dcfold[gi].clone())
                 S.pacc(S.name(pw), hip.conv2d_wgrad(_rows(dWf), _rows(Wv), 1, 1, 1, 0, S.ws, x6=False)[0].reshape(pw.shape))
                 S.pacc(S.name(pb), Wv.t() @ dcfold[gi])
-    S.tape.append(bwd_sampling)
+    S._rec(bwd_sampling)
     S.keep.append((ol, g, e, sigma, a))
     # masked_fill(~valid) after output_proj: rows of invalid anchors are zero and pass no gradient.  Forward and gradient
     # are masked in place (the gradient tensor is the fresh output of fuse_mlp's data-gradient launch, nobody else holds it).
@@ -956,7 +1075,7 @@ def layer_train(S: Step, L: _LayerPack, x: torch.Tensor, memory: torch.Tensor, a
         d = S.G.peek(om)
         if d is not None:
             T.rowmask_(d, mask_all)
-    S.tape.append(bwd_mask)
+    S._rec(bwd_mask)
     omv = om.view(G * B * J, V * C)
     S.alias(om, omv)
     f = S.linear(omv, L.fuse)
@@ -990,7 +1109,7 @@ def conv_to_planes(S: Step, x: torch.Tensor, p: TPack, planes: torch.Tensor, B: 
         S._wgrad(p, x, dz)
         if need_dx:
             S._dgrad(p, x, dz, h, w)
-    S.tape.append(bwd)
+    S._rec(bwd)
     S.keep.append((x, planes))
 
 
@@ -1017,6 +1136,12 @@ def refiners_train(S: Step, rs, B: int, V: int, hm_init: torch.Tensor, feat_all:
     hw = hgt * wid
     dev = S.dev
     S.mark_stage(1)
+    # --- own-view projection: a constant in this configuration (`offset_pred + frame_feat.detach()`, :715) - evaluated without tape, and
+    # (two-stream step) beside the token chain below: ~1 ms of convolutions under ~0.7 ms of small launches
+    S.record = False
+    with S.side_branch():
+        ff = run_stack_train(S, [r.frame_feat_proj_layers for r in rs], feat_all, need_dx_first=False)
+    S.record = True
     # --- JQA query: heatmap_proj.0 reads the (B, V, J, hw) heat maps in place, group g = view g
     hp0 = S.pack([r.heatmap_proj[0] for r in rs], need_dx=hm_grad)
     hm_rows = Img(hm_init.view(B * V, J, 1, hw)[0::V])
@@ -1038,7 +1163,7 @@ def refiners_train(S: Step, rs, B: int, V: int, hm_init: torch.Tensor, feat_all:
             dhm = torch.empty_like(hm_init)
             T.nhwc_to_planes(dxr.view(G * B, 1, J * hw), dhm, NMap(B, V * J * hw, J * hw), J * hw)
             S.G.add(hm_init, dhm)
-    S.tape.append(bwd_hp0)
+    S._rec(bwd_hp0)
     S.keep.append((t4, t))
     hm_embed = S.linear(t, S.pack([r.heatmap_proj[2] for r in rs]))
     bfb = S.linear(hip.avgpool(Img(s32_all)), S.pack([r.fc_bfb for r in rs], need_dx=False), need_dx=False)
@@ -1055,13 +1180,9 @@ def refiners_train(S: Step, rs, B: int, V: int, hm_init: torch.Tensor, feat_all:
             S.pacc(S.name(r.joint_query_embed.weight), de[g])
         S.G.add(bfb, dbfb)
         S.G.add(hm_embed, d)
-    S.tape.append(bwd_jqa)
+    S._rec(bwd_jqa)
     S.keep.append((xs,))
     x = S.linear(xs, S.pack([r.fc_query[0] for r in rs]), ACT_RELU)
-    # --- own-view projection: a constant in this configuration (`offset_pred + frame_feat.detach()`, :715) - evaluated without tape
-    S.record = False
-    ff = run_stack_train(S, [r.frame_feat_proj_layers for r in rs], feat_all, need_dx_first=False)
-    S.record = True
     # --- transformer layer over the (detached) 4-view memory
     L = _pack_layer(S, [r.transformer_layers[0] for r in rs], [(r.frame_feat_multi_view_proj.weight, r.frame_feat_multi_view_proj.bias) for r in rs],
                     [r.frame_feat_multi_view_pos_embed for r in rs])
@@ -1077,14 +1198,20 @@ def refiners_train(S: Step, rs, B: int, V: int, hm_init: torch.Tensor, feat_all:
             dx = torch.empty_like(xn)
             T.nhwc_to_planes(d.view(G * B, C, 32), dx, NMap(G * B, J * C, 0), J)
             S.G.add(xn, dx)
-    S.tape.append(bwd_tok)
+    S._rec(bwd_tok)
     S.keep.append((tok,))
     h0 = S.conv(tok, S.pack([r.head_layers[0].head[0] for r in rs]), ACT_RELU)
     h0 = S.upsample(h0)
     off = S.conv(h0, S.pack([r.head_layers[0].head[3] for r in rs]), ACT_RELU)
+    S.join_side()                                         # ff
     summed = S.add(off, None, b_const=ff)
     feat_ref = run_stack_train(S, [r.frame_feat_refined_proj_layers[0] for r in rs], summed)
-    heatmap_head_train(S, [r.conv_heatmap_layers[0] for r in rs], feat_ref, hm_ref, B, V, need_dx_first=not detach_heatmap_feat)
+    # the refined heads: forward beside whatever the caller runs next on the main stream (the lifting head's token chain; the caller
+    # joins before it reads hm_ref), reverse pass as a seed-only leaf when they see detached features
+    early, S.bwd_early = S.bwd_early, S.bwd_early or (S.bwd_side and detach_heatmap_feat)
+    with S.side_branch():
+        heatmap_head_train(S, [r.conv_heatmap_layers[0] for r in rs], feat_ref, hm_ref, B, V, need_dx_first=not detach_heatmap_feat)
+    S.bwd_early = early
     return feat_ref
 
 
@@ -1104,7 +1231,7 @@ def pose3d_train(S: Step, p3, feat_init: torch.Tensor, feat_ref: torch.Tensor, B
 
     def bwd_mem():                      # runs after every layer's sampling backward has accumulated into dmem
         S.G.add(feat_init, dmem.view(feat_init.shape))
-    S.tape.append(bwd_mem)
+    S._rec(bwd_mem)
     # --- proposal: conv stack on the refined features -> per-frame vector in the reference's (v, c, h, w) order
     cf = run_stack_train(S, [p3.conv_frame_feat], feat_ref)                     # (V*B, 8, 8, 128)
     flat = torch.empty((B, V * 128 * 64), device=dev, dtype=torch.float32)
@@ -1114,7 +1241,7 @@ def pose3d_train(S: Step, p3, feat_init: torch.Tensor, feat_ref: torch.Tensor, B
         d = S.G.pop(flat)
         if d is not None:
             S.G.add(cf, T.planes_to_nhwc(d, NMap(B, V * 8192, 8192), V * B, 128, 64, 128).view(cf.shape))
-    S.tape.append(bwd_flat)
+    S._rec(bwd_flat)
     S.keep.append((flat,))
     h = S.gelu(S.linear(flat, S.pack([p3.mlp_pred[0][0]])))
     h = S.gelu(S.linear(h, S.pack([p3.mlp_pred[1][0]])))
@@ -1164,15 +1291,25 @@ def forward_train(S: Step, net, img: torch.Tensor, ctm=None):
     J = he.num_heatmap
     dev = img.device
     front, back = he.heatmap_estimator_stereo_front, he.heatmap_estimator_stereo_back
+    # Two streams (Step.overlap): under these flags the initial heads run on detached features, the refiners on detached heat maps and
+    # memory, the refined heads on detached refined features (:273, :297, :717-721) - in the reverse pass they are leaves that produce
+    # parameter gradients only.  The gradient that reaches the encoders comes from the lifting head's sampling alone.
+    S.allow_overlap = True
+    S.G.track = S.overlap()
     feat_all, s32_all = backbone_train(S, [front.encoder, back.encoder], img, 0, 2)
     hm_init = torch.empty((B, V, J, H4, W4), device=dev, dtype=torch.float32)
     S.mark_stage(2)
+    S.bwd_side = S.bwd_early = True      # reverse pass: seed-only leaf
     heatmap_head_train(S, [he.conv_heatmap_layers_stereo_front, he.conv_heatmap_layers_stereo_back], feat_all, hm_init, B, V)
+    S.bwd_side = S.bwd_early = False
     a, mv, vd, idx = hip.argmax_rows(hm_init, he.heatmap_threshold)
     anchors, valid = a.view(B, V, J, 2), vd.view(B, V, J)
     hm_ref = torch.empty_like(hm_init)
+    S.bwd_side = True                    # reverse pass: the refiners are a leaf behind d(feat_ref)
     feat_ref = refiners_train(S, he.refiners(), B, V, hm_init, feat_all, s32_all, anchors, valid, hm_ref)
+    S.bwd_side = False
     preds, aux_p = pose3d_train(S, p3, feat_all, feat_ref, B, V, ctm)
+    S.join_side()                        # the refined heads' forward ran beside the lifting head's: hm_ref is complete from here on
     aux = {"heatmap": {"anchors_2d": anchors, "anchors_valid": valid, "argmax_idx": idx.view(B, V, J), "maxvals": mv.view(B, V, J)},
            "pose3d": aux_p}
     S.flush_buffers()

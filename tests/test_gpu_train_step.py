@@ -394,3 +394,55 @@ def test_training_step_syn_camera_against_the_oracle():
         terms, _ = tr.step(img.to(DEV), None, gp.to(DEV), gh.to(DEV))
     torch.cuda.synchronize()
     assert tr.graph is not None and torch.isfinite(terms).all()
+
+
+def test_two_stream_reverse_pass_gives_the_one_stream_gradients_bit_for_bit():
+    """Round 6 (train.Step.backward): the detached heat-map heads and the refiners are leaves of the reverse pass and run on a second
+    stream under the lifting head's / the encoders' launches, gradients that cross streams ordered through the gradient store.  Same
+    launches, same operands, another stream: every loss term, output and parameter gradient is BIT-identical to the one-stream step,
+    eagerly and as a captured hipGraph (the benchmarked form)."""
+    from egorear_amd import configs, synth, train
+    from egorear_amd.estimator import EgoPoseFormerMVFEX
+    from egorear_amd.metrics import generate_target
+    B = 4
+    args = (synth.synth_images(B, 4, seed=11).to(DEV), synth.synth_coord_trans_mat(B).to(DEV), synth.synth_gt_pose(B).to(DEV),
+            generate_target(synth.synth_joint_px(B).to(DEV)).contiguous())
+
+    def one(overlap: bool):
+        saved = train.OVERLAP
+        train.OVERLAP = overlap
+        try:
+            net = EgoPoseFormerMVFEX(**copy.deepcopy(configs.pose3d_cfg("ego4view_rw")))
+            synth.load_synth(net, 42)
+            net = net.to(DEV)
+            seen = {"side": 0, "early": 0}
+            orig = train.Step.backward
+
+            def spy(self):
+                seen["side"] += sum(isinstance(f, train._OnSide) for f in self.tape)
+                seen["early"] += sum(isinstance(f, train._OnSide) and f.early for f in self.tape)
+                return orig(self)
+            train.Step.backward = spy
+            try:
+                S, (preds, hms, _) = train.forward_backward(net, *args)
+            finally:
+                train.Step.backward = orig
+            torch.cuda.synchronize()
+            grads = {k: v.clone() for k, v in S.pgrads.items()}
+            terms, outs = S.loss_terms.clone(), [p.clone() for p in preds] + [h.clone() for h in hms]
+            # ... and three optimisation steps with the third replayed from the captured graph: the parameters after them
+            tr = train.Trainer(net, use_graph=True)
+            for _ in range(4):
+                tr.step(*args)
+            torch.cuda.synchronize()
+            assert tr.graph is not None, "the step must have been captured"
+            params = {k: v.detach().clone() for k, v in net.named_parameters()}
+            return grads, terms, outs, params, seen
+        finally:
+            train.OVERLAP = saved
+    g1, t1, o1, p1, seen1 = one(False)
+    g2, t2, o2, p2, seen2 = one(True)
+    assert seen1["side"] == 0 and seen2["side"] > 40 and 0 < seen2["early"] < seen2["side"], (seen1, seen2)
+    assert torch.equal(t1, t2) and all(torch.equal(a, b) for a, b in zip(o1, o2))
+    assert g1.keys() == g2.keys() and all(torch.equal(g1[k], g2[k]) for k in g1), [k for k in g1 if not torch.equal(g1[k], g2[k])][:5]
+    assert all(torch.equal(p1[k], p2[k]) for k in p1), [k for k in p1 if not torch.equal(p1[k], p2[k])][:5]
