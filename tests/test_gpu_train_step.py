@@ -396,11 +396,13 @@ def test_training_step_syn_camera_against_the_oracle():
     assert tr.graph is not None and torch.isfinite(terms).all()
 
 
-def test_two_stream_reverse_pass_gives_the_one_stream_gradients_bit_for_bit():
+def test_two_stream_reverse_pass_gives_the_one_stream_gradients():
     """Round 6 (train.Step.backward): the detached heat-map heads and the refiners are leaves of the reverse pass and run on a second
     stream under the lifting head's / the encoders' launches, gradients that cross streams ordered through the gradient store.  Same
-    launches, same operands, another stream: every loss term, output and parameter gradient is BIT-identical to the one-stream step,
-    eagerly and as a captured hipGraph (the benchmarked form)."""
+    launches, same operands, another stream: the forward (deterministic) is BIT-identical, every parameter gradient agrees to the
+    noise of the sampling gradients' float atomics (two runs of the SAME step differ by that much: the bar of the eager-vs-graph test
+    above), eagerly and after four updates with the step replayed from its captured hipGraph (the benchmarked form).  A missing
+    cross-stream dependency would show as a gradient made from a half-written operand: errors of order one, not 1e-6."""
     from egorear_amd import configs, synth, train
     from egorear_amd.estimator import EgoPoseFormerMVFEX
     from egorear_amd.metrics import generate_target
@@ -442,7 +444,17 @@ def test_two_stream_reverse_pass_gives_the_one_stream_gradients_bit_for_bit():
             train.OVERLAP = saved
     g1, t1, o1, p1, seen1 = one(False)
     g2, t2, o2, p2, seen2 = one(True)
+    g3, t3, o3, p3, _ = one(False)        # the one-stream step against itself: the noise floor
     assert seen1["side"] == 0 and seen2["side"] > 40 and 0 < seen2["early"] < seen2["side"], (seen1, seen2)
     assert torch.equal(t1, t2) and all(torch.equal(a, b) for a, b in zip(o1, o2))
-    assert g1.keys() == g2.keys() and all(torch.equal(g1[k], g2[k]) for k in g1), [k for k in g1 if not torch.equal(g1[k], g2[k])][:5]
-    assert all(torch.equal(p1[k], p2[k]) for k in p1), [k for k in p1 if not torch.equal(p1[k], p2[k])][:5]
+    assert g1.keys() == g2.keys()
+
+    def worst(ga, gb):
+        gmax = max(float(v.double().norm()) for v in ga.values())
+        return max(float((ga[k].double() - gb[k].double()).norm()) / (float(ga[k].double().norm()) + 1e-6 * gmax) for k in ga)
+    noise, two = worst(g1, g3), worst(g1, g2)
+    print(f"worst per-tensor gradient deviation: two streams vs one {two:.2e}, one stream vs itself {noise:.2e}")
+    assert two <= max(4 * noise, 1e-5), (two, noise)
+    for k in p1:
+        if "k_proj.bias" not in k:
+            assert float(((p1[k] - p2[k]).abs() > 2e-4).float().mean()) < 0.02, k
