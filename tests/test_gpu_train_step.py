@@ -446,7 +446,8 @@ def test_two_stream_reverse_pass_gives_the_one_stream_gradients():
     g2, t2, o2, p2, seen2 = one(True)
     g3, t3, o3, p3, _ = one(False)        # the one-stream step against itself: the noise floor
     assert seen1["side"] == 0 and seen2["side"] > 40 and 0 < seen2["early"] < seen2["side"], (seen1, seen2)
-    assert torch.equal(t1, t2) and all(torch.equal(a, b) for a, b in zip(o1, o2))
+    assert all(torch.equal(a, b) for a, b in zip(o1, o2)), "the forward is deterministic: outputs must be bit-identical"
+    assert float(((t1 - t2).abs() / t1.abs()).max()) < 1e-12, (t1, t2)      # (the loss terms are sums by double atomics: order-dependent in the last bits)
     assert g1.keys() == g2.keys()
 
     def worst(ga, gb):
