@@ -474,6 +474,244 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* dy, const
     *reinterpret_cast<f32x4*>(dx + idx * 4) = acc;
 }
 
+// ------------------------------------------------------------------ the stem's BatchNorm + ReLU + MaxPool2d without its full-resolution tensors (round 6)
+// resnet.py:16-17 in training mode used to be four passes over the (n, 128, 128, 64) tensor forward (statistics, normalise + ReLU ->
+// y, max-pool -> pooled + slot) and seven backward (max-pool adjoint -> dy, then the two BatchNorm passes over dy, y, x).  The normalised
+// tensor y and the scattered gradient dy never need to exist: the pooling kernel normalises what it reads, the reverse pass gathers a
+// pixel's gradient from the (at most (k / stride)^2) windows that chose it and recomputes the ReLU mask from x - the same arithmetic, in
+// the same order, as scale_shift_kernel / maxpool_train_kernel / maxpool_bwd_kernel / bn_partial_kernel<true> / bn_bwd_apply_kernel
+// (the results are bit-identical to the separate launches; tests/test_gpu_train_kernels.py).
+struct pool_geom {
+    int h, w, ho, wo, k, stride, pad, ipg;      // ipg: images per BatchNorm group
+    int w_shift, hw_shift, c4_shift;            // FAST launches: w, h * w and c / 4 are powers of two
+};
+
+// FAST = MaxPool2d(3, 2, 1) on power-of-two image sides and channel counts (the stem): window bounds and pixel coordinates by shifts and
+// compile-time constants; otherwise the general arithmetic of maxpool_train_kernel / maxpool_bwd_kernel.  Same values either way.
+template <bool FAST>
+struct pool_ops {
+    static __device__ __forceinline__ int K(const pool_geom& P) { return FAST ? 3 : P.k; }
+    static __device__ __forceinline__ int S(const pool_geom& P) { return FAST ? 2 : P.stride; }
+    static __device__ __forceinline__ int PAD(const pool_geom& P) { return FAST ? 1 : P.pad; }
+    // row (pixel index over all images) -> image, y, x
+    static __device__ __forceinline__ void pixel(int64_t row, const pool_geom& P, int& img, int& iy, int& ix) {
+        if (FAST) {
+            const int r = (int)row;
+            img = r >> P.hw_shift;
+            const int pix = r & ((1 << P.hw_shift) - 1);
+            iy = pix >> P.w_shift;
+            ix = pix & ((1 << P.w_shift) - 1);
+        } else {
+            const int hw = P.h * P.w;
+            img = (int)(row / hw);
+            const int pix = (int)(row - (int64_t)img * hw);
+            iy = pix / P.w;
+            ix = pix - iy * P.w;
+        }
+    }
+};
+
+// normalised + rectified value exactly as scale_shift_kernel stores it
+__device__ __forceinline__ float bn_relu_value(float x, float a, float b) {
+    const float t = x * a + b;
+    return t > 0.f ? t : 0.f;
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* x, const float* alpha, const float* shift, float* y, uint8_t* slot,
+                                                              int n, int c4, pool_geom P) {
+    typedef pool_ops<FAST> O;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)n * P.ho * P.wo * c4;
+    if (idx >= total) return;
+    int cq, ox, oy, img;
+    if (FAST) {          // (ho, wo = h / 2, w / 2: powers of two as well)
+        const int i = (int)idx;
+        cq = i & (c4 - 1);
+        const int p = i >> P.c4_shift;
+        ox = p & (P.wo - 1);
+        oy = (p >> (P.w_shift - 1)) & (P.ho - 1);
+        img = p >> (P.hw_shift - 2);
+    } else {
+        cq = (int)(idx % c4);
+        int64_t p = idx / c4;
+        ox = (int)(p % P.wo);
+        p /= P.wo;
+        oy = (int)(p % P.ho);
+        img = (int)(p / P.ho);
+    }
+    const int g = img / P.ipg;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(alpha + (g * c4 + cq) * 4);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(shift + (g * c4 + cq) * 4);
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bs[4] = {0, 0, 0, 0};
+    bool first = true;
+    const int k = O::K(P), st = O::S(P), pd = O::PAD(P);
+#pragma unroll
+    for (int dy = 0; dy < (FAST ? 3 : k); ++dy) {
+        const int iy = oy * st - pd + dy;
+        if (iy < 0 || iy >= P.h) continue;
+#pragma unroll
+        for (int dx = 0; dx < (FAST ? 3 : k); ++dx) {
+            const int ix = ox * st - pd + dx;
+            if (ix < 0 || ix >= P.w) continue;
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (((int64_t)img * P.h + iy) * P.w + ix) * (c4 * 4) + cq * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = bn_relu_value(xv[i], a[i], b[i]);
+                if (first || v > best[i]) {  // first maximum in scan order (ATen max_pool2d), as maxpool_train_kernel
+                    best[i] = v;
+                    bs[i] = dy * k + dx;
+                }
+            }
+            first = false;
+        }
+    }
+    *reinterpret_cast<f32x4*>(y + idx * 4) = best;
+    *reinterpret_cast<uint32_t*>(slot + idx * 4) = (uint32_t)bs[0] | ((uint32_t)bs[1] << 8) | ((uint32_t)bs[2] << 16) | ((uint32_t)bs[3] << 24);
+}
+
+// gradient of the normalised + rectified tensor at one pixel, gathered from the pooled gradient (maxpool_bwd_kernel's loop, its order)
+template <bool FAST>
+__device__ __forceinline__ f32x4 pool_gather(const float* dpool, const uint8_t* slot, int img, int iy, int ix, int cq, int c4, const pool_geom& P) {
+    typedef pool_ops<FAST> O;
+    const int k = O::K(P), st = O::S(P), pd = O::PAD(P);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int oy0 = (iy + pd - k + 1 + st - 1);
+    oy0 = oy0 <= 0 ? 0 : oy0 / st;
+    int ox0 = (ix + pd - k + 1 + st - 1);
+    ox0 = ox0 <= 0 ? 0 : ox0 / st;
+    const int oy1 = min((iy + pd) / st, P.ho - 1), ox1 = min((ix + pd) / st, P.wo - 1);
+    for (int oy = oy0; oy <= oy1; ++oy)
+        for (int ox = ox0; ox <= ox1; ++ox) {
+            const int me = (iy - (oy * st - pd)) * k + (ix - (ox * st - pd));
+            const int64_t o = (((int64_t)img * P.ho + oy) * P.wo + ox) * c4 + cq;
+            const uint32_t sl = *reinterpret_cast<const uint32_t*>(slot + o * 4);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dpool + o * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if ((int)((sl >> (8 * i)) & 255u) == me) acc[i] += d[i];
+        }
+    return acc;
+}
+
+// bn_partial_kernel<true> with d = [x alpha + shift > 0] * (gathered pooled gradient): same lanes, same slabs, same accumulation order
+template <bool FAST>
+__global__ __launch_bounds__(256) void bn_pool_partial_kernel(const float* x, const float* dpool, const uint8_t* slot, const float* mean,
+                                                              const float* invstd, const float* alpha, const float* shift, int64_t rpg, int c,
+                                                              int nblk, double* ws, float* mm, pool_geom P) {
+    __shared__ double red[256 * 8];
+    float* const mred = reinterpret_cast<float*>(red);
+    float hi[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    const int g = blockIdx.y, blk = blockIdx.x;
+    const int c4 = c >> 2;
+    const int rpi = 256 / c4;
+    const int cl = threadIdx.x % c4, rl = threadIdx.x / c4;
+    const int64_t chunk = (rpg + nblk - 1) / nblk;
+    const int64_t r0 = (int64_t)blk * chunk, r1 = (r0 + chunk < rpg) ? r0 + chunk : rpg;
+    const int64_t base = (int64_t)g * rpg;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + g * c + cl * 4);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + g * c + cl * 4);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(alpha + g * c + cl * 4);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(shift + g * c + cl * 4);
+    for (int64_t r = r0 + rl; r < r1; r += rpi) {
+        const int64_t row = base + r;
+        const int64_t o = row * c + cl * 4;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + o);
+        int img, iy, ix;
+        pool_ops<FAST>::pixel(row, P, img, iy, ix);
+        f32x4 d = pool_gather<FAST>(dpool, slot, img, iy, ix, cl, c4, P);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = bn_relu_value(xv[i], a[i], b[i]) > 0.f ? d[i] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s[i] += (double)d[i];
+            q[i] += (double)d[i] * (double)((xv[i] - mu[i]) * is[i]);
+            hi[i] = fmaxf(hi[i], fabsf(d[i]));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        red[threadIdx.x * 8 + i] = s[i];
+        red[threadIdx.x * 8 + 4 + i] = q[i];
+    }
+    __syncthreads();
+    if (rl == 0) {
+        for (int k = 1; k < rpi; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s[i] += red[(k * c4 + cl) * 8 + i];
+                q[i] += red[(k * c4 + cl) * 8 + 4 + i];
+            }
+    }
+    if (mm) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mred[threadIdx.x * 8 + i] = INFINITY;
+            mred[threadIdx.x * 8 + 4 + i] = hi[i];
+        }
+        __syncthreads();
+        if (rl == 0) {
+            for (int k = 1; k < rpi; ++k)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hi[i] = fmaxf(hi[i], mred[(k * c4 + cl) * 8 + 4 + i]);
+            float* m_ = mm + ((int64_t)(g * nblk + blk) * 2) * c + cl * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                m_[i] = INFINITY;
+                m_[c + i] = hi[i];
+            }
+        }
+    }
+    if (rl == 0) {
+        double* o = ws + ((int64_t)(g * nblk + blk) * 2) * c + cl * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[i] = s[i];
+            o[c + i] = q[i];
+        }
+    }
+}
+
+// bn_bwd_apply_kernel with the same recomputed d
+template <bool FAST>
+__global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float* dpool, const uint8_t* slot, const float* x, const float* mean,
+                                                                const float* invstd, const float* alpha, const float* shift, const float* dgamma,
+                                                                const float* dbeta, float* dx, int64_t rpg, int c4, int64_t total4, pool_geom P) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total4) return;
+    int cq;
+    int64_t row;
+    if (FAST) {
+        cq = (int)idx & (c4 - 1);
+        row = idx >> P.c4_shift;
+    } else {
+        cq = (int)(idx % c4);
+        row = idx / c4;
+    }
+    int img, iy, ix;
+    pool_ops<FAST>::pixel(row, P, img, iy, ix);
+    const int g = img / P.ipg;
+    const int po = (g * c4 + cq) * 4;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + po), is = *reinterpret_cast<const f32x4*>(invstd + po);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(alpha + po), b = *reinterpret_cast<const f32x4*>(shift + po);
+    const f32x4 dg = *reinterpret_cast<const f32x4*>(dgamma + po), db = *reinterpret_cast<const f32x4*>(dbeta + po);
+    const float inv_n = 1.0f / (float)rpg;
+    f32x4 d = pool_gather<FAST>(dpool, slot, img, iy, ix, cq, c4, P);
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + idx * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = bn_relu_value(xv[i], a[i], b[i]) > 0.f ? d[i] : 0.f;
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float xh = (xv[i] - mu[i]) * is[i];
+        o[i] = a[i] * (d[i] - db[i] * inv_n - xh * (dg[i] * inv_n));
+    }
+    *reinterpret_cast<f32x4*>(dx + idx * 4) = o;
+}
+
 // ------------------------------------------------------------------ bilinear x2 (align_corners=True) backward: exact adjoint
 // of upsample2x_kernel in gather form (no atomics): every source pixel collects the destination pixels whose (i0, i1)
 // pair - computed with the forward's own arithmetic - touches it.
@@ -1025,6 +1263,66 @@ extern "C" int egr_bn_backward_ex_f32(const float* dy, const float* y, const flo
     const int64_t total4 = (int64_t)groups * rows_per_group * (c / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks(total4)), dim3(256), 0, s, dy, y, x, mean, invstd, alpha, dgamma, dbeta,
                        dx, dz_out, rows_per_group, c / 4, total4);
+    return egr_launch_status();
+}
+
+static int log2_exact(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return ((1 << l) == v) ? l : -1;
+}
+
+// fast: MaxPool2d(3, 2, 1), even power-of-two sides, power-of-two channel quads, 32-bit element indices
+static int pool_geom_ok(int n, int h, int w, int c, int groups, int k, int stride, int pad, pool_geom& P, bool& fast) {
+    if (n <= 0 || groups <= 0 || n % groups != 0 || h <= 0 || w <= 0 || c % 4 != 0 || k <= 0 || k > 15 || stride <= 0 || pad < 0 || 2 * pad > k) return 0;
+    P.h = h; P.w = w; P.k = k; P.stride = stride; P.pad = pad; P.ipg = n / groups;
+    P.ho = (h + 2 * pad - k) / stride + 1;
+    P.wo = (w + 2 * pad - k) / stride + 1;
+    P.w_shift = log2_exact(w);
+    P.hw_shift = (P.w_shift >= 0 && log2_exact(h) >= 0) ? P.w_shift + log2_exact(h) : -1;
+    P.c4_shift = log2_exact(c / 4);
+    fast = k == 3 && stride == 2 && pad == 1 && h >= 2 && w >= 2 && P.w_shift >= 1 && P.hw_shift >= 2 && P.c4_shift >= 0 &&
+           (int64_t)n * h * w * (c / 4) < (1LL << 31);
+    return P.ho > 0 && P.wo > 0 && (int64_t)n * h * w < (1LL << 31);
+}
+
+extern "C" int egr_bn_relu_maxpool_f32(const float* x, const float* alpha, const float* shift, float* y, uint8_t* slot, int32_t n, int32_t h,
+                                       int32_t w, int32_t c, int32_t groups, int32_t k, int32_t stride, int32_t pad, void* stream) {
+    if (!x || !alpha || !shift || !y || !slot) return EGR_ENULL;
+    pool_geom P;
+    bool fast = false;
+    if (!pool_geom_ok(n, h, w, c, groups, k, stride, pad, P, fast)) return EGR_EINVAL;
+    if ((((uintptr_t)x) | ((uintptr_t)alpha) | ((uintptr_t)shift) | ((uintptr_t)y)) & 15 || ((uintptr_t)slot & 3)) return EGR_EINVAL;
+    const int64_t total = (int64_t)n * P.ho * P.wo * (c / 4);
+    if (fast) hipLaunchKernelGGL(bn_relu_maxpool_kernel<true>, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, x, alpha, shift, y, slot, n, c / 4, P);
+    else hipLaunchKernelGGL(bn_relu_maxpool_kernel<false>, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, x, alpha, shift, y, slot, n, c / 4, P);
+    return egr_launch_status();
+}
+
+extern "C" int egr_bn_pool_backward_f32(const float* dpool, const uint8_t* slot, const float* x, const float* mean, const float* invstd,
+                                        const float* alpha, const float* shift, int32_t n, int32_t h, int32_t w, int32_t c, int32_t groups,
+                                        int32_t k, int32_t stride, int32_t pad, float* dgamma, float* dbeta, float* dx, double* workspace,
+                                        size_t workspace_doubles, const float* xhat_max, uint32_t* amax_dx, void* stream) {
+    if (!dpool || !slot || !x || !mean || !invstd || !alpha || !shift || !dgamma || !dbeta || !dx || !workspace) return EGR_ENULL;
+    pool_geom P;
+    bool fast = false;
+    if (!pool_geom_ok(n, h, w, c, groups, k, stride, pad, P, fast)) return EGR_EINVAL;
+    const int64_t rpg = (int64_t)P.ipg * h * w;
+    if (!bn_shape_ok(rpg, c, groups)) return EGR_EINVAL;
+    if (((uintptr_t)amax_dx & 3) || ((amax_dx != nullptr) != (xhat_max != nullptr))) return EGR_EINVAL;
+    if ((((uintptr_t)dpool) | ((uintptr_t)x) | ((uintptr_t)dx)) & 15 || ((uintptr_t)slot & 3)) return EGR_EINVAL;
+    const int nblk = egr_bn_blocks(rpg);
+    const size_t sums = (size_t)groups * nblk * 2 * c;
+    if (workspace_doubles < sums + (amax_dx ? sums / 2 : 0)) return EGR_EWORKSPACE;
+    float* mm = amax_dx ? reinterpret_cast<float*>(workspace + sums) : nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    if (fast) hipLaunchKernelGGL(bn_pool_partial_kernel<true>, dim3(nblk, groups), dim3(256), 0, s, x, dpool, slot, mean, invstd, alpha, shift, rpg, c, nblk, workspace, mm, P);
+    else hipLaunchKernelGGL(bn_pool_partial_kernel<false>, dim3(nblk, groups), dim3(256), 0, s, x, dpool, slot, mean, invstd, alpha, shift, rpg, c, nblk, workspace, mm, P);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((c + BN_CH - 1) / BN_CH, groups), dim3(256), 0, s, workspace, nblk, c, dgamma, dbeta, rpg,
+                       alpha, mm, xhat_max, amax_dx);
+    const int64_t total4 = (int64_t)groups * rpg * (c / 4);
+    if (fast) hipLaunchKernelGGL(bn_pool_bwd_apply_kernel<true>, dim3(nblocks(total4)), dim3(256), 0, s, dpool, slot, x, mean, invstd, alpha, shift, dgamma, dbeta, dx, rpg, c / 4, total4, P);
+    else hipLaunchKernelGGL(bn_pool_bwd_apply_kernel<false>, dim3(nblocks(total4)), dim3(256), 0, s, dpool, slot, x, mean, invstd, alpha, shift, dgamma, dbeta, dx, rpg, c / 4, total4, P);
     return egr_launch_status();
 }
 

@@ -19,7 +19,8 @@ TRAIN_EXPORTS = [
     "egr_gelu_f32", "egr_gelu_bwd_f32", "egr_rowmask_f32", "egr_fill_f32", "egr_maxpool_train_f32", "egr_maxpool_bwd_f32",
     "egr_upsample2x_bwd_f32", "egr_stem_wgrad_f32", "egr_planes_to_nhwc_f32", "egr_nhwc_to_planes_f32", "egr_stem_im2col_f32", "egr_layernorm_bwd_f32", "egr_joint_mha_bwd_f32",
     "egr_msda_gather_bwd_f32", "egr_colsum_f32", "egr_fold_rows_f32", "egr_jqa_sum_bwd_f32", "egr_rownorm_loss_f32",
-    "egr_sumsq_f32", "egr_adamw_f32", "egr_adamw_dev_f32", "egr_set4_f32", "egr_repack_f32",   # the last one is bound in egorear_amd.repack
+    "egr_sumsq_f32", "egr_adamw_f32", "egr_adamw_dev_f32", "egr_set4_f32", "egr_bn_relu_maxpool_f32", "egr_bn_pool_backward_f32",
+    "egr_repack_f32",   # the last one is bound in egorear_amd.repack
 ]
 
 
@@ -59,6 +60,8 @@ def _bind():
     lib.egr_adamw_f32.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, vp]
     lib.egr_set4_f32.argtypes = [vp, f32, f32, f32, f32, vp]
     lib.egr_adamw_dev_f32.argtypes = [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp, f32, vp]
+    lib.egr_bn_relu_maxpool_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.egr_bn_pool_backward_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp, vp, vp]
     for name in TRAIN_EXPORTS:
         if name != "egr_repack_f32":
             getattr(lib, name).restype = C.c_int32 if name == "egr_bn_blocks" else C.c_int
@@ -82,7 +85,7 @@ def _same(a: torch.Tensor, b: torch.Tensor, what: str):
 
 class BNCtx:
     """What the backward of one grouped BatchNorm needs: raw conv output, batch statistics, alpha."""
-    __slots__ = ("x", "mean", "invstd", "alpha", "rpg", "c", "groups", "xhat_max")
+    __slots__ = ("x", "mean", "invstd", "alpha", "rpg", "c", "groups", "xhat_max", "shift", "slot", "pool")
 
 
 def bn_workspace(device) -> torch.Tensor:
@@ -92,9 +95,11 @@ def bn_workspace(device) -> torch.Tensor:
 def bn_train(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, running_mean: Optional[torch.Tensor],
              running_var: Optional[torch.Tensor], groups: int, ws: torch.Tensor, *, res: Optional[torch.Tensor] = None,
              relu: bool = True, momentum: float = 0.1, eps: float = 1e-5, out: Optional[torch.Tensor] = None,
-             amax_out: Optional[torch.Tensor] = None, want_extremes: bool = False, slabs: Optional[int] = None):
+             amax_out: Optional[torch.Tensor] = None, want_extremes: bool = False, slabs: Optional[int] = None,
+             pool: Optional[tuple] = None):
     """x: dense (groups*n, h, w, c) raw conv output.  gamma/beta/running_*: (groups, c) contiguous (running_* updated in
-    place).  Returns (y, ctx)."""
+    place).  Returns (y, ctx).  pool = (k, stride, pad): the MaxPool2d behind BatchNorm + ReLU in the same pass (the stem) - y is the
+    POOLED tensor, the normalised one is never written (egr_bn_relu_maxpool_f32); bn_backward then takes the pooled gradient."""
     _dense(x, "bn input")
     c = x.shape[-1]
     rows = x.numel() // c
@@ -108,6 +113,9 @@ def bn_train(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, running_m
     ctx.x, ctx.rpg, ctx.c, ctx.groups = x, rpg, c, groups
     st = torch.empty((5, groups, c), device=x.device, dtype=torch.float32)
     ctx.mean, ctx.invstd, ctx.alpha, shift, ctx.xhat_max = st[0], st[1], st[2], st[3], st[4]
+    ctx.shift, ctx.slot, ctx.pool = shift, None, None
+    if pool is not None and (res is not None or not relu or x.dim() != 4):
+        raise RuntimeError("egorear_amd.train.bn_train: the pooled form is BatchNorm + ReLU + MaxPool2d on an NHWC tensor, no residual")
     # amax_out: the abs-max BOUND of y from the batch extremes (no pass over y); with a residual only when that carries a record
     res_rec = getattr(res, "_egr_amax", None) if res is not None else None
     if amax_out is not None and res is not None and res_rec is None:
@@ -129,6 +137,17 @@ def bn_train(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, running_m
                 _stream(), nbytes=4.0 * x.numel())
     if not ext:
         ctx.xhat_max = None
+    if pool is not None:
+        k, stride, pad = pool
+        n, h, w, _ = x.shape
+        ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+        y = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.float32)
+        ctx.slot, ctx.pool = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.uint8), (k, stride, pad)
+        _launch("egr_bn_relu_maxpool_f32", lib.egr_bn_relu_maxpool_f32, _p(x), _p(ctx.alpha), _p(shift), _p(y), _p(ctx.slot, torch.uint8), n, h, w, c,
+                groups, k, stride, pad, _stream(), nbytes=4.0 * x.numel() + 5.0 * y.numel())
+        if amax_out is not None:
+            y._egr_amax = amax_out          # a maximum of normalised values: the bound of the normalised tensor holds
+        return y, ctx
     y = out if out is not None else torch.empty_like(x)
     if res is not None:
         _same(res, x, "bn residual")
@@ -143,7 +162,25 @@ def bn_train(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, running_m
 def bn_backward(ctx: BNCtx, dy: torch.Tensor, y: Optional[torch.Tensor], ws: torch.Tensor, want_dz: bool = False,
                 amax_dx: Optional[torch.Tensor] = None):
     """dy: gradient w.r.t. the BN(+res)(+ReLU) output y (pass y=None when no ReLU follows).  Returns
-    (dx, dgamma (groups,c), dbeta (groups,c), dz | None) with dz = dy*[y>0], the gradient of the residual branch."""
+    (dx, dgamma (groups,c), dbeta (groups,c), dz | None) with dz = dy*[y>0], the gradient of the residual branch.
+    A ctx made with pool=...: dy is the gradient of the POOLED output (y is not needed: the mask is recomputed from x)."""
+    if ctx.pool is not None:
+        if tuple(dy.shape) != tuple(ctx.slot.shape) or want_dz:
+            raise RuntimeError("egorear_amd.train.bn_backward: pooled form: dy has the pooled shape, no residual branch")
+        _dense(dy, "bn backward dy")
+        k, stride, pad = ctx.pool
+        n, h, w, c = ctx.x.shape
+        dx = torch.empty_like(ctx.x)
+        dgb = torch.empty((2, ctx.groups, ctx.c), device=dy.device, dtype=torch.float32)
+        if amax_dx is not None and (ctx.xhat_max is None or ws.numel() < int(lib.egr_bn_blocks(ctx.rpg)) * ctx.groups * 3 * ctx.c):
+            amax_dx = None
+        _launch("egr_bn_backward_f32", lib.egr_bn_pool_backward_f32, _p(dy), _p(ctx.slot, torch.uint8), _p(ctx.x), _p(ctx.mean), _p(ctx.invstd),
+                _p(ctx.alpha), _p(ctx.shift), n, h, w, c, ctx.groups, k, stride, pad, _p(dgb[0]), _p(dgb[1]), _p(dx), _p(ws, torch.float64),
+                ws.numel(), _p(ctx.xhat_max) if amax_dx is not None else None, _p(amax_dx, torch.int32), _stream(),
+                nbytes=4.0 * ctx.x.numel() * 3 + 10.0 * dy.numel())
+        if amax_dx is not None:
+            dx._egr_amax = amax_dx
+        return dx, dgb[0], dgb[1], None
     _same(dy, ctx.x, "bn backward dy")
     _dense(dy, "bn backward dy")
     if y is not None:

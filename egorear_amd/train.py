@@ -58,6 +58,7 @@ BN_IN_CONV = os.environ.get("EGR_TRAIN_BN_IN_CONV", "1") != "0"
 # kernel time), and the small latency-bound launches of the heads sit in a different phase of the reverse pass than the large ones.
 # Forking only the small launches ("small") is no better (33.7 ms): the replay of a graph with ~100 cross-stream edges costs the host
 # 21 ms per step and the device follows it.
+STEM_FUSED = os.environ.get("EGR_TRAIN_STEM_FUSED", "1") != "0"   # the stem's BatchNorm + ReLU + max-pool as one forward / one reverse launch set
 OVERLAP = os.environ.get("EGR_TRAIN_OVERLAP", "1") != "0"       # the leaves of the reverse pass on a second stream (Step.backward)
 # which parts (bits): 1 = forward branches (own-view projection, refined heads), 2 = the detached heads' reverse pass, 4 = the refiners' reverse pass
 OVERLAP_PARTS = int(os.environ.get("EGR_TRAIN_OVERLAP_PARTS", "7"))
@@ -660,7 +661,10 @@ class Step:
         self.keep.append((base, view))
 
     # ---- BatchNorm (training mode), grouped ----------------------------------------------------------------------
-    def bn(self, x: torch.Tensor, bns: Sequence[nn.BatchNorm2d], res: Optional[torch.Tensor] = None, relu: bool = True) -> torch.Tensor:
+    def bn(self, x: torch.Tensor, bns: Sequence[nn.BatchNorm2d], res: Optional[torch.Tensor] = None, relu: bool = True,
+           pool: Optional[tuple] = None) -> torch.Tensor:
+        """pool = (k, stride, pad): the MaxPool2d that follows BatchNorm + ReLU evaluated in the same pass (the stem, STEM_FUSED): the
+        result is the pooled tensor; neither the normalised tensor nor the max-pool's scattered gradient is ever written."""
         G = len(bns)
         npk = norm_pack(self.cache, bns, True)
         gamma, beta, rm, rv = npk.gamma, npk.beta, npk.rm, npk.rv
@@ -670,21 +674,26 @@ class Step:
             x._egr_bn_slabs = None
         y, ctx = T.bn_train(x, gamma, beta, rm, rv, G, self.bnws, res=res, relu=relu, momentum=b0.momentum, eps=b0.eps, slabs=slabs,
                             amax_out=self.amax.new() if (self.amax is not None and TRAIN_BOUNDS) else None,
-                            want_extremes=self.amax is not None and TRAIN_BOUNDS)      # (the backward's bound needs max |xhat| even when y gets none)
+                            want_extremes=self.amax is not None and TRAIN_BOUNDS,      # (the backward's bound needs max |xhat| even when y gets none)
+                            pool=pool)
         # nn.BatchNorm2d buffer side effects of a training forward: the running statistics go back to the modules' buffers in one launch
         # at the end of the forward, the counters are incremented there in one multi-tensor launch (flush_buffers)
         self.bn_mods += list(bns)
         self.bn_dirty = True
 
-        if relu:
+        if relu and pool is None:
             self.relu_out.add(id(y))
 
         def bwd():
             dy = self.G.pop(y)
-            dzm = self.G.pop_masked(y) if relu else None
+            dzm = self.G.pop_masked(y) if (relu and pool is None) else None
             if dy is None and dzm is None:
                 return
-            if dzm is not None:      # (part of) the gradient arrived already masked: finish the sum, no mask inside the kernels
+            if pool is not None:     # dy: gradient of the pooled tensor; the ReLU mask is recomputed from x inside the launch
+                dx, dgam, dbet, _ = T.bn_backward(ctx, dy, None, self.bnws,
+                                                  amax_dx=self.amax.new() if (self.amax is not None and TRAIN_BOUNDS) else None)
+                dz = None
+            elif dzm is not None:      # (part of) the gradient arrived already masked: finish the sum, no mask inside the kernels
                 if dy is not None:
                     dzm = T.add(dzm, T.relu_bwd(dy, y))
                 dx, dgam, dbet, _ = T.bn_backward(ctx, dzm, None, self.bnws, want_dz=False,
@@ -901,8 +910,15 @@ def backbone_train(S: Step, encs, img: torch.Tensor, view0: int, nviews: int):
     if S.record:
         S._rec(bwd_stem)
     S.keep.append((x,))
-    x = S.bn(x, [t.layer_s2[1] for t in trunks], relu=True)
-    x = S.maxpool(x, 3, 2, 1)
+    mp = trunks[0].layer_s4[0]
+    mk = mp.kernel_size if isinstance(mp.kernel_size, int) else mp.kernel_size[0]
+    ms = mp.stride if isinstance(mp.stride, int) else mp.stride[0]
+    mpad = mp.padding if isinstance(mp.padding, int) else mp.padding[0]
+    if STEM_FUSED:       # BatchNorm + ReLU + MaxPool2d in one pass, their reverse pass without the full-resolution y / dy (egr_bn_relu_maxpool_f32)
+        x = S.bn(x, [t.layer_s2[1] for t in trunks], relu=True, pool=(mk, ms, mpad))
+    else:
+        x = S.bn(x, [t.layer_s2[1] for t in trunks], relu=True)
+        x = S.maxpool(x, mk, ms, mpad)
     pyramid = []
     stages = [(t.layer_s4[1], t.layer_s8, t.layer_s16, t.layer_s32) for t in trunks]
     for si in range(4):

@@ -54,6 +54,20 @@ int egr_maxpool_bwd_f32(const float* dy, const uint8_t* slot, float* dx, int32_t
 int egr_upsample2x_bwd_f32(const float* dy, const float* y, float* dx, int32_t n, int32_t h, int32_t w, int32_t c,
                            void* stream);
 
+/* ---- the stem's BatchNorm2d(train) + ReLU + MaxPool2d(3, 2, 1) (models/backbones/resnet.py:16-17) without its full-resolution
+ * tensors (round 6).  Forward: x = raw conv output (n, h, w, c), n = groups * images per group; alpha / shift (groups, c) from
+ * egr_bn_stats_ex_f32 / egr_bn_finalize_f32; y (n, ho, wo, c) = maxpool(relu(alpha x + shift)) and the arg-max window slot of every
+ * output element - bit-identical to egr_scale_shift_f32(relu) followed by egr_maxpool_train_f32, the normalised tensor is never written.
+ * Backward: dpool = gradient of y; per input pixel the gradient of the normalised + rectified tensor is gathered from the windows that
+ * chose it and masked by [alpha x + shift > 0]; dgamma / dbeta (groups, c) and dx (n, h, w, c) - bit-identical to egr_maxpool_bwd_f32
+ * followed by egr_bn_backward_ex_f32(dy, y, x, ...), neither dy nor y exists.  workspace as egr_bn_backward_ex_f32. */
+int egr_bn_relu_maxpool_f32(const float* x, const float* alpha, const float* shift, float* y, uint8_t* slot, int32_t n, int32_t h,
+                            int32_t w, int32_t c, int32_t groups, int32_t k, int32_t stride, int32_t pad, void* stream);
+int egr_bn_pool_backward_f32(const float* dpool, const uint8_t* slot, const float* x, const float* mean, const float* invstd,
+                             const float* alpha, const float* shift, int32_t n, int32_t h, int32_t w, int32_t c, int32_t groups,
+                             int32_t k, int32_t stride, int32_t pad, float* dgamma, float* dbeta, float* dx, double* workspace,
+                             size_t workspace_doubles, const float* xhat_max, uint32_t* amax_dx, void* stream);
+
 /* ---- layout changes at the boundary: (n, c, hw) channel-major planes <-> (n, hw, cpad) channels-last, zero padded.
  * nmap places image n of the channel-major side (the (B,V,15,64,64) heat maps). */
 int egr_planes_to_nhwc_f32(const float* planes, int32_t n_inner, int64_t stride_inner, int64_t stride_outer, float* y,

@@ -512,3 +512,52 @@ def test_tiled_transpose(rows, cols):
     dst = torch.full((cols, rows), -1.0, device=DEV)
     T.transpose_into(dst, src)
     assert torch.equal(dst, src.t())
+
+
+@pytest.mark.parametrize("c,n,h,w,groups,pool", [(64, 4, 32, 32, 2, (3, 2, 1)), (64, 3, 20, 28, 1, (3, 2, 1)), (128, 2, 16, 16, 2, (2, 2, 0))])
+def test_stem_batchnorm_relu_maxpool_in_one_pass(c, n, h, w, groups, pool):
+    """egr_bn_relu_maxpool_f32 / egr_bn_pool_backward_f32 (round 6; resnet.py:16-17 in training mode): BatchNorm(train) + ReLU +
+    MaxPool2d without the normalised tensor y and without the max-pool's scattered gradient dy.  Against torch autograd in float64, and
+    BIT-identical to the separate launches it replaces (scale-shift -> max-pool with slots; max-pool adjoint -> BatchNorm backward with
+    the ReLU mask taken from y) - pooled output, slots, dx, dgamma, dbeta and the abs-max records."""
+    from egorear_amd import hip_train as T
+    from egorear_amd.hip import Img
+    k, s, p = pool
+    ws = T.bn_workspace(DEV)
+    x = rnd(groups * n, c, h, w, seed=1) * 2 + 0.3
+    x[0, :, 3:6, 3:6] = -5.0                                     # a window whose values are all negative: relu -> a tie at zero
+    x[1, :, 4, 4] = x[1, :, 4, 5]                                # ... and a positive tie inside a window (first in scan order wins)
+    gamma, beta = rnd(groups, c, seed=3) + 1.5, rnd(groups, c, seed=4)
+    ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    dyp = rnd(groups * n, c, ho, wo, seed=7)
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yref = torch.cat([F.max_pool2d(F.relu(F.batch_norm(xr[g * n:(g + 1) * n], None, None, gr[g], br[g], True, 0.1, 1e-5)), k, s, p) for g in range(groups)])
+    dx_ref, dg_ref, db_ref = torch.autograd.grad(yref, (xr, gr, br), dyp.double())
+    xd, gd, bd, dyd = nhwc(x).to(DEV), gamma.to(DEV), beta.to(DEV), nhwc(dyp).to(DEV)
+
+    def recs():
+        return torch.zeros(64, dtype=torch.int32, device=DEV), torch.zeros(64, dtype=torch.int32, device=DEV)
+    # --- the separate launches
+    r_y, r_dx = recs()
+    y_full, ctx_a = T.bn_train(xd, gd, bd, None, None, groups, ws, relu=True, amax_out=r_y, want_extremes=True)
+    pooled_a, slot_a = T.maxpool_train(Img(y_full), k, s, p)
+    dy_full = T.maxpool_bwd(dyd, slot_a, (h, w), k, s, p)
+    dx_a, dg_a, db_a, _ = T.bn_backward(ctx_a, dy_full, y_full, ws, amax_dx=r_dx)
+    # --- one pass
+    q_y, q_dx = recs()
+    pooled_b, ctx_b = T.bn_train(xd, gd, bd, None, None, groups, ws, relu=True, amax_out=q_y, want_extremes=True, pool=pool)
+    dx_b, dg_b, db_b, _ = T.bn_backward(ctx_b, dyd, None, ws, amax_dx=q_dx)
+    torch.cuda.synchronize()
+    close(pooled_b.permute(0, 3, 1, 2), yref, what="pooled")
+    close(dx_b.permute(0, 3, 1, 2), dx_ref, rel=1e-4, what="dx")
+    close(dg_b, dg_ref, rel=1e-4, what="dgamma")
+    close(db_b, db_ref, rel=1e-4, what="dbeta")
+    assert torch.equal(pooled_a.t, pooled_b) and torch.equal(slot_a, ctx_b.slot)
+    assert torch.equal(dx_a, dx_b) and torch.equal(dg_a, dg_b) and torch.equal(db_a, db_b)
+    assert torch.equal(r_y, q_y) and torch.equal(r_dx, q_dx) and pooled_b._egr_amax is q_y and dx_b._egr_amax is q_dx
+    # the pooled form has no residual branch and no un-rectified variant
+    with pytest.raises(RuntimeError):
+        T.bn_train(xd, gd, bd, None, None, groups, ws, relu=False, pool=pool)
+    with pytest.raises(RuntimeError):
+        T.bn_backward(ctx_b, dy_full, None, ws)              # a full-resolution gradient for a pooled context

@@ -271,3 +271,26 @@ def test_token_chain_entries_refuse_before_any_launch():
     assert layer(b_h0=None) == hip.ENULL and layer(h0_out=None) == hip.ENULL
     assert layer(C=128) == hip.EINVAL and layer(h0_n=32) == hip.EINVAL and layer(h0_out=P + 4) == hip.EINVAL
     assert layer(w_r0=P, b_r0=P, w_r2=P, b_r2=P, anchors3d=P, pred_out=P) == hip.EINVAL
+
+
+def test_stem_pooled_batchnorm_entries_refuse_before_any_launch():
+    """egr_bn_relu_maxpool_f32 / egr_bn_pool_backward_f32 (round 6): every refusal is a return code BEFORE a launch - raw C ABI, fake aligned
+    pointers, no GPU."""
+    from egorear_amd import hip
+    from egorear_amd import hip_train as T          # binds the argtypes
+    lib = hip.lib
+    P = 0x10000
+    fwd = lambda **kw: lib.egr_bn_relu_maxpool_f32(*[kw.get(k, d) for k, d in (("x", P), ("alpha", P), ("shift", P), ("y", P), ("slot", P), ("n", 4),    # noqa: E731
+                                                     ("h", 8), ("w", 8), ("c", 64), ("groups", 2), ("k", 3), ("stride", 2), ("pad", 1), ("stream", None))])
+    assert fwd(x=None) == hip.ENULL and fwd(slot=None) == hip.ENULL
+    assert fwd(n=3) == hip.EINVAL                      # images not divisible by groups
+    assert fwd(c=62) == hip.EINVAL and fwd(k=0) == hip.EINVAL and fwd(pad=2) == hip.EINVAL and fwd(x=P + 4) == hip.EINVAL
+    bwd = lambda **kw: lib.egr_bn_pool_backward_f32(*[kw.get(k, d) for k, d in (("dpool", P), ("slot", P), ("x", P), ("mean", P), ("invstd", P),    # noqa: E731
+                                                      ("alpha", P), ("shift", P), ("n", 4), ("h", 8), ("w", 8), ("c", 64), ("groups", 2), ("k", 3), ("stride", 2),
+                                                      ("pad", 1), ("dgamma", P), ("dbeta", P), ("dx", P), ("ws", P), ("wsn", 1 << 20), ("xhat", None),
+                                                      ("amax", None), ("stream", None))])
+    assert bwd(dx=None) == hip.ENULL and bwd(ws=None) == hip.ENULL and bwd(shift=None) == hip.ENULL
+    assert bwd(c=48) == hip.EINVAL                     # BatchNorm kernels: power-of-two channel counts from 64
+    assert bwd(amax=P) == hip.EINVAL                   # a record without the batch extremes
+    assert bwd(wsn=16) == hip.EWORKSPACE
+    assert bwd(n=5) == hip.EINVAL
