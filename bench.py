@@ -674,10 +674,15 @@ def train_leg(args, dev, rank: int, world: int, backend: str):
         return None
     kernels = {}
     if world == 1:   # per-kernel breakdown of one more (eager, instrumented) step; single process only: no collective inside
-        hip.PROFILE = []
-        tr._run(img, ctm, gt_pose, gt_hm, update=True)
-        torch.cuda.synchronize()
-        prof, hip.PROFILE = hip.PROFILE, None
+        # (on ONE stream: with the two-stream reverse pass a launch's event pair would also time whatever the other stream runs beside it)
+        overlap, train.OVERLAP = train.OVERLAP, False
+        try:
+            hip.PROFILE = []
+            tr._run(img, ctm, gt_pose, gt_hm, update=True)
+            torch.cuda.synchronize()
+            prof, hip.PROFILE = hip.PROFILE, None
+        finally:
+            train.OVERLAP = overlap
         for name, s, e, flops, nbytes, tag in prof:
             key = _kernel_key(name, tag)
             k = kernels.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})

@@ -49,10 +49,14 @@ def main():
     print(f"host enqueue time {host / a.steps * 1e3:.2f} ms/step")
     print(f"batch {B}: {dt * 1e3:.2f} ms/step, {B / dt:.1f} frames/s, loss {float(terms.sum()):.4f}, mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     # per-kernel breakdown of one step
+    # eager and instrumented even when the timed steps were graph replays - and on ONE stream: with the two-stream reverse pass a
+    # launch's event pair would also time whatever the other stream runs beside it
+    overlap, train.OVERLAP = train.OVERLAP, False
     hip.PROFILE = []
-    tr._run(img, ctm, gt_pose, gt_hm, update=True)      # eager and instrumented even when the timed steps were graph replays
+    tr._run(img, ctm, gt_pose, gt_hm, update=True)
     torch.cuda.synchronize()
     prof, hip.PROFILE = hip.PROFILE, None
+    train.OVERLAP = overlap
     if a.dump:
         with open(a.dump, "w") as f:
             for i, (name, s, e, fl, nb, tag) in enumerate(prof):
