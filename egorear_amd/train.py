@@ -62,7 +62,9 @@ STEM_FUSED = os.environ.get("EGR_TRAIN_STEM_FUSED", "1") != "0"   # the stem's B
 OVERLAP = os.environ.get("EGR_TRAIN_OVERLAP", "1") != "0"       # the leaves of the reverse pass on a second stream (Step.backward)
 # which parts (bits): 1 = forward branches (own-view projection, refined heads), 2 = the detached heads' reverse pass, 4 = the refiners' reverse pass
 # (measured and removed: the main stream's ~50 small weight gradients forked onto the side stream one by one - 25.4-25.7 -> 27.2-27.4 ms: every
-# cross-stream edge of a hipGraph costs more than the 10-us launch it takes off the chain)
+# cross-stream edge of a hipGraph costs more than the 10-us launch it takes off the chain; the lifting head's ~30 PARKED and handed over as one
+# batch at its stage marker - 26.3 ms: small launches queued on the side stream crawl beside the encoders' persistent convolutions and
+# hold up the refiners' reverse pass behind them, the final join then waits for the side stream)
 OVERLAP_PARTS = int(os.environ.get("EGR_TRAIN_OVERLAP_PARTS", "7"))
 SIDE_WGRAD = os.environ.get("EGR_TRAIN_SIDE_STREAM", "0")          # "0" | "small" (only launches below the split threshold) | "1" (all)
 SIDE_WGRAD = SIDE_WGRAD if SIDE_WGRAD in ("small", "1") else ""
