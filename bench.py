@@ -19,11 +19,17 @@ Extra objects on the line:
                  the same figures as scalars: frac_conv3x3, conv3x3_ms, conv1x1_GBps, frac_conv1x1_hbm, conv1x1_ms;
                  traffic (+ traffic_commit / traffic_file) = HBM bytes per launch replayed from the committed PMC passes.
   exact_leg    — the same forward in exact operand arithmetic (bf16x3, six products), 50 steps: prices the 22-bit trade.
-  cpu_baseline — the CPU oracle (oracle/egorear_oracle.py, a PyTorch-CPU port of the reference path)
-                 timed on this box's host cores on a bounded sample of the same workload.
-  parity_vs_cpu_oracle — the metric's "MPJPE vs ref" half: the oracle's warm-up forward of that sample checks the HIP
-                 path's output on the same frames (arg-max indices equal, largest 3-D joint deviation in cm,
-                 MPJPE of both against the seeded synthetic ground truth).
+  one_lane     — the same forward as ONE captured graph replayed back to back (what the second lane's overlap is worth).
+  cpu_baseline — the CPU oracle (oracle/egorear_oracle.py, a PyTorch-CPU port of the reference path) timed on this box's host
+                 cores on a bounded sample of the same workload: distinct frames, value = batch / MEDIAN forward time after two
+                 warm-ups; torch_num_threads, host_loadavg_1min and value_least_disturbed say how loaded the (shared) host was.
+  parity_vs_cpu_oracle — the metric's "MPJPE vs ref" half as a CENSUS over that same sample (oracle/census.py): the HIP path at the
+                 benchmarked batch size and launch policy against every oracle forward - all arg-maxes of both heat-map sets, the
+                 valid masks, the four pose sets, the tie exposure (top-2 gaps), every mismatch with the oracle-side gap and a
+                 float64 referee; MPJPE of both against the seeded synthetic ground truth.
+  scalars      — every leg once more as scalar keys (exact_fps, steady_fps, one_lane_fps, cfg2_fps, cfg3_fps, train_ms_per_step,
+                 train_frac, parity_frames, argmax_mismatches[_outside_rounding], max_joint_err_cm, frac_conv3x3, ...): at the top
+                 level, last in the line, and at the front of `roofline` (the driver's record keeps roofline / cpu_baseline / config).
   ranks        — world size, backend, and one record per rank (device index, PCI address / UUID, host, own frames/s): an N > 1 line
                  can be checked for one distinct GPU per rank (the run refuses to start otherwise unless EGR_ALLOW_SHARED_GPU=1).
   configs      — the other single-GPU configurations BASELINE.json lists, timed separately at N = 1 (never part of `value`):
