@@ -978,15 +978,21 @@ def _pack_layer(S: Step, layers, pres, poss) -> _LayerPack:
         cf = L.Wfold.shape[2]
         L.cf = cf
         # per-head forward operand (G, dh_pad, cf) and data-gradient operand (G, cf, dh) of the folded projection
-        L.head_w = [torch.stack([_pad_rows(L.Wfold[g, h * L.dh:(h + 1) * L.dh].contiguous()) for g in range(L.G)]).contiguous() for h in range(L.heads)]
-        L.head_shift = [torch.stack([_pad_vec(L.cfold[g, h * L.dh:(h + 1) * L.dh], L.dh) for g in range(L.G)]).contiguous() for h in range(L.heads)]
-        L.head_wt = [torch.stack([L.Wfold[g, h * L.dh:(h + 1) * L.dh].t().contiguous() for g in range(L.G)]).contiguous() for h in range(L.heads)]
-        # one query set (the lifting head): the heads of a layer run as the GROUPS of one launch (channel slices of one batch)
         L.heads_grouped = L.G == 1 and L.dh % 4 == 0 and cf % 4 == 0 and L.dh % 32 == 0
-        if L.heads_grouped:
-            L.head_w_all = torch.cat(L.head_w, 0).contiguous()            # (heads, dh, cf)
-            L.head_shift_all = torch.cat(L.head_shift, 0).contiguous()    # (heads, dh)
-            L.head_wt_all = torch.cat(L.head_wt, 0).contiguous()          # (heads, cf, dh)
+        if L.dh % 32 == 0:
+            # (no row padding needed) three strided copies per layer instead of one slice + pad + stack per (head, query set) - the
+            # per-step parameter glue of the four layer packs was ~170 torch launches in front of the token chains
+            W4 = L.Wfold.view(L.G, L.heads, L.dh, cf)
+            Wh = W4.transpose(0, 1).contiguous()                          # (heads, G, dh, cf)
+            Wht = W4.permute(1, 0, 3, 2).contiguous()                     # (heads, G, cf, dh)
+            sh = L.cfold.view(L.G, L.heads, L.dh).transpose(0, 1).contiguous()     # (heads, G, dh)
+            L.head_w, L.head_shift, L.head_wt = list(Wh.unbind(0)), list(sh.unbind(0)), list(Wht.unbind(0))
+            if L.heads_grouped:      # one query set (the lifting head): the heads of a layer run as the GROUPS of one launch
+                L.head_w_all, L.head_shift_all, L.head_wt_all = Wh.view(L.heads, L.dh, cf), sh.view(L.heads, L.dh), Wht.view(L.heads, cf, L.dh)
+        else:
+            L.head_w = [torch.stack([_pad_rows(L.Wfold[g, h * L.dh:(h + 1) * L.dh].contiguous()) for g in range(L.G)]).contiguous() for h in range(L.heads)]
+            L.head_shift = [torch.stack([_pad_vec(L.cfold[g, h * L.dh:(h + 1) * L.dh], L.dh) for g in range(L.G)]).contiguous() for h in range(L.heads)]
+            L.head_wt = [torch.stack([L.Wfold[g, h * L.dh:(h + 1) * L.dh].t().contiguous() for g in range(L.G)]).contiguous() for h in range(L.heads)]
     C_ = L.C
     if poss[0] is not None:
         # projected positional embeddings (G, V, hw, C): value_proj's forward operand without its bias (c_fold carries it) - was a

@@ -1,5 +1,6 @@
-mkdir -p gpurun_out/r06h
-for parts in 7 15 7 15; do
-  EGR_TRAIN_OVERLAP_PARTS=$parts python tools/train_bench.py --batch 32 --graph --steps 10 > gpurun_out/r06h/tb_p$parts.txt 2>&1
-  echo "parts=$parts rc=$? $(grep 'ms/step, ' gpurun_out/r06h/tb_p$parts.txt)"
+mkdir -p gpurun_out/r06k
+for i in 1 2; do
+  python tools/train_bench.py --batch 32 --graph --steps 10 > gpurun_out/r06k/tb_$i.txt 2>&1
+  echo "run=$i rc=$? $(grep 'ms/step, ' gpurun_out/r06k/tb_$i.txt)"
 done
+python -m pytest tests/test_gpu_train_step.py tests/test_gpu_train_b32.py tests/test_gpu_train_stages.py -x -q -m gpu > gpurun_out/r06k/t.log 2>&1; tail -3 gpurun_out/r06k/t.log
