@@ -41,8 +41,8 @@ def test_512_frames_at_the_benchmarked_arithmetic_vs_the_cpu_oracle(calib_dir):
     print("census:", json.dumps(acc))
     assert acc["frames"] == 512 and acc["argmax_compared"] == 512 * 4 * 15 * 2
     assert acc["valid_true"] > 0 and acc["valid_false"] > 0, "the sample must put maxima on both sides of the 0.5 threshold"
-    # Measured at round-6 HEAD: 0 mismatches on these 512 frames (bench.py's 256 frames of other seeds: 1, in a map whose two best
-    # positions are 2e-7 apart in the oracle).  72 of the 61 440 maps have a top-2 gap below 1e-5 and 3 below 1e-6, while the float32
+    # Measured at round-6 HEAD: 0 mismatches on these 512 frames (a 2048-frame run over other seeds, profiles/r06_v1_census_2048.json: 2,
+    # in maps whose two best positions are 8.9e-8 apart in the oracle).  72 of the 61 440 maps have a top-2 gap below 1e-5 and 3 below 1e-6, while the float32
     # oracle itself sits up to 1.5e-6 from its own float64 evaluation - such a map's arg-max is decided by the reference's summation
     # order.  So: nothing may disagree beyond that rounding class, and whatever disagrees inside it is put before the float64 referee.
     assert acc["argmax_mismatches_outside_rounding"] == 0, acc
