@@ -119,10 +119,10 @@ def compare_chunk(g, o, sd, img: torch.Tensor, O, first_frame: int = 0) -> Dict[
     return c
 
 
-def gpu_outputs(net, img_dev: torch.Tensor) -> Dict[str, object]:
+def gpu_outputs(net, img_dev: torch.Tensor, ctm_dev: Optional[torch.Tensor] = None) -> Dict[str, object]:
     """One forward of the drop-in EgoPoseFormerMVFEX on the device; everything the census compares, on the CPU."""
     with torch.no_grad():
-        preds, hms = net(img_dev)
+        preds, hms = net(img_dev) if ctm_dev is None else net(img_dev, ctm_dev)
     aux = net.__dict__["_egr_last_aux"]
     vp = aux["pose3d"].get("anchors_valid")
     return {"preds": [p.cpu() for p in preds], "hms": [h.cpu() for h in hms], "argmax_idx": aux["heatmap"]["argmax_idx"].cpu(),
@@ -130,9 +130,9 @@ def gpu_outputs(net, img_dev: torch.Tensor) -> Dict[str, object]:
             "valid_p": vp.cpu() if vp is not None else None}
 
 
-def oracle_outputs(sd, cams, img: torch.Tensor, O) -> Dict[str, object]:
+def oracle_outputs(sd, cams, img: torch.Tensor, O, ctm: Optional[torch.Tensor] = None) -> Dict[str, object]:
     with torch.no_grad():
-        preds, hms, aux = O.mvfex_forward(sd, cams, img)
+        preds, hms, aux = O.mvfex_forward(sd, cams, img, ctm)
     vp = aux["pose3d"].get("anchors_valid")
     return {"preds": preds, "hms": hms, "argmax_idx": aux["heatmap"]["argmax_idx"], "valid_h": aux["heatmap"]["anchors_valid"],
             "maxvals": aux["heatmap"]["maxvals"], "valid_p": vp}
@@ -143,16 +143,17 @@ def _slice(d: Dict[str, object], lo: int, hi: int) -> Dict[str, object]:
 
 
 def run(net, sd, cams, O, batches: List[torch.Tensor], dev, oracle_batch: int = 8, log: Optional[Callable[[str], None]] = None,
-        times: Optional[List[float]] = None) -> Dict[str, float]:
+        times: Optional[List[float]] = None, ctms: Optional[List[torch.Tensor]] = None) -> Dict[str, float]:
     """Each element of `batches` is one device batch (the benchmarked size, e.g. 64 frames): ONE HIP forward per batch under the shipped
     launch policy, the oracle over the same frames in chunks of `oracle_batch`.  `times` collects the oracle's per-chunk seconds."""
     acc = None
     for bi, img in enumerate(batches):
-        g = gpu_outputs(net, img.to(dev))
+        ctm = ctms[bi] if ctms is not None else None       # (ego4view_rw: per-frame coord_trans_mat)
+        g = gpu_outputs(net, img.to(dev), ctm.to(dev) if ctm is not None else None)
         for lo in range(0, img.shape[0], oracle_batch):
             hi = min(lo + oracle_batch, img.shape[0])
             t0 = time.perf_counter()
-            o = oracle_outputs(sd, cams, img[lo:hi], O)
+            o = oracle_outputs(sd, cams, img[lo:hi], O, ctm[lo:hi] if ctm is not None else None)
             if times is not None:
                 times.append(time.perf_counter() - t0)
             acc = merge(acc, compare_chunk(_slice(g, lo, hi), o, sd, img[lo:hi], O, first_frame=bi * img.shape[0] + lo))
