@@ -294,3 +294,36 @@ def test_stem_pooled_batchnorm_entries_refuse_before_any_launch():
     assert bwd(amax=P) == hip.EINVAL                   # a record without the batch extremes
     assert bwd(wsn=16) == hip.EWORKSPACE
     assert bwd(n=5) == hip.EINVAL
+
+
+def test_launch_policy_from_environment_and_overrides():
+    """hip.LaunchPolicy (round 6): the environment -> fields mapping of the process default, the thread-local override and the
+    exact-arithmetic variant - no GPU involved."""
+    import threading
+    from egorear_amd import engine, hip
+    p = hip.LaunchPolicy.from_env({})
+    assert (p.w_format, p.h2, p.layer_h2, p.x6_min_rows, p.x6_min_flops, p.chain, p.chain_big_min_rows, p.wgrad_x6) == ("f16x2", True, True, 4096, 5e8, True, 65536, True)
+    q = hip.LaunchPolicy.from_env({"EGR_W_FORMAT": "bf16x3", "EGR_X6_MIN_ROWS": "0", "EGR_CONV_CHAIN": "0", "EGR_FUSED_QUERY": "0"})
+    assert (q.w_format, q.h2, q.layer_h2, q.x6_min_rows, q.chain, q.fused_query, q.wgrad_x6) == ("bf16x3", False, False, 0, False, False, True)
+    assert hip.LaunchPolicy.from_env({"EGR_W_FORMAT": "f32"}).wgrad_x6 is False and hip.LaunchPolicy.from_env({"EGR_LAYER_H2": "0"}).layer_h2 is False
+    e = p.exact()
+    assert (e.w_format, e.h2, e.layer_h2) == ("bf16x3", False, False) and p.h2 is True          # a copy: the original is untouched
+    default = hip.POLICY
+    seen = {}
+
+    def other_thread():
+        seen["h2"], seen["fmt"] = hip.H2, engine.W_FORMAT          # another thread does not see this thread's override
+    with hip.use_policy(e):
+        assert hip.H2 is False and engine.W_FORMAT == "bf16x3" and engine.LAYER_H2 is False and hip.policy() is e
+        t = threading.Thread(target=other_thread)
+        t.start()
+        t.join()
+        with hip.use_policy(None):                                   # None: no change
+            assert hip.policy() is e
+    assert hip.policy() is default and (seen["h2"], seen["fmt"]) == (default.h2, default.w_format)
+    saved = hip.X6_MIN_ROWS
+    try:
+        hip.X6_MIN_ROWS = 123                                        # assigning the historical attribute changes the process default
+        assert hip.POLICY.x6_min_rows == 123 and hip.policy().x6_min_rows == 123
+    finally:
+        hip.X6_MIN_ROWS = saved
