@@ -58,6 +58,7 @@ BN_IN_CONV = os.environ.get("EGR_TRAIN_BN_IN_CONV", "1") != "0"
 # kernel time), and the small latency-bound launches of the heads sit in a different phase of the reverse pass than the large ones.
 # Forking only the small launches ("small") is no better (33.7 ms): the replay of a graph with ~100 cross-stream edges costs the host
 # 21 ms per step and the device follows it.
+WGRAD_DIRECT = os.environ.get("EGR_TRAIN_WGRAD_DIRECT", "1") != "0"   # aligned single Linear layers: the weight gradient lands in the flat gradient buffer itself
 STEM_FUSED = os.environ.get("EGR_TRAIN_STEM_FUSED", "1") != "0"   # the stem's BatchNorm + ReLU + max-pool as one forward / one reverse launch set
 OVERLAP = os.environ.get("EGR_TRAIN_OVERLAP", "1") != "0"       # the leaves of the reverse pass on a second stream (Step.backward)
 # which parts (bits): 1 = forward branches (own-view projection, refined heads), 2 = the detached heads' reverse pass, 4 = the refiners' reverse pass
@@ -558,9 +559,17 @@ class Step:
         """Weight / bias gradients of every group.  x4 (G*n, h, w, cin_pad), dz4 (G*n, ho, wo, cout_pad) dense."""
         xi, di = Img(x4), Img(dz4)
         big = hip.wgrad_is_split(xi, di, p.kh, p.kw, p.groups)
+        # a plain, unpadded single Linear / 1x1 conv: the packed gradient IS the parameter's layout - written straight into its place in
+        # the flat gradient buffer, no unpack copy (mlp_pred.0: 268 MB read + 268 MB written by the step's repack launch)
+        direct = None
+        if (WGRAD_DIRECT and p.groups == 1 and len(p.wmeta[0]) == 1 and p.kh * p.kw == 1 and p.cin_pad == p.cin and p.cout_pad == p.cout
+                and p.wmeta[0][0][2] == 0 and p.wmeta[0][0][3] == p.cin and not SIDE_WGRAD):
+            dst = self.gdst(p.wmeta[0][0][0])
+            if dst.is_contiguous() and dst.numel() == p.cout * p.cin and dst.data_ptr() % 16 == 0:
+                direct = dst.view(p.cout, p.cin)
         if not SIDE_WGRAD or self.side is None or (big and SIDE_WGRAD == "small"):
             dws, dbs = hip.conv2d_wgrad(xi, di, p.kh, p.kw, p.stride, p.pad, self.ws, want_bias=p.bmeta is not None, groups=p.groups,
-                                        amax_arena=self.amax)
+                                        amax_arena=self.amax, dw=direct)
         else:
             main = torch.cuda.current_stream()
             if big:
@@ -578,7 +587,7 @@ class Step:
         Kp = p.cin_pad * taps
         for g in range(p.groups):       # packed (rows, cin_pad/32, taps, 32) pieces -> OIHW (column slices) of the parameters' gradients
             r0 = 0
-            for name, rows, ci0, cin_tot in p.wmeta[g]:
+            for name, rows, ci0, cin_tot in (p.wmeta[g] if direct is None else []):
                 self.gtable.add(repack.UNPACK, dws, self.gdst(name), 0, rows=rows, cin=p.cin, cin_tot=cin_tot, ci0=ci0, cin_pad=p.cin_pad,
                                 taps=taps, total=rows * p.cin * taps, src_off=(g * p.cout_pad + r0) * Kp)
                 r0 += rows
