@@ -459,3 +459,37 @@ def test_two_stream_reverse_pass_gives_the_one_stream_gradients():
     for k in p1:
         if "k_proj.bias" not in k:
             assert float(((p1[k] - p2[k]).abs() > 2e-4).float().mean()) < 0.02, k
+
+
+def test_direct_weight_gradient_of_aligned_linears_equals_the_unpacked_copy():
+    """Round 6 (Step._wgrad, EGR_TRAIN_WGRAD_DIRECT): a plain, unpadded single Linear / 1x1 conv's weight gradient is written straight into
+    the parameter-shaped destination instead of a packed buffer that the step's repack launch copies - same launch, same values:
+    bit-identical for every such tensor (mlp_pred.0's 2048 x 32768 matrix among them)."""
+    from egorear_amd import configs, synth, train
+    from egorear_amd.estimator import EgoPoseFormerMVFEX
+    from egorear_amd.metrics import generate_target
+    B = 4
+    args = (synth.synth_images(B, 4, seed=21).to(DEV), synth.synth_coord_trans_mat(B).to(DEV), synth.synth_gt_pose(B).to(DEV),
+            generate_target(synth.synth_joint_px(B).to(DEV)).contiguous())
+
+    def one(direct: bool):
+        saved = train.WGRAD_DIRECT
+        train.WGRAD_DIRECT = direct
+        try:
+            net = EgoPoseFormerMVFEX(**copy.deepcopy(configs.pose3d_cfg("ego4view_rw")))
+            synth.load_synth(net, 42)
+            S, _ = train.forward_backward(net.to(DEV), *args)
+            torch.cuda.synchronize()
+            return {k: v.clone() for k, v in S.pgrads.items()}
+        finally:
+            train.WGRAD_DIRECT = saved
+    a, b = one(False), one(True)
+    assert a.keys() == b.keys()
+    big = "pose3d_estimator.mlp_pred.0.0.weight"
+    assert big in a and a[big].shape == (2048, 32768) and torch.equal(a[big], b[big])
+    # the lifting head's own Linear layers sit behind deterministic launches only: bit-identical, whichever way their gradient travelled
+    same = [k for k in a if k.startswith("pose3d_estimator.mlp_pred.") or k.startswith("pose3d_estimator.query_gen_mlp.")]
+    assert len(same) >= 6 and all(torch.equal(a[k], b[k]) for k in same), [k for k in same if not torch.equal(a[k], b[k])]
+    gmax = max(float(v.double().norm()) for v in a.values())
+    worst = max(float((a[k].double() - b[k].double()).norm()) / (float(a[k].double().norm()) + 1e-6 * gmax) for k in a)
+    assert worst < 1e-5, worst          # (elsewhere: the noise of the sampling gradients' float atomics between two runs)
