@@ -17,7 +17,11 @@ Extra objects on the line:
                  16-bit dense peak (2516.6 TFLOP/s); the algorithmic rate is given beside it (`algorithmic_tflops`).
                  `families` prices the 3x3 launches (MFMA-bound) and the 1x1 launches (HBM-bound) each against its own roof;
                  the same figures as scalars: frac_conv3x3, conv3x3_ms, conv1x1_GBps, frac_conv1x1_hbm, conv1x1_ms;
-                 traffic (+ traffic_commit / traffic_file) = HBM bytes per launch replayed from the committed PMC passes.
+                 traffic = HBM bytes per launch MEASURED IN THIS RUN (round 6; traffic_live true): before this process touches the
+                 GPU it runs itself twice as a child under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE` (--pmc-child:
+                 three eager forwards of the benchmarked batch; separate passes, FETCH x 2 on gfx950; ~10 s each); the committed
+                 summary's figure rides along as traffic_replayed (+ traffic_replayed_commit) and takes over (traffic_commit /
+                 traffic_file) when rocprofv3 is unavailable, the passes fail, or --no-live-pmc / EGR_BENCH_LIVE_PMC=0 is given.
   exact_leg    — the same forward in exact operand arithmetic (bf16x3, six products), 50 steps: prices the 22-bit trade.
   one_lane     — the same forward as ONE captured graph replayed back to back (what the second lane's overlap is worth).
   cpu_baseline — the CPU oracle (oracle/egorear_oracle.py, a PyTorch-CPU port of the reference path) timed on this box's host
@@ -166,6 +170,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("EGR_BENCH_LANES", "2")),
                     help="captured forwards in flight (runner.PipelinedForward): consecutive steps overlap on that many streams")
+    ap.add_argument("--pmc-child", action="store_true", help="(internal) the profiled workload of the live PMC passes: --steps eager forwards, nothing else")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not measure roofline.traffic in this run (two rocprofv3 child passes, ~40 s); "
+                                                               "replay the committed PMC summary instead")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-iters", type=int, default=30)      # + 2 warm-ups = 32 forwards of 8 = 256 frames = four GPU batches of 64; ~15 s on the GPU box's 16 host threads
@@ -233,6 +240,87 @@ def _pmc_traffic(batch: int, fmt: str = "", launches_per_step: int = 0):
                                            "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH x 2 on gfx950); null when the launch count of this run differs"}
     except Exception:
         return None, None
+
+
+def _pmc_family(kernel_name: str) -> str:
+    """Which entry of the traffic summary a kernel belongs to (the rule of tools/pmc_traffic.py)."""
+    import re
+    nm = kernel_name
+    tapx = "conv_tapx_kernel" in nm or "conv_pw_chain_kernel" in nm or "conv_pw2_kernel" in nm
+    split = "conv_igemm_x6" in nm or "conv_igemm_tap" in nm or "conv_pw_x6" in nm or tapx
+    h2 = tapx or (split and re.search(r",\s*2>\(", nm.replace(") ", ")")) is not None)
+    if "conv_igemm" in nm or "conv_pw_x6" in nm or tapx:
+        return ("f16x2" if h2 else "bf16x3") if split else "f32"
+    return "other"
+
+
+def live_pmc_traffic(batch: int, forwards: int = 3, timeout_s: int = 150):
+    """HBM bytes per launch of the implicit-GEMM kernels MEASURED IN THIS RUN: two child processes of this same script under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md prescribes; FETCH_SIZE x 2 on
+    gfx950, both in KB), each running `forwards` eager forwards of the benchmarked batch and nothing else (--pmc-child).  Called
+    BEFORE this process touches the GPU.  Returns ({family: {"hbm_bytes_per_launch", "launches_per_forward"}}, provenance) or (None, reason)."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rp is None:
+        return None, "rocprofv3 not found"
+    root = tempfile.mkdtemp(prefix="egr_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    sums, counts = {}, {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(root, counter.lower())
+            cmd = [rp, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", "--batch", str(batch), "--steps", str(forwards)]
+            _log(f"live PMC pass {counter}: {' '.join(cmd[:8])} ... --pmc-child")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            files = glob.glob(out + "/**/*counter_collection.csv", recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"{counter} pass failed (rc {r.returncode}): {r.stdout.decode(errors='replace')[-300:]}"
+            per, seen = collections.defaultdict(float), collections.defaultdict(set)
+            with open(files[0]) as f:
+                for row in csv.DictReader(f):
+                    if row["Counter_Name"] != counter:
+                        continue
+                    k = _pmc_family(row["Kernel_Name"])
+                    per[k] += float(row["Counter_Value"])
+                    seen[k].add(row["Dispatch_Id"])
+            sums[counter], counts[counter] = per, {k: len(v) for k, v in seen.items()}
+    except Exception as exc:       # (timeout, unreadable CSV ...): the replayed figure stays in charge
+        return None, f"{type(exc).__name__}: {exc}"
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    res = {}
+    for fam, n in counts["FETCH_SIZE"].items():
+        nw = counts["WRITE_SIZE"].get(fam, 0)
+        if fam == "other" or n == 0 or nw == 0:
+            continue
+        res[fam] = {"hbm_bytes_per_launch": 2.0 * sums["FETCH_SIZE"][fam] * 1024 / n + sums["WRITE_SIZE"][fam] * 1024 / nw,
+                    "launches_per_forward": n / forwards, "launches_counted": n}
+    prov = {"measured_in_this_run": True, "forwards_profiled": forwards,
+            "note": "two child processes of bench.py (--pmc-child: eager forwards of the benchmarked batch only) under rocprofv3 --kernel-trace --pmc "
+                    "FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x 2 on gfx950, before this process touched the GPU"}
+    return res, prov
+
+
+def pmc_child(args):
+    """--pmc-child: `--steps` eager forwards of `--batch` frames, nothing else (the workload of live_pmc_traffic's profiled passes)."""
+    import torch
+    from egorear_amd import configs, synth
+    from egorear_amd.estimator import EgoPoseFormerMVFEX
+    dev = torch.device("cuda", 0)
+    net = EgoPoseFormerMVFEX(**copy.deepcopy(configs.pose3d_cfg("ego4view_syn"))).eval()
+    synth.load_synth(net, 42)
+    net = net.to(dev)
+    img = synth.synth_images(args.batch, 4, seed=1234).to(dev)
+    with torch.no_grad():
+        for _ in range(args.steps):
+            net(img)
+    torch.cuda.synchronize()
 
 
 def _pmc_traffic_train(batch: int, key: str):
@@ -724,9 +812,17 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if args.pmc_child:
+        return pmc_child(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    live_traffic, live_prov = None, None
+    if rank == 0 and world == 1 and not args.no_live_pmc and not args.no_graph and os.environ.get("EGR_BENCH_LIVE_PMC", "1") != "0":
+        # (before anything here touches the GPU; --no-graph runs are the profiled ones themselves: no nesting)
+        live_traffic, live_prov = live_pmc_traffic(args.batch if args.global_batch <= 0 else args.global_batch)
+        if live_traffic is None:
+            _log(f"live PMC passes unavailable ({live_prov}); roofline.traffic is replayed from the committed summary")
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
@@ -847,8 +943,17 @@ def main():
                     if tag.startswith("unique") and tag[6:].isdigit():
                         k["unique_bytes"] = k.get("unique_bytes", 0.0) + float(tag[6:])
             dom = max(kernels, key=lambda n: kernels[n]["ms"])
-            roof = _roofline(dom, kernels[dom], *_pmc_traffic(B, "f16x2" if dom.endswith("[f16x2]") else ("bf16x3" if dom.endswith("[bf16x3]") else "f32"),
-                                                              kernels[dom]["launches"]))
+            fam = "f16x2" if dom.endswith("[f16x2]") else ("bf16x3" if dom.endswith("[bf16x3]") else "f32")
+            replayed, replay_src = _pmc_traffic(B, fam, kernels[dom]["launches"])
+            lt = (live_traffic or {}).get(fam)
+            if lt is not None and abs(lt["launches_per_forward"] - kernels[dom]["launches"]) < 0.5:
+                # measured in THIS run; the committed summary's figure rides along for comparison
+                roof = _roofline(dom, kernels[dom], lt["hbm_bytes_per_launch"], dict(live_prov, launches_counted=lt["launches_counted"]))
+                roof["traffic_replayed"], roof["traffic_replayed_commit"] = replayed, (replay_src or {}).get("commit")
+            else:
+                roof = _roofline(dom, kernels[dom], replayed, replay_src)
+                if live_traffic is None and live_prov:
+                    roof["traffic_live_unavailable"] = str(live_prov)[:300]
             roof["families"] = _family_roofs(fams)
             # the same per-family figures as SCALAR keys (a parser that keeps scalars only loses `families`)
             f3, f1 = roof["families"].get("conv3x3[f16x2]"), roof["families"].get("conv1x1[f16x2]")
@@ -861,7 +966,8 @@ def main():
                 roof["frac_conv1x1_hbm"] = f1["frac"]
                 roof["conv1x1_ms"] = f1["kernel_ms_per_step"]
             ts = roof.get("traffic_source") or {}
-            roof["traffic_commit"] = ts.get("commit")                      # commit the replayed PMC passes were collected at (null: no traffic figure)
+            roof["traffic_live"] = bool(ts.get("measured_in_this_run"))    # true: the PMC passes ran as child processes of this very run
+            roof["traffic_commit"] = ts.get("commit")                      # commit the replayed PMC passes were collected at (null: live, or no figure)
             roof["traffic_file"] = ts.get("replayed_from")
             roof["all_kernels_ms_per_step"] = round(sum(v["ms"] for v in kernels.values()), 3)
             roof["note"] = ("kernel times come from ONE instrumented eager forward after the timed region (a HIP event pair around every launch, one stream): "
@@ -999,6 +1105,7 @@ def main():
             "frac_conv3x3": _get(roof, "frac_conv3x3"), "conv3x3_ms": _get(roof, "conv3x3_ms"),
             "frac_conv1x1_hbm": _get(roof, "frac_conv1x1_hbm"), "conv1x1_ms": _get(roof, "conv1x1_ms"),
             "all_kernels_ms_per_step": _get(roof, "all_kernels_ms_per_step"), "launches_per_forward": len(prof) if rank == 0 else None,
+            "traffic_live": _get(roof, "traffic_live"),
         }
         if roof is not None:
             head = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic")
