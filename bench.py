@@ -22,6 +22,8 @@ Extra objects on the line:
                  three eager forwards of the benchmarked batch; separate passes, FETCH x 2 on gfx950; ~10 s each); the committed
                  summary's figure rides along as traffic_replayed (+ traffic_replayed_commit) and takes over (traffic_commit /
                  traffic_file) when rocprofv3 is unavailable, the passes fail, or --no-live-pmc / EGR_BENCH_LIVE_PMC=0 is given.
+                 mfma_busy_frac / mfma_busy_frac_conv3x3: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) of the whole family /
+                 of the role-split 3x3 launches, from a third child pass of the same kind.
   exact_leg    — the same forward in exact operand arithmetic (bf16x3, six products), 50 steps: prices the 22-bit trade.
   one_lane     — the same forward as ONE captured graph replayed back to back (what the second lane's overlap is worth).
   cpu_baseline — the CPU oracle (oracle/egorear_oracle.py, a PyTorch-CPU port of the reference path) timed on this box's host
@@ -254,11 +256,20 @@ def _pmc_family(kernel_name: str) -> str:
     return "other"
 
 
+def _pmc_is_tapx3x3(kernel_name: str) -> bool:
+    """conv_tapx_kernel<WM, WN, FN, STRIDE, ...> with STRIDE 1 / 2: the role-split 3x3 launches (STRIDE 0 = its wide 1x1 mode)."""
+    import re
+    m = re.search(r"conv_tapx_kernel<\s*\d+\s*,\s*\d+\s*,\s*\d+\s*,\s*(\d+)", kernel_name)
+    return bool(m) and m.group(1) != "0"
+
+
 def live_pmc_traffic(batch: int, forwards: int = 3, timeout_s: int = 150):
-    """HBM bytes per launch of the implicit-GEMM kernels MEASURED IN THIS RUN: two child processes of this same script under
-    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md prescribes; FETCH_SIZE x 2 on
-    gfx950, both in KB), each running `forwards` eager forwards of the benchmarked batch and nothing else (--pmc-child).  Called
-    BEFORE this process touches the GPU.  Returns ({family: {"hbm_bytes_per_launch", "launches_per_forward"}}, provenance) or (None, reason)."""
+    """HBM bytes per launch and matrix-pipe utilisation of the implicit-GEMM kernels MEASURED IN THIS RUN: three child processes of this
+    same script under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE` / `SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE` (separate
+    passes, as MI355X_MICROARCH.md prescribes; FETCH_SIZE x 2 on gfx950, both in KB; MFMA-busy cycles are summed over the chip's 1024
+    SIMDs, GRBM_GUI_ACTIVE over its 8 XCDs), each running `forwards` eager forwards of the benchmarked batch and nothing else
+    (--pmc-child).  Called BEFORE this process touches the GPU.  Returns ({family: {"hbm_bytes_per_launch", "launches_per_forward",
+    "mfma_busy_frac", ...}}, provenance) or (None, reason); family "tapx3x3" = the role-split 3x3 launches alone."""
     import collections
     import csv
     import glob
@@ -270,40 +281,49 @@ def live_pmc_traffic(batch: int, forwards: int = 3, timeout_s: int = 150):
         return None, "rocprofv3 not found"
     root = tempfile.mkdtemp(prefix="egr_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
-    sums, counts = {}, {}
+    sums = collections.defaultdict(lambda: collections.defaultdict(float))      # counter -> family -> sum
+    seen = collections.defaultdict(lambda: collections.defaultdict(set))        # counter -> family -> dispatch ids
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(root, counter.lower())
-            cmd = [rp, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+        for counters in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE")):
+            out = os.path.join(root, counters[0].lower())
+            cmd = [rp, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
                    "--pmc-child", "--batch", str(batch), "--steps", str(forwards)]
-            _log(f"live PMC pass {counter}: {' '.join(cmd[:8])} ... --pmc-child")
+            _log(f"live PMC pass {' '.join(counters)}: rocprofv3 --kernel-trace --pmc ... -- python3 bench.py --pmc-child")
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
             files = glob.glob(out + "/**/*counter_collection.csv", recursive=True)
             if r.returncode != 0 or not files:
-                return None, f"{counter} pass failed (rc {r.returncode}): {r.stdout.decode(errors='replace')[-300:]}"
-            per, seen = collections.defaultdict(float), collections.defaultdict(set)
+                if counters[0] == "SQ_VALU_MFMA_BUSY_CYCLES":
+                    break                      # (the traffic passes stand on their own)
+                return None, f"{counters[0]} pass failed (rc {r.returncode}): {r.stdout.decode(errors='replace')[-300:]}"
             with open(files[0]) as f:
                 for row in csv.DictReader(f):
-                    if row["Counter_Name"] != counter:
+                    c = row["Counter_Name"]
+                    if c not in counters:
                         continue
-                    k = _pmc_family(row["Kernel_Name"])
-                    per[k] += float(row["Counter_Value"])
-                    seen[k].add(row["Dispatch_Id"])
-            sums[counter], counts[counter] = per, {k: len(v) for k, v in seen.items()}
+                    fams = [_pmc_family(row["Kernel_Name"])]
+                    if _pmc_is_tapx3x3(row["Kernel_Name"]):
+                        fams.append("tapx3x3")
+                    for k in fams:
+                        sums[c][k] += float(row["Counter_Value"])
+                        seen[c][k].add(row["Dispatch_Id"])
     except Exception as exc:       # (timeout, unreadable CSV ...): the replayed figure stays in charge
         return None, f"{type(exc).__name__}: {exc}"
     finally:
         shutil.rmtree(root, ignore_errors=True)
     res = {}
-    for fam, n in counts["FETCH_SIZE"].items():
-        nw = counts["WRITE_SIZE"].get(fam, 0)
+    for fam, ids in seen["FETCH_SIZE"].items():
+        n, nw = len(ids), len(seen["WRITE_SIZE"].get(fam, ()))
         if fam == "other" or n == 0 or nw == 0:
             continue
-        res[fam] = {"hbm_bytes_per_launch": 2.0 * sums["FETCH_SIZE"][fam] * 1024 / n + sums["WRITE_SIZE"][fam] * 1024 / nw,
-                    "launches_per_forward": n / forwards, "launches_counted": n}
+        e = {"hbm_bytes_per_launch": 2.0 * sums["FETCH_SIZE"][fam] * 1024 / n + sums["WRITE_SIZE"][fam] * 1024 / nw,
+             "launches_per_forward": n / forwards, "launches_counted": n}
+        gui = sums["GRBM_GUI_ACTIVE"].get(fam, 0.0)
+        if gui > 0:
+            e["mfma_busy_frac"] = sums["SQ_VALU_MFMA_BUSY_CYCLES"][fam] / (gui / 8.0 * 1024.0)
+        res[fam] = e
     prov = {"measured_in_this_run": True, "forwards_profiled": forwards,
-            "note": "two child processes of bench.py (--pmc-child: eager forwards of the benchmarked batch only) under rocprofv3 --kernel-trace --pmc "
-                    "FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x 2 on gfx950, before this process touched the GPU"}
+            "note": "child processes of bench.py (--pmc-child: eager forwards of the benchmarked batch only) under rocprofv3 --kernel-trace --pmc "
+                    "FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, separate passes, FETCH x 2 on gfx950, before this process touched the GPU"}
     return res, prov
 
 
@@ -950,6 +970,11 @@ def main():
                 # measured in THIS run; the committed summary's figure rides along for comparison
                 roof = _roofline(dom, kernels[dom], lt["hbm_bytes_per_launch"], dict(live_prov, launches_counted=lt["launches_counted"]))
                 roof["traffic_replayed"], roof["traffic_replayed_commit"] = replayed, (replay_src or {}).get("commit")
+                if "mfma_busy_frac" in lt:      # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), same child passes
+                    roof["mfma_busy_frac"] = round(lt["mfma_busy_frac"], 4)
+                t3 = (live_traffic or {}).get("tapx3x3")
+                if t3 and "mfma_busy_frac" in t3:
+                    roof["mfma_busy_frac_conv3x3"] = round(t3["mfma_busy_frac"], 4)
             else:
                 roof = _roofline(dom, kernels[dom], replayed, replay_src)
                 if live_traffic is None and live_prov:
@@ -1092,20 +1117,22 @@ def main():
                 d = d.get(k) if isinstance(d, dict) else None
             return d
         tr_roof = _get(train, "roofline") or {}
-        scal = {
-            "exact_fps": _get(exact, "value"), "steady_fps": _get(steady, "value"), "one_lane_fps": _get(one_lane, "value"),
-            "cfg2_fps": _get(cfg_legs, "config2_heatmap_4view", "value"), "cfg3_fps": _get(cfg_legs, "config3_heatmap_mvfex", "value"),
-            "train_ms_per_step": _get(train, "ms_per_step"), "train_fps": _get(train, "value"), "train_frac": tr_roof.get("frac"),
-            "train_dominant_kernel": tr_roof.get("kernel"), "train_launches_per_step": _get(train, "launches_per_step"),
-            "parity_frames": _get(parity_line, "frames"), "argmax_compared": _get(parity_line, "argmax_compared"),
-            "argmax_mismatches": _get(parity_line, "argmax_mismatches"), "valid_mask_mismatches": _get(parity_line, "valid_mask_mismatches"),
-            "argmax_mismatches_outside_rounding": _get(parity_line, "argmax_mismatches_outside_rounding"),
-            "argmax_mismatches_fp64_sides_with_hip": _get(parity_line, "argmax_mismatches_fp64_sides_with_hip"),
-            "max_joint_err_cm": _get(parity_line, "max_joint_err_cm"), "top2_gap_below_1e-5": _get(parity_line, "top2_gap_below_1e-5"),
+        scal = {      # (ordered by what a record that keeps only the first ~two dozen scalars of `roofline` must see)
+            "traffic_live": _get(roof, "traffic_live"), "mfma_busy_frac": _get(roof, "mfma_busy_frac"),
+            "mfma_busy_frac_conv3x3": _get(roof, "mfma_busy_frac_conv3x3"),
             "frac_conv3x3": _get(roof, "frac_conv3x3"), "conv3x3_ms": _get(roof, "conv3x3_ms"),
             "frac_conv1x1_hbm": _get(roof, "frac_conv1x1_hbm"), "conv1x1_ms": _get(roof, "conv1x1_ms"),
+            "exact_fps": _get(exact, "value"), "steady_fps": _get(steady, "value"), "one_lane_fps": _get(one_lane, "value"),
+            "train_ms_per_step": _get(train, "ms_per_step"), "train_frac": tr_roof.get("frac"),
+            "parity_frames": _get(parity_line, "frames"), "argmax_mismatches": _get(parity_line, "argmax_mismatches"),
+            "argmax_mismatches_outside_rounding": _get(parity_line, "argmax_mismatches_outside_rounding"),
+            "max_joint_err_cm": _get(parity_line, "max_joint_err_cm"),
+            "cfg2_fps": _get(cfg_legs, "config2_heatmap_4view", "value"), "cfg3_fps": _get(cfg_legs, "config3_heatmap_mvfex", "value"),
+            "train_fps": _get(train, "value"), "train_dominant_kernel": tr_roof.get("kernel"), "train_launches_per_step": _get(train, "launches_per_step"),
+            "argmax_compared": _get(parity_line, "argmax_compared"), "valid_mask_mismatches": _get(parity_line, "valid_mask_mismatches"),
+            "argmax_mismatches_fp64_sides_with_hip": _get(parity_line, "argmax_mismatches_fp64_sides_with_hip"),
+            "top2_gap_below_1e-5": _get(parity_line, "top2_gap_below_1e-5"),
             "all_kernels_ms_per_step": _get(roof, "all_kernels_ms_per_step"), "launches_per_forward": len(prof) if rank == 0 else None,
-            "traffic_live": _get(roof, "traffic_live"),
         }
         if roof is not None:
             head = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic")
