@@ -424,3 +424,24 @@ def test_eight_rank_rehearsal_of_the_bench_plumbing():
     with pytest.raises(SystemExit, match="not divisible"):
         bench.frames_per_rank(64, 500, 8)
     assert bench.frames_per_rank(64, 0, 8) == 64
+
+
+def test_bench_pmc_kernel_families_and_live_pass_fallback(monkeypatch):
+    """bench.py's live PMC passes (round 6): the kernel-name -> family rule of the reduction (the same as tools/pmc_traffic.py) and the
+    fallback when rocprofv3 does not exist (the committed summary then stays in charge) - no GPU."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    fam = bench._pmc_family
+    assert fam("void (anonymous namespace)::conv_tapx_kernel<1, 4, 2, 2, false, 0>(egrc::ConvArgs)") == "f16x2"
+    assert fam("void (anonymous namespace)::conv_pw_x6_kernel<8, 4, 0, 2>(egrc::ConvArgs)") == "f16x2"
+    assert fam("void (anonymous namespace)::conv_pw_x6_kernel<8, 4, 0, 3>(egrc::ConvArgs)") == "bf16x3"
+    assert fam("void (anonymous namespace)::conv_pw2_kernel<0, 8>((anonymous namespace)::ChainArgs)") == "f16x2"
+    assert fam("void (anonymous namespace)::conv_igemm_kernel<64, 64, 2, 2>(egrc::ConvArgs)") == "f32"
+    assert fam("void (anonymous namespace)::stem_x6_kernel<true, 2>(StemArgs)") == "other"
+    assert bench._pmc_is_tapx3x3("conv_tapx_kernel<2, 2, 2, 1, true, 0>(egrc::ConvArgs)") and bench._pmc_is_tapx3x3("conv_tapx_kernel<1, 4, 2, 2, false, 0>(x)")
+    assert not bench._pmc_is_tapx3x3("conv_tapx_kernel<1, 4, 1, 0, false, 0>(egrc::ConvArgs)") and not bench._pmc_is_tapx3x3("conv_pw_x6_kernel<8, 4, 0, 2>(x)")
+    import shutil
+    monkeypatch.setattr(shutil, "which", lambda name: None)
+    monkeypatch.setattr(os.path, "exists", lambda p: False if "rocprofv3" in p else True)
+    res, why = bench.live_pmc_traffic(64)
+    assert res is None and "rocprofv3" in why
