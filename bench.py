@@ -279,7 +279,10 @@ def live_pmc_traffic(batch: int, forwards: int = 3, timeout_s: int = 150):
     rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if rp is None:
         return None, "rocprofv3 not found"
-    root = tempfile.mkdtemp(prefix="egr_pmc_", dir="/tmp")
+    try:
+        root = tempfile.mkdtemp(prefix="egr_pmc_", dir="/tmp")
+    except OSError as exc:
+        return None, f"no scratch directory: {exc}"
     env = dict(os.environ, TMPDIR="/tmp")
     sums = collections.defaultdict(lambda: collections.defaultdict(float))      # counter -> family -> sum
     seen = collections.defaultdict(lambda: collections.defaultdict(set))        # counter -> family -> dispatch ids
