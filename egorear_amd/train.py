@@ -491,17 +491,7 @@ class Step:
     def backward(self):
         side = getattr(self, "side", None)
 
-        budget = [int(os.environ.get("EGR_TRAIN_OVERLAP_MAXSIDE", "1000000"))]      # (diagnostic: only the first n leaves go to the side stream)
-
         def on_side(fn):
-            budget[0] -= 1
-            if budget[0] < 0:
-                if os.environ.get("EGR_TRAIN_OVERLAP_TRACE"):
-                    pass
-                return fn()
-            if os.environ.get("EGR_TRAIN_OVERLAP_TRACE"):
-                import sys
-                print("side:", getattr(fn, "__qualname__", fn), file=sys.stderr)
             self._on_side = True
             try:
                 with torch.cuda.stream(side):
