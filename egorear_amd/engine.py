@@ -308,7 +308,9 @@ def invalidate(mod: nn.Module):
 def set_policy(mod: nn.Module, pol: Optional["hip.LaunchPolicy"]) -> None:
     """Give `mod` (and everything below it) its own launch policy - None: follow the process default again.  Packs are dropped (they
     are made under a policy: weight format, fused-layer images); two modules with different policies coexist in one process, and
-    a forward activates its module's policy for the calling thread only (hip.use_policy)."""
+    a forward activates its module's policy for the calling thread only (hip.use_policy).  The inference entry points honour it; the
+    training step (egorear_amd.train) follows the AMBIENT policy of the thread that drives it - wrap the step in hip.use_policy(p) to
+    train under another one."""
     for m in mod.modules():
         if pol is None:
             m.__dict__.pop("_egr_policy", None)
